@@ -1,0 +1,1237 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see so101_oracle.hpp for scope, citations and pinning status).
+// fp64, one env, deliberately plain loops: every stage is a literal restatement, not an optimised
+// implementation.  The HIP product path under so101_sim_amd/csrc shares no code with this file.
+#include "so101_oracle.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+typedef double real;
+const real MINVAL = 1e-15;   // mjMINVAL
+const real MINIMP = 1e-4, MAXIMP = 0.9999;
+enum { G_PLANE = 0, G_SPHERE = 1, G_CAPSULE = 2, G_CYLINDER = 3, G_BOX = 4, G_MESH = 5 };
+enum { J_NONE = 0, J_HINGE = 1, J_FREE = 2 };
+enum { C_FRICTION = 0, C_LIMIT = 1, C_CONTACT = 2 };
+
+// ---------------------------------------------------------------- small vector helpers
+inline real dot3(const real* a, const real* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+inline void cross3(real* o, const real* a, const real* b) {
+  real x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+inline real norm3(const real* a) { return std::sqrt(dot3(a, a)); }
+inline real normalize3(real* a) {
+  real n = norm3(a);
+  if (n < MINVAL) { a[0] = 1; a[1] = 0; a[2] = 0; return 0; }
+  a[0] /= n; a[1] /= n; a[2] /= n; return n;
+}
+inline void mulmatvec3(real* o, const real* m, const real* v) {   // row-major 3x3
+  real x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2];
+  real y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2];
+  real z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+inline void mulmatTvec3(real* o, const real* m, const real* v) {
+  real x = m[0] * v[0] + m[3] * v[1] + m[6] * v[2];
+  real y = m[1] * v[0] + m[4] * v[1] + m[7] * v[2];
+  real z = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+inline void mulmat3(real* o, const real* a, const real* b) {
+  real t[9];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
+    t[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+  std::memcpy(o, t, sizeof t);
+}
+inline void quat2mat(real* m, const real* q) {
+  real w = q[0], x = q[1], y = q[2], z = q[3];
+  m[0] = 1 - 2 * (y * y + z * z); m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+  m[3] = 2 * (x * y + w * z); m[4] = 1 - 2 * (x * x + z * z); m[5] = 2 * (y * z - w * x);
+  m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = 1 - 2 * (x * x + y * y);
+}
+inline void mulquat(real* o, const real* a, const real* b) {
+  real t[4] = {a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3],
+               a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+               a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1],
+               a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]};
+  std::memcpy(o, t, sizeof t);
+}
+inline void normquat(real* q) {
+  real n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
+  for (int i = 0; i < 4; i++) q[i] /= n;
+}
+inline void rotvecquat(real* o, const real* v, const real* q) {   // mju_rotVecQuat
+  real m[9]; quat2mat(m, q); mulmatvec3(o, m, v);
+}
+// mju_mat2Quat restated (branch on the largest diagonal combination)
+inline void mat2quat(real* q, const real* m) {
+  real t = m[0] + m[4] + m[8];
+  if (t > 0) {
+    real s = std::sqrt(t + 1) * 2; q[0] = 0.25 * s; q[1] = (m[7] - m[5]) / s; q[2] = (m[2] - m[6]) / s; q[3] = (m[3] - m[1]) / s;
+  } else if (m[0] > m[4] && m[0] > m[8]) {
+    real s = std::sqrt(1 + m[0] - m[4] - m[8]) * 2; q[0] = (m[7] - m[5]) / s; q[1] = 0.25 * s; q[2] = (m[1] + m[3]) / s; q[3] = (m[2] + m[6]) / s;
+  } else if (m[4] > m[8]) {
+    real s = std::sqrt(1 + m[4] - m[0] - m[8]) * 2; q[0] = (m[2] - m[6]) / s; q[1] = (m[1] + m[3]) / s; q[2] = 0.25 * s; q[3] = (m[5] + m[7]) / s;
+  } else {
+    real s = std::sqrt(1 + m[8] - m[0] - m[4]) * 2; q[0] = (m[3] - m[1]) / s; q[1] = (m[2] + m[6]) / s; q[2] = (m[5] + m[7]) / s; q[3] = 0.25 * s;
+  }
+  normquat(q);
+}
+
+// ---------------------------------------------------------------- blob reader
+struct Blob {
+  std::map<std::string, std::pair<const void*, uint32_t>> ent;
+  std::map<std::string, int> kind;
+  bool parse(const void* p, size_t bytes) {
+    const uint8_t* b = (const uint8_t*)p;
+    uint32_t magic, ver, rb, n;
+    std::memcpy(&magic, b, 4); std::memcpy(&ver, b + 4, 4); std::memcpy(&rb, b + 8, 4); std::memcpy(&n, b + 12, 4);
+    if (magic != 0x424D3153u || ver != 3 || rb != 8) return false;
+    for (uint32_t k = 0; k < n; k++) {
+      const uint8_t* e = b + 16 + 48 * k;
+      char name[33]; std::memcpy(name, e, 32); name[32] = 0;
+      uint32_t kd, cnt; uint64_t off;
+      std::memcpy(&kd, e + 32, 4); std::memcpy(&cnt, e + 36, 4); std::memcpy(&off, e + 40, 8);
+      if (off + (size_t)cnt * (kd ? 8 : 4) > bytes) return false;
+      ent[name] = {b + off, cnt}; kind[name] = kd;
+    }
+    return true;
+  }
+  std::vector<int> I(const char* n) const {
+    auto it = ent.find(n); std::vector<int> v;
+    if (it == ent.end()) { std::fprintf(stderr, "oracle: blob entry %s missing\n", n); return v; }
+    v.resize(it->second.second); std::memcpy(v.data(), it->second.first, 4 * v.size()); return v;
+  }
+  std::vector<real> R(const char* n) const {
+    auto it = ent.find(n); std::vector<real> v;
+    if (it == ent.end()) { std::fprintf(stderr, "oracle: blob entry %s missing\n", n); return v; }
+    v.resize(it->second.second); std::memcpy(v.data(), it->second.first, 8 * v.size()); return v;
+  }
+  int i(const char* n) const { return I(n)[0]; }
+  real r(const char* n) const { return R(n)[0]; }
+};
+
+struct Model {
+  int nq, nv, nu, nbody, ngeom, nvert, npair, narm, nfree;
+  real dt, gravity[3], impratio, tolerance, mpr_tol, meaninertia;
+  int iterations, mpr_iter, elliptic;
+  std::vector<int> body_parent, body_jnttype, body_qposadr, body_dofadr, body_weldid, arm_body, free_body,
+      jnt_limited, dof_body, act_dof, act_ctrllimited, act_forcelimited, geom_type, geom_body, geom_condim,
+      geom_priority, geom_vertadr, geom_vertnum, pair_geom;
+  std::vector<real> body_pos, body_quat, body_ipos, body_iquat, body_mass, body_inertia, body_invweight0,
+      body_bvh_aabb, jnt_axis, jnt_range, jnt_solref, jnt_solimp, dof_solref, dof_solimp, dof_armature,
+      dof_frictionloss, dof_damping, dof_invweight0, act_gain, act_bias, act_ctrlrange, act_forcerange,
+      geom_pos, geom_quat, geom_size, geom_friction, geom_solref, geom_solimp, geom_solmix, geom_margin,
+      geom_gap, geom_rbound, geom_center, geom_aabb, mesh_vert;
+  std::vector<int> body_hinge;   // body -> hinge index or -1
+  // task
+  int obj_body, con_body, nbox;
+  std::vector<real> box_pos, box_half, obj_lo, obj_hi, obj_yaw, con_lo, con_hi, home_ctrl;
+};
+
+struct Contact {
+  real pos[3], frame[9], dist;
+  int g1, g2, dim;
+  real friction[5], solref[2], solimp[5], mu;
+};
+
+struct Support { real p[3]; };
+
+}  // namespace
+
+struct orc_sim {
+  Model m;
+  // state
+  std::vector<real> qpos, qvel, ctrl, warm;
+  // derived
+  std::vector<real> xpos, xquat, xmat, xipos, ximat, gpos, gmat, S, M, Minv, bias, qfrc_act, act_force,
+      qacc_smooth, qacc;
+  std::vector<Contact> con;
+  // constraints
+  int nefc = 0, solver_iter = 0;
+  std::vector<real> J, efc_pos, efc_D, efc_R, efc_aref, efc_force, efc_floss, efc_b, AR;
+  std::vector<int> efc_type, efc_id, efc_dim;
+  int iterations; real tolerance; bool collide = true;
+  // env layer
+  orc_env_cfg cfg{};
+  int step_count = 0; uint64_t episode = 0; bool need_reset = true; real ep_return = 0;
+  real ring[5][6]; int ring_head = 0;
+  real delayed[6];
+  real cmd[6];
+};
+
+namespace {
+
+// ================================================================ kinematics
+void kinematics(orc_sim* s) {
+  const Model& m = s->m;
+  int nb = m.nbody;
+  s->xpos.assign(3 * nb, 0); s->xquat.assign(4 * nb, 0); s->xmat.assign(9 * nb, 0);
+  s->xipos.assign(3 * nb, 0); s->ximat.assign(9 * nb, 0);
+  s->xquat[0] = 1; s->xmat[0] = s->xmat[4] = s->xmat[8] = 1; s->ximat[0] = s->ximat[4] = s->ximat[8] = 1;
+  for (int b = 1; b < nb; b++) {
+    int p = m.body_parent[b];
+    real* xp = &s->xpos[3 * b]; real* xq = &s->xquat[4 * b];
+    if (m.body_jnttype[b] == J_FREE) {
+      const real* q = &s->qpos[m.body_qposadr[b]];
+      xp[0] = q[0]; xp[1] = q[1]; xp[2] = q[2];
+      xq[0] = q[3]; xq[1] = q[4]; xq[2] = q[5]; xq[3] = q[6];
+      normquat(xq);
+    } else {
+      real t[3]; mulmatvec3(t, &s->xmat[9 * p], &m.body_pos[3 * b]);
+      for (int k = 0; k < 3; k++) xp[k] = s->xpos[3 * p + k] + t[k];
+      mulquat(xq, &s->xquat[4 * p], &m.body_quat[4 * b]);
+      if (m.body_jnttype[b] == J_HINGE) {
+        int h = m.body_hinge[b];
+        real ang = s->qpos[m.body_qposadr[b]];
+        const real* ax = &m.jnt_axis[3 * h];
+        real sn = std::sin(0.5 * ang), jq[4] = {std::cos(0.5 * ang), ax[0] * sn, ax[1] * sn, ax[2] * sn};
+        mulquat(xq, xq, jq);
+      }
+      normquat(xq);
+    }
+    quat2mat(&s->xmat[9 * b], xq);
+    real t[3]; mulmatvec3(t, &s->xmat[9 * b], &m.body_ipos[3 * b]);
+    for (int k = 0; k < 3; k++) s->xipos[3 * b + k] = xp[k] + t[k];
+    real im[9]; quat2mat(im, &m.body_iquat[4 * b]);
+    mulmat3(&s->ximat[9 * b], &s->xmat[9 * b], im);
+  }
+  s->gpos.assign(3 * m.ngeom, 0); s->gmat.assign(9 * m.ngeom, 0);
+  for (int g = 0; g < m.ngeom; g++) {
+    int b = m.geom_body[g];
+    real t[3]; mulmatvec3(t, &s->xmat[9 * b], &m.geom_pos[3 * g]);
+    for (int k = 0; k < 3; k++) s->gpos[3 * g + k] = s->xpos[3 * b + k] + t[k];
+    real gm[9]; quat2mat(gm, &m.geom_quat[4 * g]);
+    mulmat3(&s->gmat[9 * g], &s->xmat[9 * b], gm);
+  }
+  // motion axes S[d] = (omega ; velocity of the point at the world origin)
+  s->S.assign(6 * m.nv, 0);
+  for (int b = 1; b < nb; b++) {
+    int d = m.body_dofadr[b];
+    const real* xp = &s->xpos[3 * b];
+    if (m.body_jnttype[b] == J_HINGE) {
+      real a[3]; mulmatvec3(a, &s->xmat[9 * b], &m.jnt_axis[3 * m.body_hinge[b]]);
+      real* r = &s->S[6 * d];
+      r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; cross3(r + 3, xp, a);
+    } else if (m.body_jnttype[b] == J_FREE) {
+      for (int k = 0; k < 3; k++) {
+        s->S[6 * (d + k) + 3 + k] = 1;
+        real* r = &s->S[6 * (d + 3 + k)];
+        real a[3] = {s->xmat[9 * b + k], s->xmat[9 * b + 3 + k], s->xmat[9 * b + 6 + k]};
+        r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; cross3(r + 3, xp, a);
+      }
+    }
+  }
+}
+
+bool is_ancestor(const Model& m, int a, int d) {   // a == d or a is an ancestor of d
+  while (d != 0) { if (d == a) return true; d = m.body_parent[d]; }
+  return a == 0;
+}
+
+// ================================================================ CRBA: composite inertia about the world origin
+void crba(orc_sim* s) {
+  const Model& m = s->m;
+  int nb = m.nbody, nv = m.nv;
+  std::vector<real> Ic(36 * nb, 0);
+  for (int b = 1; b < nb; b++) {
+    real mass = m.body_mass[b];
+    if (mass <= 0) continue;
+    const real* c = &s->xipos[3 * b];
+    const real* R = &s->ximat[9 * b];
+    real I[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+      real v = 0;
+      for (int k = 0; k < 3; k++) v += R[3 * i + k] * m.body_inertia[3 * b + k] * R[3 * j + k];
+      I[3 * i + j] = v;
+    }
+    real cx[9] = {0, -c[2], c[1], c[2], 0, -c[0], -c[1], c[0], 0};
+    real cx2[9]; mulmat3(cx2, cx, cx);
+    real* o = &Ic[36 * b];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+      o[6 * i + j] = I[3 * i + j] - mass * cx2[3 * i + j];
+      o[6 * i + 3 + j] = mass * cx[3 * i + j];
+      o[6 * (3 + i) + j] = -mass * cx[3 * i + j];
+      o[6 * (3 + i) + 3 + j] = (i == j) ? mass : 0;
+    }
+  }
+  for (int b = nb - 1; b >= 1; b--) {
+    int p = m.body_parent[b];
+    for (int k = 0; k < 36; k++) Ic[36 * p + k] += Ic[36 * b + k];
+  }
+  s->M.assign(nv * nv, 0);
+  for (int r = 0; r < nv; r++) for (int c = 0; c < nv; c++) {
+    int br = m.dof_body[r], bc = m.dof_body[c], bb;
+    if (is_ancestor(m, bc, br)) bb = br; else if (is_ancestor(m, br, bc)) bb = bc; else continue;
+    real t[6];
+    for (int i = 0; i < 6; i++) { t[i] = 0; for (int j = 0; j < 6; j++) t[i] += Ic[36 * bb + 6 * i + j] * s->S[6 * c + j]; }
+    real v = 0; for (int i = 0; i < 6; i++) v += s->S[6 * r + i] * t[i];
+    s->M[r * nv + c] = v;
+  }
+  for (int d = 0; d < nv; d++) s->M[d * nv + d] += m.dof_armature[d];   // armature on the diagonal
+  // dense inverse through Cholesky (M is SPD); the oracle favours clarity over sparsity
+  std::vector<real> L(s->M);
+  for (int j = 0; j < nv; j++) {
+    for (int k = 0; k < j; k++) for (int i = j; i < nv; i++) L[i * nv + j] -= L[i * nv + k] * L[j * nv + k];
+    real d = std::sqrt(L[j * nv + j]);
+    for (int i = j; i < nv; i++) L[i * nv + j] /= d;
+  }
+  s->Minv.assign(nv * nv, 0);
+  for (int c = 0; c < nv; c++) {
+    std::vector<real> y(nv, 0);
+    for (int i = 0; i < nv; i++) {
+      real v = (i == c) ? 1 : 0;
+      for (int k = 0; k < i; k++) v -= L[i * nv + k] * y[k];
+      y[i] = v / L[i * nv + i];
+    }
+    for (int i = nv - 1; i >= 0; i--) {
+      real v = y[i];
+      for (int k = i + 1; k < nv; k++) v -= L[k * nv + i] * s->Minv[k * nv + c];
+      s->Minv[i * nv + c] = v / L[i * nv + i];
+    }
+  }
+}
+
+// ================================================================ RNE bias (Coriolis/centrifugal + gravity), qacc = 0
+void rne_bias(orc_sim* s) {
+  const Model& m = s->m;
+  int nb = m.nbody;
+  std::vector<real> w(3 * nb, 0), al(3 * nb, 0), ao(3 * nb, 0), f(3 * nb, 0), n(3 * nb, 0);
+  for (int k = 0; k < 3; k++) ao[k] = -m.gravity[k];   // gravity as base acceleration
+  for (int b = 1; b < nb; b++) {
+    int p = m.body_parent[b];
+    real* wb = &w[3 * b]; real* ab = &al[3 * b]; real* aob = &ao[3 * b];
+    if (m.body_jnttype[b] == J_FREE) {
+      const real* v = &s->qvel[m.body_dofadr[b]];
+      mulmatvec3(wb, &s->xmat[9 * b], v + 3);         // body-frame angular velocity -> world
+      for (int k = 0; k < 3; k++) { ab[k] = 0; aob[k] = -m.gravity[k]; }
+    } else {
+      real d[3]; for (int k = 0; k < 3; k++) d[k] = s->xpos[3 * b + k] - s->xpos[3 * p + k];
+      real t1[3], t2[3];
+      cross3(t1, &al[3 * p], d); cross3(t2, &w[3 * p], d); cross3(t2, &w[3 * p], t2);
+      for (int k = 0; k < 3; k++) { aob[k] = ao[3 * p + k] + t1[k] + t2[k]; wb[k] = w[3 * p + k]; ab[k] = al[3 * p + k]; }
+      if (m.body_jnttype[b] == J_HINGE) {
+        real a[3]; mulmatvec3(a, &s->xmat[9 * b], &m.jnt_axis[3 * m.body_hinge[b]]);
+        real qd = s->qvel[m.body_dofadr[b]];
+        real t[3]; cross3(t, &w[3 * p], a);
+        for (int k = 0; k < 3; k++) { wb[k] += a[k] * qd; ab[k] += t[k] * qd; }
+      }
+    }
+    real mass = m.body_mass[b];
+    if (mass > 0) {
+      real r[3]; for (int k = 0; k < 3; k++) r[k] = s->xipos[3 * b + k] - s->xpos[3 * b + k];
+      real t1[3], t2[3]; cross3(t1, ab, r); cross3(t2, wb, r); cross3(t2, wb, t2);
+      real F[3]; for (int k = 0; k < 3; k++) F[k] = mass * (aob[k] + t1[k] + t2[k]);
+      const real* R = &s->ximat[9 * b];
+      real Iw[3], Ia[3], lw[3], la[3];
+      mulmatTvec3(lw, R, wb); mulmatTvec3(la, R, ab);
+      for (int k = 0; k < 3; k++) { lw[k] *= m.body_inertia[3 * b + k]; la[k] *= m.body_inertia[3 * b + k]; }
+      mulmatvec3(Iw, R, lw); mulmatvec3(Ia, R, la);
+      real N[3]; cross3(N, wb, Iw);
+      real rF[3]; cross3(rF, r, F);
+      for (int k = 0; k < 3; k++) { f[3 * b + k] += F[k]; n[3 * b + k] += Ia[k] + N[k] + rF[k]; }
+    }
+  }
+  s->bias.assign(m.nv, 0);
+  for (int b = nb - 1; b >= 1; b--) {
+    int p = m.body_parent[b], d = m.body_dofadr[b];
+    if (m.body_jnttype[b] == J_HINGE) {
+      real a[3]; mulmatvec3(a, &s->xmat[9 * b], &m.jnt_axis[3 * m.body_hinge[b]]);
+      s->bias[d] = dot3(a, &n[3 * b]);
+    } else if (m.body_jnttype[b] == J_FREE) {
+      for (int k = 0; k < 3; k++) s->bias[d + k] = f[3 * b + k];
+      real t[3]; mulmatTvec3(t, &s->xmat[9 * b], &n[3 * b]);
+      for (int k = 0; k < 3; k++) s->bias[d + 3 + k] = t[k];
+    }
+    if (p != 0) {
+      real dd[3]; for (int k = 0; k < 3; k++) dd[k] = s->xpos[3 * b + k] - s->xpos[3 * p + k];
+      real t[3]; cross3(t, dd, &f[3 * b]);
+      for (int k = 0; k < 3; k++) { f[3 * p + k] += f[3 * b + k]; n[3 * p + k] += n[3 * b + k] + t[k]; }
+    }
+  }
+}
+
+// ================================================================ actuation (scene_pbr.xml:11 `general`, affine bias)
+void actuation(orc_sim* s) {
+  const Model& m = s->m;
+  s->qfrc_act.assign(m.nv, 0); s->act_force.assign(m.nu, 0);
+  for (int a = 0; a < m.nu; a++) {
+    int d = m.act_dof[a];
+    real c = s->ctrl[a];
+    if (m.act_ctrllimited[a]) c = std::min(std::max(c, m.act_ctrlrange[2 * a]), m.act_ctrlrange[2 * a + 1]);
+    // hinge joint transmission: length = qpos, velocity = qvel of the joint (arm dofs precede free bodies)
+    real force = m.act_gain[a] * c + m.act_bias[3 * a] + m.act_bias[3 * a + 1] * s->qpos[d] + m.act_bias[3 * a + 2] * s->qvel[d];
+    if (m.act_forcelimited[a]) force = std::min(std::max(force, m.act_forcerange[2 * a]), m.act_forcerange[2 * a + 1]);
+    s->act_force[a] = force;
+    s->qfrc_act[d] += force;
+  }
+}
+
+// ================================================================ collision
+// support point of geom g in world direction dir (libccd-style support mapping per geom type)
+void support(const orc_sim* s, int g, const real* dir, real* out) {
+  const Model& m = s->m;
+  const real* R = &s->gmat[9 * g]; const real* P = &s->gpos[3 * g];
+  real dl[3]; mulmatTvec3(dl, R, dir);
+  real loc[3] = {0, 0, 0};
+  const real* sz = &m.geom_size[3 * g];
+  switch (m.geom_type[g]) {
+    case G_SPHERE: { real n = norm3(dl); if (n > MINVAL) for (int k = 0; k < 3; k++) loc[k] = sz[0] * dl[k] / n; break; }
+    case G_BOX: for (int k = 0; k < 3; k++) loc[k] = dl[k] >= 0 ? sz[k] : -sz[k]; break;
+    case G_CAPSULE: {
+      real n = norm3(dl);
+      if (n > MINVAL) for (int k = 0; k < 3; k++) loc[k] = sz[0] * dl[k] / n;
+      loc[2] += dl[2] >= 0 ? sz[1] : -sz[1];
+      break;
+    }
+    case G_CYLINDER: {
+      real n = std::sqrt(dl[0] * dl[0] + dl[1] * dl[1]);
+      if (n > MINVAL) { loc[0] = sz[0] * dl[0] / n; loc[1] = sz[0] * dl[1] / n; }
+      loc[2] = dl[2] >= 0 ? sz[1] : -sz[1];
+      break;
+    }
+    case G_MESH: {
+      const real* v = &m.mesh_vert[3 * m.geom_vertadr[g]];
+      int n = m.geom_vertnum[g], best = 0; real bv = -1e300;
+      for (int i = 0; i < n; i++) { real d = dot3(v + 3 * i, dl); if (d > bv) { bv = d; best = i; } }
+      for (int k = 0; k < 3; k++) loc[k] = v[3 * best + k];
+      break;
+    }
+    default: break;
+  }
+  real w[3]; mulmatvec3(w, R, loc);
+  for (int k = 0; k < 3; k++) out[k] = P[k] + w[k];
+}
+
+void geom_center(const orc_sim* s, int g, real* out) {
+  real w[3]; mulmatvec3(w, &s->gmat[9 * g], &s->m.geom_center[3 * g]);
+  for (int k = 0; k < 3; k++) out[k] = s->gpos[3 * g + k] + w[k];
+}
+
+// Minkowski-difference support  v = s1(dir) - s2(-dir)  plus the two witnesses (libccd ccd_support_t)
+struct MV { real v[3], a[3], b[3]; };
+void mdsupport(const orc_sim* s, int g1, int g2, const real* dir, const real* org, MV* o) {
+  real nd[3] = {-dir[0], -dir[1], -dir[2]};
+  support(s, g1, dir, o->a); support(s, g2, nd, o->b);
+  for (int k = 0; k < 3; k++) { o->a[k] -= org[k]; o->b[k] -= org[k]; o->v[k] = o->a[k] - o->b[k]; }
+}
+
+inline bool isz(real x) { return std::fabs(x) < 1e-10; }   // CCD_EPS-style zero test
+
+// squared distance of the origin to triangle (x0,B,C) with witness (libccd ccdVec3PointTriDist2 for P=0)
+real origin_tri_dist2(const real* x0, const real* B, const real* C, real* wit) {
+  real d1[3], d2[3], a[3];
+  for (int k = 0; k < 3; k++) { d1[k] = B[k] - x0[k]; d2[k] = C[k] - x0[k]; a[k] = x0[k]; }
+  real u = dot3(a, a), v = dot3(d1, d1), w = dot3(d2, d2), p = dot3(a, d1), q = dot3(a, d2), r = dot3(d1, d2);
+  real den = w * v - r * r, sp = -1, tp = -1;
+  if (!isz(den)) { sp = (q * r - w * p) / den; tp = (-sp * r - q) / w; }
+  auto seg = [&](const real* P0, const real* P1, real* wt) {   // origin to segment
+    real dd[3] = {P1[0] - P0[0], P1[1] - P0[1], P1[2] - P0[2]};
+    real t = -dot3(P0, dd) / std::max(dot3(dd, dd), MINVAL);
+    t = std::min(std::max(t, 0.0), 1.0);
+    for (int k = 0; k < 3; k++) wt[k] = P0[k] + t * dd[k];
+    return dot3(wt, wt);
+  };
+  if ((isz(sp) || sp > 0) && (isz(sp - 1) || sp < 1) && (isz(tp) || tp > 0) && (isz(tp - 1) || tp < 1) &&
+      (isz(tp + sp - 1) || tp + sp < 1)) {
+    for (int k = 0; k < 3; k++) wit[k] = x0[k] + sp * d1[k] + tp * d2[k];
+    return dot3(wit, wit);
+  }
+  real w1[3], w2[3], w3[3];
+  real e1 = seg(x0, B, w1), e2 = seg(x0, C, w2), e3 = seg(B, C, w3);
+  real best = e1; std::memcpy(wit, w1, sizeof w1);
+  if (e2 < best) { best = e2; std::memcpy(wit, w2, sizeof w2); }
+  if (e3 < best) { best = e3; std::memcpy(wit, w3, sizeof w3); }
+  return best;
+}
+
+// MPR penetration (libccd ccdMPRPenetration restated).  Returns true when the geoms intersect and
+// fills depth, dir (from g1 into g2) and pos (world).
+bool mpr_penetration(const orc_sim* s, int g1, int g2, real* depth, real* dir, real* pos) {
+  const Model& m = s->m;
+  real org[3]; geom_center(s, g1, org);       // work in a frame centred on geom1 (conditioning only)
+  real c1[3] = {0, 0, 0}, c2[3]; geom_center(s, g2, c2);
+  for (int k = 0; k < 3; k++) c2[k] -= org[k];
+  MV v0, v1, v2, v3, v4;
+  for (int k = 0; k < 3; k++) { v0.a[k] = c1[k]; v0.b[k] = c2[k]; v0.v[k] = c1[k] - c2[k]; }
+  if (isz(v0.v[0]) && isz(v0.v[1]) && isz(v0.v[2])) v0.v[0] += 1e-5;
+  real d[3] = {-v0.v[0], -v0.v[1], -v0.v[2]}; normalize3(d);
+  mdsupport(s, g1, g2, d, org, &v1);
+  real dt = dot3(v1.v, d);
+  if (isz(dt) || dt < 0) return false;
+  cross3(d, v0.v, v1.v);
+  int state = 0;   // 0: portal found, 1: touching at v1, 2: origin on segment v0-v1
+  if (isz(norm3(d))) {
+    state = (isz(v1.v[0]) && isz(v1.v[1]) && isz(v1.v[2])) ? 1 : 2;
+  } else {
+    normalize3(d);
+    mdsupport(s, g1, g2, d, org, &v2);
+    dt = dot3(v2.v, d);
+    if (isz(dt) || dt < 0) return false;
+    real va[3], vb[3];
+    for (int k = 0; k < 3; k++) { va[k] = v1.v[k] - v0.v[k]; vb[k] = v2.v[k] - v0.v[k]; }
+    cross3(d, va, vb); normalize3(d);
+    if (dot3(d, v0.v) > 0) { std::swap(v1, v2); for (int k = 0; k < 3; k++) d[k] = -d[k]; }
+    bool have3 = false;
+    for (int guard = 0; guard < 100 && !have3; guard++) {
+      mdsupport(s, g1, g2, d, org, &v3);
+      dt = dot3(v3.v, d);
+      if (isz(dt) || dt < 0) return false;
+      bool cont = false;
+      cross3(va, v1.v, v3.v);
+      dt = dot3(va, v0.v);
+      if (dt < 0 && !isz(dt)) { v2 = v3; cont = true; }
+      if (!cont) {
+        cross3(va, v3.v, v2.v);
+        dt = dot3(va, v0.v);
+        if (dt < 0 && !isz(dt)) { v1 = v3; cont = true; }
+      }
+      if (cont) {
+        for (int k = 0; k < 3; k++) { va[k] = v1.v[k] - v0.v[k]; vb[k] = v2.v[k] - v0.v[k]; }
+        cross3(d, va, vb); normalize3(d);
+      } else have3 = true;
+    }
+    if (!have3) return false;
+  }
+  auto portal_dir = [&](real* o) {
+    real a[3], b[3];
+    for (int k = 0; k < 3; k++) { a[k] = v2.v[k] - v1.v[k]; b[k] = v3.v[k] - v1.v[k]; }
+    cross3(o, a, b); normalize3(o);
+  };
+  auto reach_tol = [&](const MV& x, const real* dd) {
+    real dv1 = dot3(v1.v, dd), dv2 = dot3(v2.v, dd), dv3 = dot3(v3.v, dd), dv4 = dot3(x.v, dd);
+    real dm = std::min(std::min(dv4 - dv1, dv4 - dv2), dv4 - dv3);
+    return isz(dm - m.mpr_tol) || dm < m.mpr_tol;
+  };
+  auto expand = [&](const MV& x) {
+    real v4v0[3]; cross3(v4v0, x.v, v0.v);
+    real t = dot3(v1.v, v4v0);
+    if (t > 0) { t = dot3(v2.v, v4v0); if (t > 0) v1 = x; else v3 = x; }
+    else { t = dot3(v3.v, v4v0); if (t > 0) v2 = x; else v1 = x; }
+  };
+  if (state == 1) {           // touching contact
+    *depth = 0; dir[0] = dir[1] = dir[2] = 0;
+    for (int k = 0; k < 3; k++) pos[k] = 0.5 * (v1.a[k] + v1.b[k]) + org[k];
+    return true;
+  }
+  if (state == 2) {           // origin on the v0-v1 segment
+    for (int k = 0; k < 3; k++) { pos[k] = 0.5 * (v1.a[k] + v1.b[k]) + org[k]; dir[k] = v1.v[k]; }
+    *depth = normalize3(dir);
+    return true;
+  }
+  // refine portal until it encapsulates the origin
+  for (int guard = 0;; guard++) {
+    portal_dir(d);
+    dt = dot3(d, v1.v);
+    if (isz(dt) || dt > 0) break;                       // portal encapsules origin
+    mdsupport(s, g1, g2, d, org, &v4);
+    dt = dot3(v4.v, d);
+    if (!(isz(dt) || dt > 0)) return false;             // cannot encapsule origin
+    if (reach_tol(v4, d) || guard > 100) return false;
+    expand(v4);
+  }
+  // find penetration
+  for (int it = 0;; it++) {
+    portal_dir(d);
+    mdsupport(s, g1, g2, d, org, &v4);
+    if (reach_tol(v4, d) || it > m.mpr_iter) {
+      real pd[3];
+      real d2 = origin_tri_dist2(v1.v, v2.v, v3.v, pd);
+      *depth = std::sqrt(d2);
+      if (isz(pd[0]) && isz(pd[1]) && isz(pd[2])) { *depth = 0; for (int k = 0; k < 3; k++) dir[k] = d[k]; }
+      else { for (int k = 0; k < 3; k++) dir[k] = pd[k]; normalize3(dir); }
+      // position (libccd findPos): barycentric weights of the origin ray within the portal
+      real b[4], t[3];
+      cross3(t, v1.v, v2.v); b[0] = dot3(t, v3.v);
+      cross3(t, v3.v, v2.v); b[1] = dot3(t, v0.v);
+      cross3(t, v0.v, v1.v); b[2] = dot3(t, v3.v);
+      cross3(t, v2.v, v1.v); b[3] = dot3(t, v0.v);
+      real sum = b[0] + b[1] + b[2] + b[3];
+      if (isz(sum) || sum < 0) {
+        b[0] = 0;
+        cross3(t, v2.v, v3.v); b[1] = dot3(t, d);
+        cross3(t, v3.v, v1.v); b[2] = dot3(t, d);
+        cross3(t, v1.v, v2.v); b[3] = dot3(t, d);
+        sum = b[1] + b[2] + b[3];
+      }
+      real inv = 1.0 / sum;
+      const MV* vs[4] = {&v0, &v1, &v2, &v3};
+      for (int k = 0; k < 3; k++) {
+        real p1 = 0, p2 = 0;
+        for (int i = 0; i < 4; i++) { p1 += b[i] * vs[i]->a[k]; p2 += b[i] * vs[i]->b[k]; }
+        pos[k] = 0.5 * (p1 + p2) * inv + org[k];
+      }
+      return true;
+    }
+    expand(v4);
+  }
+}
+
+void make_frame(real* fr) {   // mju_makeFrame: fr[0:3] given (unit); fill two tangents
+  real* x = fr; real* y = fr + 3; real* z = fr + 6;
+  y[0] = y[1] = y[2] = 0;
+  if (x[1] < 0.5 && x[1] > -0.5) y[1] = 1; else y[2] = 1;
+  real t = dot3(x, y);
+  for (int k = 0; k < 3; k++) y[k] -= t * x[k];
+  normalize3(y);
+  cross3(z, x, y);
+}
+
+void world_aabb(const orc_sim* s, int g, real* lo, real* hi) {
+  const Model& m = s->m;
+  const real* R = &s->gmat[9 * g];
+  const real* c = &m.geom_aabb[6 * g]; const real* h = c + 3;
+  real cw[3]; mulmatvec3(cw, R, c);
+  for (int i = 0; i < 3; i++) {
+    real e = std::fabs(R[3 * i]) * h[0] + std::fabs(R[3 * i + 1]) * h[1] + std::fabs(R[3 * i + 2]) * h[2];
+    lo[i] = s->gpos[3 * g + i] + cw[i] - e; hi[i] = s->gpos[3 * g + i] + cw[i] + e;
+  }
+}
+
+void set_contact_params(const Model& m, Contact& c, int g1, int g2) {
+  // mj_contactParam at equal priority: condim max, friction max, solref/solimp solmix-weighted
+  c.dim = std::max(m.geom_condim[g1], m.geom_condim[g2]);
+  real f[3];
+  for (int k = 0; k < 3; k++) f[k] = std::max(m.geom_friction[3 * g1 + k], m.geom_friction[3 * g2 + k]);
+  c.friction[0] = c.friction[1] = f[0]; c.friction[2] = f[1]; c.friction[3] = c.friction[4] = f[2];
+  real s1 = m.geom_solmix[g1], s2 = m.geom_solmix[g2];
+  real mix = (s1 >= MINVAL && s2 >= MINVAL) ? s1 / (s1 + s2) : (s1 < MINVAL && s2 < MINVAL ? 0.5 : (s1 < MINVAL ? 0.0 : 1.0));
+  if (m.geom_priority[g1] > m.geom_priority[g2]) mix = 1; else if (m.geom_priority[g1] < m.geom_priority[g2]) mix = 0;
+  for (int k = 0; k < 2; k++) c.solref[k] = mix * m.geom_solref[2 * g1 + k] + (1 - mix) * m.geom_solref[2 * g2 + k];
+  for (int k = 0; k < 5; k++) c.solimp[k] = mix * m.geom_solimp[5 * g1 + k] + (1 - mix) * m.geom_solimp[5 * g2 + k];
+}
+
+void collision(orc_sim* s) {
+  const Model& m = s->m;
+  s->con.clear();
+  if (!s->collide) return;
+  std::vector<real> lo(3 * m.ngeom), hi(3 * m.ngeom);
+  for (int g = 0; g < m.ngeom; g++) world_aabb(s, g, &lo[3 * g], &hi[3 * g]);
+  for (int p = 0; p < m.npair; p++) {
+    int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
+    if (m.geom_type[g1] > m.geom_type[g2]) std::swap(g1, g2);   // collision table is upper-triangular in type
+    Contact c;
+    if (m.geom_type[g1] == G_PLANE) {
+      // plane : convex  — deepest support point against the plane normal (one contact)
+      const real* R = &s->gmat[9 * g1];
+      real nrm[3] = {R[2], R[5], R[8]}, nn[3] = {-R[2], -R[5], -R[8]}, sp[3];
+      // cheap reject on the world box
+      real lowest = 0;
+      for (int k = 0; k < 3; k++) lowest += nrm[k] * ((nrm[k] >= 0 ? lo[3 * g2 + k] : hi[3 * g2 + k]) - s->gpos[3 * g1 + k]);
+      if (lowest > 0) continue;
+      support(s, g2, nn, sp);
+      real t[3] = {sp[0] - s->gpos[3 * g1], sp[1] - s->gpos[3 * g1 + 1], sp[2] - s->gpos[3 * g1 + 2]};
+      real dist = dot3(t, nrm);
+      if (dist >= 0) continue;
+      c.dist = dist;
+      for (int k = 0; k < 3; k++) { c.frame[k] = nrm[k]; c.pos[k] = sp[k] - 0.5 * dist * nrm[k]; }
+    } else {
+      bool sep = false;
+      for (int k = 0; k < 3; k++) if (lo[3 * g1 + k] > hi[3 * g2 + k] || lo[3 * g2 + k] > hi[3 * g1 + k]) sep = true;
+      if (sep) continue;
+      real depth, dir[3], pos[3];
+      if (!mpr_penetration(s, g1, g2, &depth, dir, pos)) continue;
+      if (depth <= 0) continue;               // margin 0: only penetrating contacts are kept
+      c.dist = -depth;
+      for (int k = 0; k < 3; k++) { c.frame[k] = dir[k]; c.pos[k] = pos[k]; }
+    }
+    c.g1 = g1; c.g2 = g2;
+    make_frame(c.frame);
+    set_contact_params(m, c, g1, g2);
+    s->con.push_back(c);
+  }
+}
+
+// ================================================================ constraints
+void point_jacobian(const orc_sim* s, int body, const real* p, real* Jp, real* Jr) {   // 3 x nv each
+  const Model& m = s->m;
+  int nv = m.nv;
+  std::fill(Jp, Jp + 3 * nv, 0.0); std::fill(Jr, Jr + 3 * nv, 0.0);
+  for (int d = 0; d < nv; d++) {
+    if (!is_ancestor(m, m.dof_body[d], body)) continue;
+    const real* w = &s->S[6 * d]; const real* vo = w + 3;
+    real t[3]; cross3(t, w, p);
+    for (int k = 0; k < 3; k++) { Jp[k * nv + d] = vo[k] + t[k]; Jr[k * nv + d] = w[k]; }
+  }
+}
+
+real impedance(const real* solimp_in, real pos) {
+  real dmin = std::min(std::max(solimp_in[0], MINIMP), MAXIMP), dmax = std::min(std::max(solimp_in[1], MINIMP), MAXIMP);
+  real width = std::max(solimp_in[2], 0.0), mid = std::min(std::max(solimp_in[3], MINIMP), MAXIMP), power = std::max(solimp_in[4], 1.0);
+  if (dmin == dmax || width <= MINVAL) return 0.5 * (dmin + dmax);
+  real x = std::fabs(pos) / width;
+  if (x >= 1) return dmax;
+  if (x <= 0) return dmin;
+  real y;
+  if (power == 1) y = x;
+  else if (x <= mid) y = std::pow(x, power) / std::pow(mid, power - 1);
+  else y = 1 - std::pow(1 - x, power) / std::pow(1 - mid, power - 1);
+  return dmin + y * (dmax - dmin);
+}
+
+void make_constraints(orc_sim* s, bool freeze_arm) {
+  const Model& m = s->m;
+  int nv = m.nv;
+  // count rows
+  struct Row { int type, id, dim; };
+  std::vector<Row> rows;
+  for (int d = 0; d < nv; d++) if (m.dof_frictionloss[d] > 0) rows.push_back({C_FRICTION, d, 1});
+  std::vector<std::pair<int, int>> lim;   // (hinge, side)
+  for (int h = 0; h < m.narm; h++) if (m.jnt_limited[h]) {
+    real q = s->qpos[m.body_qposadr[m.arm_body[h]]];
+    if (q - m.jnt_range[2 * h] < 0) lim.push_back({h, 0});
+    if (m.jnt_range[2 * h + 1] - q < 0) lim.push_back({h, 1});
+  }
+  for (size_t k = 0; k < lim.size(); k++) rows.push_back({C_LIMIT, (int)k, 1});
+  for (size_t k = 0; k < s->con.size(); k++) rows.push_back({C_CONTACT, (int)k, m.elliptic ? s->con[k].dim : 1});
+  int nefc = 0; for (auto& r : rows) nefc += r.dim;
+  s->nefc = nefc;
+  s->J.assign((size_t)nefc * nv, 0); s->efc_pos.assign(nefc, 0); s->efc_D.assign(nefc, 0); s->efc_R.assign(nefc, 0);
+  s->efc_aref.assign(nefc, 0); s->efc_force.assign(nefc, 0); s->efc_floss.assign(nefc, 0); s->efc_b.assign(nefc, 0);
+  s->efc_type.assign(nefc, 0); s->efc_id.assign(nefc, 0); s->efc_dim.assign(nefc, 1);
+  std::vector<real> Jp(3 * nv), Jr(3 * nv), Jp2(3 * nv), Jr2(3 * nv);
+  int i = 0;
+  for (auto& r : rows) {
+    real solref[2], solimp[5], diag[6] = {0, 0, 0, 0, 0, 0}, pos = 0;
+    if (r.type == C_FRICTION) {
+      int d = r.id;
+      s->J[(size_t)i * nv + d] = 1;
+      s->efc_floss[i] = m.dof_frictionloss[d];
+      int h = m.body_hinge[m.dof_body[d]];
+      std::memcpy(solref, &m.dof_solref[2 * h], sizeof solref); std::memcpy(solimp, &m.dof_solimp[5 * h], sizeof solimp);
+      diag[0] = m.dof_invweight0[d];
+    } else if (r.type == C_LIMIT) {
+      int h = lim[r.id].first, side = lim[r.id].second;
+      int b = m.arm_body[h], d = m.body_dofadr[b];
+      real q = s->qpos[m.body_qposadr[b]];
+      pos = side == 0 ? q - m.jnt_range[2 * h] : m.jnt_range[2 * h + 1] - q;
+      s->J[(size_t)i * nv + d] = side == 0 ? 1 : -1;
+      std::memcpy(solref, &m.jnt_solref[2 * h], sizeof solref); std::memcpy(solimp, &m.jnt_solimp[5 * h], sizeof solimp);
+      diag[0] = m.dof_invweight0[d];
+    } else {
+      Contact& c = s->con[r.id];
+      int b1 = m.geom_body[c.g1], b2 = m.geom_body[c.g2];
+      point_jacobian(s, b1, c.pos, Jp.data(), Jr.data());
+      point_jacobian(s, b2, c.pos, Jp2.data(), Jr2.data());
+      for (int j = 0; j < r.dim; j++) {
+        const real* ax = &c.frame[3 * (j < 3 ? j : j - 3)];
+        const real* A1 = j < 3 ? Jp.data() : Jr.data(); const real* A2 = j < 3 ? Jp2.data() : Jr2.data();
+        for (int d = 0; d < nv; d++) {
+          real v = 0;
+          for (int k = 0; k < 3; k++) v += ax[k] * (A2[k * nv + d] - A1[k * nv + d]);
+          s->J[(size_t)(i + j) * nv + d] = v;
+        }
+      }
+      pos = c.dist;
+      std::memcpy(solref, c.solref, sizeof solref); std::memcpy(solimp, c.solimp, sizeof solimp);
+      real tran = m.body_invweight0[2 * b1] + m.body_invweight0[2 * b2];
+      real rot = m.body_invweight0[2 * b1 + 1] + m.body_invweight0[2 * b2 + 1];
+      for (int j = 0; j < r.dim; j++) diag[j] = j < 3 ? tran : rot;
+    }
+    if (freeze_arm) { /* arm is restored after every substep by the caller; nothing to mask here */ }
+    // impedance, regulariser, reference acceleration (mj_makeImpedance restated)
+    if (solref[0] > 0) solref[0] = std::max(solref[0], 2 * m.dt);       // refsafe
+    real imp = impedance(solimp, pos);
+    real dmax = std::min(std::max(solimp[1], MINIMP), MAXIMP);
+    real K, B;
+    if (solref[0] > 0) { K = 1 / std::max(MINVAL, dmax * dmax * solref[0] * solref[0] * solref[1] * solref[1]); B = 2 / std::max(MINVAL, dmax * solref[0]); }
+    else { K = -solref[0] / std::max(MINVAL, dmax * dmax); B = -solref[1] / std::max(MINVAL, dmax); }
+    for (int j = 0; j < r.dim; j++) {
+      s->efc_type[i + j] = r.type; s->efc_id[i + j] = r.id; s->efc_dim[i + j] = r.dim; s->efc_pos[i + j] = pos;
+      s->efc_R[i + j] = std::max(MINVAL, (1 - imp) * diag[j] / imp);
+    }
+    if (r.type == C_CONTACT && r.dim > 1) {
+      Contact& c = s->con[r.id];
+      s->efc_R[i + 1] = s->efc_R[i] / std::max(MINVAL, m.impratio);
+      c.mu = c.friction[0] * std::sqrt(s->efc_R[i + 1] / s->efc_R[i]);
+      for (int j = 2; j < r.dim; j++)
+        s->efc_R[i + j] = std::max(MINVAL, s->efc_R[i + 1] * c.friction[0] * c.friction[0] / (c.friction[j - 1] * c.friction[j - 1]));
+    }
+    for (int j = 0; j < r.dim; j++) {
+      real vel = 0;
+      for (int d = 0; d < nv; d++) vel += s->J[(size_t)(i + j) * nv + d] * s->qvel[d];
+      bool fric = (r.type == C_FRICTION) || (r.type == C_CONTACT && j > 0);
+      s->efc_aref[i + j] = -B * vel - (fric ? 0.0 : K * imp * pos);
+      s->efc_D[i + j] = 1 / s->efc_R[i + j];
+    }
+    i += r.dim;
+  }
+}
+
+// QCQP:  min 0.5 x'Ax + b'x  s.t.  sum (x_i/d_i)^2 <= r^2   (mju_QCQP restated, n <= 5)
+bool qcqp(real* res, const real* Ain, const real* bin, const real* d, real r, int n) {
+  real A[25], b[5], P[25], y[5], z[5];
+  for (int i = 0; i < n; i++) { b[i] = bin[i] * d[i]; for (int j = 0; j < n; j++) A[i * n + j] = Ain[i * n + j] * d[i] * d[j]; }
+  real la = 0;
+  for (int iter = 0; iter < 20; iter++) {
+    for (int i = 0; i < n * n; i++) P[i] = A[i];
+    for (int i = 0; i < n; i++) P[i * n + i] += la;
+    // Cholesky in place (lower)
+    bool ok = true;
+    for (int j = 0; j < n && ok; j++) {
+      real v = P[j * n + j];
+      for (int k = 0; k < j; k++) v -= P[j * n + k] * P[j * n + k];
+      if (v < MINVAL) { ok = false; break; }
+      v = std::sqrt(v); P[j * n + j] = v;
+      for (int i = j + 1; i < n; i++) {
+        real w = P[i * n + j];
+        for (int k = 0; k < j; k++) w -= P[i * n + k] * P[j * n + k];
+        P[i * n + j] = w / v;
+      }
+    }
+    if (!ok) { for (int i = 0; i < n; i++) res[i] = 0; return false; }
+    auto solve = [&](real* out, const real* rhs) {
+      real t[5];
+      for (int i = 0; i < n; i++) { real v = rhs[i]; for (int k = 0; k < i; k++) v -= P[i * n + k] * t[k]; t[i] = v / P[i * n + i]; }
+      for (int i = n - 1; i >= 0; i--) { real v = t[i]; for (int k = i + 1; k < n; k++) v -= P[k * n + i] * out[k]; out[i] = v / P[i * n + i]; }
+    };
+    real nb[5]; for (int i = 0; i < n; i++) nb[i] = -b[i];
+    solve(y, nb);
+    real val = -r * r; for (int i = 0; i < n; i++) val += y[i] * y[i];
+    if (val < 1e-10) break;
+    solve(z, y);
+    real deriv = 0; for (int i = 0; i < n; i++) deriv += -2 * y[i] * z[i];
+    real delta = -val / deriv;
+    if (delta < 1e-10) break;
+    la += delta;
+  }
+  for (int i = 0; i < n; i++) res[i] = y[i] * d[i];
+  return la != 0;
+}
+
+// force from a primal acceleration (mj_constraintUpdate restated) — used for the PGS warm start
+void constraint_update(orc_sim* s, const real* jar) {
+  int i = 0;
+  while (i < s->nefc) {
+    int tp = s->efc_type[i], dim = s->efc_dim[i];
+    if (tp == C_FRICTION) {
+      real f = -s->efc_D[i] * jar[i], fl = s->efc_floss[i];
+      s->efc_force[i] = std::min(std::max(f, -fl), fl);
+    } else if (tp == C_LIMIT || dim == 1) {
+      s->efc_force[i] = jar[i] < 0 ? -s->efc_D[i] * jar[i] : 0;
+    } else {
+      const Contact& c = s->con[s->efc_id[i]];
+      real mu = c.mu, U[6];
+      U[0] = jar[i] * mu;
+      real T = 0;
+      for (int j = 1; j < dim; j++) { U[j] = jar[i + j] * c.friction[j - 1]; T += U[j] * U[j]; }
+      T = std::sqrt(T);
+      real N = U[0];
+      if ((N >= mu * T) || (T <= 0 && N >= 0)) { for (int j = 0; j < dim; j++) s->efc_force[i + j] = 0; }
+      else if ((mu * N + T <= 0) || (T <= 0 && N < 0)) { for (int j = 0; j < dim; j++) s->efc_force[i + j] = -s->efc_D[i + j] * jar[i + j]; }
+      else {
+        real Dm = s->efc_D[i] / std::max(mu * mu * (1 + mu * mu), MINVAL), NmT = N - mu * T;
+        s->efc_force[i] = -Dm * NmT * mu;
+        for (int j = 1; j < dim; j++) s->efc_force[i + j] = -s->efc_force[i] / T * U[j] * c.friction[j - 1];
+      }
+    }
+    i += dim;
+  }
+}
+
+void solve_pgs(orc_sim* s) {
+  const Model& m = s->m;
+  int nv = m.nv, n = s->nefc;
+  s->solver_iter = 0;
+  s->qacc = s->qacc_smooth;
+  if (n == 0) return;
+  // B = Minv J^T ; AR = J B + diag(R) ; b = J qacc_smooth - aref
+  std::vector<real> Bm((size_t)nv * n, 0);
+  for (int r = 0; r < n; r++) for (int d = 0; d < nv; d++) {
+    real v = 0; for (int k = 0; k < nv; k++) v += s->Minv[d * nv + k] * s->J[(size_t)r * nv + k];
+    Bm[(size_t)d * n + r] = v;
+  }
+  s->AR.assign((size_t)n * n, 0);
+  for (int r = 0; r < n; r++) for (int c = 0; c < n; c++) {
+    real v = 0; for (int d = 0; d < nv; d++) v += s->J[(size_t)r * nv + d] * Bm[(size_t)d * n + c];
+    s->AR[(size_t)r * n + c] = v + (r == c ? s->efc_R[r] : 0);
+  }
+  for (int r = 0; r < n; r++) {
+    real v = 0; for (int d = 0; d < nv; d++) v += s->J[(size_t)r * nv + d] * s->qacc_smooth[d];
+    s->efc_b[r] = v - s->efc_aref[r];
+  }
+  // warm start from the previous qacc (mujoco warmstart(): map to forces, keep if dual cost < 0)
+  {
+    std::vector<real> jar(n);
+    for (int r = 0; r < n; r++) {
+      real v = 0; for (int d = 0; d < nv; d++) v += s->J[(size_t)r * nv + d] * s->warm[d];
+      jar[r] = v - s->efc_aref[r];
+    }
+    constraint_update(s, jar.data());
+    real cost = 0;
+    for (int r = 0; r < n; r++) {
+      real v = 0; for (int c = 0; c < n; c++) v += s->AR[(size_t)r * n + c] * s->efc_force[c];
+      cost += s->efc_force[r] * (0.5 * v + s->efc_b[r]);
+    }
+    if (cost > 0) std::fill(s->efc_force.begin(), s->efc_force.end(), 0.0);
+  }
+  real scale = 1 / (m.meaninertia * std::max(1, nv));
+  real* f = s->efc_force.data();
+  for (int iter = 0; iter < s->iterations; iter++) {
+    real improvement = 0;
+    int i = 0;
+    while (i < n) {
+      int dim = s->efc_dim[i], tp = s->efc_type[i];
+      real res[6], old[6], Athis[36];
+      for (int j = 0; j < dim; j++) {
+        real v = s->efc_b[i + j];
+        for (int c = 0; c < n; c++) v += s->AR[(size_t)(i + j) * n + c] * f[c];
+        res[j] = v; old[j] = f[i + j];
+      }
+      for (int j = 0; j < dim; j++) for (int k = 0; k < dim; k++) Athis[j * dim + k] = s->AR[(size_t)(i + j) * n + i + k];
+      if (dim == 1) {
+        f[i] -= res[0] / Athis[0];
+        if (tp == C_FRICTION) { real fl = s->efc_floss[i]; f[i] = std::min(std::max(f[i], -fl), fl); }
+        else if (f[i] < 0) f[i] = 0;
+      } else {
+        const Contact& c = s->con[s->efc_id[i]];
+        // normal / ray update
+        if (f[i] < MINVAL) {
+          f[i] -= res[0] / Athis[0];
+          if (f[i] < 0) f[i] = 0;
+          for (int j = 1; j < dim; j++) f[i + j] = 0;
+        } else {
+          real v[6], v1[6], denom = 0, vr = 0;
+          for (int j = 0; j < dim; j++) v[j] = f[i + j];
+          for (int j = 0; j < dim; j++) { v1[j] = 0; for (int k = 0; k < dim; k++) v1[j] += Athis[j * dim + k] * v[k]; }
+          for (int j = 0; j < dim; j++) { denom += v[j] * v1[j]; vr += v[j] * res[j]; }
+          if (denom >= MINVAL) {
+            real x = -vr / denom;
+            if (f[i] + x * v[0] < 0) x = -f[i] / v[0];
+            for (int j = 0; j < dim; j++) f[i + j] += x * v[j];
+          }
+        }
+        // friction update with the normal fixed
+        if (f[i] >= MINVAL) {
+          int nf = dim - 1;
+          real Ac[25], bc[5], v[5];
+          for (int j = 0; j < nf; j++) {
+            for (int k = 0; k < nf; k++) Ac[j * nf + k] = Athis[(j + 1) * dim + k + 1];
+            bc[j] = res[j + 1];
+            for (int k = 0; k < nf; k++) bc[j] -= Ac[j * nf + k] * old[k + 1];
+            bc[j] += Athis[(j + 1) * dim] * (f[i] - old[0]);
+          }
+          bool active = qcqp(v, Ac, bc, c.friction, f[i], nf);
+          if (active) {
+            real ssq = 0; for (int j = 0; j < nf; j++) ssq += (v[j] / c.friction[j]) * (v[j] / c.friction[j]);
+            real sc = std::sqrt(f[i] * f[i] / std::max(MINVAL, ssq));
+            for (int j = 0; j < nf; j++) v[j] *= sc;
+          }
+          for (int j = 0; j < nf; j++) f[i + 1 + j] = v[j];
+        }
+      }
+      // cost change; revert on increase
+      real delta[6], change = 0;
+      for (int j = 0; j < dim; j++) delta[j] = f[i + j] - old[j];
+      for (int j = 0; j < dim; j++) {
+        real v = 0; for (int k = 0; k < dim; k++) v += Athis[j * dim + k] * delta[k];
+        change += delta[j] * (0.5 * v + res[j]);
+      }
+      if (change > 1e-10) { for (int j = 0; j < dim; j++) f[i + j] = old[j]; change = 0; }
+      improvement -= change;
+      i += dim;
+    }
+    s->solver_iter = iter + 1;
+    if (improvement * scale < s->tolerance) break;
+  }
+  for (int d = 0; d < nv; d++) {
+    real v = s->qacc_smooth[d];
+    for (int r = 0; r < n; r++) v += Bm[(size_t)d * n + r] * f[r];
+    s->qacc[d] = v;
+  }
+}
+
+void forward(orc_sim* s, bool freeze_arm) {
+  const Model& m = s->m;
+  int nv = m.nv;
+  kinematics(s);
+  crba(s);
+  rne_bias(s);
+  actuation(s);
+  s->qacc_smooth.assign(nv, 0);
+  for (int r = 0; r < nv; r++) {
+    real v = 0;
+    for (int c = 0; c < nv; c++) v += s->Minv[r * nv + c] * (s->qfrc_act[c] - s->bias[c]);   // damping = 0 in this model
+    s->qacc_smooth[r] = v;
+  }
+  collision(s);
+  make_constraints(s, freeze_arm);
+  solve_pgs(s);
+}
+
+void euler(orc_sim* s) {
+  const Model& m = s->m;
+  real dt = m.dt;
+  for (int d = 0; d < m.nv; d++) s->qvel[d] += dt * s->qacc[d];
+  for (int b = 1; b < m.nbody; b++) {
+    int qa = m.body_qposadr[b], d = m.body_dofadr[b];
+    if (m.body_jnttype[b] == J_HINGE) s->qpos[qa] += dt * s->qvel[d];
+    else if (m.body_jnttype[b] == J_FREE) {
+      for (int k = 0; k < 3; k++) s->qpos[qa + k] += dt * s->qvel[d + k];
+      real w[3] = {s->qvel[d + 3], s->qvel[d + 4], s->qvel[d + 5]};
+      real ang = dt * normalize3(w);           // mju_quatIntegrate
+      real sn = std::sin(0.5 * ang), dq[4] = {std::cos(0.5 * ang), w[0] * sn, w[1] * sn, w[2] * sn};
+      mulquat(&s->qpos[qa + 3], &s->qpos[qa + 3], dq);
+      normquat(&s->qpos[qa + 3]);
+    }
+  }
+  s->warm = s->qacc;
+}
+
+void substeps(orc_sim* s, int nsub, bool freeze_arm) {
+  const Model& m = s->m;
+  std::vector<real> q0, v0;
+  if (freeze_arm) { q0.assign(s->qpos.begin(), s->qpos.begin() + m.narm); v0.assign(s->qvel.begin(), s->qvel.begin() + m.narm); }
+  for (int k = 0; k < nsub; k++) {
+    forward(s, freeze_arm);
+    euler(s);
+    if (freeze_arm) {   // dm_control JointStaticIsolator: non-prop joints restored after every step
+      std::copy(q0.begin(), q0.end(), s->qpos.begin()); std::copy(v0.begin(), v0.end(), s->qvel.begin());
+    }
+  }
+}
+
+// ================================================================ reward (so100_hand_over.py:238-275)
+struct Box { real pos[3], quat[4], half[3]; };
+
+bool overlap_aabb_oobb(const real* half0, const Box& b) {   // oobb_utils.overlap_aabb_oobb (:202-248)
+  real av[8][3], ov[8][3];
+  for (int i = 0; i < 8; i++) {
+    int iz = i / 4, ixy = i % 4, ix = ixy % 2, iy = ixy / 2;
+    real t[3] = {ix ? 1.0 : 0.0, iy ? 1.0 : 0.0, iz ? 1.0 : 0.0};
+    real loc[3];
+    for (int k = 0; k < 3; k++) { av[i][k] = -half0[k] * (1 - t[k]) + half0[k] * t[k]; loc[k] = -b.half[k] * (1 - t[k]) + b.half[k] * t[k]; }
+    real r[3]; rotvecquat(r, loc, b.quat);
+    for (int k = 0; k < 3; k++) ov[i][k] = b.pos[k] + r[k];
+  }
+  real axes[6][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int k = 0; k < 3; k++) { real e[3] = {0, 0, 0}; e[k] = 1; rotvecquat(axes[3 + k], e, b.quat); }
+  for (int a = 0; a < 6; a++) {
+    real mx0 = -1e300, mn0 = 1e300, mx1 = -1e300, mn1 = 1e300;
+    for (int i = 0; i < 8; i++) {
+      real p0 = dot3(av[i], axes[a]), p1 = dot3(ov[i], axes[a]);
+      mx0 = std::max(mx0, p0); mn0 = std::min(mn0, p0); mx1 = std::max(mx1, p1); mn1 = std::min(mn1, p1);
+    }
+    if (mx0 < mn1 || mn0 > mx1) return false;     // strict: touching counts as overlap
+  }
+  return true;
+}
+
+bool overlap_oobb_oobb(const Box& b0, const Box& b1) {       // oobb_utils.overlap_oobb_oobb (:251-273)
+  real inv[4] = {b0.quat[0], -b0.quat[1], -b0.quat[2], -b0.quat[3]};
+  real dp[3] = {b1.pos[0] - b0.pos[0], b1.pos[1] - b0.pos[1], b1.pos[2] - b0.pos[2]};
+  Box r;
+  rotvecquat(r.pos, dp, inv);
+  mulquat(r.quat, inv, b1.quat);
+  std::memcpy(r.half, b1.half, sizeof r.half);
+  return overlap_aabb_oobb(b0.half, r);
+}
+
+real reward(orc_sim* s) {
+  const Model& m = s->m;
+  kinematics(s);
+  // any_props_moving: max |linear velocity| >= 1e-3 for either prop (success_detector_utils.py:22-28)
+  int props[2] = {m.obj_body, m.con_body};
+  for (int p = 0; p < 2; p++) {
+    int d = m.body_dofadr[props[p]];
+    real mx = std::max(std::fabs(s->qvel[d]), std::max(std::fabs(s->qvel[d + 1]), std::fabs(s->qvel[d + 2])));
+    if (mx >= 1e-3) return 0.0;
+  }
+  // object: one box = (xipos, ximat -> quat, bvh root aabb) since the prop body has >1 geom
+  Box ob;
+  int b = m.obj_body;
+  mat2quat(ob.quat, &s->ximat[9 * b]);
+  real ctr[3]; rotvecquat(ctr, &m.body_bvh_aabb[6 * b], ob.quat);
+  for (int k = 0; k < 3; k++) { ob.pos[k] = ctr[k] + s->xipos[3 * b + k]; ob.half[k] = m.body_bvh_aabb[6 * b + 3 + k]; }
+  int cb = m.con_body;
+  const real* cpos = &s->xpos[3 * cb]; const real* cq = &s->xquat[4 * cb];
+  for (int k = 0; k < m.nbox; k++) {
+    Box cw;                                       // transform_oobb (:175-199)
+    real r[3]; rotvecquat(r, &m.box_pos[3 * k], cq);
+    for (int j = 0; j < 3; j++) { cw.pos[j] = cpos[j] + r[j]; cw.half[j] = m.box_half[3 * k + j]; }
+    real ident[4] = {1, 0, 0, 0};
+    mulquat(cw.quat, cq, ident);
+    if (!overlap_oobb_oobb(ob, cw)) return 0.0;
+  }
+  return 1.0;
+}
+
+// ================================================================ counter RNG (Philox4x32-10)
+void philox(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; r++) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+double rng_uniform(uint64_t seed, uint64_t env, uint64_t episode, uint32_t draw) {
+  uint32_t c[4] = {(uint32_t)env, (uint32_t)(env >> 32), (uint32_t)episode, draw};
+  philox(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  return (double)(c[0] >> 8) * (1.0 / 16777216.0);   // 24-bit mantissa: exact in f32 and f64
+}
+
+void env_obs(const orc_sim* s, real* obs) {
+  // joints_pos (delayed 5 control steps) | undelayed_joints_pos | commanded_joints_pos
+  for (int k = 0; k < 6; k++) { obs[k] = s->delayed[k]; obs[6 + k] = s->qpos[k]; obs[12 + k] = s->cmd[k]; }
+}
+
+void env_reset(orc_sim* s) {
+  const Model& m = s->m;
+  uint32_t draw = 0;
+  auto U = [&](real lo, real hi) { real u = rng_uniform(s->cfg.seed, s->cfg.env_id, s->episode, draw++); return lo + u * (hi - lo); };
+  std::fill(s->qpos.begin(), s->qpos.end(), 0.0); std::fill(s->qvel.begin(), s->qvel.end(), 0.0);
+  std::fill(s->warm.begin(), s->warm.end(), 0.0);
+  for (int k = 0; k < 6; k++) { s->ctrl[k] = m.home_ctrl[k] + s->cfg.offsets[k]; s->cmd[k] = s->ctrl[k]; }
+  int qo = m.body_qposadr[m.obj_body], qc = m.body_qposadr[m.con_body];
+  // object: position then yaw (so100_hand_over.py:209-214), collisions ignored
+  for (int k = 0; k < 3; k++) s->qpos[qo + k] = U(m.obj_lo[k], m.obj_hi[k]);
+  real yaw = U(m.obj_yaw[0], m.obj_yaw[1]);
+  s->qpos[qo + 3] = std::cos(0.5 * yaw); s->qpos[qo + 4] = 0; s->qpos[qo + 5] = 0; s->qpos[qo + 6] = std::sin(0.5 * yaw);
+  s->qpos[qc + 3] = 1;
+  // container: rejection-sampled until none of its geoms is in penetrating contact (<=20 tries)
+  for (int attempt = 0; attempt < 20; attempt++) {
+    for (int k = 0; k < 3; k++) s->qpos[qc + k] = U(m.con_lo[k], m.con_hi[k]);
+    kinematics(s); collision(s);
+    bool hit = false;
+    for (auto& c : s->con) if (m.geom_body[c.g1] == m.con_body || m.geom_body[c.g2] == m.con_body) hit = true;
+    if (!hit) break;
+  }
+  // settle with the arm restored after every substep, until |qvel|<1e-3 and |qacc|<1e-2 on the props
+  for (int k = 0; k < s->cfg.settle_max_substeps; k++) {
+    substeps(s, 1, true);
+    real mv = 0, ma = 0;
+    for (int d = m.narm; d < m.nv; d++) { mv = std::max(mv, std::fabs(s->qvel[d])); ma = std::max(ma, std::fabs(s->qacc[d])); }
+    if (mv < 1e-3 && ma < 1e-2) break;
+  }
+  for (int r = 0; r < 5; r++) for (int k = 0; k < 6; k++) s->ring[r][k] = s->qpos[k];   // INITIAL_VALUE padding
+  for (int k = 0; k < 6; k++) s->delayed[k] = s->qpos[k];
+  s->ring_head = 0; s->step_count = 0; s->ep_return = 0; s->need_reset = false; s->episode++;
+}
+
+}  // namespace
+
+// ==================================================================== C API
+extern "C" {
+
+orc_sim* orc_create(const void* blob, size_t bytes) {
+  Blob b;
+  if (!b.parse(blob, bytes)) return nullptr;
+  orc_sim* s = new orc_sim();
+  Model& m = s->m;
+  m.nq = b.i("nq"); m.nv = b.i("nv"); m.nu = b.i("nu"); m.nbody = b.i("nbody"); m.ngeom = b.i("ngeom");
+  m.nvert = b.i("nvert"); m.npair = b.i("npair"); m.narm = b.i("narm"); m.nfree = b.i("nfree");
+  m.dt = b.r("opt_timestep"); auto g = b.R("opt_gravity"); for (int k = 0; k < 3; k++) m.gravity[k] = g[k];
+  m.impratio = b.r("opt_impratio"); m.tolerance = b.r("opt_tolerance"); m.iterations = b.i("opt_iterations");
+  m.elliptic = b.i("opt_cone_elliptic"); m.mpr_tol = b.r("opt_mpr_tolerance"); m.mpr_iter = b.i("opt_mpr_iterations");
+  m.meaninertia = b.r("stat_meaninertia");
+#define LI(x) m.x = b.I(#x)
+#define LR(x) m.x = b.R(#x)
+  LI(body_parent); LI(body_jnttype); LI(body_qposadr); LI(body_dofadr); LI(body_weldid); LI(arm_body); LI(free_body);
+  LI(jnt_limited); LI(dof_body); LI(act_dof); LI(act_ctrllimited); LI(act_forcelimited); LI(geom_type); LI(geom_body);
+  LI(geom_condim); LI(geom_priority); LI(geom_vertadr); LI(geom_vertnum); LI(pair_geom);
+  LR(body_pos); LR(body_quat); LR(body_ipos); LR(body_iquat); LR(body_mass); LR(body_inertia); LR(body_invweight0);
+  LR(body_bvh_aabb); LR(jnt_axis); LR(jnt_range); LR(jnt_solref); LR(jnt_solimp); LR(dof_solref); LR(dof_solimp);
+  LR(dof_armature); LR(dof_frictionloss); LR(dof_damping); LR(dof_invweight0); LR(act_gain); LR(act_bias);
+  LR(act_ctrlrange); LR(act_forcerange); LR(geom_pos); LR(geom_quat); LR(geom_size); LR(geom_friction); LR(geom_solref);
+  LR(geom_solimp); LR(geom_solmix); LR(geom_margin); LR(geom_gap); LR(geom_rbound); LR(geom_center); LR(geom_aabb);
+  LR(mesh_vert);
+#undef LI
+#undef LR
+  m.body_hinge.assign(m.nbody, -1);
+  for (int h = 0; h < m.narm; h++) m.body_hinge[m.arm_body[h]] = h;
+  m.obj_body = b.i("task_object_body"); m.con_body = b.i("task_container_body"); m.nbox = b.i("task_nbox");
+  m.box_pos = b.R("task_box_pos"); m.box_half = b.R("task_box_half"); m.obj_lo = b.R("task_obj_pos_lo");
+  m.obj_hi = b.R("task_obj_pos_hi"); m.obj_yaw = b.R("task_obj_yaw"); m.con_lo = b.R("task_con_pos_lo");
+  m.con_hi = b.R("task_con_pos_hi"); m.home_ctrl = b.R("task_home_ctrl");
+  s->qpos.assign(m.nq, 0); s->qvel.assign(m.nv, 0); s->ctrl.assign(m.nu, 0); s->warm.assign(m.nv, 0);
+  s->qacc.assign(m.nv, 0); s->qacc_smooth.assign(m.nv, 0);
+  for (int f = 0; f < m.nfree; f++) s->qpos[m.body_qposadr[m.free_body[f]] + 3] = 1;
+  s->iterations = m.iterations; s->tolerance = m.tolerance;
+  s->cfg.settle_max_substeps = 1000; s->cfg.last_step = 1 << 30;
+  std::memset(s->ring, 0, sizeof s->ring); std::memset(s->cmd, 0, sizeof s->cmd); std::memset(s->delayed, 0, sizeof s->delayed);
+  return s;
+}
+void orc_destroy(orc_sim* s) { delete s; }
+int orc_nq(const orc_sim* s) { return s->m.nq; }
+int orc_nv(const orc_sim* s) { return s->m.nv; }
+int orc_nu(const orc_sim* s) { return s->m.nu; }
+void orc_set_solver(orc_sim* s, int it, double tol) { if (it > 0) s->iterations = it; if (tol >= 0) s->tolerance = tol; }
+void orc_set_collision(orc_sim* s, int e) { s->collide = e != 0; }
+void orc_set_state(orc_sim* s, const double* q, const double* v, const double* w) {
+  if (q) std::copy(q, q + s->m.nq, s->qpos.begin());
+  if (v) std::copy(v, v + s->m.nv, s->qvel.begin());
+  if (w) std::copy(w, w + s->m.nv, s->warm.begin());
+}
+void orc_get_state(const orc_sim* s, double* q, double* v, double* w) {
+  if (q) std::copy(s->qpos.begin(), s->qpos.end(), q);
+  if (v) std::copy(s->qvel.begin(), s->qvel.end(), v);
+  if (w) std::copy(s->warm.begin(), s->warm.end(), w);
+}
+void orc_set_ctrl(orc_sim* s, const double* c) { std::copy(c, c + s->m.nu, s->ctrl.begin()); }
+void orc_substeps(orc_sim* s, int n, int fz) { substeps(s, n, fz != 0); }
+void orc_forward(orc_sim* s, int fz) { forward(s, fz != 0); }
+int orc_ncon(const orc_sim* s) { return (int)s->con.size(); }
+int orc_nefc(const orc_sim* s) { return s->nefc; }
+int orc_solver_iter(const orc_sim* s) { return s->solver_iter; }
+void orc_get_M(const orc_sim* s, double* M) { std::copy(s->M.begin(), s->M.end(), M); }
+void orc_get_bias(const orc_sim* s, double* b) { std::copy(s->bias.begin(), s->bias.end(), b); }
+void orc_get_qacc(const orc_sim* s, double* a, double* as) {
+  if (a) std::copy(s->qacc.begin(), s->qacc.end(), a);
+  if (as) std::copy(s->qacc_smooth.begin(), s->qacc_smooth.end(), as);
+}
+void orc_get_actuator_force(const orc_sim* s, double* f) { std::copy(s->act_force.begin(), s->act_force.end(), f); }
+void orc_get_contact(const orc_sim* s, int k, double* o) {
+  const Contact& c = s->con[k];
+  for (int i = 0; i < 3; i++) { o[i] = c.pos[i]; o[3 + i] = c.frame[i]; }
+  o[6] = c.dist; o[7] = c.g1; o[8] = c.g2; o[9] = c.dim;
+}
+void orc_get_efc_force(const orc_sim* s, double* f) { std::copy(s->efc_force.begin(), s->efc_force.end(), f); }
+void orc_get_body_pose(const orc_sim* s, int b, double* p, double* q) {
+  for (int k = 0; k < 3; k++) p[k] = s->xpos[3 * b + k];
+  for (int k = 0; k < 4; k++) q[k] = s->xquat[4 * b + k];
+}
+double orc_max_prop_qacc(const orc_sim* s) {
+  double ma = 0; for (int d = s->m.narm; d < s->m.nv; d++) ma = std::max(ma, std::fabs(s->qacc[d])); return ma;
+}
+double orc_reward(orc_sim* s) { return reward(s); }
+int orc_overlap_oobb(const double* a, const double* b) {
+  Box b0, b1;
+  std::memcpy(b0.pos, a, 24); std::memcpy(b0.quat, a + 3, 32); std::memcpy(b0.half, a + 7, 24);
+  std::memcpy(b1.pos, b, 24); std::memcpy(b1.quat, b + 3, 32); std::memcpy(b1.half, b + 7, 24);
+  return overlap_oobb_oobb(b0, b1) ? 1 : 0;
+}
+void orc_env_config(orc_sim* s, const orc_env_cfg* c) { s->cfg = *c; s->need_reset = true; s->episode = 0; }
+void orc_env_reset(orc_sim* s) { env_reset(s); }
+void orc_env_obs(const orc_sim* s, double* o) { env_obs(s, o); }
+int orc_env_step_count(const orc_sim* s) { return s->step_count; }
+double orc_env_return(const orc_sim* s) { return s->ep_return; }
+void orc_env_step(orc_sim* s, const double* action, double* obs, double* rew, double* disc, int* st) {
+  if (s->need_reset) {     // first call, or the call after LAST: reset and return FIRST
+    env_reset(s);
+    env_obs(s, obs); *rew = 0; *disc = 1; *st = 0;
+    return;
+  }
+  for (int k = 0; k < 6; k++) { s->ctrl[k] = action[k] + s->cfg.offsets[k]; s->cmd[k] = s->ctrl[k]; }
+  substeps(s, 10, false);
+  s->step_count++;
+  // delay ring (50 physics steps = 5 control steps): read the value of step k-5, then store step k
+  for (int k = 0; k < 6; k++) { s->delayed[k] = s->ring[s->ring_head][k]; s->ring[s->ring_head][k] = s->qpos[k]; }
+  s->ring_head = (s->ring_head + 1) % 5;
+  real r = reward(s);
+  bool success = r >= 1.0, timeout = s->step_count >= s->cfg.last_step;
+  *rew = r; *disc = success ? 0.0 : 1.0; *st = (success || timeout) ? 2 : 1;
+  s->ep_return += r;
+  env_obs(s, obs);
+  if (*st == 2) s->need_reset = true;
+}
+double orc_rng_uniform(uint64_t seed, uint64_t env, uint64_t ep, uint32_t draw) { return rng_uniform(seed, env, ep, draw); }
+}

@@ -1,0 +1,137 @@
+"""SO100 hand-over scene assembly: scene_pbr.xml + object prop + container prop + task constants.
+
+Mirrors what `SO100HandOver.__init__` composes (so101_sim/tasks/so100_hand_over.py:128-236) on top
+of `SO100Arena` (so101_sim/tasks/base/so100_task.py:386-395): the object prop is attached first,
+then the container (:169, :199), container meshes are scaled (:187-192), overlap boxes come from
+`SO100_HANDOVER_CONFIGS` (:80-118) and the reset distributions from :37-55.
+
+Compiled blobs are committed under `blobs/` so that nothing at run time needs the MJCF/mesh assets;
+`compile_scene` regenerates them when an asset tree is available (env `SO101_ASSETS`, or the
+reference checkout in this container).
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+
+from . import blob as blobfmt
+from . import mjcf
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+BLOB_DIR = os.path.join(_HERE, "blobs")
+
+TABLE_HEIGHT = 0.4     # so100_hand_over.py:34
+RESET_HEIGHT = 0.05    # so100_hand_over.py:35
+
+# so100_hand_over.py:80-118 (numbers are task configuration data)
+HANDOVER_CONFIGS = {
+    "banana": dict(
+        object_model="ycb/011_banana/google_64k/model.xml",
+        container_model="ycb/024_bowl/google_64k/model.xml",
+        container_mesh_scale=1.5, success_threshold=0.1,
+        overlap_boxes=[dict(position=np.array([-0.017, -0.045, 0.035]) * 1.5,
+                            half_extents=np.array([0.02, 0.02, 0.01]) * 1.5)],
+        instruction="pick up the banana and put it in the bowl using the SO100 arm"),
+    "pen": dict(
+        object_model="edr/pen/model.xml",
+        container_model="gso/BIA_Cordon_Bleu_White_Porcelain_Utensil_Holder_900028/model.xml",
+        container_mesh_scale=0.6, success_threshold=0.05,
+        overlap_boxes=[dict(position=np.array([0.0, 0.0, 0.02666]) * 0.6,
+                            half_extents=np.array([0.04666, 0.04666, 0.025]) * 0.6),
+                       dict(position=np.array([0.0, 0.0, 0.25]) * 0.6,
+                            half_extents=np.array([0.1, 0.1, 0.01666]) * 0.6)],
+        instruction="pick up the pen and put it in the container using the SO100 arm"),
+}
+
+SO100_HOME_CTRL = np.array([0.0, -1.57079, 1.57079, 1.57079, -1.57079, 0.0])   # so100_task.py:45-47
+
+
+def find_assets() -> str | None:
+    for cand in (os.environ.get("SO101_ASSETS"), "/root/reference/so101_sim/assets"):
+        if cand and os.path.isdir(os.path.join(cand, "so100")):
+            return cand
+    return None
+
+
+def time_limit_last_step(time_limit: float, control_timestep: float = 0.02, timestep: float = 0.002) -> int:
+    """Index (1-based) of the control step on which `physics.time() >= time_limit` first holds,
+    replaying MuJoCo's fp64 `time += timestep` accumulation."""
+    nsub = int(round(control_timestep / timestep))
+    t, step = 0.0, 0
+    while True:
+        step += 1
+        for _ in range(nsub):
+            t += timestep
+        if t >= time_limit:
+            return step
+
+
+def compile_scene(object_name: str, assets: str | None = None) -> dict:
+    assets = assets or find_assets()
+    if assets is None:
+        raise FileNotFoundError("MJCF assets not found: set SO101_ASSETS to .../so101_sim/assets")
+    cfg = HANDOVER_CONFIGS[object_name]
+    sc = mjcf.SceneCompiler()
+    sc.add_scene(os.path.join(assets, "so100", "scene_pbr.xml"))
+    obj = sc.add_free_prop(os.path.join(assets, cfg["object_model"]), "object")
+    con = sc.add_free_prop(os.path.join(assets, cfg["container_model"]), "container",
+                           mesh_scale=cfg["container_mesh_scale"])
+    out = mjcf.finalize(sc)
+    m = out["model"]
+    nbox = len(cfg["overlap_boxes"])
+    m.update(
+        task_object_body=obj, task_container_body=con, task_nbox=nbox,
+        task_box_pos=np.array([b["position"] for b in cfg["overlap_boxes"]]),
+        task_box_half=np.array([b["half_extents"] for b in cfg["overlap_boxes"]]),
+        task_dist_threshold=cfg["success_threshold"],
+        task_obj_pos_lo=np.array([0.2, -0.1, TABLE_HEIGHT + RESET_HEIGHT]),
+        task_obj_pos_hi=np.array([0.3, 0.1, TABLE_HEIGHT + RESET_HEIGHT]),
+        task_obj_yaw=np.array([-np.pi * 0.1, np.pi * 0.1]),
+        task_con_pos_lo=np.array([-0.3, -0.1, TABLE_HEIGHT + RESET_HEIGHT]),
+        task_con_pos_hi=np.array([-0.2, 0.1, TABLE_HEIGHT + RESET_HEIGHT]),
+        task_home_ctrl=SO100_HOME_CTRL,
+    )
+    out["meta"]["instruction"] = cfg["instruction"]
+    out["meta"]["object_name"] = object_name
+    return out
+
+
+def blob_paths(object_name: str) -> tuple[str, str, str]:
+    stem = os.path.join(BLOB_DIR, f"so100_handover_{object_name}")
+    return stem + ".f32.bin", stem + ".f64.bin", stem + ".json"
+
+
+def write_blobs(object_name: str, assets: str | None = None):
+    out = compile_scene(object_name, assets)
+    p32, p64, pj = blob_paths(object_name)
+    os.makedirs(BLOB_DIR, exist_ok=True)
+    with open(p32, "wb") as f:
+        f.write(blobfmt.pack(out["model"], np.float32))
+    with open(p64, "wb") as f:
+        f.write(blobfmt.pack(out["model"], np.float64))
+    with open(pj, "w") as f:
+        json.dump(out["meta"], f, indent=1)
+    return out
+
+
+def load_blob(object_name: str, real: str = "f32") -> tuple[bytes, dict]:
+    p32, p64, pj = blob_paths(object_name)
+    path = p32 if real == "f32" else p64
+    if not os.path.exists(path):
+        write_blobs(object_name)
+    with open(path, "rb") as f:
+        raw = f.read()
+    with open(pj) as f:
+        meta = json.load(f)
+    return raw, meta
+
+
+if __name__ == "__main__":
+    import sys
+    for name in (sys.argv[1:] or ["banana", "pen"]):
+        o = write_blobs(name)
+        m = o["model"]
+        print(name, {k: m[k] for k in ("nq", "nv", "nu", "nbody", "ngeom", "nvert", "npair")},
+              "proxy:", o["meta"]["proxy_inertia"])
