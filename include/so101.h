@@ -1,0 +1,131 @@
+/* so101.h — C ABI of libso101_hip.so: the MI355X (gfx950) batched step of the SO100/SO101
+ * hand-over environments.
+ *
+ * The reference (tuul-ai/so101_sim) has no FFI for this path: its boundary is the Python API
+ *   so101_sim/task_suite.py:103-155   create_task_env(...) -> dm_control composer.Environment
+ *   env.reset() / env.step(action)    (dm_control loop; hooks in so101_sim/tasks/base/so100_task.py:266-320,
+ *                                      so101_sim/tasks/so100_hand_over.py:238-323)
+ * and all arithmetic happens inside mujoco.mj_step (third party).  Each entry point below names the
+ * reference call it stands in for.  The Python shim so101_sim_amd/env.py binds these with ctypes
+ * (INTEGRATION.md shows the binding a reference maintainer would add).
+ *
+ * Conventions
+ *  - return 0 on success, negative so101_status otherwise; no C++ exception crosses the boundary;
+ *    so101_last_error() gives a message for the last failing call on that handle (or on create).
+ *  - every array argument is a DEVICE pointer owned by the caller (tensor.data_ptr()); the library
+ *    never frees caller memory and keeps bound pointers until so101_destroy / the next bind.
+ *  - state arrays are struct-of-arrays with the env index fastest: qpos[nq][N], qvel[nv][N], ...
+ *    so that lanes reading one scalar for consecutive envs coalesce.
+ *  - `hip_stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream); calls are
+ *    asynchronous with respect to the host.
+ *  - a handle is bound to one device and is not thread-safe.
+ */
+#ifndef SO101_H_
+#define SO101_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SO101_ABI_VERSION 1
+#define SO101_OBS_DIM 18      /* joints_pos(6, delayed) | undelayed_joints_pos(6) | commanded_joints_pos(6) */
+#define SO101_ACT_DIM 6
+#define SO101_RING_DEPTH 5    /* joints_pos delay: 0.1 s = 5 control steps (so100_task.py:81,196-198) */
+
+typedef enum {
+  SO101_OK = 0,
+  SO101_ERR_ARG = -1,        /* NULL/invalid argument */
+  SO101_ERR_MODEL = -2,      /* blob rejected (magic/version/dims outside the compiled limits) */
+  SO101_ERR_HIP = -3,        /* HIP runtime error (message holds hipGetErrorString) */
+  SO101_ERR_STATE = -4       /* call order violated (e.g. step before bind_state) */
+} so101_status;
+
+typedef struct so101_sim so101_sim; /* opaque */
+
+/* Caller-owned device buffers holding the per-env state (struct-of-arrays, N fastest). */
+typedef struct {
+  float* qpos;         /* [nq][N]  generalized positions          (physics.data.qpos) */
+  float* qvel;         /* [nv][N]  generalized velocities         (physics.data.qvel) */
+  float* ctrl;         /* [nu][N]  actuator controls, UNclamped   (physics.data.ctrl) */
+  float* warmstart;    /* [nv][N]  previous qacc (solver warm start, data.qacc_warmstart) */
+  float* obs_ring;     /* [SO101_RING_DEPTH][6][N] joints_pos delay line */
+  float* ep_return;    /* [N] running sum of rewards of the current episode */
+  int32_t* step_count; /* [N] control steps since reset */
+  int32_t* episode;    /* [N] episode counter (keys the reset RNG) */
+} so101_buffers;
+
+/* Tunables that the reference fixes through its MJCF / dm_control arguments. */
+typedef struct {
+  float action_offset[SO101_ACT_DIM]; /* calibration homing offsets added to every action
+                                         (scripts/so101_calibration.py:62-88; zeros when the file is absent) */
+  int32_t last_step;       /* control step on which physics.time() >= time_limit first holds
+                              (task_suite.py:151; fp64 accumulation replayed on the host) */
+  int32_t n_substeps;      /* control_timestep / physics timestep = 10 (task_suite.py:41) */
+  int32_t solver_iterations; /* PGS iteration cap; <=0 keeps the model's (100) */
+  float solver_tolerance;  /* PGS early-exit tolerance; <0 keeps the model's (1e-8) */
+  int32_t settle_max_substeps; /* PropPlacer settle budget, 1000 = 2.0 s (so100_hand_over.py:222-229) */
+  int32_t terminate_on_success; /* SO100Task terminate_episode (so100_task.py:120,297-302) */
+  uint64_t env_id_base;    /* global index of env 0 of this handle (multi-GPU sharding) */
+} so101_config;
+
+int so101_version(void);
+
+/* Compile-time limits of this build, for the host shim's sanity checks. */
+int so101_max_contacts(void);
+
+/* Replaces: composer.Environment construction + MuJoCo model compile (task_suite.py:148-155).
+ * model_blob: f32 blob from so101_sim_amd/model/blob.py (host memory, copied).  Allocates the
+ * device copy of the model and internal scratch only. */
+int so101_create(const void* model_blob, size_t blob_bytes, int n_envs, int hip_device, uint64_t seed,
+                 so101_sim** out);
+void so101_destroy(so101_sim* sim);
+
+int so101_default_config(so101_config* cfg);
+int so101_configure(so101_sim* sim, const so101_config* cfg);
+int so101_bind_state(so101_sim* sim, const so101_buffers* buffers);
+
+/* Replaces: env.reset() -> task.initialize_episode (so100_task.py:304-320, so100_hand_over.py:320-323):
+ * arm qpos/qvel = 0, ctrl = home + offsets, object/container placement drawn from the counter RNG keyed
+ * (seed, env_id, episode), container rejection-sampled against collisions, props settled with the arm
+ * held, delay line filled with the reset value.  mask: [N] bytes, nonzero = reset that env; NULL = all. */
+int so101_reset(so101_sim* sim, const uint8_t* mask, void* hip_stream);
+
+/* Replaces: env.step(action): before_step (so100_task.py:266-287), n_substeps x mj_step, observables
+ * (so100_task.py:323-368 with the delays of :189-210), get_reward (so100_hand_over.py:238-275),
+ * get_discount / termination (so100_task.py:292-302) and the time limit (task_suite.py:151).
+ * Envs whose previous step was LAST are reset first and report FIRST (dm_control auto-reset).
+ *   action    [N][6]  float32, row-major as the caller's (N,6) tensor
+ *   obs       [N][SO101_OBS_DIM]
+ *   reward    [N]  in {0,1}      discount [N] in {0,1}      step_type [N]: 0 FIRST, 1 MID, 2 LAST */
+int so101_step(so101_sim* sim, const float* action, float* obs, float* reward, float* discount,
+               uint8_t* step_type, void* hip_stream);
+
+/* Physics only: n_substeps of mj_step on every env with the bound ctrl; no task logic.
+ * freeze_arm != 0 restores the arm's qpos/qvel after every substep (PropPlacer settle). */
+int so101_physics(so101_sim* sim, int n_substeps, int freeze_arm, void* hip_stream);
+
+/* Reward of the current state (SO100HandOver.get_reward, overlap mode) -> reward[N]. */
+int so101_reward(so101_sim* sim, float* reward, void* hip_stream);
+
+/* Episode returns for logging (copied from the bound ep_return). */
+int so101_get_returns(so101_sim* sim, float* out, void* hip_stream);
+
+/* Diagnostics of the most recent substep, per env: [N][SO101_DIAG_DIM] int32
+ *   0 ncon, 1 nefc, 2 solver iterations, 3 broadphase candidates, 4 overflow flags. */
+#define SO101_DIAG_DIM 8
+int so101_get_diag(so101_sim* sim, int32_t* out, void* hip_stream);
+
+/* Stage dump of one forward pass (no integration) for parity tests against the oracle:
+ * out is [N][SO101_DEBUG_DIM] float32; layout documented in csrc/so101_device.hpp (DBG_*). */
+#define SO101_DEBUG_DIM 1024
+int so101_debug_forward(so101_sim* sim, float* out, void* hip_stream);
+
+const char* so101_last_error(const so101_sim* sim);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SO101_H_ */

@@ -1,0 +1,1420 @@
+// Device code of the batched SO100 hand-over step: ONE ENVIRONMENT PER WAVEFRONT (64 lanes).
+//
+// Stages per physics substep (MuJoCo mj_step order; the reference drives 10 of them per env.step,
+// so101_sim/task_suite.py:41):
+//   kinematics -> CRBA (arm 6x6) + inverse -> RNE bias -> actuation -> smooth acceleration
+//   -> geom AABBs -> broadphase over the statically filtered pair list -> MPR narrowphase with
+//   wave-parallel hull support -> constraint rows (dof frictionloss, joint limits, elliptic contacts)
+//   -> PGS in velocity space -> semi-implicit Euler.
+// Lane use: "uniform" code is executed identically by all lanes on wave-uniform values; "lane-
+// parallel" code maps lanes to dofs / geoms / pairs / contacts / hull vertices.  All cross-lane data
+// flows through LDS (EnvLDS) between wave_sync() points or through the helpers in wave.hpp.
+//
+// Free bodies are carried in centre-of-mass twist coordinates inside the solver (inverse inertia is
+// then 1/m and a symmetric 3x3), and mapped back to MuJoCo's (origin velocity, body-frame angular
+// velocity) coordinates for integration; the PGS force iterates are invariant to that change of
+// velocity coordinates.
+#pragma once
+#include "so101_model.hpp"
+#include "wave.hpp"
+
+#define DEV __device__ __forceinline__
+#define MINVAL_F 1e-15f
+#define MINIMP_F 1e-4f
+#define MAXIMP_F 0.9999f
+#define EPS_F 1.1920929e-7f
+
+// ------------------------------------------------------------------ small math
+DEV float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+DEV void cross3(float* o, const float* a, const float* b) {
+  float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+DEV float normalize3(float* a) {
+  float n = sqrtf(dot3(a, a));
+  if (n < MINVAL_F) { a[0] = 1.f; a[1] = 0.f; a[2] = 0.f; return 0.f; }
+  float inv = 1.f / n;
+  a[0] *= inv; a[1] *= inv; a[2] *= inv;
+  return n;
+}
+DEV void matvec3(float* o, const float* m, const float* v) {
+  float x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2];
+  float y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2];
+  float z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+DEV void matTvec3(float* o, const float* m, const float* v) {
+  float x = m[0] * v[0] + m[3] * v[1] + m[6] * v[2];
+  float y = m[1] * v[0] + m[4] * v[1] + m[7] * v[2];
+  float z = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+DEV void matmul3(float* o, const float* a, const float* b) {
+  float t[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) t[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+#pragma unroll
+  for (int i = 0; i < 9; i++) o[i] = t[i];
+}
+DEV void quat2mat(float* m, const float* q) {
+  float w = q[0], x = q[1], y = q[2], z = q[3];
+  m[0] = 1.f - 2.f * (y * y + z * z); m[1] = 2.f * (x * y - w * z); m[2] = 2.f * (x * z + w * y);
+  m[3] = 2.f * (x * y + w * z); m[4] = 1.f - 2.f * (x * x + z * z); m[5] = 2.f * (y * z - w * x);
+  m[6] = 2.f * (x * z - w * y); m[7] = 2.f * (y * z + w * x); m[8] = 1.f - 2.f * (x * x + y * y);
+}
+DEV void mulquat(float* o, const float* a, const float* b) {
+  float w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  float x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  float y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  float z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  o[0] = w; o[1] = x; o[2] = y; o[3] = z;
+}
+DEV void normquat(float* q) {
+  float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < MINVAL_F) { q[0] = 1.f; q[1] = q[2] = q[3] = 0.f; return; }
+  float inv = 1.f / n;
+  q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
+}
+DEV void rotvecquat(float* o, const float* v, const float* q) {
+  float m[9]; quat2mat(m, q); matvec3(o, m, v);
+}
+DEV void mat2quat(float* q, const float* m) {
+  float t = m[0] + m[4] + m[8];
+  if (t > 0.f) {
+    float s = sqrtf(t + 1.f) * 2.f; q[0] = 0.25f * s; q[1] = (m[7] - m[5]) / s; q[2] = (m[2] - m[6]) / s; q[3] = (m[3] - m[1]) / s;
+  } else if (m[0] > m[4] && m[0] > m[8]) {
+    float s = sqrtf(1.f + m[0] - m[4] - m[8]) * 2.f; q[0] = (m[7] - m[5]) / s; q[1] = 0.25f * s; q[2] = (m[1] + m[3]) / s; q[3] = (m[2] + m[6]) / s;
+  } else if (m[4] > m[8]) {
+    float s = sqrtf(1.f + m[4] - m[0] - m[8]) * 2.f; q[0] = (m[2] - m[6]) / s; q[1] = (m[1] + m[3]) / s; q[2] = 0.25f * s; q[3] = (m[5] + m[7]) / s;
+  } else {
+    float s = sqrtf(1.f + m[8] - m[0] - m[4]) * 2.f; q[0] = (m[3] - m[1]) / s; q[1] = (m[2] + m[6]) / s; q[2] = (m[5] + m[7]) / s; q[3] = 0.25f * s;
+  }
+  normquat(q);
+}
+// symmetric 3x3 packed as xx yy zz xy xz yz
+DEV void symvec3(float* o, const float* s, const float* v) {
+  float x = s[0] * v[0] + s[3] * v[1] + s[4] * v[2];
+  float y = s[3] * v[0] + s[1] * v[1] + s[5] * v[2];
+  float z = s[4] * v[0] + s[5] * v[1] + s[2] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+// o = R * S * R^T for symmetric S
+DEV void rotsym(float* o, const float* R, const float* s) {
+  float t[9];   // t = R*S
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    t[3 * i + 0] = R[3 * i] * s[0] + R[3 * i + 1] * s[3] + R[3 * i + 2] * s[4];
+    t[3 * i + 1] = R[3 * i] * s[3] + R[3 * i + 1] * s[1] + R[3 * i + 2] * s[5];
+    t[3 * i + 2] = R[3 * i] * s[4] + R[3 * i + 1] * s[5] + R[3 * i + 2] * s[2];
+  }
+  o[0] = t[0] * R[0] + t[1] * R[1] + t[2] * R[2];
+  o[1] = t[3] * R[3] + t[4] * R[4] + t[5] * R[5];
+  o[2] = t[6] * R[6] + t[7] * R[7] + t[8] * R[8];
+  o[3] = t[0] * R[3] + t[1] * R[4] + t[2] * R[5];
+  o[4] = t[0] * R[6] + t[1] * R[7] + t[2] * R[8];
+  o[5] = t[3] * R[6] + t[4] * R[7] + t[5] * R[8];
+}
+DEV int tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+
+// ------------------------------------------------------------------ kinematics (uniform)
+DEV void kinematics(const DevModel* m, EnvLDS& L) {
+  int lane = wave_lane();
+  // arm chain: every lane walks the 6 links on uniform values; lane 0 publishes to LDS
+  float xp[3] = {m->base_pos[0], m->base_pos[1], m->base_pos[2]};
+  float xq[4] = {m->base_quat[0], m->base_quat[1], m->base_quat[2], m->base_quat[3]};
+  float R[9]; quat2mat(R, xq);
+#pragma unroll
+  for (int k = 0; k < NARM; k++) {
+    float t[3]; matvec3(t, R, m->arm_pos[k]);
+    xp[0] += t[0]; xp[1] += t[1]; xp[2] += t[2];
+    mulquat(xq, xq, m->arm_quat[k]);
+    float half = 0.5f * L.qpos[k], sn = sinf(half), cs = cosf(half);
+    float jq[4] = {cs, m->arm_axis[k][0] * sn, m->arm_axis[k][1] * sn, m->arm_axis[k][2] * sn};
+    mulquat(xq, xq, jq);
+    normquat(xq);
+    quat2mat(R, xq);
+    float ax[3]; matvec3(ax, R, m->arm_axis[k]);
+    float ip[3]; matvec3(ip, R, m->arm_ipos[k]);
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) { L.xpos[k][i] = xp[i]; L.axis[k][i] = ax[i]; L.xipos[k][i] = xp[i] + ip[i]; }
+#pragma unroll
+      for (int i = 0; i < 9; i++) L.xmat[k][i] = R[i];
+    }
+  }
+  // free bodies: lanes 0..NFREE-1
+  if (lane < NFREE) {
+    int f = lane, b = NARM + f;
+    const float* q = &L.qpos[NARM + 7 * f];
+    float fq[4] = {q[3], q[4], q[5], q[6]};
+    normquat(fq);
+    float Rf[9]; quat2mat(Rf, fq);
+    float ip[3]; matvec3(ip, Rf, m->free_ipos[f]);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { L.xpos[b][i] = q[i]; L.xipos[b][i] = q[i] + ip[i]; }
+#pragma unroll
+    for (int i = 0; i < 9; i++) L.xmat[b][i] = Rf[i];
+  }
+  wave_sync();
+  // world inertia of every dynamic body (lane-parallel)
+  if (lane < NDYN) {
+    const float* Ib = lane < NARM ? m->arm_Ib[lane] : m->free_Ib[lane - NARM];
+    float o[6]; rotsym(o, L.xmat[lane], Ib);
+#pragma unroll
+    for (int i = 0; i < 6; i++) L.Iw[lane][i] = o[i];
+    if (lane >= NARM) {
+      int f = lane - NARM;
+      float oi[6]; rotsym(oi, L.xmat[lane], m->free_Ibinv[f]);
+#pragma unroll
+      for (int i = 0; i < 6; i++) L.fIinv[f][i] = oi[i];
+      L.fminv[f] = 1.f / m->free_mass[f];
+    }
+  }
+  wave_sync();
+}
+
+// ------------------------------------------------------------------ CRBA + inverse of the arm block
+DEV void crba_arm(const DevModel* m, EnvLDS& L) {
+  int lane = wave_lane();
+  // composite (mass, COM, inertia about COM) of the sub-chain k..5 — uniform backward pass
+  float mc[NARM], Cc[NARM][3], Ic[NARM][6];
+  float cm = 0.f, cC[3] = {0.f, 0.f, 0.f}, cI[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = NARM - 1; k >= 0; k--) {
+    float m1 = m->arm_mass[k], mt = m1 + cm;
+    float c1[3] = {L.xipos[k][0], L.xipos[k][1], L.xipos[k][2]};
+    float C[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) C[i] = (m1 * c1[i] + cm * cC[i]) / mt;
+    float d1[3] = {c1[0] - C[0], c1[1] - C[1], c1[2] - C[2]};
+    float d2[3] = {cC[0] - C[0], cC[1] - C[1], cC[2] - C[2]};
+    float dd1 = dot3(d1, d1), dd2 = dot3(d2, d2);
+    float I[6];
+    I[0] = L.Iw[k][0] + cI[0] + m1 * (dd1 - d1[0] * d1[0]) + cm * (dd2 - d2[0] * d2[0]);
+    I[1] = L.Iw[k][1] + cI[1] + m1 * (dd1 - d1[1] * d1[1]) + cm * (dd2 - d2[1] * d2[1]);
+    I[2] = L.Iw[k][2] + cI[2] + m1 * (dd1 - d1[2] * d1[2]) + cm * (dd2 - d2[2] * d2[2]);
+    I[3] = L.Iw[k][3] + cI[3] - m1 * d1[0] * d1[1] - cm * d2[0] * d2[1];
+    I[4] = L.Iw[k][4] + cI[4] - m1 * d1[0] * d1[2] - cm * d2[0] * d2[2];
+    I[5] = L.Iw[k][5] + cI[5] - m1 * d1[1] * d1[2] - cm * d2[1] * d2[2];
+    cm = mt;
+#pragma unroll
+    for (int i = 0; i < 3; i++) cC[i] = C[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) cI[i] = I[i];
+    mc[k] = cm;
+#pragma unroll
+    for (int i = 0; i < 3; i++) Cc[k][i] = cC[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) Ic[k][i] = cI[i];
+  }
+  // M[j][k], k<=j: lane e owns entry e of the packed lower triangle (21 entries)
+  float Mfull[NARM][NARM];
+#pragma unroll
+  for (int j = 0; j < NARM; j++)
+#pragma unroll
+    for (int k = 0; k <= j; k++) {
+      float ak[3] = {L.axis[k][0], L.axis[k][1], L.axis[k][2]};
+      float aj[3] = {L.axis[j][0], L.axis[j][1], L.axis[j][2]};
+      float rk[3] = {Cc[j][0] - L.xpos[k][0], Cc[j][1] - L.xpos[k][1], Cc[j][2] - L.xpos[k][2]};
+      float rj[3] = {Cc[j][0] - L.xpos[j][0], Cc[j][1] - L.xpos[j][1], Cc[j][2] - L.xpos[j][2]};
+      float hl[3]; cross3(hl, ak, rk);
+      hl[0] *= mc[j]; hl[1] *= mc[j]; hl[2] *= mc[j];
+      float ha[3]; symvec3(ha, Ic[j], ak);
+      float t[3]; cross3(t, rj, hl);
+      float v = aj[0] * (ha[0] + t[0]) + aj[1] * (ha[1] + t[1]) + aj[2] * (ha[2] + t[2]);
+      if (j == k) v += m->armature[j];
+      Mfull[j][k] = v; Mfull[k][j] = v;
+    }
+  // Cholesky (uniform) then lane c solves for column c of the inverse
+  float Lc[NARM][NARM];
+#pragma unroll
+  for (int j = 0; j < NARM; j++) {
+    float d = Mfull[j][j];
+#pragma unroll
+    for (int k = 0; k < j; k++) d -= Lc[j][k] * Lc[j][k];
+    d = sqrtf(d);
+    Lc[j][j] = d;
+    float inv = 1.f / d;
+#pragma unroll
+    for (int i = j + 1; i < NARM; i++) {
+      float v = Mfull[i][j];
+#pragma unroll
+      for (int k = 0; k < j; k++) v -= Lc[i][k] * Lc[j][k];
+      Lc[i][j] = v * inv;
+    }
+  }
+  if (lane < NARM) {
+    float y[NARM], x[NARM];
+#pragma unroll
+    for (int i = 0; i < NARM; i++) {
+      float v = (i == lane) ? 1.f : 0.f;
+#pragma unroll
+      for (int k = 0; k < i; k++) v -= Lc[i][k] * y[k];
+      y[i] = v / Lc[i][i];
+    }
+#pragma unroll
+    for (int i = NARM - 1; i >= 0; i--) {
+      float v = y[i];
+#pragma unroll
+      for (int k = i + 1; k < NARM; k++) v -= Lc[k][i] * x[k];
+      x[i] = v / Lc[i][i];
+    }
+#pragma unroll
+    for (int i = 0; i < NARM; i++) { L.Minv[i][lane] = x[i]; L.Marm[i][lane] = Mfull[i][lane]; }
+  }
+  wave_sync();
+}
+
+// ------------------------------------------------------------------ RNE bias, actuation, smooth acceleration
+DEV void smooth_dynamics(const DevModel* m, EnvLDS& L) {
+  int lane = wave_lane();
+  // --- arm: recursive Newton-Euler with zero joint acceleration and gravity as base acceleration
+  float w[3] = {0.f, 0.f, 0.f}, al[3] = {0.f, 0.f, 0.f}, ao[3] = {-m->grav[0], -m->grav[1], -m->grav[2]};
+  float pp[3] = {m->base_pos[0], m->base_pos[1], m->base_pos[2]};
+  float fk[NARM][3], nk[NARM][3];
+#pragma unroll
+  for (int k = 0; k < NARM; k++) {
+    float d[3] = {L.xpos[k][0] - pp[0], L.xpos[k][1] - pp[1], L.xpos[k][2] - pp[2]};
+    float t1[3], t2[3];
+    cross3(t1, al, d); cross3(t2, w, d); cross3(t2, w, t2);
+    ao[0] += t1[0] + t2[0]; ao[1] += t1[1] + t2[1]; ao[2] += t1[2] + t2[2];
+    float a[3] = {L.axis[k][0], L.axis[k][1], L.axis[k][2]};
+    float qd = L.qvel[k];
+    float wa[3]; cross3(wa, w, a);
+    al[0] += wa[0] * qd; al[1] += wa[1] * qd; al[2] += wa[2] * qd;
+    w[0] += a[0] * qd; w[1] += a[1] * qd; w[2] += a[2] * qd;
+    float r[3] = {L.xipos[k][0] - L.xpos[k][0], L.xipos[k][1] - L.xpos[k][1], L.xipos[k][2] - L.xpos[k][2]};
+    cross3(t1, al, r); cross3(t2, w, r); cross3(t2, w, t2);
+    float mass = m->arm_mass[k];
+    float F[3] = {mass * (ao[0] + t1[0] + t2[0]), mass * (ao[1] + t1[1] + t2[1]), mass * (ao[2] + t1[2] + t2[2])};
+    float Iw_[3], Ia[3], N[3], rF[3];
+    symvec3(Iw_, L.Iw[k], w); symvec3(Ia, L.Iw[k], al);
+    cross3(N, w, Iw_); cross3(rF, r, F);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { fk[k][i] = F[i]; nk[k][i] = Ia[i] + N[i] + rF[i]; pp[i] = L.xpos[k][i]; }
+  }
+  float bias[NARM];
+#pragma unroll
+  for (int k = NARM - 1; k >= 0; k--) {
+    bias[k] = L.axis[k][0] * nk[k][0] + L.axis[k][1] * nk[k][1] + L.axis[k][2] * nk[k][2];
+    if (k > 0) {
+      float dd[3] = {L.xpos[k][0] - L.xpos[k - 1][0], L.xpos[k][1] - L.xpos[k - 1][1], L.xpos[k][2] - L.xpos[k - 1][2]};
+      float t[3]; cross3(t, dd, fk[k]);
+#pragma unroll
+      for (int i = 0; i < 3; i++) { fk[k - 1][i] += fk[k][i]; nk[k - 1][i] += nk[k][i] + t[i]; }
+    }
+  }
+  // --- actuation (lane = actuator = dof for this model): clamp ctrl, affine bias, clamp force
+  if (lane < NARM) {
+    float c = L.ctrl[lane];
+    if (m->ctrllimited[lane]) c = fminf(fmaxf(c, m->ctrlrange[lane][0]), m->ctrlrange[lane][1]);
+    float force = m->act_gain[lane] * c + m->act_bias[lane][0] + m->act_bias[lane][1] * L.qpos[lane] + m->act_bias[lane][2] * L.qvel[lane];
+    if (m->forcelimited[lane]) force = fminf(fmaxf(force, m->forcerange[lane][0]), m->forcerange[lane][1]);
+    float b = 0.f;
+#pragma unroll
+    for (int k = 0; k < NARM; k++) if (k == lane) b = bias[k];
+    L.bias[lane] = b;
+    L.tau[lane] = force - b;
+  }
+  wave_sync();
+  if (lane < NARM) {
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < NARM; c++) v += L.Minv[lane][c] * L.tau[c];
+    L.qacc_arm[lane] = v;
+  }
+  // --- free bodies in COM-twist coordinates: a_com = g, alpha = Iinv (-w x I w)
+  if (lane >= 32 && lane < 32 + NFREE) {
+    int f = lane - 32, b = NARM + f;
+    const float* qv = &L.qvel[NARM + 6 * f];
+    float wb[3] = {qv[3], qv[4], qv[5]}, ww[3];
+    matvec3(ww, L.xmat[b], wb);
+    float r[3] = {L.xipos[b][0] - L.xpos[b][0], L.xipos[b][1] - L.xpos[b][1], L.xipos[b][2] - L.xpos[b][2]};
+    float wr[3]; cross3(wr, ww, r);
+    float Iw_[3]; symvec3(Iw_, L.Iw[b], ww);
+    float g[3]; cross3(g, ww, Iw_);
+    g[0] = -g[0]; g[1] = -g[1]; g[2] = -g[2];
+    float alp[3]; symvec3(alp, L.fIinv[f], g);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      L.fvel[f][i] = qv[i] + wr[i]; L.fvel[f][3 + i] = ww[i];
+      L.facc[f][i] = m->grav[i]; L.facc[f][3 + i] = alp[i];
+    }
+  }
+  wave_sync();
+}
+
+// ------------------------------------------------------------------ geometry
+struct GeomW { int type, vadr, vnum; float size[3], R[9], p[3], c[3]; };
+
+DEV void load_geom(const DevModel* m, const EnvLDS& L, int g, GeomW& G) {
+  G.type = m->geom_type[g]; G.vadr = m->geom_vertadr[g]; G.vnum = m->geom_vertnum[g];
+  const float* gp = m->geom_pos + 3 * g; const float* gm = m->geom_mat + 9 * g;
+  const float* gc = m->geom_center + 3 * g;
+#pragma unroll
+  for (int i = 0; i < 3; i++) G.size[i] = m->geom_size[3 * g + i];
+  int d = m->geom_dyn[g];
+  float lp[3] = {gp[0], gp[1], gp[2]}, lm[9], lc[3] = {gc[0], gc[1], gc[2]};
+#pragma unroll
+  for (int i = 0; i < 9; i++) lm[i] = gm[i];
+  if (d < 0) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) G.R[i] = lm[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) G.p[i] = lp[i];
+  } else {
+    float t[3]; matvec3(t, L.xmat[d], lp);
+#pragma unroll
+    for (int i = 0; i < 3; i++) G.p[i] = L.xpos[d][i] + t[i];
+    matmul3(G.R, L.xmat[d], lm);
+  }
+  float cw[3]; matvec3(cw, G.R, lc);
+#pragma unroll
+  for (int i = 0; i < 3; i++) G.c[i] = G.p[i] + cw[i];
+}
+
+// support point (world) of G in world direction dir; wave-parallel over hull vertices for meshes
+DEV void support(const DevModel* m, const GeomW& G, const float* dir, float* out) {
+  float dl[3]; matTvec3(dl, G.R, dir);
+  float loc[3] = {0.f, 0.f, 0.f};
+  if (G.type == G_MESH) {
+    int lane = wave_lane();
+    float best = -3.0e38f; int bi = 0x7fffffff;
+    const float* x = m->vx + G.vadr; const float* y = m->vy + G.vadr; const float* z = m->vz + G.vadr;
+    for (int i = lane; i < G.vnum; i += WAVE) {
+      float d = x[i] * dl[0] + y[i] * dl[1] + z[i] * dl[2];
+      if (d > best) { best = d; bi = i; }
+    }
+    wave_argmax(best, bi);
+    loc[0] = x[bi]; loc[1] = y[bi]; loc[2] = z[bi];
+  } else if (G.type == G_BOX) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) loc[i] = dl[i] >= 0.f ? G.size[i] : -G.size[i];
+  } else if (G.type == G_CAPSULE) {
+    float n = sqrtf(dot3(dl, dl));
+    if (n > MINVAL_F) { float s = G.size[0] / n; loc[0] = s * dl[0]; loc[1] = s * dl[1]; loc[2] = s * dl[2]; }
+    loc[2] += dl[2] >= 0.f ? G.size[1] : -G.size[1];
+  } else if (G.type == G_CYLINDER) {
+    float n = sqrtf(dl[0] * dl[0] + dl[1] * dl[1]);
+    if (n > MINVAL_F) { float s = G.size[0] / n; loc[0] = s * dl[0]; loc[1] = s * dl[1]; }
+    loc[2] = dl[2] >= 0.f ? G.size[1] : -G.size[1];
+  } else if (G.type == G_SPHERE) {
+    float n = sqrtf(dot3(dl, dl));
+    if (n > MINVAL_F) { float s = G.size[0] / n; loc[0] = s * dl[0]; loc[1] = s * dl[1]; loc[2] = s * dl[2]; }
+  }
+  float w[3]; matvec3(w, G.R, loc);
+  out[0] = G.p[0] + w[0]; out[1] = G.p[1] + w[1]; out[2] = G.p[2] + w[2];
+}
+
+struct MV { float v[3], a[3], b[3]; };
+
+DEV void mdsupport(const DevModel* m, const GeomW& G1, const GeomW& G2, const float* dir, const float* org, MV& o) {
+  float nd[3] = {-dir[0], -dir[1], -dir[2]};
+  support(m, G1, dir, o.a);
+  support(m, G2, nd, o.b);
+#pragma unroll
+  for (int i = 0; i < 3; i++) { o.a[i] -= org[i]; o.b[i] -= org[i]; o.v[i] = o.a[i] - o.b[i]; }
+}
+
+DEV bool isz(float x) { return fabsf(x) < EPS_F; }
+
+DEV float seg_origin(const float* P0, const float* P1, float* wt) {
+  float dd[3] = {P1[0] - P0[0], P1[1] - P0[1], P1[2] - P0[2]};
+  float t = -dot3(P0, dd) / fmaxf(dot3(dd, dd), 1e-30f);
+  t = fminf(fmaxf(t, 0.f), 1.f);
+  wt[0] = P0[0] + t * dd[0]; wt[1] = P0[1] + t * dd[1]; wt[2] = P0[2] + t * dd[2];
+  return dot3(wt, wt);
+}
+
+DEV float origin_tri_dist2(const float* x0, const float* B, const float* C, float* wit) {
+  float d1[3] = {B[0] - x0[0], B[1] - x0[1], B[2] - x0[2]}, d2[3] = {C[0] - x0[0], C[1] - x0[1], C[2] - x0[2]};
+  float v = dot3(d1, d1), w = dot3(d2, d2), p = dot3(x0, d1), q = dot3(x0, d2), r = dot3(d1, d2);
+  float den = w * v - r * r, sp = -1.f, tp = -1.f;
+  if (fabsf(den) > 1e-30f) { sp = (q * r - w * p) / den; tp = (-sp * r - q) / w; }
+  if ((isz(sp) || sp > 0.f) && (isz(sp - 1.f) || sp < 1.f) && (isz(tp) || tp > 0.f) && (isz(tp - 1.f) || tp < 1.f) &&
+      (isz(tp + sp - 1.f) || tp + sp < 1.f)) {
+    wit[0] = x0[0] + sp * d1[0] + tp * d2[0]; wit[1] = x0[1] + sp * d1[1] + tp * d2[1]; wit[2] = x0[2] + sp * d1[2] + tp * d2[2];
+    return dot3(wit, wit);
+  }
+  float w1[3], w2[3], w3[3];
+  float e1 = seg_origin(x0, B, w1), e2 = seg_origin(x0, C, w2), e3 = seg_origin(B, C, w3);
+  float best = e1; wit[0] = w1[0]; wit[1] = w1[1]; wit[2] = w1[2];
+  if (e2 < best) { best = e2; wit[0] = w2[0]; wit[1] = w2[1]; wit[2] = w2[2]; }
+  if (e3 < best) { best = e3; wit[0] = w3[0]; wit[1] = w3[1]; wit[2] = w3[2]; }
+  return best;
+}
+
+#define MVCOPY(dst, src) do { _Pragma("unroll") for (int _i = 0; _i < 3; _i++) { (dst).v[_i] = (src).v[_i]; (dst).a[_i] = (src).a[_i]; (dst).b[_i] = (src).b[_i]; } } while (0)
+
+// MPR penetration query (XenoCollide / libccd ccdMPRPenetration).  Entirely wave-uniform control flow.
+DEV bool mpr_penetration(const DevModel* m, const GeomW& G1, const GeomW& G2, float* depth, float* dir, float* pos) {
+  float org[3] = {G1.c[0], G1.c[1], G1.c[2]};
+  MV v0, v1, v2, v3, v4;
+#pragma unroll
+  for (int i = 0; i < 3; i++) { v0.a[i] = 0.f; v0.b[i] = G2.c[i] - org[i]; v0.v[i] = -v0.b[i]; }
+  if (isz(v0.v[0]) && isz(v0.v[1]) && isz(v0.v[2])) v0.v[0] += 1e-5f;
+  float d[3] = {-v0.v[0], -v0.v[1], -v0.v[2]};
+  normalize3(d);
+  mdsupport(m, G1, G2, d, org, v1);
+  float dt = dot3(v1.v, d);
+  if (isz(dt) || dt < 0.f) return false;
+  cross3(d, v0.v, v1.v);
+  float dn = sqrtf(dot3(d, d));
+  if (isz(dn)) {
+    if (isz(v1.v[0]) && isz(v1.v[1]) && isz(v1.v[2])) {     // touching contact
+      *depth = 0.f; dir[0] = dir[1] = dir[2] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; i++) pos[i] = 0.5f * (v1.a[i] + v1.b[i]) + org[i];
+      return true;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) { pos[i] = 0.5f * (v1.a[i] + v1.b[i]) + org[i]; dir[i] = v1.v[i]; }
+    *depth = normalize3(dir);                                 // origin on the v0-v1 segment
+    return true;
+  }
+  normalize3(d);
+  mdsupport(m, G1, G2, d, org, v2);
+  dt = dot3(v2.v, d);
+  if (isz(dt) || dt < 0.f) return false;
+  float va[3], vb[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) { va[i] = v1.v[i] - v0.v[i]; vb[i] = v2.v[i] - v0.v[i]; }
+  cross3(d, va, vb); normalize3(d);
+  if (dot3(d, v0.v) > 0.f) {
+    MV t; MVCOPY(t, v1); MVCOPY(v1, v2); MVCOPY(v2, t);
+    d[0] = -d[0]; d[1] = -d[1]; d[2] = -d[2];
+  }
+  bool have3 = false;
+  for (int guard = 0; guard < 100 && !have3; guard++) {
+    mdsupport(m, G1, G2, d, org, v3);
+    dt = dot3(v3.v, d);
+    if (isz(dt) || dt < 0.f) return false;
+    bool cont = false;
+    cross3(va, v1.v, v3.v);
+    dt = dot3(va, v0.v);
+    if (dt < 0.f && !isz(dt)) { MVCOPY(v2, v3); cont = true; }
+    if (!cont) {
+      cross3(va, v3.v, v2.v);
+      dt = dot3(va, v0.v);
+      if (dt < 0.f && !isz(dt)) { MVCOPY(v1, v3); cont = true; }
+    }
+    if (cont) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) { va[i] = v1.v[i] - v0.v[i]; vb[i] = v2.v[i] - v0.v[i]; }
+      cross3(d, va, vb); normalize3(d);
+    } else have3 = true;
+  }
+  if (!have3) return false;
+  // refine the portal until it encloses the origin ray, then push it to the surface
+  bool inside = false;
+  for (int it = 0; it < 200; it++) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) { va[i] = v2.v[i] - v1.v[i]; vb[i] = v3.v[i] - v1.v[i]; }
+    cross3(d, va, vb); normalize3(d);
+    if (!inside) {
+      dt = dot3(d, v1.v);
+      if (isz(dt) || dt > 0.f) { inside = true; it = -1; continue; }   // portal encapsules origin: start penetration phase
+    }
+    mdsupport(m, G1, G2, d, org, v4);
+    float dv1 = dot3(v1.v, d), dv2 = dot3(v2.v, d), dv3 = dot3(v3.v, d), dv4 = dot3(v4.v, d);
+    float dm = fminf(fminf(dv4 - dv1, dv4 - dv2), dv4 - dv3);
+    bool reached = isz(dm - m->mpr_tol) || dm < m->mpr_tol;
+    if (!inside) {
+      if (!(isz(dv4) || dv4 > 0.f)) return false;     // cannot encapsule origin
+      if (reached || it > 100) return false;
+    } else if (reached || it > m->mpr_iter) {
+      float pd[3];
+      float d2 = origin_tri_dist2(v1.v, v2.v, v3.v, pd);
+      *depth = sqrtf(d2);
+      if (isz(pd[0]) && isz(pd[1]) && isz(pd[2])) { *depth = 0.f; dir[0] = d[0]; dir[1] = d[1]; dir[2] = d[2]; }
+      else { dir[0] = pd[0]; dir[1] = pd[1]; dir[2] = pd[2]; normalize3(dir); }
+      float b[4], t[3];
+      cross3(t, v1.v, v2.v); b[0] = dot3(t, v3.v);
+      cross3(t, v3.v, v2.v); b[1] = dot3(t, v0.v);
+      cross3(t, v0.v, v1.v); b[2] = dot3(t, v3.v);
+      cross3(t, v2.v, v1.v); b[3] = dot3(t, v0.v);
+      float sum = b[0] + b[1] + b[2] + b[3];
+      if (isz(sum) || sum < 0.f) {
+        b[0] = 0.f;
+        cross3(t, v2.v, v3.v); b[1] = dot3(t, d);
+        cross3(t, v3.v, v1.v); b[2] = dot3(t, d);
+        cross3(t, v1.v, v2.v); b[3] = dot3(t, d);
+        sum = b[1] + b[2] + b[3];
+      }
+      float inv = 1.f / sum;
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        float p1 = b[0] * v0.a[i] + b[1] * v1.a[i] + b[2] * v2.a[i] + b[3] * v3.a[i];
+        float p2 = b[0] * v0.b[i] + b[1] * v1.b[i] + b[2] * v2.b[i] + b[3] * v3.b[i];
+        pos[i] = 0.5f * (p1 + p2) * inv + org[i];
+      }
+      return true;
+    }
+    // expand portal
+    float v4v0[3]; cross3(v4v0, v4.v, v0.v);
+    float t1 = dot3(v1.v, v4v0);
+    if (t1 > 0.f) {
+      float t2 = dot3(v2.v, v4v0);
+      if (t2 > 0.f) MVCOPY(v1, v4); else MVCOPY(v3, v4);
+    } else {
+      float t3 = dot3(v3.v, v4v0);
+      if (t3 > 0.f) MVCOPY(v2, v4); else MVCOPY(v1, v4);
+    }
+  }
+  return false;
+}
+
+DEV void make_frame(float* fr) {
+  float* x = fr; float* y = fr + 3; float* z = fr + 6;
+  y[0] = 0.f; y[1] = 0.f; y[2] = 0.f;
+  if (x[1] < 0.5f && x[1] > -0.5f) y[1] = 1.f; else y[2] = 1.f;
+  float t = dot3(x, y);
+  y[0] -= t * x[0]; y[1] -= t * x[1]; y[2] -= t * x[2];
+  normalize3(y);
+  cross3(z, x, y);
+}
+
+// ------------------------------------------------------------------ collision driver
+DEV void collision(const DevModel* m, EnvLDS& L) {
+  int lane = wave_lane();
+  // world boxes of all geoms (lane-parallel)
+  for (int g = lane; g < m->ngeom; g += WAVE) {
+    const float* ab = m->geom_aabb + 6 * g;
+    const float* gp = m->geom_pos + 3 * g; const float* gm = m->geom_mat + 9 * g;
+    int d = m->geom_dyn[g];
+    float R[9], p[3];
+    if (d < 0) {
+#pragma unroll
+      for (int i = 0; i < 9; i++) R[i] = gm[i];
+#pragma unroll
+      for (int i = 0; i < 3; i++) p[i] = gp[i];
+    } else {
+      float lm[9], lp[3] = {gp[0], gp[1], gp[2]};
+#pragma unroll
+      for (int i = 0; i < 9; i++) lm[i] = gm[i];
+      matmul3(R, L.xmat[d], lm);
+      float t[3]; matvec3(t, L.xmat[d], lp);
+#pragma unroll
+      for (int i = 0; i < 3; i++) p[i] = L.xpos[d][i] + t[i];
+    }
+    float c[3] = {ab[0], ab[1], ab[2]}, h[3] = {ab[3], ab[4], ab[5]}, cw[3];
+    matvec3(cw, R, c);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      float e = fabsf(R[3 * i]) * h[0] + fabsf(R[3 * i + 1]) * h[1] + fabsf(R[3 * i + 2]) * h[2];
+      L.aabb[g][i] = p[i] + cw[i] - e; L.aabb[g][3 + i] = p[i] + cw[i] + e;
+    }
+  }
+  if (lane == 0) { L.ncand = 0; L.ncon = 0; L.narmcon = 0; }
+  wave_sync();
+  // broadphase: lanes stride the static pair list; survivors appended in pair order
+  int base = 0;
+  for (int p0 = 0; p0 < m->npair; p0 += WAVE) {
+    int p = p0 + lane;
+    bool hit = false; int g1 = 0, g2 = 0;
+    if (p < m->npair) {
+      g1 = m->pair[2 * p]; g2 = m->pair[2 * p + 1];
+      if (m->geom_type[g1] > m->geom_type[g2]) { int t = g1; g1 = g2; g2 = t; }
+      if (m->geom_type[g1] == G_PLANE) {
+        // plane: test the lowest corner of the other box against the plane
+        const float* gm = m->geom_mat + 9 * g1; const float* gp = m->geom_pos + 3 * g1;
+        float n[3] = {gm[2], gm[5], gm[8]}, low = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; i++) low += n[i] * ((n[i] >= 0.f ? L.aabb[g2][i] : L.aabb[g2][3 + i]) - gp[i]);
+        hit = low <= 0.f;
+      } else {
+        hit = true;
+#pragma unroll
+        for (int i = 0; i < 3; i++) if (L.aabb[g1][i] > L.aabb[g2][3 + i] || L.aabb[g2][i] > L.aabb[g1][3 + i]) hit = false;
+      }
+    }
+    unsigned long long mask = wave_ballot(hit);
+    int idx = base + wave_prefix(mask);
+    if (hit && idx < MAXCAND) { L.cand[idx][0] = (unsigned short)g1; L.cand[idx][1] = (unsigned short)g2; }
+    base += __popcll(mask);
+  }
+  if (lane == 0) { L.ncand = base < MAXCAND ? base : MAXCAND; if (base > MAXCAND) L.overflow |= 1; }
+  wave_sync();
+  // narrowphase: uniform loop over candidates
+  int ncand = L.ncand, ncon = 0;
+  for (int k = 0; k < ncand; k++) {
+    int g1 = L.cand[k][0], g2 = L.cand[k][1];
+    GeomW G1, G2;
+    load_geom(m, L, g1, G1); load_geom(m, L, g2, G2);
+    float dist, nrm[3], pos[3];
+    bool ok;
+    if (G1.type == G_PLANE) {
+      nrm[0] = G1.R[2]; nrm[1] = G1.R[5]; nrm[2] = G1.R[8];
+      float nn[3] = {-nrm[0], -nrm[1], -nrm[2]}, sp[3];
+      support(m, G2, nn, sp);
+      float t[3] = {sp[0] - G1.p[0], sp[1] - G1.p[1], sp[2] - G1.p[2]};
+      dist = dot3(t, nrm);
+      ok = dist < 0.f;
+#pragma unroll
+      for (int i = 0; i < 3; i++) pos[i] = sp[i] - 0.5f * dist * nrm[i];
+    } else {
+      float depth;
+      ok = mpr_penetration(m, G1, G2, &depth, nrm, pos);
+      ok = ok && depth > 0.f;
+      dist = -depth;
+    }
+    if (!ok) continue;
+    if (ncon >= MAXCON) { if (lane == 0) L.overflow |= 2; break; }
+    if (lane == 0) {
+      Contact& c = L.con[ncon];
+      c.dist = dist;
+      float fr[9] = {nrm[0], nrm[1], nrm[2], 0, 0, 0, 0, 0, 0};
+      make_frame(fr);
+#pragma unroll
+      for (int i = 0; i < 9; i++) c.frame[i] = fr[i];
+#pragma unroll
+      for (int i = 0; i < 3; i++) c.pos[i] = pos[i];
+      c.d1 = m->geom_dyn[g1]; c.d2 = m->geom_dyn[g2]; c.g1 = g1; c.g2 = g2;
+      int cd1 = m->geom_condim[g1], cd2 = m->geom_condim[g2];
+      c.dim = cd1 > cd2 ? cd1 : cd2;
+#pragma unroll
+      for (int i = 0; i < 3; i++) c.fric[i] = fmaxf(m->geom_friction[3 * g1 + i], m->geom_friction[3 * g2 + i]);
+      // solref / solimp mixed with equal weights (solmix = 1 on every geom of these scenes); stash in aref/f
+      c.aref[0] = 0.5f * (m->geom_solref[2 * g1] + m->geom_solref[2 * g2]);
+      c.aref[1] = 0.5f * (m->geom_solref[2 * g1 + 1] + m->geom_solref[2 * g2 + 1]);
+#pragma unroll
+      for (int i = 0; i < 5; i++) c.f[i] = 0.5f * (m->geom_solimp[5 * g1 + i] + m->geom_solimp[5 * g2 + i]);
+      c.armslot = -1;
+    }
+    ncon++;
+  }
+  if (lane == 0) L.ncon = ncon;
+  wave_sync();
+}
+
+// ------------------------------------------------------------------ constraint rows
+DEV float impedance(const float* solimp, float pos) {
+  float dmin = fminf(fmaxf(solimp[0], MINIMP_F), MAXIMP_F), dmax = fminf(fmaxf(solimp[1], MINIMP_F), MAXIMP_F);
+  float width = fmaxf(solimp[2], 0.f), mid = fminf(fmaxf(solimp[3], MINIMP_F), MAXIMP_F), power = fmaxf(solimp[4], 1.f);
+  if (dmin == dmax || width <= MINVAL_F) return 0.5f * (dmin + dmax);
+  float x = fabsf(pos) / width;
+  if (x >= 1.f) return dmax;
+  if (x <= 0.f) return dmin;
+  float y;
+  if (power == 1.f) y = x;
+  else if (x <= mid) y = powf(x, power) / powf(mid, power - 1.f);
+  else y = 1.f - powf(1.f - x, power) / powf(1.f - mid, power - 1.f);
+  return dmin + y * (dmax - dmin);
+}
+
+DEV void kb_from_solref(const DevModel* m, const float* solref_in, const float* solimp, float* K, float* B) {
+  float s0 = solref_in[0], s1 = solref_in[1];
+  float dmax = fminf(fmaxf(solimp[1], MINIMP_F), MAXIMP_F);
+  if (s0 > 0.f) {
+    s0 = fmaxf(s0, 2.f * m->dt);     // refsafe
+    *K = 1.f / fmaxf(MINVAL_F, dmax * dmax * s0 * s0 * s1 * s1);
+    *B = 2.f / fmaxf(MINVAL_F, dmax * s0);
+  } else {
+    *K = -s0 / fmaxf(MINVAL_F, dmax * dmax);
+    *B = -s1 / fmaxf(MINVAL_F, dmax);
+  }
+}
+
+// Jacobian row of contact axis `u` (translational or rotational) against arm link `link`: out[d], d<=link
+DEV void arm_jac_row(const EnvLDS& L, int link, const float* p, const float* u, bool rot, float* out) {
+#pragma unroll
+  for (int d = 0; d < NARM; d++) {
+    float v = 0.f;
+    if (d <= link) {
+      const float* a = L.axis[d];
+      if (rot) v = dot3(u, a);
+      else {
+        float r[3] = {p[0] - L.xpos[d][0], p[1] - L.xpos[d][1], p[2] - L.xpos[d][2]}, t[3];
+        cross3(t, a, r);
+        v = dot3(u, t);
+      }
+    }
+    out[d] = v;
+  }
+}
+
+DEV void make_constraints(const DevModel* m, EnvLDS& L) {
+  int lane = wave_lane();
+  // ---- scalar rows: frictionloss (dof order) then active joint limits (joint order) — lane 0 builds the list
+  if (lane == 0) {
+    int n = 0;
+    for (int d = 0; d < NARM; d++) if (m->frictionloss[d] > 0.f) {
+      Row1& r = L.row[n++];
+      float imp = impedance(m->dof_solimp, 0.f), K, B;
+      kb_from_solref(m, m->dof_solref, m->dof_solimp, &K, &B);
+      r.dof = d; r.sign = 1.f; r.floss = m->frictionloss[d];
+      r.R = fmaxf(MINVAL_F, (1.f - imp) * m->dof_invweight0[d] / imp);
+      r.aref = -B * L.qvel[d];
+      r.f = 0.f; r.Ainv = 1.f / (L.Minv[d][d] + r.R);
+    }
+    for (int h = 0; h < NARM; h++) if (m->limited[h]) {
+      float q = L.qpos[h];
+      for (int side = 0; side < 2; side++) {
+        float pos = side == 0 ? q - m->range[h][0] : m->range[h][1] - q;
+        if (pos < 0.f) {
+          Row1& r = L.row[n++];
+          float imp = impedance(m->jnt_solimp, pos), K, B;
+          kb_from_solref(m, m->jnt_solref, m->jnt_solimp, &K, &B);
+          r.dof = h; r.sign = side == 0 ? 1.f : -1.f; r.floss = 0.f;
+          r.R = fmaxf(MINVAL_F, (1.f - imp) * m->dof_invweight0[h] / imp);
+          r.aref = -B * r.sign * L.qvel[h] - K * imp * pos;
+          r.f = 0.f; r.Ainv = 1.f / (L.Minv[h][h] + r.R);
+        }
+      }
+    }
+    L.nrow = n;
+    // arm-pool slots for contacts that touch an arm link (in contact order)
+    int slots = 0;
+    for (int k = 0; k < L.ncon; k++) {
+      Contact& c = L.con[k];
+      if ((c.d1 >= 0 && c.d1 < NARM) || (c.d2 >= 0 && c.d2 < NARM)) {
+        if (slots < MAXARMCON) c.armslot = slots++;
+        else { c.armslot = -2; L.overflow |= 4; }    // pool exhausted: contact is dropped below
+      }
+    }
+    L.narmcon = slots;
+  }
+  wave_sync();
+  // ---- contact rows: lane = contact
+  int ncon = L.ncon;
+  if (lane < ncon) {
+    Contact& c = L.con[lane];
+    int dim = c.dim;
+    float solref[2] = {c.aref[0], c.aref[1]}, solimp[5] = {c.f[0], c.f[1], c.f[2], c.f[3], c.f[4]};
+    float imp = impedance(solimp, c.dist), K, B;
+    kb_from_solref(m, solref, solimp, &K, &B);
+    float tran = 0.f, rotw = 0.f;
+    if (c.d1 >= 0) { tran += m->dyn_invweight0[c.d1][0]; rotw += m->dyn_invweight0[c.d1][1]; }
+    if (c.d2 >= 0) { tran += m->dyn_invweight0[c.d2][0]; rotw += m->dyn_invweight0[c.d2][1]; }
+    float R0 = fmaxf(MINVAL_F, (1.f - imp) * tran / imp);
+    float R1 = R0 / fmaxf(MINVAL_F, m->impratio);
+    float mu0 = c.fric[0];
+    c.R[0] = R0; c.R[1] = R1;
+    c.R[2] = fmaxf(MINVAL_F, R1 * mu0 * mu0 / (c.fric[1] * c.fric[1]));
+    c.R[3] = fmaxf(MINVAL_F, R1 * mu0 * mu0 / (c.fric[2] * c.fric[2]));
+    c.mu = mu0 * sqrtf(R1 / R0);
+    if (c.armslot == -2) { c.dim = 0; dim = 0; }
+    // per-row world "wrench directions": translational rows j<3 use frame[j]; rotational rows frame[j-3]
+    float A[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; j++)
+#pragma unroll
+      for (int k = 0; k < 6; k++) A[j][k] = 0.f;
+    float vel[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+      int d = side == 0 ? c.d1 : c.d2;
+      float sgn = side == 0 ? -1.f : 1.f;
+      if (d >= NARM) {
+        int f = d - NARM;
+        float r[3] = {c.pos[0] - L.xipos[d][0], c.pos[1] - L.xipos[d][1], c.pos[2] - L.xipos[d][2]};
+        float ul[6][3], ua[6][3], Iua[6][3];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+          const float* u = &c.frame[3 * (j % 3)];
+          if (j < 3) { ul[j][0] = u[0]; ul[j][1] = u[1]; ul[j][2] = u[2]; cross3(ua[j], r, u); }
+          else { ul[j][0] = ul[j][1] = ul[j][2] = 0.f; ua[j][0] = u[0]; ua[j][1] = u[1]; ua[j][2] = u[2]; }
+          symvec3(Iua[j], L.fIinv[f], ua[j]);
+          vel[j] += sgn * (dot3(ul[j], &L.fvel[f][0]) + dot3(ua[j], &L.fvel[f][3]));
+        }
+        float mi = L.fminv[f];
+#pragma unroll
+        for (int j = 0; j < 6; j++)
+#pragma unroll
+          for (int k = 0; k <= j; k++) A[j][k] += mi * dot3(ul[j], ul[k]) + dot3(ua[j], Iua[k]);
+      } else if (d >= 0 && c.armslot >= 0) {
+        ArmCon& ac = L.armcon[c.armslot];
+        float J[6][NARM], Bm[6][NARM];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+          arm_jac_row(L, d, c.pos, &c.frame[3 * (j % 3)], j >= 3, J[j]);
+#pragma unroll
+          for (int q = 0; q < NARM; q++) {
+            float v = 0.f;
+#pragma unroll
+            for (int s = 0; s < NARM; s++) v += L.Minv[q][s] * J[j][s];
+            Bm[j][q] = v;
+          }
+          float vj = 0.f;
+#pragma unroll
+          for (int q = 0; q < NARM; q++) { vj += J[j][q] * L.qvel[q]; ac.J[j][q] = sgn * J[j][q]; ac.B[j][q] = sgn * Bm[j][q]; }
+          vel[j] += sgn * vj;
+        }
+#pragma unroll
+        for (int j = 0; j < 6; j++)
+#pragma unroll
+          for (int k = 0; k <= j; k++) {
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < NARM; q++) v += J[j][q] * Bm[k][q];
+            A[j][k] += v;
+          }
+      }
+    }
+    const float Rj[6] = {c.R[0], c.R[1], c.R[1], c.R[2], c.R[3], c.R[3]};
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      A[j][j] += Rj[j];
+      c.aref[j] = -B * vel[j] - (j == 0 ? K * imp * c.dist : 0.f);
+      c.f[j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++)
+#pragma unroll
+      for (int k = 0; k <= j; k++) c.A[j * (j + 1) / 2 + k] = A[j][k];
+    // inverse of the friction block (rows 1..dim-1), via Cholesky; rows >= dim are decoupled (identity)
+    float Lf[5][5], Inv[5][5];
+    int nf = dim - 1;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      float dj = (j < nf) ? A[j + 1][j + 1] : 1.f;
+#pragma unroll
+      for (int k = 0; k < j; k++) dj -= Lf[j][k] * Lf[j][k];
+      dj = sqrtf(fmaxf(dj, 1e-30f));
+      Lf[j][j] = dj;
+#pragma unroll
+      for (int i = j + 1; i < 5; i++) {
+        float v = (i < nf && j < nf) ? A[i + 1][j + 1] : 0.f;
+#pragma unroll
+        for (int k = 0; k < j; k++) v -= Lf[i][k] * Lf[j][k];
+        Lf[i][j] = v / dj;
+      }
+    }
+#pragma unroll
+    for (int col = 0; col < 5; col++) {
+      float y[5];
+#pragma unroll
+      for (int i = 0; i < 5; i++) {
+        float v = (i == col) ? 1.f : 0.f;
+#pragma unroll
+        for (int k = 0; k < i; k++) v -= Lf[i][k] * y[k];
+        y[i] = v / Lf[i][i];
+      }
+#pragma unroll
+      for (int i = 4; i >= 0; i--) {
+        float v = y[i];
+#pragma unroll
+        for (int k = i + 1; k < 5; k++) v -= Lf[k][i] * Inv[k][col];
+        Inv[i][col] = v / Lf[i][i];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 5; j++)
+#pragma unroll
+      for (int k = 0; k <= j; k++) c.Ai[j * (j + 1) / 2 + k] = Inv[j][k];
+  }
+  wave_sync();
+}
+
+// ------------------------------------------------------------------ QCQP (uniform): min 0.5 x'Ax + b'x s.t. sum (x_i/d_i)^2 <= r^2
+DEV bool qcqp(float* res, const float* A /*5x5 full*/, const float* b, const float* dd, float r, int n) {
+  float As[5][5], bs[5], y[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    bs[i] = i < n ? b[i] * dd[i] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 5; j++) As[i][j] = (i < n && j < n) ? A[5 * i + j] * dd[i] * dd[j] : (i == j ? 1.f : 0.f);
+  }
+  float la = 0.f;
+  for (int iter = 0; iter < 20; iter++) {
+    float P[5][5];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      float v = As[j][j] + (j < n ? la : 0.f);
+#pragma unroll
+      for (int k = 0; k < j; k++) v -= P[j][k] * P[j][k];
+      if (v < MINVAL_F) ok = false;
+      v = sqrtf(fmaxf(v, 1e-30f));
+      P[j][j] = v;
+#pragma unroll
+      for (int i = j + 1; i < 5; i++) {
+        float w = As[i][j];
+#pragma unroll
+        for (int k = 0; k < j; k++) w -= P[i][k] * P[j][k];
+        P[i][j] = w / v;
+      }
+    }
+    if (!ok) {
+#pragma unroll
+      for (int i = 0; i < 5; i++) res[i] = 0.f;
+      return false;
+    }
+    float t[5], z[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) { float v = -bs[i]; _Pragma("unroll") for (int k = 0; k < i; k++) v -= P[i][k] * t[k]; t[i] = v / P[i][i]; }
+#pragma unroll
+    for (int i = 4; i >= 0; i--) { float v = t[i]; _Pragma("unroll") for (int k = i + 1; k < 5; k++) v -= P[k][i] * y[k]; y[i] = v / P[i][i]; }
+    float val = -r * r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) if (i < n) val += y[i] * y[i];
+    if (val < 1e-10f) break;
+#pragma unroll
+    for (int i = 0; i < 5; i++) { float v = (i < n) ? y[i] : 0.f; _Pragma("unroll") for (int k = 0; k < i; k++) v -= P[i][k] * t[k]; t[i] = v / P[i][i]; }
+#pragma unroll
+    for (int i = 4; i >= 0; i--) { float v = t[i]; _Pragma("unroll") for (int k = i + 1; k < 5; k++) v -= P[k][i] * z[k]; z[i] = v / P[i][i]; }
+    float deriv = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; i++) if (i < n) deriv += -2.f * y[i] * z[i];
+    float delta = -val / deriv;
+    if (delta < 1e-10f) break;
+    la += delta;
+  }
+#pragma unroll
+  for (int i = 0; i < 5; i++) res[i] = (i < n) ? y[i] * dd[i] : 0.f;
+  return la != 0.f;
+}
+
+// acceleration of body `d` projected on the 6 rows of contact c (signed for side)
+DEV void contact_jacc(const EnvLDS& L, const Contact& c, float* jv /*6*/, bool use_warm, const float* warm_arm, const float (*warm_free)[6]) {
+#pragma unroll
+  for (int j = 0; j < 6; j++) jv[j] = 0.f;
+#pragma unroll
+  for (int side = 0; side < 2; side++) {
+    int d = side == 0 ? c.d1 : c.d2;
+    float sgn = side == 0 ? -1.f : 1.f;
+    if (d >= NARM) {
+      int f = d - NARM;
+      const float* acc = use_warm ? warm_free[f] : L.facc[f];
+      float r[3] = {c.pos[0] - L.xipos[d][0], c.pos[1] - L.xipos[d][1], c.pos[2] - L.xipos[d][2]};
+      float al[3] = {acc[0], acc[1], acc[2]}, aa[3] = {acc[3], acc[4], acc[5]};
+      float t[3]; cross3(t, aa, r);           // (r x u).alpha = u.(alpha x r)
+      float pl[3] = {al[0] + t[0], al[1] + t[1], al[2] + t[2]};
+#pragma unroll
+      for (int j = 0; j < 3; j++) { jv[j] += sgn * dot3(&c.frame[3 * j], pl); jv[3 + j] += sgn * dot3(&c.frame[3 * j], aa); }
+    } else if (d >= 0 && c.armslot >= 0) {
+      const ArmCon& ac = L.armcon[c.armslot];
+      const float* acc = use_warm ? warm_arm : L.qacc_arm;
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < NARM; q++) v += ac.J[j][q] * acc[q];     // sign already folded into J
+        jv[j] += v;
+      }
+    }
+  }
+}
+
+// apply a force change df[6] of contact c to the accelerations (uniform; lanes < NARM / lane 0 write)
+DEV void contact_apply(EnvLDS& L, const Contact& c, const float* df) {
+  int lane = wave_lane();
+  float F[3], T0[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    F[i] = c.frame[i] * df[0] + c.frame[3 + i] * df[1] + c.frame[6 + i] * df[2];
+    T0[i] = c.frame[i] * df[3] + c.frame[3 + i] * df[4] + c.frame[6 + i] * df[5];
+  }
+#pragma unroll
+  for (int side = 0; side < 2; side++) {
+    int d = side == 0 ? c.d1 : c.d2;
+    float sgn = side == 0 ? -1.f : 1.f;
+    if (d >= NARM) {
+      int f = d - NARM;
+      float r[3] = {c.pos[0] - L.xipos[d][0], c.pos[1] - L.xipos[d][1], c.pos[2] - L.xipos[d][2]};
+      float T[3]; cross3(T, r, F);
+      T[0] += T0[0]; T[1] += T0[1]; T[2] += T0[2];
+      float da[3]; symvec3(da, L.fIinv[f], T);
+      float mi = L.fminv[f];
+      if (lane < 3) L.facc[f][lane] += sgn * mi * F[lane];
+      else if (lane < 6) L.facc[f][lane] += sgn * da[lane - 3];
+    } else if (d >= 0 && c.armslot >= 0) {
+      const ArmCon& ac = L.armcon[c.armslot];
+      if (lane < NARM) {
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; j++) v += ac.B[j][lane] * df[j];
+        L.qacc_arm[lane] += v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ PGS (velocity space, rows in MuJoCo order)
+DEV void solve_pgs(const DevModel* m, EnvLDS& L, int max_iter, float tolerance) {
+  int lane = wave_lane();
+  int nrow = L.nrow, ncon = L.ncon;
+  if (lane == 0) L.iters = 0;
+  if (nrow + ncon == 0) { wave_sync(); return; }
+  // ---- warm start: forces from the previous qacc (mj_constraintUpdate), kept iff the dual cost is negative
+  {
+    // previous qacc in solver coordinates
+    float warm_arm[NARM], warm_free[NFREE][6];
+#pragma unroll
+    for (int d = 0; d < NARM; d++) warm_arm[d] = L.warm[d];
+#pragma unroll
+    for (int f = 0; f < NFREE; f++) {
+      int b = NARM + f;
+      const float* wq = &L.warm[NARM + 6 * f];
+      float wb[3] = {wq[3], wq[4], wq[5]}, alp[3];
+      matvec3(alp, L.xmat[b], wb);
+      float r[3] = {L.xipos[b][0] - L.xpos[b][0], L.xipos[b][1] - L.xpos[b][1], L.xipos[b][2] - L.xpos[b][2]};
+      float ww[3] = {L.fvel[f][3], L.fvel[f][4], L.fvel[f][5]};
+      float t1[3], t2[3];
+      cross3(t1, alp, r); cross3(t2, ww, r); cross3(t2, ww, t2);
+#pragma unroll
+      for (int i = 0; i < 3; i++) { warm_free[f][i] = wq[i] + t1[i] + t2[i]; warm_free[f][3 + i] = alp[i]; }
+    }
+    if (lane < nrow) {
+      Row1& r = L.row[lane];
+      float jar = r.sign * L.warm[r.dof] - r.aref;
+      float D = 1.f / r.R, f = -D * jar;
+      if (r.floss > 0.f) f = fminf(fmaxf(f, -r.floss), r.floss);
+      else f = jar < 0.f ? f : 0.f;
+      r.f = f;
+    }
+    if (lane < ncon) {
+      Contact& c = L.con[lane];
+      float jar[6];
+      contact_jacc(L, c, jar, true, warm_arm, warm_free);
+      const float Rj[6] = {c.R[0], c.R[1], c.R[1], c.R[2], c.R[3], c.R[3]};
+      const float fr[5] = {c.fric[0], c.fric[0], c.fric[1], c.fric[2], c.fric[2]};
+      int dim = c.dim;
+#pragma unroll
+      for (int j = 0; j < 6; j++) jar[j] -= c.aref[j];
+      float mu = c.mu, U[6], T = 0.f;
+      U[0] = jar[0] * mu;
+#pragma unroll
+      for (int j = 1; j < 6; j++) { U[j] = (j < dim) ? jar[j] * fr[j - 1] : 0.f; T += U[j] * U[j]; }
+      T = sqrtf(T);
+      float N = U[0], fo[6];
+      if ((N >= mu * T) || (T <= 0.f && N >= 0.f)) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) fo[j] = 0.f;
+      } else if ((mu * N + T <= 0.f) || (T <= 0.f && N < 0.f)) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) fo[j] = (j < dim) ? -jar[j] / Rj[j] : 0.f;
+      } else {
+        float Dm = (1.f / Rj[0]) / fmaxf(mu * mu * (1.f + mu * mu), MINVAL_F), NmT = N - mu * T;
+        fo[0] = -Dm * NmT * mu;
+#pragma unroll
+        for (int j = 1; j < 6; j++) fo[j] = (j < dim) ? -fo[0] / T * U[j] * fr[j - 1] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 6; j++) c.f[j] = fo[j];
+    }
+    wave_sync();
+    // dual cost  sum f.(0.5*(A f) + b) with A f evaluated through the accelerations the forces produce
+    if (lane < NARM) L.scratch[lane] = L.qacc_arm[lane];
+    if (lane >= 32 && lane < 32 + 6 * NFREE) L.scratch[8 + lane - 32] = L.facc[(lane - 32) / 6][(lane - 32) % 6];
+    wave_sync();
+    for (int k = 0; k < nrow; k++) {
+      float f = L.row[k].f, sg = L.row[k].sign; int d = L.row[k].dof;
+      if (lane < NARM) L.qacc_arm[lane] += L.Minv[lane][d] * sg * f;
+    }
+    wave_sync();
+    for (int k = 0; k < ncon; k++) {
+      float df[6];
+#pragma unroll
+      for (int j = 0; j < 6; j++) df[j] = L.con[k].f[j];
+      contact_apply(L, L.con[k], df);
+      wave_sync();
+    }
+    // now acc = smooth + Minv J^T f ;  A f = J(acc - smooth) + R f ;  b = J smooth - aref
+    float cost = 0.f;
+    if (lane < nrow) {
+      Row1& r = L.row[lane];
+      float jn = r.sign * L.qacc_arm[r.dof], js = r.sign * L.scratch[r.dof];
+      cost += r.f * (0.5f * (jn - js + r.R * r.f) + js - r.aref);
+    }
+    wave_sync();
+    float jn6[6] = {0, 0, 0, 0, 0, 0};
+    if (lane < ncon) contact_jacc(L, L.con[lane], jn6, false, nullptr, nullptr);
+    wave_sync();
+    // swap smooth accelerations back in to evaluate J*smooth, keep the warm ones in registers
+    float keep_arm = lane < NARM ? L.qacc_arm[lane] : 0.f;
+    float keep_free = (lane >= 32 && lane < 32 + 6 * NFREE) ? L.facc[(lane - 32) / 6][(lane - 32) % 6] : 0.f;
+    wave_sync();
+    if (lane < NARM) L.qacc_arm[lane] = L.scratch[lane];
+    if (lane >= 32 && lane < 32 + 6 * NFREE) L.facc[(lane - 32) / 6][(lane - 32) % 6] = L.scratch[8 + lane - 32];
+    wave_sync();
+    if (lane < ncon) {
+      Contact& c = L.con[lane];
+      float js6[6];
+      contact_jacc(L, c, js6, false, nullptr, nullptr);
+      const float Rj[6] = {c.R[0], c.R[1], c.R[1], c.R[2], c.R[3], c.R[3]};
+#pragma unroll
+      for (int j = 0; j < 6; j++) if (j < c.dim) cost += c.f[j] * (0.5f * (jn6[j] - js6[j] + Rj[j] * c.f[j]) + js6[j] - c.aref[j]);
+    }
+    cost = wave_sum_f(cost);
+    wave_sync();
+    if (cost > 0.f) {       // worse than zero forces: cold start (accelerations are already the smooth ones)
+      if (lane < nrow) L.row[lane].f = 0.f;
+      if (lane < ncon) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) L.con[lane].f[j] = 0.f;
+      }
+    } else {
+      if (lane < NARM) L.qacc_arm[lane] = keep_arm;
+      if (lane >= 32 && lane < 32 + 6 * NFREE) L.facc[(lane - 32) / 6][(lane - 32) % 6] = keep_free;
+    }
+    wave_sync();
+  }
+  // ---- main iteration
+  float scale = 1.f / (m->meaninertia * (float)NV);
+  int it = 0;
+  for (; it < max_iter; it++) {
+    float improvement = 0.f;
+    for (int k = 0; k < nrow; k++) {
+      Row1& r = L.row[k];
+      int d = r.dof; float sg = r.sign, fold = r.f;
+      float res = sg * L.qacc_arm[d] - r.aref + r.R * fold;
+      float Add = 1.f / r.Ainv;
+      float fnew = fold - res * r.Ainv;
+      if (r.floss > 0.f) fnew = fminf(fmaxf(fnew, -r.floss), r.floss);
+      else if (fnew < 0.f) fnew = 0.f;
+      float df = fnew - fold;
+      float change = df * (0.5f * Add * df + res);
+      if (change > 1e-10f) { df = 0.f; change = 0.f; fnew = fold; }
+      improvement -= change;
+      wave_sync();
+      if (lane < NARM) L.qacc_arm[lane] += L.Minv[lane][d] * sg * df;
+      if (lane == 0) r.f = fnew;
+      wave_sync();
+    }
+    for (int k = 0; k < ncon; k++) {
+      Contact& c = L.con[k];
+      int dim = c.dim;
+      if (dim == 0) continue;
+      float res[6], old[6], f[6];
+      contact_jacc(L, c, res, false, nullptr, nullptr);
+      const float Rj[6] = {c.R[0], c.R[1], c.R[1], c.R[2], c.R[3], c.R[3]};
+      const float fr[5] = {c.fric[0], c.fric[0], c.fric[1], c.fric[2], c.fric[2]};
+      float A[6][6];
+#pragma unroll
+      for (int j = 0; j < 6; j++)
+#pragma unroll
+        for (int q = 0; q <= j; q++) { float v = c.A[j * (j + 1) / 2 + q]; A[j][q] = v; A[q][j] = v; }
+#pragma unroll
+      for (int j = 0; j < 6; j++) { old[j] = c.f[j]; f[j] = old[j]; res[j] = (j < dim) ? res[j] - c.aref[j] + Rj[j] * old[j] : 0.f; }
+      // normal / ray update
+      if (f[0] < MINVAL_F) {
+        f[0] -= res[0] / A[0][0];
+        if (f[0] < 0.f) f[0] = 0.f;
+#pragma unroll
+        for (int j = 1; j < 6; j++) f[j] = 0.f;
+      } else {
+        float denom = 0.f, vr = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+          float v1 = 0.f;
+#pragma unroll
+          for (int q = 0; q < 6; q++) v1 += A[j][q] * f[q];
+          denom += f[j] * v1; vr += f[j] * res[j];
+        }
+        if (denom >= MINVAL_F) {
+          float x = -vr / denom;
+          if (f[0] + x * f[0] < 0.f) x = -1.f;
+#pragma unroll
+          for (int j = 0; j < 6; j++) f[j] += x * old[j];
+        }
+      }
+      // friction update with the normal fixed
+      if (f[0] >= MINVAL_F && dim > 1) {
+        float bc[5], v[5];
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+          float b = res[j + 1];
+#pragma unroll
+          for (int q = 0; q < 5; q++) b -= A[j + 1][q + 1] * old[q + 1];
+          b += A[j + 1][0] * (f[0] - old[0]);
+          bc[j] = (j + 1 < dim) ? b : 0.f;
+        }
+        // unconstrained minimum through the precomputed inverse
+        float ssq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+          float s = 0.f;
+#pragma unroll
+          for (int q = 0; q < 5; q++) s -= c.Ai[tri(j, q)] * bc[q];
+          v[j] = (j + 1 < dim) ? s : 0.f;
+          ssq += (v[j] / fr[j]) * (v[j] / fr[j]);
+        }
+        if (ssq - f[0] * f[0] >= 1e-10f) {
+          // outside the cone: Newton iteration on the multiplier (mju_QCQP)
+          float Ac[25];
+#pragma unroll
+          for (int j = 0; j < 5; j++)
+#pragma unroll
+            for (int q = 0; q < 5; q++) Ac[5 * j + q] = A[j + 1][q + 1];
+          bool active = qcqp(v, Ac, bc, fr, f[0], dim - 1);
+          if (active) {
+            float s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 5; j++) s2 += (v[j] / fr[j]) * (v[j] / fr[j]);
+            float sc = sqrtf(f[0] * f[0] / fmaxf(MINVAL_F, s2));
+#pragma unroll
+            for (int j = 0; j < 5; j++) v[j] *= sc;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 5; j++) f[j + 1] = v[j];
+      }
+      float df[6], change = 0.f;
+#pragma unroll
+      for (int j = 0; j < 6; j++) df[j] = f[j] - old[j];
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        float v1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 6; q++) v1 += A[j][q] * df[q];
+        change += df[j] * (0.5f * v1 + res[j]);
+      }
+      if (change > 1e-10f) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) { df[j] = 0.f; f[j] = old[j]; }
+        change = 0.f;
+      }
+      improvement -= change;
+      wave_sync();
+      contact_apply(L, c, df);
+      if (lane < 6) c.f[lane] = f[0] * (lane == 0) + f[1] * (lane == 1) + f[2] * (lane == 2) + f[3] * (lane == 3) + f[4] * (lane == 4) + f[5] * (lane == 5);
+      wave_sync();
+    }
+    if (improvement * scale < tolerance) { it++; break; }
+  }
+  if (lane == 0) L.iters = it;
+  wave_sync();
+}
+
+// ------------------------------------------------------------------ forward + Euler
+DEV void forward(const DevModel* m, EnvLDS& L, int max_iter, float tolerance) {
+  kinematics(m, L);
+  crba_arm(m, L);
+  smooth_dynamics(m, L);
+  collision(m, L);
+  make_constraints(m, L);
+  solve_pgs(m, L, max_iter, tolerance);
+  // back to MuJoCo's generalized accelerations
+  int lane = wave_lane();
+  if (lane < NARM) L.qacc[lane] = L.qacc_arm[lane];
+  if (lane >= 32 && lane < 32 + NFREE) {
+    int f = lane - 32, b = NARM + f;
+    float r[3] = {L.xipos[b][0] - L.xpos[b][0], L.xipos[b][1] - L.xpos[b][1], L.xipos[b][2] - L.xpos[b][2]};
+    float al[3] = {L.facc[f][3], L.facc[f][4], L.facc[f][5]}, ww[3] = {L.fvel[f][3], L.fvel[f][4], L.fvel[f][5]};
+    float t1[3], t2[3], ab[3];
+    cross3(t1, al, r); cross3(t2, ww, r); cross3(t2, ww, t2);
+    matTvec3(ab, L.xmat[b], al);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { L.qacc[NARM + 6 * f + i] = L.facc[f][i] - t1[i] - t2[i]; L.qacc[NARM + 6 * f + 3 + i] = ab[i]; }
+  }
+  wave_sync();
+}
+
+DEV void euler(const DevModel* m, EnvLDS& L) {
+  int lane = wave_lane();
+  float dt = m->dt;
+  if (lane < NV) { L.qvel[lane] += dt * L.qacc[lane]; L.warm[lane] = L.qacc[lane]; }
+  wave_sync();
+  if (lane < NARM) L.qpos[lane] += dt * L.qvel[lane];
+  if (lane >= 32 && lane < 32 + NFREE) {
+    int f = lane - 32;
+    float* q = &L.qpos[NARM + 7 * f]; const float* v = &L.qvel[NARM + 6 * f];
+    q[0] += dt * v[0]; q[1] += dt * v[1]; q[2] += dt * v[2];
+    float w[3] = {v[3], v[4], v[5]};
+    float ang = dt * normalize3(w);
+    float sn = sinf(0.5f * ang), dq[4] = {cosf(0.5f * ang), w[0] * sn, w[1] * sn, w[2] * sn};
+    float qq[4] = {q[3], q[4], q[5], q[6]};
+    mulquat(qq, qq, dq);
+    normquat(qq);
+    q[3] = qq[0]; q[4] = qq[1]; q[5] = qq[2]; q[6] = qq[3];
+  }
+  wave_sync();
+}
+
+DEV void substep(const DevModel* m, EnvLDS& L, int max_iter, float tolerance, bool freeze_arm) {
+  forward(m, L, max_iter, tolerance);
+  euler(m, L);
+  if (freeze_arm) {   // dm_control JointStaticIsolator: non-prop joints restored after every step
+    int lane = wave_lane();
+    if (lane < NARM) { L.qpos[lane] = L.arm0_q[lane]; L.qvel[lane] = L.arm0_v[lane]; }
+    wave_sync();
+  }
+}
+
+// ------------------------------------------------------------------ reward (uniform): so100_hand_over.py:238-275
+struct BoxW { float pos[3], quat[4], half[3]; };
+
+DEV bool overlap_aabb_oobb(const float* half0, const BoxW& b) {
+  float R[9]; quat2mat(R, b.quat);
+  // 6 face axes only, strict inequalities (oobb_utils.py:223-246); projections of the 8 corners reduce to centre +- extent
+  bool sep = false;
+#pragma unroll
+  for (int a = 0; a < 6; a++) {
+    float ax[3];
+    if (a < 3) { ax[0] = a == 0; ax[1] = a == 1; ax[2] = a == 2; }
+    else { ax[0] = R[a - 3]; ax[1] = R[3 + a - 3]; ax[2] = R[6 + a - 3]; }
+    float mx0 = -3e38f, mn0 = 3e38f, mx1 = -3e38f, mn1 = 3e38f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      float sx = (i & 1) ? 1.f : -1.f, sy = (i & 2) ? 1.f : -1.f, sz = (i & 4) ? 1.f : -1.f;
+      float av[3] = {sx * half0[0], sy * half0[1], sz * half0[2]};
+      float lv[3] = {sx * b.half[0], sy * b.half[1], sz * b.half[2]}, ov[3];
+      matvec3(ov, R, lv);
+      ov[0] += b.pos[0]; ov[1] += b.pos[1]; ov[2] += b.pos[2];
+      float p0 = dot3(av, ax), p1 = dot3(ov, ax);
+      mx0 = fmaxf(mx0, p0); mn0 = fminf(mn0, p0); mx1 = fmaxf(mx1, p1); mn1 = fminf(mn1, p1);
+    }
+    if (mx0 < mn1 || mn0 > mx1) sep = true;
+  }
+  return !sep;
+}
+
+DEV bool overlap_oobb_oobb(const BoxW& b0, const BoxW& b1) {
+  float inv[4] = {b0.quat[0], -b0.quat[1], -b0.quat[2], -b0.quat[3]};
+  float dp[3] = {b1.pos[0] - b0.pos[0], b1.pos[1] - b0.pos[1], b1.pos[2] - b0.pos[2]};
+  BoxW r;
+  rotvecquat(r.pos, dp, inv);
+  mulquat(r.quat, inv, b1.quat);
+  r.half[0] = b1.half[0]; r.half[1] = b1.half[1]; r.half[2] = b1.half[2];
+  return overlap_aabb_oobb(b0.half, r);
+}
+
+// requires kinematics() of the current qpos to be in LDS
+DEV float task_reward(const DevModel* m, const EnvLDS& L) {
+  // any_props_moving: linear part only, >= 1e-3 (success_detector_utils.py:22-28)
+#pragma unroll
+  for (int f = 0; f < NFREE; f++) {
+    const float* v = &L.qvel[NARM + 6 * f];
+    float mx = fmaxf(fabsf(v[0]), fmaxf(fabsf(v[1]), fabsf(v[2])));
+    if (mx >= 1e-3f) return 0.f;
+  }
+  int ob = NARM + 0, cb = NARM + 1;
+  BoxW o;
+  float im[9], xim[9];
+  quat2mat(im, m->free_iquat[0]);
+  matmul3(xim, L.xmat[ob], im);
+  mat2quat(o.quat, xim);
+  float ctr[3]; rotvecquat(ctr, m->free_bvh[0], o.quat);
+#pragma unroll
+  for (int i = 0; i < 3; i++) { o.pos[i] = ctr[i] + L.xipos[ob][i]; o.half[i] = m->free_bvh[0][3 + i]; }
+  const float* cq_ = &L.qpos[NARM + 7 + 3];
+  float cq[4] = {cq_[0], cq_[1], cq_[2], cq_[3]};
+  normquat(cq);
+  for (int k = 0; k < m->nbox; k++) {
+    BoxW cw;
+    float r[3]; rotvecquat(r, m->box_pos[k], cq);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { cw.pos[i] = L.xpos[cb][i] + r[i]; cw.half[i] = m->box_half[k][i]; }
+    float ident[4] = {1.f, 0.f, 0.f, 0.f};
+    mulquat(cw.quat, cq, ident);
+    if (!overlap_oobb_oobb(o, cw)) return 0.f;
+  }
+  return 1.f;
+}
+
+// ------------------------------------------------------------------ counter RNG (Philox4x32-10), 24-bit uniforms
+DEV float rng_uniform(unsigned long long seed, unsigned long long env, unsigned int episode, unsigned int draw) {
+  unsigned int c0 = (unsigned int)env, c1 = (unsigned int)(env >> 32), c2 = episode, c3 = draw;
+  unsigned int k0 = (unsigned int)seed, k1 = (unsigned int)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    unsigned int n0 = (unsigned int)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned int)p1, n2 = (unsigned int)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned int)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return (float)(c0 >> 8) * (1.0f / 16777216.0f);
+}

@@ -1,0 +1,375 @@
+// libso101_hip.so — C ABI (include/so101.h) over the gfx950 kernels.  Host side: blob parsing, device
+// copy of the model, launch plumbing.  No torch types, no CPU compute path: every entry point that
+// does physics launches a HIP kernel or fails.
+#include "../../include/so101.h"
+#include "so101_kernels.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct BlobView {
+  std::map<std::string, std::pair<const uint8_t*, uint32_t>> ent;
+  bool parse(const void* p, size_t bytes, std::string& err) {
+    if (bytes < 16) { err = "blob too small"; return false; }
+    const uint8_t* b = (const uint8_t*)p;
+    uint32_t magic, ver, rb, n;
+    memcpy(&magic, b, 4); memcpy(&ver, b + 4, 4); memcpy(&rb, b + 8, 4); memcpy(&n, b + 12, 4);
+    if (magic != 0x424D3153u) { err = "bad blob magic"; return false; }
+    if (ver != 3) { err = "unsupported blob version"; return false; }
+    if (rb != 4) { err = "the HIP library needs the f32 blob"; return false; }
+    if (16 + (size_t)48 * n > bytes) { err = "truncated blob directory"; return false; }
+    for (uint32_t k = 0; k < n; k++) {
+      const uint8_t* e = b + 16 + 48 * k;
+      char name[33]; memcpy(name, e, 32); name[32] = 0;
+      uint32_t kd, cnt; uint64_t off;
+      memcpy(&kd, e + 32, 4); memcpy(&cnt, e + 36, 4); memcpy(&off, e + 40, 8);
+      if (off + (size_t)cnt * 4 > bytes) { err = std::string("truncated blob entry ") + name; return false; }
+      ent[name] = {b + off, cnt};
+    }
+    return true;
+  }
+  bool has(const char* n) const { return ent.count(n) != 0; }
+  std::vector<int> I(const char* n) const {
+    std::vector<int> v; auto it = ent.find(n);
+    if (it != ent.end()) { v.resize(it->second.second); memcpy(v.data(), it->second.first, 4 * v.size()); }
+    return v;
+  }
+  std::vector<float> F(const char* n) const {
+    std::vector<float> v; auto it = ent.find(n);
+    if (it != ent.end()) { v.resize(it->second.second); memcpy(v.data(), it->second.first, 4 * v.size()); }
+    return v;
+  }
+};
+
+void h_quat2mat(float* m, const float* q) {
+  float w = q[0], x = q[1], y = q[2], z = q[3];
+  m[0] = 1 - 2 * (y * y + z * z); m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+  m[3] = 2 * (x * y + w * z); m[4] = 1 - 2 * (x * x + z * z); m[5] = 2 * (y * z - w * x);
+  m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = 1 - 2 * (x * x + y * y);
+}
+void h_mulquat(float* o, const float* a, const float* b) {
+  float t[4] = {a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]};
+  memcpy(o, t, sizeof t);
+}
+void h_matmul(float* o, const float* a, const float* b) {
+  float t[9];
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) t[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+  memcpy(o, t, sizeof t);
+}
+// I = R diag(d) R^T packed xx yy zz xy xz yz
+void h_inertia(float* o, const float* iquat, const float* diag, bool inverse) {
+  float R[9]; h_quat2mat(R, iquat);
+  float d[3] = {inverse ? 1.f / diag[0] : diag[0], inverse ? 1.f / diag[1] : diag[1], inverse ? 1.f / diag[2] : diag[2]};
+  auto e = [&](int i, int j) { return R[3 * i] * d[0] * R[3 * j] + R[3 * i + 1] * d[1] * R[3 * j + 1] + R[3 * i + 2] * d[2] * R[3 * j + 2]; };
+  o[0] = e(0, 0); o[1] = e(1, 1); o[2] = e(2, 2); o[3] = e(0, 1); o[4] = e(0, 2); o[5] = e(1, 2);
+}
+
+}  // namespace
+
+struct so101_sim {
+  int n_envs = 0, device = 0;
+  uint64_t seed = 0;
+  DevModel hm{};               // host copy (device pointers inside)
+  DevModel* dm = nullptr;      // device copy
+  std::vector<void*> owned;    // device allocations to free
+  so101_config cfg{};
+  DevBuffers buf{};
+  bool bound = false;
+  unsigned char* need_reset = nullptr;
+  int* diag = nullptr;
+  std::string err;
+};
+
+namespace {
+
+bool hip_ok(so101_sim* s, hipError_t e, const char* what) {
+  if (e == hipSuccess) return true;
+  s->err = std::string(what) + ": " + hipGetErrorString(e);
+  return false;
+}
+
+template <typename T>
+bool upload(so101_sim* s, const std::vector<T>& v, const T** out) {
+  void* p = nullptr;
+  size_t bytes = std::max<size_t>(v.size(), 1) * sizeof(T);
+  if (!hip_ok(s, hipMalloc(&p, bytes), "hipMalloc(model)")) return false;
+  s->owned.push_back(p);
+  if (!v.empty() && !hip_ok(s, hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy(model)")) return false;
+  *out = (const T*)p;
+  return true;
+}
+
+StepParams make_params(const so101_sim* s) {
+  StepParams P{};
+  for (int k = 0; k < NU; k++) P.action_offset[k] = s->cfg.action_offset[k];
+  P.last_step = s->cfg.last_step; P.n_substeps = s->cfg.n_substeps;
+  P.iterations = s->cfg.solver_iterations > 0 ? s->cfg.solver_iterations : s->hm.iterations;
+  P.tolerance = s->cfg.solver_tolerance >= 0.f ? s->cfg.solver_tolerance : s->hm.tolerance;
+  P.settle_max = s->cfg.settle_max_substeps; P.terminate_on_success = s->cfg.terminate_on_success;
+  P.n_envs = s->n_envs; P.seed = s->seed; P.env_id_base = s->cfg.env_id_base;
+  return P;
+}
+
+int build_model(so101_sim* s, const BlobView& b) {
+  auto fail = [&](const std::string& msg) { s->err = msg; return (int)SO101_ERR_MODEL; };
+  const char* need[] = {"nq", "nv", "nu", "nbody", "ngeom", "narm", "nfree", "arm_body", "free_body", "body_parent", "body_pos",
+                        "body_quat", "body_jnttype", "geom_type", "geom_body", "mesh_vert", "pair_geom", "task_object_body"};
+  for (const char* n : need) if (!b.has(n)) return fail(std::string("blob entry missing: ") + n);
+  DevModel& M = s->hm;
+  int nq = b.I("nq")[0], nv = b.I("nv")[0], nu = b.I("nu")[0], nbody = b.I("nbody")[0], ngeom = b.I("ngeom")[0];
+  int narm = b.I("narm")[0], nfree = b.I("nfree")[0];
+  if (narm != NARM || nfree != NFREE || nq != NQ || nv != NV || nu != NU)
+    return fail("model topology outside this build (need a 6-hinge chain and 2 free bodies)");
+  if (ngeom > MAXGEOM) return fail("too many collision geoms for this build");
+  auto arm_body = b.I("arm_body"), free_body = b.I("free_body"), parent = b.I("body_parent"), jt = b.I("body_jnttype");
+  auto bpos = b.F("body_pos"), bquat = b.F("body_quat"), ipos = b.F("body_ipos"), iquat = b.F("body_iquat");
+  auto mass = b.F("body_mass"), inertia = b.F("body_inertia"), invw = b.F("body_invweight0"), bvh = b.F("body_bvh_aabb");
+  for (int k = 1; k < NARM; k++) if (parent[arm_body[k]] != arm_body[k - 1]) return fail("arm links do not form a serial chain");
+  if (jt[parent[arm_body[0]]] != 0) return fail("arm base must be static");
+  for (int f = 0; f < NFREE; f++) if (parent[free_body[f]] != 0) return fail("free bodies must be children of the world");
+  if (b.I("task_object_body")[0] != free_body[0] || b.I("task_container_body")[0] != free_body[1])
+    return fail("free bodies must be ordered (object, container)");
+  // world pose of static bodies
+  std::vector<float> wpos(3 * nbody, 0.f), wquat(4 * nbody, 0.f);
+  std::vector<int> is_static(nbody, 0);
+  wquat[0] = 1.f; is_static[0] = 1;
+  for (int i = 1; i < nbody; i++) {
+    if (jt[i] != 0 || !is_static[parent[i]]) continue;
+    is_static[i] = 1;
+    float R[9]; h_quat2mat(R, &wquat[4 * parent[i]]);
+    for (int k = 0; k < 3; k++) wpos[3 * i + k] = wpos[3 * parent[i] + k] + R[3 * k] * bpos[3 * i] + R[3 * k + 1] * bpos[3 * i + 1] + R[3 * k + 2] * bpos[3 * i + 2];
+    h_mulquat(&wquat[4 * i], &wquat[4 * parent[i]], &bquat[4 * i]);
+  }
+  int base = parent[arm_body[0]];
+  for (int k = 0; k < 3; k++) M.base_pos[k] = wpos[3 * base + k];
+  for (int k = 0; k < 4; k++) M.base_quat[k] = wquat[4 * base + k];
+  M.ngeom = ngeom; M.npair = b.I("npair")[0]; M.nvert = b.I("nvert")[0];
+  M.iterations = b.I("opt_iterations")[0]; M.mpr_iter = b.I("opt_mpr_iterations")[0]; M.nbox = b.I("task_nbox")[0];
+  if (M.nbox > 2) return fail("at most 2 overlap boxes");
+  if (!b.I("opt_cone_elliptic")[0]) return fail("only elliptic cones are implemented (scene_pbr.xml:4)");
+  M.dt = b.F("opt_timestep")[0]; auto g = b.F("opt_gravity"); for (int k = 0; k < 3; k++) M.grav[k] = g[k];
+  M.impratio = b.F("opt_impratio")[0]; M.tolerance = b.F("opt_tolerance")[0]; M.mpr_tol = b.F("opt_mpr_tolerance")[0];
+  M.meaninertia = b.F("stat_meaninertia")[0];
+  auto axis = b.F("jnt_axis"), range = b.F("jnt_range"), arma = b.F("dof_armature"), floss = b.F("dof_frictionloss");
+  auto limited = b.I("jnt_limited");
+  auto dofw = b.F("dof_invweight0"), damping = b.F("dof_damping");
+  auto jsr = b.F("jnt_solref"), jsi = b.F("jnt_solimp"), dsr = b.F("dof_solref"), dsi = b.F("dof_solimp");
+  for (int k = 0; k < NARM; k++) {
+    int bi = arm_body[k];
+    for (int i = 0; i < 3; i++) { M.arm_pos[k][i] = bpos[3 * bi + i]; M.arm_axis[k][i] = axis[3 * k + i]; M.arm_ipos[k][i] = ipos[3 * bi + i]; }
+    for (int i = 0; i < 4; i++) M.arm_quat[k][i] = bquat[4 * bi + i];
+    h_inertia(M.arm_Ib[k], &iquat[4 * bi], &inertia[3 * bi], false);
+    M.arm_mass[k] = mass[bi]; M.armature[k] = arma[k]; M.frictionloss[k] = floss[k];
+    M.range[k][0] = range[2 * k]; M.range[k][1] = range[2 * k + 1]; M.limited[k] = limited[k];
+    if (damping[k] != 0.f) return fail("joint damping is outside this build (SO100 arm has none)");
+    for (int i = 0; i < 2; i++) if (jsr[2 * k + i] != jsr[i] || dsr[2 * k + i] != dsr[i]) return fail("per-joint solref must be uniform");
+    for (int i = 0; i < 5; i++) if (jsi[5 * k + i] != jsi[i] || dsi[5 * k + i] != dsi[i]) return fail("per-joint solimp must be uniform");
+  }
+  for (int i = 0; i < 2; i++) { M.jnt_solref[i] = jsr[i]; M.dof_solref[i] = dsr[i]; }
+  for (int i = 0; i < 5; i++) { M.jnt_solimp[i] = jsi[i]; M.dof_solimp[i] = dsi[i]; }
+  for (int d = 0; d < NV; d++) M.dof_invweight0[d] = dofw[d];
+  auto again = b.F("act_gain"), abias = b.F("act_bias"), acr = b.F("act_ctrlrange"), afr = b.F("act_forcerange");
+  auto acl = b.I("act_ctrllimited"), afl = b.I("act_forcelimited"), adof = b.I("act_dof");
+  for (int a = 0; a < NU; a++) {
+    if (adof[a] != a) return fail("actuator a must drive dof a");
+    M.act_gain[a] = again[a];
+    for (int i = 0; i < 3; i++) M.act_bias[a][i] = abias[3 * a + i];
+    for (int i = 0; i < 2; i++) { M.ctrlrange[a][i] = acr[2 * a + i]; M.forcerange[a][i] = afr[2 * a + i]; }
+    M.ctrllimited[a] = acl[a]; M.forcelimited[a] = afl[a];
+  }
+  std::vector<int> dyn_of_body(nbody, -1);
+  for (int k = 0; k < NARM; k++) dyn_of_body[arm_body[k]] = k;
+  for (int f = 0; f < NFREE; f++) {
+    int bi = free_body[f];
+    dyn_of_body[bi] = NARM + f;
+    M.free_mass[f] = mass[bi];
+    for (int i = 0; i < 3; i++) M.free_ipos[f][i] = ipos[3 * bi + i];
+    for (int i = 0; i < 4; i++) M.free_iquat[f][i] = iquat[4 * bi + i];
+    h_inertia(M.free_Ib[f], &iquat[4 * bi], &inertia[3 * bi], false);
+    h_inertia(M.free_Ibinv[f], &iquat[4 * bi], &inertia[3 * bi], true);
+    for (int i = 0; i < 6; i++) M.free_bvh[f][i] = bvh[6 * bi + i];
+  }
+  for (int bi = 0; bi < nbody; bi++) if (dyn_of_body[bi] >= 0) { M.dyn_invweight0[dyn_of_body[bi]][0] = invw[2 * bi]; M.dyn_invweight0[dyn_of_body[bi]][1] = invw[2 * bi + 1]; }
+  auto bp = b.F("task_box_pos"), bh = b.F("task_box_half");
+  for (int k = 0; k < M.nbox; k++) for (int i = 0; i < 3; i++) { M.box_pos[k][i] = bp[3 * k + i]; M.box_half[k][i] = bh[3 * k + i]; }
+  auto olo = b.F("task_obj_pos_lo"), ohi = b.F("task_obj_pos_hi"), oy = b.F("task_obj_yaw"), clo = b.F("task_con_pos_lo"), chi = b.F("task_con_pos_hi"), hc = b.F("task_home_ctrl");
+  for (int i = 0; i < 3; i++) { M.obj_lo[i] = olo[i]; M.obj_hi[i] = ohi[i]; M.con_lo[i] = clo[i]; M.con_hi[i] = chi[i]; }
+  M.obj_yaw[0] = oy[0]; M.obj_yaw[1] = oy[1];
+  for (int i = 0; i < NU; i++) M.home_ctrl[i] = hc[i];
+  // geoms: dynamic ones keep body-local frames, static ones are resolved to world frames here
+  auto gtype = b.I("geom_type"), gbody = b.I("geom_body"), gcondim = b.I("geom_condim"), gva = b.I("geom_vertadr"), gvn = b.I("geom_vertnum");
+  auto gpos = b.F("geom_pos"), gquat = b.F("geom_quat"), gsize = b.F("geom_size"), gfr = b.F("geom_friction"), gsr = b.F("geom_solref");
+  auto gsi = b.F("geom_solimp"), gctr = b.F("geom_center"), gaabb = b.F("geom_aabb"), gmix = b.F("geom_solmix"), gmargin = b.F("geom_margin"), ggap = b.F("geom_gap");
+  auto gprio = b.I("geom_priority");
+  std::vector<int> gdyn(ngeom);
+  std::vector<float> gp(3 * ngeom), gm(9 * ngeom);
+  for (int i = 0; i < ngeom; i++) {
+    if (gmix[i] != 1.f || gmargin[i] != 0.f || ggap[i] != 0.f || gprio[i] != 0) return fail("geom solmix/margin/gap/priority must be default");
+    int bi = gbody[i];
+    gdyn[i] = dyn_of_body[bi];
+    float lm[9]; h_quat2mat(lm, &gquat[4 * i]);
+    if (gdyn[i] >= 0) {
+      memcpy(&gm[9 * i], lm, sizeof lm);
+      for (int k = 0; k < 3; k++) gp[3 * i + k] = gpos[3 * i + k];
+    } else {
+      if (!is_static[bi]) return fail("geom on an unsupported body");
+      float R[9]; h_quat2mat(R, &wquat[4 * bi]);
+      h_matmul(&gm[9 * i], R, lm);
+      for (int k = 0; k < 3; k++) gp[3 * i + k] = wpos[3 * bi + k] + R[3 * k] * gpos[3 * i] + R[3 * k + 1] * gpos[3 * i + 1] + R[3 * k + 2] * gpos[3 * i + 2];
+    }
+  }
+  auto mv = b.F("mesh_vert");
+  int nvert = M.nvert;
+  std::vector<float> vx(nvert), vy(nvert), vz(nvert);
+  for (int i = 0; i < nvert; i++) { vx[i] = mv[3 * i]; vy[i] = mv[3 * i + 1]; vz[i] = mv[3 * i + 2]; }
+  auto pairs = b.I("pair_geom");
+  bool ok = upload(s, gtype, &M.geom_type) && upload(s, gdyn, &M.geom_dyn) && upload(s, gcondim, &M.geom_condim) &&
+            upload(s, gva, &M.geom_vertadr) && upload(s, gvn, &M.geom_vertnum) && upload(s, gp, &M.geom_pos) &&
+            upload(s, gm, &M.geom_mat) && upload(s, gsize, &M.geom_size) && upload(s, gfr, &M.geom_friction) &&
+            upload(s, gsr, &M.geom_solref) && upload(s, gsi, &M.geom_solimp) && upload(s, gctr, &M.geom_center) &&
+            upload(s, gaabb, &M.geom_aabb) && upload(s, vx, &M.vx) && upload(s, vy, &M.vy) && upload(s, vz, &M.vz) &&
+            upload(s, pairs, &M.pair);
+  if (!ok) return SO101_ERR_HIP;
+  void* dm = nullptr;
+  if (!hip_ok(s, hipMalloc(&dm, sizeof(DevModel)), "hipMalloc(DevModel)")) return SO101_ERR_HIP;
+  s->owned.push_back(dm);
+  if (!hip_ok(s, hipMemcpy(dm, &M, sizeof(DevModel), hipMemcpyHostToDevice), "hipMemcpy(DevModel)")) return SO101_ERR_HIP;
+  s->dm = (DevModel*)dm;
+  return SO101_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int so101_version(void) { return SO101_ABI_VERSION; }
+int so101_max_contacts(void) { return MAXCON; }
+
+int so101_default_config(so101_config* cfg) {
+  if (!cfg) return SO101_ERR_ARG;
+  memset(cfg, 0, sizeof *cfg);
+  cfg->last_step = 1 << 30; cfg->n_substeps = 10; cfg->solver_iterations = 0; cfg->solver_tolerance = -1.f;
+  cfg->settle_max_substeps = 1000; cfg->terminate_on_success = 1; cfg->env_id_base = 0;
+  return SO101_OK;
+}
+
+int so101_create(const void* blob, size_t bytes, int n_envs, int device, uint64_t seed, so101_sim** out) {
+  if (!blob || !out || n_envs <= 0) { g_create_error = "so101_create: bad argument"; return SO101_ERR_ARG; }
+  *out = nullptr;
+  so101_sim* s = new so101_sim();
+  s->n_envs = n_envs; s->device = device; s->seed = seed;
+  so101_default_config(&s->cfg);
+  BlobView b;
+  int rc = SO101_OK;
+  if (!b.parse(blob, bytes, s->err)) rc = SO101_ERR_MODEL;
+  if (rc == SO101_OK && !hip_ok(s, hipSetDevice(device), "hipSetDevice")) rc = SO101_ERR_HIP;
+  if (rc == SO101_OK) rc = build_model(s, b);
+  if (rc == SO101_OK) {
+    void* p = nullptr;
+    if (!hip_ok(s, hipMalloc(&p, n_envs), "hipMalloc(need_reset)")) rc = SO101_ERR_HIP;
+    else { s->owned.push_back(p); s->need_reset = (unsigned char*)p; if (!hip_ok(s, hipMemset(p, 1, n_envs), "hipMemset")) rc = SO101_ERR_HIP; }
+  }
+  if (rc == SO101_OK) {
+    void* p = nullptr;
+    if (!hip_ok(s, hipMalloc(&p, sizeof(int) * SO101_DIAG_DIM * (size_t)n_envs), "hipMalloc(diag)")) rc = SO101_ERR_HIP;
+    else { s->owned.push_back(p); s->diag = (int*)p; if (!hip_ok(s, hipMemset(p, 0, sizeof(int) * SO101_DIAG_DIM * (size_t)n_envs), "hipMemset")) rc = SO101_ERR_HIP; }
+  }
+  if (rc != SO101_OK) { g_create_error = s->err; so101_destroy(s); return rc; }
+  *out = s;
+  return SO101_OK;
+}
+
+void so101_destroy(so101_sim* s) {
+  if (!s) return;
+  for (void* p : s->owned) (void)hipFree(p);
+  delete s;
+}
+
+int so101_configure(so101_sim* s, const so101_config* cfg) {
+  if (!s || !cfg) return SO101_ERR_ARG;
+  if (cfg->n_substeps <= 0 || cfg->settle_max_substeps < 0) { s->err = "so101_configure: bad substep counts"; return SO101_ERR_ARG; }
+  s->cfg = *cfg;
+  return SO101_OK;
+}
+
+int so101_bind_state(so101_sim* s, const so101_buffers* b) {
+  if (!s || !b) return SO101_ERR_ARG;
+  if (!b->qpos || !b->qvel || !b->ctrl || !b->warmstart || !b->obs_ring || !b->ep_return || !b->step_count || !b->episode) {
+    s->err = "so101_bind_state: NULL buffer"; return SO101_ERR_ARG;
+  }
+  s->buf.qpos = b->qpos; s->buf.qvel = b->qvel; s->buf.ctrl = b->ctrl; s->buf.warm = b->warmstart; s->buf.ring = b->obs_ring;
+  s->buf.ep_return = b->ep_return; s->buf.step_count = b->step_count; s->buf.episode = b->episode;
+  s->bound = true;
+  return SO101_OK;
+}
+
+#define REQUIRE_BOUND(s) do { if (!(s)) return SO101_ERR_ARG; if (!(s)->bound) { (s)->err = "state buffers not bound (call so101_bind_state)"; return SO101_ERR_STATE; } } while (0)
+#define LAUNCH_CHECK(s, name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { (s)->err = std::string(name) + ": " + hipGetErrorString(e_); return SO101_ERR_HIP; } } while (0)
+
+int so101_reset(so101_sim* s, const uint8_t* mask, void* stream) {
+  REQUIRE_BOUND(s);
+  hipLaunchKernelGGL(k_reset, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, make_params(s), s->buf, mask, s->need_reset, s->diag);
+  LAUNCH_CHECK(s, "k_reset");
+  return SO101_OK;
+}
+
+int so101_step(so101_sim* s, const float* action, float* obs, float* reward, float* discount, uint8_t* step_type, void* stream) {
+  REQUIRE_BOUND(s);
+  if (!action || !obs || !reward || !discount || !step_type) { s->err = "so101_step: NULL argument"; return SO101_ERR_ARG; }
+  hipLaunchKernelGGL(k_step, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, make_params(s), s->buf, action, obs, reward,
+                     discount, step_type, s->need_reset, s->diag);
+  LAUNCH_CHECK(s, "k_step");
+  return SO101_OK;
+}
+
+int so101_physics(so101_sim* s, int nsub, int freeze, void* stream) {
+  REQUIRE_BOUND(s);
+  if (nsub < 0) return SO101_ERR_ARG;
+  hipLaunchKernelGGL(k_physics, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, make_params(s), s->buf, nsub, freeze, s->diag);
+  LAUNCH_CHECK(s, "k_physics");
+  return SO101_OK;
+}
+
+int so101_reward(so101_sim* s, float* reward, void* stream) {
+  REQUIRE_BOUND(s);
+  if (!reward) return SO101_ERR_ARG;
+  hipLaunchKernelGGL(k_reward, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, make_params(s), s->buf, reward);
+  LAUNCH_CHECK(s, "k_reward");
+  return SO101_OK;
+}
+
+int so101_get_returns(so101_sim* s, float* out, void* stream) {
+  REQUIRE_BOUND(s);
+  if (!out) return SO101_ERR_ARG;
+  if (!hip_ok(s, hipMemcpyAsync(out, s->buf.ep_return, sizeof(float) * (size_t)s->n_envs, hipMemcpyDeviceToDevice, (hipStream_t)stream), "hipMemcpyAsync(returns)"))
+    return SO101_ERR_HIP;
+  return SO101_OK;
+}
+
+int so101_get_diag(so101_sim* s, int32_t* out, void* stream) {
+  if (!s || !out) return SO101_ERR_ARG;
+  if (!hip_ok(s, hipMemcpyAsync(out, s->diag, sizeof(int) * SO101_DIAG_DIM * (size_t)s->n_envs, hipMemcpyDeviceToDevice, (hipStream_t)stream), "hipMemcpyAsync(diag)"))
+    return SO101_ERR_HIP;
+  return SO101_OK;
+}
+
+int so101_debug_forward(so101_sim* s, float* out, void* stream) {
+  REQUIRE_BOUND(s);
+  if (!out) return SO101_ERR_ARG;
+  hipLaunchKernelGGL(k_debug_forward, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, make_params(s), s->buf, out);
+  LAUNCH_CHECK(s, "k_debug_forward");
+  return SO101_OK;
+}
+
+const char* so101_last_error(const so101_sim* s) { return s ? s->err.c_str() : g_create_error.c_str(); }
+
+}  // extern "C"

@@ -1,0 +1,252 @@
+"""Batched dm_env-style environment over the HIP step library.
+
+Mirrors the surface callers of the reference use:
+    env.reset() -> TimeStep         env.step(action) -> TimeStep        env.action_spec()
+    env.observation_spec()          env.close()         env.task.get_instruction()     env.physics
+`composer.Environment` semantics kept: FIRST has reward/discount None; a step after LAST resets and
+returns FIRST; no bounds validation of actions; wrong action length raises ValueError
+(scripts/so101_calibration.py:71-72).
+
+N == 1 (`SingleEnvironment`, what `create_task_env` returns by default) yields numpy observations
+with exactly the reference's keys and shapes; N > 1 (`BatchedEnvironment`) yields torch tensors on
+the GPU with a leading env dimension.  PyTorch is only the array container: every number is produced
+by the kernels behind include/so101.h.
+"""
+from __future__ import annotations
+
+import collections
+import os
+
+import numpy as np
+
+from . import native
+from ._dmenv import BoundedArray, Array, StepType, TimeStep
+from .calibration import SO101Calibration
+from .model import scenes
+
+DEFAULT_CONTROL_TIMESTEP = 0.02
+PHYSICS_TIMESTEP = 0.002
+_JOINT_DELAY_STEPS = 5       # 0.1 s / 0.02 s  (so100_task.py:81,196-201)
+_PHYSICS_DELAY_STEPS = 15    # 0.3 s / 0.02 s  (so100_task.py:80,204-210)
+
+
+class SO100HandOverTask:
+    """Host-side description of `SO100HandOver` (so101_sim/tasks/so100_hand_over.py:121-236)."""
+
+    def __init__(self, object_name, reward_based_on_overlap=True, **kwargs):
+        if object_name not in scenes.HANDOVER_CONFIGS:
+            raise ValueError(f"Invalid object name: {object_name}, must be one of {scenes.HANDOVER_CONFIGS.keys()}")
+        if not reward_based_on_overlap:
+            raise NotImplementedError("contact+distance reward mode (so100_hand_over.py:277-318) is not built yet")
+        self.object_name = object_name
+        self.control_timestep = float(kwargs.pop("control_timestep", DEFAULT_CONTROL_TIMESTEP))
+        self.cameras = tuple(kwargs.pop("cameras", ()))
+        self.image_observation_enabled = bool(kwargs.pop("image_observation_enabled", True))
+        self.terminate_episode = bool(kwargs.pop("terminate_episode", True))
+        self.rotation_joint_limit = float(kwargs.pop("rotation_joint_limit", np.pi))
+        self._instruction = scenes.HANDOVER_CONFIGS[object_name]["instruction"]
+        # the calibration file is looked up relative to the CWD at construction time, as in the reference
+        self.calibration = SO101Calibration()
+
+    def get_instruction(self):
+        return self._instruction
+
+
+class _PhysicsView:
+    """Partial stand-in for `env.physics`: exposes `.data.qpos/.qvel/.ctrl` views of env 0 and
+    `.time()`; rendering is out of scope."""
+
+    class _Data:
+        pass
+
+    def __init__(self, env):
+        self._env = env
+        self.data = self._Data()
+
+    def _refresh(self):
+        e = self._env
+        self.data.qpos = e.qpos[:, 0].detach().cpu().numpy().astype(np.float64)
+        self.data.qvel = e.qvel[:, 0].detach().cpu().numpy().astype(np.float64)
+        self.data.ctrl = e.ctrl[:, 0].detach().cpu().numpy().astype(np.float64)
+        return self
+
+    def time(self):
+        return float(self._env.step_count[0].item()) * self._env.task.control_timestep
+
+    def get_state(self):
+        self._refresh()
+        return np.concatenate([self.data.qpos, self.data.qvel])
+
+    def render(self, *a, **k):
+        raise NotImplementedError("rendering is outside the MI355X hot path (SURVEY.md 8b)")
+
+
+class BatchedEnvironment:
+    def __init__(self, task: SO100HandOverTask, n_envs: int = 1, time_limit: float = float("inf"),
+                 random_state=None, device=None, env_id_base: int = 0, solver_iterations: int = 0,
+                 solver_tolerance: float = -1.0, settle_max_substeps: int = 1000):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("so101_sim_amd needs a ROCm GPU (MI355X): the step path has no CPU fallback")
+        self.torch = torch
+        self.task = task
+        self.n_envs = int(n_envs)
+        self.device = torch.device(device if device is not None else "cuda:0")
+        if isinstance(random_state, np.random.RandomState):
+            seed = int(random_state.randint(0, 2**31 - 1))
+        elif random_state is None:
+            seed = int.from_bytes(os.urandom(4), "little")
+        else:
+            seed = int(random_state)
+        self.seed = seed
+        blob, self.meta = scenes.load_blob(task.object_name, "f32")
+        dev_index = self.device.index or 0
+        with torch.cuda.device(self.device):
+            self.sim = native.Sim(blob, self.n_envs, device=dev_index, seed=seed)
+        N = self.n_envs
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=self.device)
+        self.qpos, self.qvel, self.ctrl, self.warm = z(20, N), z(18, N), z(6, N), z(18, N)
+        self.ring, self.ep_return = z(native.RING_DEPTH, 6, N), z(N)
+        self.step_count, self.episode = z(N, dt=torch.int32), z(N, dt=torch.int32)
+        self.obs, self.reward, self.discount = z(N, native.OBS_DIM), z(N), z(N)
+        self.step_type = z(N, dt=torch.uint8)
+        self._action = z(N, native.ACT_DIM)
+        self.sim.bind(*(t.data_ptr() for t in (self.qpos, self.qvel, self.ctrl, self.warm, self.ring,
+                                                 self.ep_return, self.step_count, self.episode)))
+        nsub = int(round(task.control_timestep / PHYSICS_TIMESTEP))
+        last = scenes.time_limit_last_step(time_limit, task.control_timestep, PHYSICS_TIMESTEP) if np.isfinite(time_limit) else 1 << 30
+        self.last_step = last
+        self.sim.configure(action_offset=[float(x) for x in task.calibration.homing_offsets], last_step=last,
+                           n_substeps=nsub, solver_iterations=int(solver_iterations),
+                           solver_tolerance=float(solver_tolerance), settle_max_substeps=int(settle_max_substeps),
+                           terminate_on_success=int(task.terminate_episode), env_id_base=int(env_id_base))
+        self.physics = _PhysicsView(self)
+        self._physics = self.physics
+
+    # ------------------------------------------------------------------ specs
+    def action_spec(self) -> BoundedArray:
+        # so100_task.py:232-251: ctrlrange with [0] := +-rotation_joint_limit and [5] := [0, 0.08]
+        lo = np.full(6, -3.14158, dtype=np.float32)
+        hi = np.full(6, 3.14158, dtype=np.float32)
+        lo[0], hi[0] = -self.task.rotation_joint_limit, self.task.rotation_joint_limit
+        lo[5], hi[5] = 0.0, 0.08
+        return BoundedArray((6,), np.float32, lo, hi)
+
+    def observation_spec(self):
+        spec = collections.OrderedDict()
+        spec["commanded_joints_pos"] = Array((6,), np.float64, "commanded_joints_pos")
+        spec["joints_pos"] = Array((6,), np.float64, "joints_pos")
+        spec["joints_vel"] = Array((0,), np.float64, "joints_vel")
+        if self.task.image_observation_enabled:
+            spec["physics_state"] = Array((38,), np.float64, "physics_state")
+        spec["undelayed_joints_pos"] = Array((6,), np.float64, "undelayed_joints_pos")
+        spec["undelayed_joints_vel"] = Array((0,), np.float64, "undelayed_joints_vel")
+        if self.task.image_observation_enabled:
+            spec["delayed_physics_state"] = Array((38,), np.float64, "delayed_physics_state")
+        return spec
+
+    # ------------------------------------------------------------------ stepping (tensors in, tensors out)
+    def _stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def reset_all(self):
+        self.sim.reset(None, self._stream())
+        N = self.n_envs
+        self.obs[:, 0:6] = self.qpos[0:6].t()
+        self.obs[:, 6:12] = self.qpos[0:6].t()
+        self.obs[:, 12:18] = self.ctrl.t()
+        self.step_type.zero_()
+        self.reward.zero_()
+        self.discount.fill_(1.0)
+        return self.obs
+
+    def step_tensor(self, action):
+        """action: float tensor [N, 6] on the device. Fills and returns (obs, reward, discount, step_type)."""
+        torch = self.torch
+        if action.shape != (self.n_envs, 6):
+            raise ValueError(f"Expected 6 joint positions, got {tuple(action.shape)}")
+        self._action.copy_(action)
+        self.sim.step(self._action.data_ptr(), self.obs.data_ptr(), self.reward.data_ptr(), self.discount.data_ptr(),
+                      self.step_type.data_ptr(), self._stream())
+        return self.obs, self.reward, self.discount, self.step_type
+
+    def _obs_dict(self):
+        o = collections.OrderedDict()
+        o["commanded_joints_pos"] = self.obs[:, 12:18]
+        o["joints_pos"] = self.obs[:, 0:6]
+        o["joints_vel"] = self.obs[:, 0:0]
+        o["undelayed_joints_pos"] = self.obs[:, 6:12]
+        o["undelayed_joints_vel"] = self.obs[:, 0:0]
+        return o
+
+    def reset(self) -> TimeStep:
+        self.reset_all()
+        return TimeStep(self.step_type, None, None, self._obs_dict())
+
+    def step(self, action) -> TimeStep:
+        torch = self.torch
+        a = torch.as_tensor(action, dtype=torch.float32, device=self.device)
+        if a.dim() == 1:
+            a = a.unsqueeze(0)
+        self.step_tensor(a)
+        return TimeStep(self.step_type, self.reward, self.discount, self._obs_dict())
+
+    def episode_returns(self):
+        out = self.torch.empty_like(self.ep_return)
+        self.sim.get_returns(out.data_ptr(), self._stream())
+        return out
+
+    def diagnostics(self):
+        d = self.torch.zeros(self.n_envs, native.DIAG_DIM, dtype=self.torch.int32, device=self.device)
+        self.sim.get_diag(d.data_ptr(), self._stream())
+        return d
+
+    def close(self):
+        self.sim.close()
+
+
+class SingleEnvironment(BatchedEnvironment):
+    """N = 1 facade with the reference's numpy observation dict (keys/order:
+    examples/so101_rl_breakdown.ipynb:65; shapes :115-122)."""
+
+    def __init__(self, task, **kw):
+        super().__init__(task, n_envs=1, **kw)
+        self._state_ring = collections.deque(maxlen=_PHYSICS_DELAY_STEPS)
+
+    def _physics_state(self):
+        return np.concatenate([self.qpos[:, 0].detach().cpu().numpy(), self.qvel[:, 0].detach().cpu().numpy()]).astype(np.float64)
+
+    def _np_obs(self, first: bool):
+        ob = self.obs[0].detach().cpu().numpy().astype(np.float64)
+        o = collections.OrderedDict()
+        o["commanded_joints_pos"] = ob[12:18].copy()
+        o["joints_pos"] = ob[0:6].copy()
+        o["joints_vel"] = np.zeros((0,), dtype=np.float64)
+        if self.task.image_observation_enabled:
+            state = self._physics_state()
+            if first:
+                self._state_ring.clear()
+                self._state_ring.extend([state] * _PHYSICS_DELAY_STEPS)   # INITIAL_VALUE padding
+            delayed = self._state_ring[0]
+            self._state_ring.append(state)
+            o["physics_state"] = state
+        o["undelayed_joints_pos"] = ob[6:12].copy()
+        o["undelayed_joints_vel"] = np.zeros((0,), dtype=np.float64)
+        if self.task.image_observation_enabled:
+            o["delayed_physics_state"] = delayed
+        return o
+
+    def reset(self) -> TimeStep:
+        self.reset_all()
+        self.torch.cuda.synchronize(self.device)
+        return TimeStep(StepType.FIRST, None, None, self._np_obs(first=True))
+
+    def step(self, action) -> TimeStep:
+        a = np.asarray(action, dtype=np.float64).reshape(-1)
+        if len(a) != 6:
+            raise ValueError(f"Expected 6 joint positions, got {len(a)}")
+        self.step_tensor(self.torch.as_tensor(a, dtype=self.torch.float32, device=self.device).unsqueeze(0))
+        st = StepType(int(self.step_type[0].item()))
+        if st == StepType.FIRST:
+            return TimeStep(st, None, None, self._np_obs(first=True))
+        return TimeStep(st, float(self.reward[0].item()), float(self.discount[0].item()), self._np_obs(first=False))

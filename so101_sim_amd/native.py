@@ -1,0 +1,142 @@
+"""ctypes binding of libso101_hip.so (C ABI in include/so101.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `python -m so101_sim_amd.build`.  There is no
+CPU fallback: if the shared object is missing or a call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libso101_hip.so")
+
+OBS_DIM = 18
+ACT_DIM = 6
+RING_DEPTH = 5
+DIAG_DIM = 8
+DEBUG_DIM = 1024
+
+# debug_forward layout (csrc/so101_kernels.hpp DBG_*)
+DBG = dict(M=0, MINV=36, BIAS=72, SMOOTH=78, QACC=96, COUNTS=114, XPOS=120, CON=144, FORCE=464, ROWF=656, REWARD=672)
+
+EXPORTS = (
+    "so101_version", "so101_max_contacts", "so101_create", "so101_destroy", "so101_default_config",
+    "so101_configure", "so101_bind_state", "so101_reset", "so101_step", "so101_physics", "so101_reward",
+    "so101_get_returns", "so101_get_diag", "so101_debug_forward", "so101_last_error",
+)
+
+
+class Buffers(C.Structure):
+    _fields_ = [("qpos", C.c_void_p), ("qvel", C.c_void_p), ("ctrl", C.c_void_p), ("warmstart", C.c_void_p),
+                ("obs_ring", C.c_void_p), ("ep_return", C.c_void_p), ("step_count", C.c_void_p),
+                ("episode", C.c_void_p)]
+
+
+class Config(C.Structure):
+    _fields_ = [("action_offset", C.c_float * ACT_DIM), ("last_step", C.c_int32), ("n_substeps", C.c_int32),
+                ("solver_iterations", C.c_int32), ("solver_tolerance", C.c_float),
+                ("settle_max_substeps", C.c_int32), ("terminate_on_success", C.c_int32),
+                ("env_id_base", C.c_uint64)]
+
+
+_libs: dict[str, C.CDLL] = {}
+
+
+def load_library(path: str | None = None) -> C.CDLL:
+    path = path or LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback for the step path.")
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.so101_version.restype = C.c_int
+    L.so101_max_contacts.restype = C.c_int
+    L.so101_create.restype = C.c_int
+    L.so101_create.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_uint64, C.POINTER(vp)]
+    L.so101_destroy.argtypes = [vp]
+    L.so101_default_config.argtypes = [C.POINTER(Config)]
+    L.so101_configure.argtypes = [vp, C.POINTER(Config)]
+    L.so101_bind_state.argtypes = [vp, C.POINTER(Buffers)]
+    L.so101_reset.argtypes = [vp, vp, vp]
+    L.so101_step.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.so101_physics.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.so101_reward.argtypes = [vp, vp, vp]
+    L.so101_get_returns.argtypes = [vp, vp, vp]
+    L.so101_get_diag.argtypes = [vp, vp, vp]
+    L.so101_debug_forward.argtypes = [vp, vp, vp]
+    L.so101_last_error.restype = C.c_char_p
+    L.so101_last_error.argtypes = [vp]
+    _libs[path] = L
+    return L
+
+
+class Sim:
+    """Thin handle wrapper. All array arguments are raw device addresses (ints)."""
+
+    def __init__(self, blob_f32: bytes, n_envs: int, device: int = 0, seed: int = 0, lib_path: str | None = None):
+        self.L = load_library(lib_path)
+        self.n_envs = int(n_envs)
+        h = C.c_void_p()
+        rc = self.L.so101_create(blob_f32, len(blob_f32), self.n_envs, int(device), int(seed), C.byref(h))
+        if rc != 0:
+            msg = self.L.so101_last_error(None)
+            raise RuntimeError(f"so101_create failed ({rc}): {msg.decode() if msg else '?'}")
+        self.h = h
+        self.cfg = Config()
+        self.L.so101_default_config(C.byref(self.cfg))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.so101_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.L.so101_last_error(self.h)
+            raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+
+    def configure(self, **kw):
+        for k, v in kw.items():
+            if k == "action_offset":
+                for i in range(ACT_DIM):
+                    self.cfg.action_offset[i] = float(v[i])
+            else:
+                if not hasattr(self.cfg, k):
+                    raise AttributeError(k)
+                setattr(self.cfg, k, v)
+        self._check(self.L.so101_configure(self.h, C.byref(self.cfg)), "so101_configure")
+
+    def bind(self, qpos, qvel, ctrl, warmstart, obs_ring, ep_return, step_count, episode):
+        b = Buffers(qpos, qvel, ctrl, warmstart, obs_ring, ep_return, step_count, episode)
+        self._check(self.L.so101_bind_state(self.h, C.byref(b)), "so101_bind_state")
+
+    def reset(self, mask=None, stream=0):
+        self._check(self.L.so101_reset(self.h, mask, stream), "so101_reset")
+
+    def step(self, action, obs, reward, discount, step_type, stream=0):
+        self._check(self.L.so101_step(self.h, action, obs, reward, discount, step_type, stream), "so101_step")
+
+    def physics(self, n_substeps: int, freeze_arm: bool = False, stream=0):
+        self._check(self.L.so101_physics(self.h, int(n_substeps), int(freeze_arm), stream), "so101_physics")
+
+    def reward(self, out, stream=0):
+        self._check(self.L.so101_reward(self.h, out, stream), "so101_reward")
+
+    def get_returns(self, out, stream=0):
+        self._check(self.L.so101_get_returns(self.h, out, stream), "so101_get_returns")
+
+    def get_diag(self, out, stream=0):
+        self._check(self.L.so101_get_diag(self.h, out, stream), "so101_get_diag")
+
+    def debug_forward(self, out, stream=0):
+        self._check(self.L.so101_debug_forward(self.h, out, stream), "so101_debug_forward")

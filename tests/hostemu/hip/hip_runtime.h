@@ -1,0 +1,61 @@
+// TEST HARNESS ONLY — a minimal stand-in for <hip/hip_runtime.h> so that the product's kernel source
+// (so101_sim_amd/csrc/*.hpp, so101_hip.hip) can be compiled with g++ and executed on the CPU with one
+// OS thread per lane.  Used by tests/ to debug kernel logic without a GPU; never shipped, never
+// loaded by the product package (so101_sim_amd/native.py only loads libso101_hip.so).
+#pragma once
+#include <pthread.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#define __device__
+#define __global__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+
+struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+struct emu_idx { unsigned x, y, z; };
+extern thread_local emu_idx threadIdx;
+extern thread_local emu_idx blockIdx;
+extern pthread_barrier_t emu_barrier;
+extern float emu_xchg_f[64];
+extern int emu_xchg_i[64];
+extern unsigned long long emu_xchg_u;
+
+inline void __syncthreads() { pthread_barrier_wait(&emu_barrier); }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+using std::max;
+using std::min;
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+enum { hipSuccess = 0 };
+enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToDevice = 3 };
+inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? 0 : 1; }
+inline hipError_t hipFree(void* p) { free(p); return 0; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return 0; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return 0; }
+inline hipError_t hipSetDevice(int) { return 0; }
+inline hipError_t hipGetLastError() { return 0; }
+
+template <typename K, typename... A>
+void emu_launch(K kernel, dim3 grid, dim3 block, A... args) {
+  for (unsigned b = 0; b < grid.x; b++) {
+    pthread_barrier_init(&emu_barrier, nullptr, block.x);
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < block.x; t++)
+      th.emplace_back([=]() { threadIdx = {t, 0, 0}; blockIdx = {b, 0, 0}; kernel(args...); });
+    for (auto& x : th) x.join();
+    pthread_barrier_destroy(&emu_barrier);
+  }
+}
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emu_launch(kernel, grid, block, __VA_ARGS__)

@@ -1,0 +1,35 @@
+// TEST HARNESS ONLY — lane-thread emulation of so101_sim_amd/csrc/wave.hpp (pre-included with -include so
+// that the product header's include guard skips the gfx950 implementation).
+#ifndef SO101_WAVE_HPP_
+#define SO101_WAVE_HPP_
+#include <hip/hip_runtime.h>
+#define WAVE 64
+inline int wave_lane() { return threadIdx.x; }
+inline void wave_sync() { __syncthreads(); }
+inline float wave_max_f(float v) {
+  emu_xchg_f[threadIdx.x] = v; __syncthreads();
+  float m = emu_xchg_f[0]; for (int i = 1; i < 64; i++) m = std::fmax(m, emu_xchg_f[i]);
+  __syncthreads(); return m;
+}
+inline float wave_sum_f(float v) {
+  emu_xchg_f[threadIdx.x] = v; __syncthreads();
+  // same butterfly order as the device version so that rounding matches
+  float t[64]; for (int i = 0; i < 64; i++) t[i] = emu_xchg_f[i];
+  for (int s = 32; s >= 1; s >>= 1) { float u[64]; for (int i = 0; i < 64; i++) u[i] = t[i] + t[i ^ s]; for (int i = 0; i < 64; i++) t[i] = u[i]; }
+  __syncthreads(); return t[threadIdx.x];
+}
+inline unsigned long long wave_ballot(bool p) {
+  emu_xchg_i[threadIdx.x] = p; __syncthreads();
+  unsigned long long m = 0; for (int i = 0; i < 64; i++) if (emu_xchg_i[i]) m |= 1ull << i;
+  __syncthreads(); return m;
+}
+inline int wave_prefix(unsigned long long mask) { return __builtin_popcountll(mask & ((1ull << threadIdx.x) - 1ull)); }
+inline float wave_bcast_f(float v, int src) { emu_xchg_f[threadIdx.x] = v; __syncthreads(); float r = emu_xchg_f[src]; __syncthreads(); return r; }
+inline int wave_bcast_i(int v, int src) { emu_xchg_i[threadIdx.x] = v; __syncthreads(); int r = emu_xchg_i[src]; __syncthreads(); return r; }
+inline void wave_argmax(float& val, int& idx) {
+  emu_xchg_f[threadIdx.x] = val; emu_xchg_i[threadIdx.x] = idx; __syncthreads();
+  float m = emu_xchg_f[0]; for (int i = 1; i < 64; i++) m = std::fmax(m, emu_xchg_f[i]);
+  int b = 0x7fffffff; for (int i = 0; i < 64; i++) if (emu_xchg_f[i] == m) b = std::min(b, emu_xchg_i[i]);
+  __syncthreads(); val = m; idx = b;
+}
+#endif

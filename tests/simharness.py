@@ -1,0 +1,136 @@
+"""Test helper: drives the C ABI (include/so101.h) with explicit state arrays.
+
+backend="gpu": torch CUDA tensors + the in-tree libso101_hip.so (the product path, MI355X).
+backend="emu": numpy arrays + tests/hostemu/_build/libso101_emu.so — the SAME kernel source compiled
+               with g++ against a fake HIP runtime, one OS thread per lane.  Debug aid for CPU-only
+               runs; it is never the thing whose parity is claimed.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+
+import numpy as np
+
+from so101_sim_amd import native
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+EMU_LIB = os.path.join(_HERE, "hostemu", "_build", "libso101_emu.so")
+NQ, NV, NU = 20, 18, 6
+
+
+def build_emu():
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "hostemu"), "-s"])
+    return EMU_LIB
+
+
+class ArraySim:
+    def __init__(self, blob_f32: bytes, n_envs: int, backend: str = "gpu", seed: int = 0, **cfg):
+        self.N = n_envs
+        self.backend = backend
+        if backend == "gpu":
+            import torch
+            self.torch = torch
+            self.dev = torch.device("cuda:0")
+            self.sim = native.Sim(blob_f32, n_envs, device=0, seed=seed)
+            z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=self.dev)
+            i32, u8 = torch.int32, torch.uint8
+        else:
+            self.sim = native.Sim(blob_f32, n_envs, device=0, seed=seed, lib_path=build_emu())
+            z = lambda *s, dt=np.float32: np.zeros(s, dtype=dt)
+            i32, u8 = np.int32, np.uint8
+        N = n_envs
+        self.qpos, self.qvel, self.ctrl, self.warm = z(NQ, N), z(NV, N), z(NU, N), z(NV, N)
+        self.ring, self.ep_return = z(5, 6, N), z(N)
+        self.step_count, self.episode = z(N, dt=i32), z(N, dt=i32)
+        self.action, self.obs = z(N, 6), z(N, 18)
+        self.reward_, self.discount, self.step_type = z(N), z(N), z(N, dt=u8)
+        self.diag = z(N, native.DIAG_DIM, dt=i32)
+        self.dbg = z(N, native.DEBUG_DIM)
+        # free-body quaternions default to identity
+        self.set_state(np.tile(np.concatenate([np.zeros(6), [0, 0, 0, 1, 0, 0, 0] * 2])[:, None], (1, N)))
+        p = self.ptr
+        self.sim.bind(p(self.qpos), p(self.qvel), p(self.ctrl), p(self.warm), p(self.ring), p(self.ep_return),
+                      p(self.step_count), p(self.episode))
+        if cfg:
+            self.sim.configure(**cfg)
+
+    # -- helpers
+    def ptr(self, a):
+        return a.data_ptr() if self.backend == "gpu" else a.ctypes.data
+
+    def _put(self, dst, src):
+        src = np.asarray(src)
+        if self.backend == "gpu":
+            dst.copy_(self.torch.as_tensor(src.astype(np.float32) if dst.dtype == self.torch.float32 else src).to(self.dev).reshape(dst.shape))
+        else:
+            dst[...] = src.reshape(dst.shape)
+
+    def _get(self, a):
+        if self.backend == "gpu":
+            self.torch.cuda.synchronize()
+            return a.detach().cpu().numpy().copy()
+        return a.copy()
+
+    def stream(self):
+        return self.torch.cuda.current_stream().cuda_stream if self.backend == "gpu" else 0
+
+    # -- state (arrays are [dim, N])
+    def set_state(self, qpos=None, qvel=None, ctrl=None, warm=None):
+        for dst, src in ((self.qpos, qpos), (self.qvel, qvel), (self.ctrl, ctrl), (self.warm, warm)):
+            if src is not None:
+                self._put(dst, src)
+
+    def get_state(self):
+        return self._get(self.qpos).astype(np.float64), self._get(self.qvel).astype(np.float64), self._get(self.warm).astype(np.float64)
+
+    def configure(self, **kw):
+        self.sim.configure(**kw)
+
+    def physics(self, nsub=10, freeze_arm=False):
+        self.sim.physics(nsub, freeze_arm, self.stream())
+
+    def reset(self, mask=None):
+        if mask is None:
+            self.sim.reset(None, self.stream())
+        else:
+            m = np.asarray(mask, dtype=np.uint8)
+            if self.backend == "gpu":
+                mt = self.torch.as_tensor(m).to(self.dev)
+                self.sim.reset(mt.data_ptr(), self.stream())
+                self.torch.cuda.synchronize()
+            else:
+                self.sim.reset(m.ctypes.data, 0)
+
+    def step(self, action):
+        self._put(self.action, np.asarray(action, dtype=np.float32))
+        p = self.ptr
+        self.sim.step(p(self.action), p(self.obs), p(self.reward_), p(self.discount), p(self.step_type), self.stream())
+        return self._get(self.obs), self._get(self.reward_), self._get(self.discount), self._get(self.step_type)
+
+    def reward(self):
+        self.sim.reward(self.ptr(self.reward_), self.stream())
+        return self._get(self.reward_)
+
+    def get_diag(self):
+        self.sim.get_diag(self.ptr(self.diag), self.stream())
+        return self._get(self.diag)
+
+    def debug_forward(self):
+        self.sim.debug_forward(self.ptr(self.dbg), self.stream())
+        d = self._get(self.dbg).astype(np.float64)
+        D = native.DBG
+        out = []
+        for e in range(self.N):
+            r = d[e]
+            ncon = int(r[D["COUNTS"]])
+            cons = [dict(pos=r[D["CON"] + 10 * k: D["CON"] + 10 * k + 3], normal=r[D["CON"] + 10 * k + 3: D["CON"] + 10 * k + 6],
+                         dist=r[D["CON"] + 10 * k + 6], geom1=int(r[D["CON"] + 10 * k + 7]), geom2=int(r[D["CON"] + 10 * k + 8]),
+                         dim=int(r[D["CON"] + 10 * k + 9]), force=r[D["FORCE"] + 6 * k: D["FORCE"] + 6 * k + 6]) for k in range(ncon)]
+            out.append(dict(M=r[D["M"]:D["M"] + 36].reshape(6, 6), Minv=r[D["MINV"]:D["MINV"] + 36].reshape(6, 6),
+                            bias=r[D["BIAS"]:D["BIAS"] + 6], qacc_smooth=r[D["SMOOTH"]:D["SMOOTH"] + 18],
+                            qacc=r[D["QACC"]:D["QACC"] + 18], ncon=ncon, nrow=int(r[D["COUNTS"] + 1]),
+                            iters=int(r[D["COUNTS"] + 2]), ncand=int(r[D["COUNTS"] + 3]), overflow=int(r[D["COUNTS"] + 4]),
+                            xpos=r[D["XPOS"]:D["XPOS"] + 24].reshape(8, 3), contacts=cons,
+                            rowf=r[D["ROWF"]:D["ROWF"] + 12], reward=r[D["REWARD"]]))
+        return out
