@@ -93,6 +93,12 @@ int so101_bind_state(so101_sim* sim, const so101_buffers* buffers);
  * held, delay line filled with the reset value.  mask: [N] bytes, nonzero = reset that env; NULL = all. */
 int so101_reset(so101_sim* sim, const uint8_t* mask, void* hip_stream);
 
+/* Starts an episode from whatever state the caller wrote into the bound buffers (checkpoint restore,
+ * known-answer tests): ctrl = home + offsets, delay line filled with the current joints_pos,
+ * step_count/ep_return cleared, no placement, no settle.  The reference's equivalent is
+ * physics.set_state(...) followed by the observation updater's reset (dm_control). */
+int so101_begin_episode(so101_sim* sim, void* hip_stream);
+
 /* Replaces: env.step(action): before_step (so100_task.py:266-287), n_substeps x mj_step, observables
  * (so100_task.py:323-368 with the delays of :189-210), get_reward (so100_hand_over.py:238-275),
  * get_discount / termination (so100_task.py:292-302) and the time limit (task_suite.py:151).

@@ -65,6 +65,7 @@ def lib():
         L.orc_overlap_oobb.argtypes = [dp, dp]
         L.orc_env_config.argtypes = [C.c_void_p, C.POINTER(EnvCfg)]
         L.orc_env_reset.argtypes = [C.c_void_p]
+        L.orc_env_begin.argtypes = [C.c_void_p]
         L.orc_env_step.argtypes = [C.c_void_p, dp, dp, dp, dp, C.POINTER(C.c_int)]
         L.orc_env_obs.argtypes = [C.c_void_p, dp]
         L.orc_env_return.restype = C.c_double
@@ -181,6 +182,10 @@ class Oracle:
 
     def env_reset(self):
         self.L.orc_env_reset(self.h)
+        return self.env_obs()
+
+    def env_begin(self):
+        self.L.orc_env_begin(self.h)
         return self.env_obs()
 
     def env_obs(self):

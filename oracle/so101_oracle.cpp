@@ -1211,6 +1211,11 @@ int orc_overlap_oobb(const double* a, const double* b) {
 }
 void orc_env_config(orc_sim* s, const orc_env_cfg* c) { s->cfg = *c; s->need_reset = true; s->episode = 0; }
 void orc_env_reset(orc_sim* s) { env_reset(s); }
+void orc_env_begin(orc_sim* s) {
+  for (int k = 0; k < 6; k++) { s->ctrl[k] = s->m.home_ctrl[k] + s->cfg.offsets[k]; s->cmd[k] = s->ctrl[k]; s->delayed[k] = s->qpos[k]; }
+  for (int r = 0; r < 5; r++) for (int k = 0; k < 6; k++) s->ring[r][k] = s->qpos[k];
+  s->ring_head = 0; s->step_count = 0; s->ep_return = 0; s->need_reset = false;
+}
 void orc_env_obs(const orc_sim* s, double* o) { env_obs(s, o); }
 int orc_env_step_count(const orc_sim* s) { return s->step_count; }
 double orc_env_return(const orc_sim* s) { return s->ep_return; }

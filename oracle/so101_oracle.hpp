@@ -88,6 +88,8 @@ void orc_env_reset(orc_sim*);
 // reward, discount, step_type (0 FIRST,1 MID,2 LAST).  Auto-resets when called after LAST.
 void orc_env_step(orc_sim*, const double* action, double* obs18, double* reward, double* discount,
                   int* step_type);
+// adopt the current state as the post-reset state of a new episode (for known-answer tests)
+void orc_env_begin(orc_sim*);
 void orc_env_obs(const orc_sim*, double* obs18);
 int orc_env_step_count(const orc_sim*);
 double orc_env_return(const orc_sim*);

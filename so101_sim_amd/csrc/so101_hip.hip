@@ -322,6 +322,13 @@ int so101_reset(so101_sim* s, const uint8_t* mask, void* stream) {
   return SO101_OK;
 }
 
+int so101_begin_episode(so101_sim* s, void* stream) {
+  REQUIRE_BOUND(s);
+  hipLaunchKernelGGL(k_begin, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, make_params(s), s->buf, s->need_reset);
+  LAUNCH_CHECK(s, "k_begin");
+  return SO101_OK;
+}
+
 int so101_step(so101_sim* s, const float* action, float* obs, float* reward, float* discount, uint8_t* step_type, void* stream) {
   REQUIRE_BOUND(s);
   if (!action || !obs || !reward || !discount || !step_type) { s->err = "so101_step: NULL argument"; return SO101_ERR_ARG; }

@@ -118,6 +118,16 @@ __global__ void __launch_bounds__(64) k_reset(const DevModel* m, StepParams P, D
   if (wave_lane() == 0) need_reset[e] = 0;
 }
 
+__global__ void __launch_bounds__(64) k_begin(const DevModel* m, StepParams P, DevBuffers B, unsigned char* need_reset) {
+  int e = blockIdx.x, lane = wave_lane(), N = P.n_envs;
+  if (lane < NARM) {
+    float q = B.qpos[(size_t)lane * N + e];
+    for (int r = 0; r < 5; r++) B.ring[((size_t)r * NARM + lane) * N + e] = q;
+    B.ctrl[(size_t)lane * N + e] = m->home_ctrl[lane] + P.action_offset[lane];
+  }
+  if (lane == 0) { B.step_count[e] = 0; B.ep_return[e] = 0.f; need_reset[e] = 0; }
+}
+
 __global__ void __launch_bounds__(64) k_step(const DevModel* m, StepParams P, DevBuffers B, const float* action, float* obs,
                                              float* reward, float* discount, unsigned char* step_type,
                                              unsigned char* need_reset, int* diag) {
@@ -137,13 +147,13 @@ __global__ void __launch_bounds__(64) k_step(const DevModel* m, StepParams P, De
     if (lane == 0) { reward[e] = 0.f; discount[e] = 1.f; step_type[e] = 0; need_reset[e] = 0; }
     return;
   }
+  int sc = B.step_count[e] + 1;
   load_state(L, B, e, N);
   // before_step: ctrl = action + homing offsets, unclamped (so100_task.py:266-287)
   if (lane < NU) L.ctrl[lane] = action[(size_t)e * NU + lane] + P.action_offset[lane];
   wave_sync();
   for (int s = 0; s < P.n_substeps; s++) substep(m, L, P.iterations, P.tolerance, false);
   kinematics(m, L);     // position-dependent quantities of the post-step state (legacy step2/step1 order)
-  int sc = B.step_count[e] + 1;
   // joints_pos delay line: read the value of control step k-5, then store step k
   int slot = (sc - 1) % 5;
   if (lane < NARM) {

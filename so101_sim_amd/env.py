@@ -30,6 +30,20 @@ _JOINT_DELAY_STEPS = 5       # 0.1 s / 0.02 s  (so100_task.py:81,196-201)
 _PHYSICS_DELAY_STEPS = 15    # 0.3 s / 0.02 s  (so100_task.py:80,204-210)
 
 
+def so100_action_spec(rotation_joint_limit: float = np.pi) -> BoundedArray:
+    """SO100Task.action_spec (so100_task.py:232-251): ctrlrange of scene_pbr.xml:11 (+-3.14158) with
+    [0] := +-rotation_joint_limit and [5] := [0, 0.08]; shape (6,), float32."""
+    lo = np.full(6, -3.14158, dtype=np.float32)
+    hi = np.full(6, 3.14158, dtype=np.float32)
+    lo[0], hi[0] = -rotation_joint_limit, rotation_joint_limit
+    lo[5], hi[5] = 0.0, 0.08
+    return BoundedArray((6,), np.float32, lo, hi)
+
+
+OBSERVATION_KEYS = ("commanded_joints_pos", "joints_pos", "joints_vel", "physics_state", "undelayed_joints_pos",
+                    "undelayed_joints_vel", "delayed_physics_state")   # examples/so101_rl_breakdown.ipynb:65 (cameras excluded)
+
+
 class SO100HandOverTask:
     """Host-side description of `SO100HandOver` (so101_sim/tasks/so100_hand_over.py:121-236)."""
 
@@ -125,12 +139,7 @@ class BatchedEnvironment:
 
     # ------------------------------------------------------------------ specs
     def action_spec(self) -> BoundedArray:
-        # so100_task.py:232-251: ctrlrange with [0] := +-rotation_joint_limit and [5] := [0, 0.08]
-        lo = np.full(6, -3.14158, dtype=np.float32)
-        hi = np.full(6, 3.14158, dtype=np.float32)
-        lo[0], hi[0] = -self.task.rotation_joint_limit, self.task.rotation_joint_limit
-        lo[5], hi[5] = 0.0, 0.08
-        return BoundedArray((6,), np.float32, lo, hi)
+        return so100_action_spec(self.task.rotation_joint_limit)
 
     def observation_spec(self):
         spec = collections.OrderedDict()

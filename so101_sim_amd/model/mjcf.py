@@ -18,7 +18,7 @@ import numpy as np
 
 from . import meshes as mm
 
-# geom type codes shared with csrc/ and oracle/ (include/so101_model.h)
+# geom type codes (same numbering as csrc/so101_model.hpp)
 GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX, GEOM_MESH = 0, 1, 2, 3, 4, 5
 _GEOM_TYPES = {"plane": GEOM_PLANE, "sphere": GEOM_SPHERE, "capsule": GEOM_CAPSULE,
                "cylinder": GEOM_CYLINDER, "box": GEOM_BOX, "mesh": GEOM_MESH}

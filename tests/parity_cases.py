@@ -1,0 +1,186 @@
+"""Shared parity scenarios: the kernels behind the C ABI (backend "gpu" = MI355X product path,
+backend "emu" = same kernel source under the CPU lane-thread harness) against the fp64 oracle on
+identical seeded inputs.
+
+Tolerances (fp32 kernels vs fp64 oracle), stated once here and used by both test modules:
+  * free-space arm, one control step:            |dqpos| <= 2e-6 rel, |dqvel| <= 2e-5 rel  (SURVEY KAT-1 bar: 2e-6)
+  * forward-pass stages:                         M, bias: 2e-6 rel; smooth qacc 5e-6 rel; contact dist 2e-6 m abs,
+                                                 contact position 2e-5 m; constrained qacc 2e-3 rel of max|qacc|
+                                                 (PGS stopped at its iteration cap on both sides, fp32 vs fp64 iterates)
+  * resting contact, one control step:           |dqpos| <= 2e-5, |dqvel| <= 5e-3
+  * reward, discount, step_type, contact counts: bit-exact / equal
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from oracle.oracle import Oracle
+
+KAT_PROPS = np.array([2.65129794e-01, 4.09270959e-03, 4.21711098e-01, 9.99246834e-01, -1.69673020e-04, 9.86495446e-05, 3.88036861e-02,
+                      -2.17988678e-01, -3.96717335e-02, 4.22621829e-01, 9.99999456e-01, -5.82714664e-04, -8.65621822e-04, -8.25292623e-06])
+
+
+def valid_arm_states(blob64, n, seed=0, spread=0.6):
+    """Random arm configurations/velocities whose geoms touch nothing (checked with the oracle)."""
+    rng = np.random.RandomState(seed)
+    o = Oracle(blob64)
+    Q, V = [], []
+    while len(Q) < n:
+        q = np.concatenate([rng.uniform(-spread, spread, 6) * [1, 0.6, 1, 1, 1, 0.5] + [0, -0.3, 0.6, 0.3, 0, 0.3], KAT_PROPS])
+        o.set_state(q, np.zeros(18), None)
+        o.forward()
+        names_ok = all(c["geom1"] >= 19 for c in o.contacts())       # only table/prop contacts (geom ids >= 19)
+        if names_ok:
+            Q.append(q)
+            V.append(np.concatenate([rng.uniform(-1.5, 1.5, 6), np.zeros(12)]))
+    return np.array(Q).T, np.array(V).T
+
+
+def check_forward_stages(make_sim, blobs, n=4, seed=0):
+    Q, V = valid_arm_states(blobs["f64"], n, seed)
+    rng = np.random.RandomState(seed + 1)
+    CT = rng.uniform(-1.5, 1.5, size=(6, n))
+    sim = make_sim(n)
+    sim.set_state(Q, V, CT, np.zeros((18, n)))
+    dbg = sim.debug_forward()
+    for e in range(n):
+        o = Oracle(blobs["f64"])
+        o.set_state(Q[:, e], V[:, e], np.zeros(18))
+        o.set_ctrl(CT[:, e])
+        o.forward()
+        a, asm = o.qacc()
+        d = dbg[e]
+        M = o.M()[:6, :6]
+        assert np.abs(d["M"] - M).max() <= 2e-6 * np.abs(M).max()
+        assert np.abs(d["bias"] - o.bias()[:6]).max() <= 2e-6 * max(1.0, np.abs(o.bias()[:6]).max())
+        assert np.abs(d["qacc_smooth"] - asm).max() <= 5e-6 * np.abs(asm).max()
+        oc = o.contacts()
+        assert d["ncon"] == len(oc) and d["overflow"] == 0
+        for c, c2 in zip(d["contacts"], oc):
+            assert (c["geom1"], c["geom2"], c["dim"]) == (c2["geom1"], c2["geom2"], c2["dim"])
+            assert abs(c["dist"] - c2["dist"]) <= 2e-6
+            assert np.abs(c["pos"] - c2["pos"]).max() <= 2e-5
+        assert np.abs(d["qacc"] - a).max() <= 2e-3 * np.abs(a).max()
+        assert d["reward"] == o.reward()
+
+
+def check_kat1(make_sim, blobs, golden):
+    """Notebook KAT-1 through the product path: reset state -> step([0,0,0,0,0,0.5]) with calibration."""
+    k = golden["kat1"]
+    ob = k["observation"]
+    start = np.array(ob["delayed_physics_state"])
+    sim = make_sim(1, action_offset=[28, 42, 18, -21, 1009, -158])
+    sim.set_state(start[:20, None], start[20:, None], np.zeros((6, 1)), np.zeros((18, 1)))
+    sim.begin_episode()
+    obs, rew, disc, st = sim.step(np.array([k["action"]]))
+    q, v, _ = sim.get_state()
+    ps = np.array(ob["physics_state"])
+    assert np.max(np.abs((q[:6, 0] - ps[:6]) / ps[:6])) <= 2e-6
+    assert np.max(np.abs((v[:6, 0] - ps[20:26]) / ps[20:26])) <= 2e-6
+    np.testing.assert_array_equal(obs[0, 12:18], np.array(ob["commanded_joints_pos"], dtype=np.float32))   # unclamped ctrl
+    np.testing.assert_array_equal(obs[0, 0:6], 0)                                                          # delayed
+    np.testing.assert_allclose(obs[0, 6:12], ob["undelayed_joints_pos"], rtol=2e-6)
+    assert rew[0] == 0.0 and disc[0] == 1.0 and st[0] == 1
+    assert np.max(np.abs(q[6:9, 0] - ps[6:9])) < 5e-6 and np.max(np.abs(q[13:16, 0] - ps[13:16])) < 5e-6
+
+
+def check_control_step(make_sim, blobs, n=4, seed=3, iterations=100):
+    Q, V = valid_arm_states(blobs["f64"], n, seed)
+    rng = np.random.RandomState(seed + 1)
+    CT = rng.uniform(-1.0, 1.0, size=(6, n))
+    sim = make_sim(n, solver_iterations=iterations)
+    sim.set_state(Q, V, CT, np.zeros((18, n)))
+    sim.physics(10)
+    q1, v1, _ = sim.get_state()
+    for e in range(n):
+        o = Oracle(blobs["f64"])
+        o.set_solver(iterations, -1.0)
+        o.set_state(Q[:, e], V[:, e], np.zeros(18))
+        o.set_ctrl(CT[:, e])
+        o.substeps(10)
+        qo, vo, _ = o.get_state()
+        arm_contact = any(c["geom1"] < 19 for c in o.contacts())
+        tol_q, tol_v = (2e-4, 5e-2) if arm_contact else (2e-5, 5e-3)
+        assert np.abs(q1[:6, e] - qo[:6]).max() <= max(tol_q, 2e-6 * np.abs(qo[:6]).max()), e
+        assert np.abs(v1[:6, e] - vo[:6]).max() <= max(tol_v, 2e-5 * np.abs(vo[:6]).max()), e
+        assert np.abs(q1[6:, e] - qo[6:]).max() <= tol_q and np.abs(v1[6:, e] - vo[6:]).max() <= tol_v, e
+
+
+def reward_states(blobs, n, seed=5):
+    """Banana poses scattered around the bowl's overlap box, some moving: exercises gate and SAT."""
+    from so101_sim_amd.model import blob as blobfmt
+    m = blobfmt.unpack(blobs["f64"])
+    rng = np.random.RandomState(seed)
+    Q, V = np.zeros((20, n)), np.zeros((18, n))
+    ipos = m["body_ipos"].reshape(-1, 3)[11]
+    for e in range(n):
+        cq = np.array([1.0, 0, 0, 0]) + rng.normal(scale=0.05, size=4) * (e % 3 > 0)
+        cq /= np.linalg.norm(cq)
+        Q[13:16, e] = [-0.25 + rng.uniform(-0.03, 0.03), rng.uniform(-0.05, 0.05), 0.4226]
+        Q[16:20, e] = cq
+        oq = rng.normal(size=4)
+        oq /= np.linalg.norm(oq)
+        Q[9:13, e] = oq
+        Q[6:9, e] = Q[13:16, e] + m["task_box_pos"] - ipos + rng.uniform(-0.09, 0.09, 3) * (e % 2)
+        if e % 5 == 4:
+            V[6 + rng.randint(3), e] = rng.choice([0.9e-3, 1e-3, 1.1e-3, -2e-3])
+        if e % 7 == 6:
+            V[12 + rng.randint(3), e] = rng.choice([0.9e-3, 1.5e-3])
+        V[9:12, e] = rng.normal(size=3)        # angular velocity must not matter
+    return Q, V
+
+
+def check_reward_bitexact(make_sim, blobs, n=64):
+    Q, V = reward_states(blobs, n)
+    sim = make_sim(n)
+    sim.set_state(Q, V, np.zeros((6, n)), np.zeros((18, n)))
+    r = sim.reward()
+    o = Oracle(blobs["f64"])
+    want = []
+    for e in range(n):
+        o.set_state(Q[:, e], V[:, e], None)
+        want.append(o.reward())
+    want = np.array(want)
+    assert set(np.unique(r)) <= {0.0, 1.0}
+    assert 0 < want.sum() < n                          # both outcomes are exercised
+    np.testing.assert_array_equal(r, want.astype(np.float32))
+
+
+def check_env_semantics(make_sim, blobs, n=2, settle=30, steps=8, last_step=7, seed=11, iterations=30):
+    """reset -> steps -> LAST at the time limit -> auto-reset FIRST, against the oracle's env layer."""
+    sim = make_sim(n, seed=seed, settle_max_substeps=settle, last_step=last_step, solver_iterations=iterations, env_id_base=100)
+    sim.reset()
+    q0, v0, _ = sim.get_state()
+    oracles = []
+    for e in range(n):
+        o = Oracle(blobs["f64"])
+        o.set_solver(iterations, -1.0)
+        o.env_config(seed=seed, env_id=100 + e, last_step=last_step, settle_max_substeps=settle)
+        o.env_reset()
+        qo, vo, _ = o.get_state()
+        # identical RNG draws: placement equal to f32 rounding before settle drift accumulates
+        assert np.abs(q0[:, e] - qo).max() < 5e-5, (e, np.abs(q0[:, e] - qo).max())
+        assert np.all(q0[:6, e] == 0)
+        oracles.append(o)
+    rng = np.random.RandomState(seed)
+    undelayed_hist = []
+    for t in range(1, steps + 1):
+        act = rng.uniform(-0.4, 0.4, size=(n, 6)).astype(np.float32)
+        obs, rew, disc, st = sim.step(act)
+        for e, o in enumerate(oracles):
+            oo, orew, odisc, ost = o.env_step(act[e].astype(np.float64))
+            assert (rew[e], disc[e], st[e]) == (orew, odisc, ost), (t, e)
+            if ost != 0:
+                np.testing.assert_allclose(obs[e, 6:12], oo[6:12], atol=5e-5)
+                np.testing.assert_allclose(obs[e, 0:6], oo[0:6], atol=5e-5)
+                np.testing.assert_array_equal(obs[e, 12:18], act[e])          # commanded = raw action (offsets 0)
+        undelayed_hist.append(obs[:, 6:12].copy())
+        if t <= last_step:
+            assert np.all(st == (2 if t == last_step else 1))
+            if t <= 5:
+                assert np.all(obs[:, 0:6] == 0)                                # still the reset value
+            else:
+                np.testing.assert_array_equal(obs[:, 0:6], undelayed_hist[t - 6])   # value of control step t-5
+        elif t == last_step + 1:
+            assert np.all(st == 0)                                             # auto-reset: FIRST
+            assert np.all(obs[:, 0:12] == 0)

@@ -102,6 +102,9 @@ class ArraySim:
             else:
                 self.sim.reset(m.ctypes.data, 0)
 
+    def begin_episode(self):
+        self.sim.begin_episode(self.stream())
+
     def step(self, action):
         self._put(self.action, np.asarray(action, dtype=np.float32))
         p = self.ptr

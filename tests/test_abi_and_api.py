@@ -1,0 +1,101 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports everything
+include/so101.h declares, rejects bad blobs without touching a GPU, and the Python registry/factory
+behaves like so101_sim/task_suite.py."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    from so101_sim_amd import native
+    header = open(os.path.join(ROOT, "include", "so101.h")).read()
+    declared = set(re.findall(r"\b(so101_[a-z_]+)\s*\(", header))
+    assert declared == set(native.EXPORTS)
+    lib = native.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.so101_version() == 1 and lib.so101_max_contacts() >= 16
+
+
+def test_create_rejects_bad_blobs_without_gpu(hip_lib, blobs):
+    from so101_sim_amd import native
+    with pytest.raises(RuntimeError, match="bad blob magic"):
+        native.Sim(b"\0" * 64, 4)
+    with pytest.raises(RuntimeError, match="f32 blob"):
+        native.Sim(blobs["f64"], 4)
+    with pytest.raises(RuntimeError, match="truncated"):
+        native.Sim(blobs["f32"][:4000], 4)
+    lib = native.load_library()
+    assert lib.so101_configure(None, None) == -1 and lib.so101_step(None, None, None, None, None, None, None) == -1
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from so101_sim_amd import native
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        native.load_library(str(tmp_path / "nope.so"))
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "so101_sim_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                text = open(os.path.join(base, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", text, re.M) or "so101_oracle" in text or "oracle/" in text:
+                    bad.append(f)
+    assert not bad, bad
+
+
+def test_registry_matches_reference_names():
+    from so101_sim_amd import task_suite
+    keys = list(task_suite.TASK_FACTORIES.keys())
+    assert len(keys) == 22
+    assert keys[:3] == ["BlocksSpelling", "BowlOnRack", "DesktopWrapHeadphone"] and keys[-2:] == ["SO100HandOverPen", "SO100HandOverBanana"]
+    assert task_suite.TASK_FACTORIES["SO100HandOverBanana"][1] == {"object_name": "banana"}
+    assert task_suite.DEFAULT_CONTROL_TIMESTEP == 0.02
+    assert task_suite.DEFAULT_CAMERAS == ("overhead_cam", "worms_eye_cam", "wrist_cam_left", "wrist_cam_right")
+
+
+def test_factory_errors_like_reference():
+    from so101_sim_amd import task_suite
+    with pytest.raises(ValueError, match="Unknown task_name: Nope. Available tasks:"):
+        task_suite.create_task_env("Nope", time_limit=1.0)
+    with pytest.raises(NotImplementedError):
+        task_suite.create_task_env("HandOverBanana", time_limit=1.0)          # ALOHA: registry key exists, not built
+    with pytest.raises(ValueError, match="Invalid object name"):
+        task_suite.SO100HandOver(object_name="mug")
+
+
+def test_task_kwargs_and_calibration_cwd_quirk(tmp_path, monkeypatch):
+    from so101_sim_amd import task_suite
+    monkeypatch.chdir(tmp_path)
+    t = task_suite.SO100HandOver(object_name="banana", control_timestep=0.02, cameras=())
+    assert np.all(t.calibration.homing_offsets == 0)                            # file not found -> zeros, silently
+    assert t.get_instruction() == "pick up the banana and put it in the bowl using the SO100 arm"
+    os.makedirs(tmp_path / "calibration")
+    (tmp_path / "calibration" / "red_arm.json").write_text(
+        '{"shoulder_pan": {"homing_offset": 28}, "shoulder_lift": {"homing_offset": 42}, "elbow_flex": {"homing_offset": 18},'
+        ' "wrist_flex": {"homing_offset": -21}, "wrist_roll": {"homing_offset": 1009}, "gripper": {"homing_offset": -158}}')
+    t = task_suite.SO100HandOver(object_name="banana")
+    assert list(t.calibration.homing_offsets) == [28, 42, 18, -21, 1009, -158]
+    with pytest.raises(ValueError, match="Expected 6 joint positions, got 5"):
+        t.calibration.apply_calibration_to_action(np.zeros(5))
+
+
+def test_dmenv_lookalikes():
+    from so101_sim_amd._dmenv import StepType, TimeStep
+    ts = TimeStep(StepType.FIRST, None, None, {})
+    assert ts.first() and not ts.mid() and not ts.last() and ts.reward is None and ts.discount is None
+    assert TimeStep(StepType.LAST, 1.0, 0.0, {}).last()
+
+
+def test_shard_ranges_partition_the_envs():
+    from so101_sim_amd.distributed import shard_range
+    for n, w in ((262144, 8), (4096, 2), (10, 3)):
+        spans = [shard_range(n, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))

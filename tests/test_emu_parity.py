@@ -1,0 +1,34 @@
+"""CPU-only: the product's kernel source executed under the lane-thread emulation harness
+(tests/hostemu) against the fp64 oracle.  This exercises the kernel LOGIC without a GPU; the parity
+claims proper are made by tests/test_gpu_parity.py on MI355X with the same scenarios."""
+import pytest
+
+from tests import parity_cases as pc
+from tests.simharness import ArraySim
+
+
+@pytest.fixture(scope="module")
+def make_sim(blobs):
+    def f(n, seed=0, **cfg):
+        return ArraySim(blobs["f32"], n, backend="emu", seed=seed, **cfg)
+    return f
+
+
+def test_forward_stages(make_sim, blobs):
+    pc.check_forward_stages(make_sim, blobs, n=2)
+
+
+def test_kat1_through_the_kernels(make_sim, blobs, golden):
+    pc.check_kat1(make_sim, blobs, golden)
+
+
+def test_one_control_step(make_sim, blobs):
+    pc.check_control_step(make_sim, blobs, n=2, iterations=20)
+
+
+def test_reward_bitexact(make_sim, blobs):
+    pc.check_reward_bitexact(make_sim, blobs, n=24)
+
+
+def test_env_semantics(make_sim, blobs):
+    pc.check_env_semantics(make_sim, blobs, n=1, settle=10, steps=8, last_step=7, iterations=10)

@@ -1,0 +1,111 @@
+"""MI355X parity tests: the HIP path, called through the C ABI, against the fp64 oracle on the same
+seeded inputs, plus size-independent properties at the benchmark size (4096 envs)."""
+import numpy as np
+import pytest
+
+from tests import parity_cases as pc
+from tests.simharness import ArraySim
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def make_sim(blobs):
+    def f(n, seed=0, **cfg):
+        return ArraySim(blobs["f32"], n, backend="gpu", seed=seed, **cfg)
+    return f
+
+
+def test_native_library_is_the_hip_build():
+    import os
+    from so101_sim_amd import native
+    assert os.path.exists(native.LIB_PATH)
+    assert native.load_library().so101_version() == 1
+
+
+def test_forward_stages(make_sim, blobs):
+    pc.check_forward_stages(make_sim, blobs, n=16)
+
+
+def test_kat1_through_the_kernels(make_sim, blobs, golden):
+    pc.check_kat1(make_sim, blobs, golden)
+
+
+def test_one_control_step(make_sim, blobs):
+    pc.check_control_step(make_sim, blobs, n=16, iterations=100)
+
+
+def test_reward_bitexact(make_sim, blobs):
+    pc.check_reward_bitexact(make_sim, blobs, n=512)
+
+
+def test_env_semantics(make_sim, blobs):
+    pc.check_env_semantics(make_sim, blobs, n=4, settle=200, steps=9, last_step=7, iterations=50)
+
+
+def test_full_settle_matches_oracle(make_sim, blobs):
+    """reset with the reference's full 1000-substep settle budget: rest pose vs oracle, KAT-2 heights."""
+    from oracle.oracle import Oracle
+    sim = make_sim(3, seed=21)
+    sim.reset()
+    q, v, _ = sim.get_state()
+    for e in range(3):
+        o = Oracle(blobs["f64"])
+        o.env_config(seed=21, env_id=e)
+        o.env_reset()
+        qo, vo, _ = o.get_state()
+        assert np.abs(q[6:9, e] - qo[6:9]).max() < 2e-3 and np.abs(q[13:16, e] - qo[13:16]).max() < 2e-3
+        assert abs(q[8, e] - qo[8]) < 2e-5                       # banana rest height
+    assert np.all(q[:6] == 0) and np.all(v[:6] == 0)
+
+
+def test_determinism_and_shard_invariance(make_sim, blobs):
+    """Same seed => bit-identical trajectories; per-env RNG keyed by GLOBAL env id, so a shard starting at
+    env_id_base=k reproduces envs k.. of the unsharded run."""
+    n, steps = 8, 3
+    rng = np.random.RandomState(0)
+    acts = rng.uniform(-0.5, 0.5, size=(steps, n, 6)).astype(np.float32)
+
+    def run(count, base, a):
+        s = make_sim(count, seed=5, settle_max_substeps=100, solver_iterations=20, env_id_base=base)
+        s.reset()
+        for t in range(steps):
+            s.step(a[t])
+        return s.get_state()[0]
+    full = run(n, 0, acts)
+    again = run(n, 0, acts)
+    np.testing.assert_array_equal(full, again)
+    shard = run(n // 2, n // 2, acts[:, n // 2:])
+    np.testing.assert_array_equal(full[:, n // 2:], shard)
+
+
+def test_properties_at_benchmark_size(make_sim, blobs):
+    """4096 envs (BASELINE.json configs[1]): invariants that do not need the oracle."""
+    n = 4096
+    sim = make_sim(n, seed=1, solver_iterations=20, last_step=500)
+    sim.reset()
+    q, v, _ = sim.get_state()
+    assert np.all(np.isfinite(q)) and np.all(np.isfinite(v))
+    assert np.all(q[:6] == 0)
+    np.testing.assert_allclose(np.linalg.norm(q[9:13], axis=0), 1.0, atol=1e-5)
+    np.testing.assert_allclose(np.linalg.norm(q[16:20], axis=0), 1.0, atol=1e-5)
+    lo = np.array([-np.pi, -3.14158, -3.14158, -3.14158, -3.14158, 0.0], dtype=np.float32)
+    hi = np.array([np.pi, 3.14158, 3.14158, 3.14158, 3.14158, 0.08], dtype=np.float32)
+    rng = np.random.RandomState(2)
+    total = np.zeros(n)
+    for t in range(10):
+        act = rng.uniform(lo, hi, size=(n, 6)).astype(np.float32)
+        obs, rew, disc, st = sim.step(act)
+        total += rew
+        assert set(np.unique(rew)) <= {0.0, 1.0} and set(np.unique(st)) <= {1, 2}
+        assert np.all(disc[rew == 0] == 1.0)
+        np.testing.assert_array_equal(obs[:, 12:18], act)
+    q, v, _ = sim.get_state()
+    assert np.all(np.isfinite(q)) and np.all(np.isfinite(v))
+    rlo = np.array([-2.2, -3.14158, 0, -2, -3.14158, -0.2])[:, None]
+    rhi = np.array([2.2, 0.2, 3.14158, 1.8, 3.14158, 2])[:, None]
+    assert np.all(q[:6] > rlo - 0.15) and np.all(q[:6] < rhi + 0.15)          # soft joint limits hold
+    d = sim.get_diag()
+    assert np.all(d[:, 4] == 0), "contact/candidate overflow at benchmark size"
+    ep = sim._get(sim.ep_return)
+    np.testing.assert_array_equal(ep, total.astype(np.float32))

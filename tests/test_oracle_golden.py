@@ -1,0 +1,164 @@
+"""The CPU oracle against every known-answer vector the reference holds for this path:
+notebook KAT-1/2/3, the time-limit table, the compile-time constants, and the SAT truth table produced
+by executing the reference's own oobb_utils.py."""
+import numpy as np
+
+from oracle.oracle import Oracle, overlap_oobb, rng_uniform
+from so101_sim_amd.model import blob as blobfmt
+from so101_sim_amd.model import scenes
+
+CALIB = [28, 42, 18, -21, 1009, -158]     # calibration/red_arm.json homing offsets
+
+
+def test_kat1_one_control_step(blobs, golden):
+    k = golden["kat1"]
+    ob = k["observation"]
+    o = Oracle(blobs["f64"])
+    o.env_config(offsets=CALIB)
+    start = np.array(ob["delayed_physics_state"])           # = state at reset (INITIAL_VALUE padding)
+    o.set_state(start[:20], start[20:], np.zeros(18))
+    o.env_begin()
+    obs, rew, disc, st = o.env_step(k["action"])
+    q, v, _ = o.get_state()
+    ps = np.array(ob["physics_state"])
+    # hard assertions: free-space arm, to the notebook's print precision
+    assert np.max(np.abs((q[:6] - ps[:6]) / ps[:6])) < 5e-9
+    assert np.max(np.abs((v[:6] - ps[20:26]) / ps[20:26])) < 5e-9
+    np.testing.assert_allclose(obs[12:18], ob["commanded_joints_pos"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(obs[0:6], ob["joints_pos"], rtol=0, atol=0)            # delayed: still the reset value
+    np.testing.assert_allclose(obs[6:12], ob["undelayed_joints_pos"], rtol=0, atol=5e-9)
+    assert rew == k["reward"] == 0.0 and disc == k["discount"] == 1.0 and st == 1
+    assert ob["joints_vel"] == [] and ob["undelayed_joints_vel"] == []
+    # soft assertions (prop mass is a proxy: the visual meshes are missing blobs): resting props stay put
+    assert np.max(np.abs(q[6:9] - ps[6:9])) < 2e-6 and np.max(np.abs(q[13:16] - ps[13:16])) < 2e-6
+
+
+def test_kat1_pins_frictionloss_and_armature(blobs, golden):
+    """Dropping either term moves the answer by >1e-4 relative, so KAT-1 really pins them."""
+    m = blobfmt.unpack(blobs["f64"])
+    ps = np.array(golden["kat1"]["observation"]["physics_state"])
+    start = np.array(golden["kat1"]["observation"]["delayed_physics_state"])
+    for field in ("dof_frictionloss", "dof_armature"):
+        mm = {k: (np.zeros_like(v) if k == field else v) for k, v in m.items()}
+        o = Oracle(blobfmt.pack(mm, np.float64))
+        o.env_config(offsets=CALIB)
+        o.set_state(start[:20], start[20:], np.zeros(18))
+        o.env_begin()
+        o.env_step(golden["kat1"]["action"])
+        q, _, _ = o.get_state()
+        assert np.max(np.abs((q[:6] - ps[:6]) / ps[:6])) > 1e-4, field
+
+
+def test_kat2_reset_state(blobs, golden):
+    ob = golden["kat2"]["observation"]
+    np.testing.assert_allclose(ob["commanded_joints_pos"], scenes.SO100_HOME_CTRL, atol=1e-12)   # no calibration file
+    o = Oracle(blobs["f64"])
+    o.env_config(seed=3, env_id=0)
+    obs = o.env_reset()
+    q, v, _ = o.get_state()
+    assert np.all(q[:6] == 0) and np.all(v[:6] == 0)                  # arm untouched by placement and settle
+    np.testing.assert_allclose(obs[12:18], scenes.SO100_HOME_CTRL, atol=1e-12)
+    assert np.all(obs[0:12] == 0)
+    assert 0.2 - 2e-3 <= q[6] <= 0.3 + 2e-3 and -0.1 - 2e-3 <= q[7] <= 0.1 + 2e-3    # object placement box (+settle drift)
+    assert -0.3 - 2e-3 <= q[13] <= -0.2 + 2e-3
+    yaw = 2 * np.arctan2(q[12], q[9])
+    assert abs(yaw) <= 0.1 * np.pi + 1e-2
+    # rest heights: notebook banana z = 0.42171 (both KATs); bowl on the flat table z = 0.422622 (KAT-1)
+    assert abs(q[8] - ob["physics_state"][8]) < 1e-4
+    assert abs(q[15] - golden["kat1"]["observation"]["physics_state"][15]) < 5e-5 or q[15] > 0.4227   # or on the puck
+
+
+def test_kat3_api_facts(blobs, golden):
+    k = golden["kat3"]
+    from so101_sim_amd.env import OBSERVATION_KEYS, so100_action_spec
+    assert [x for x in k["obs_keys"] if "cam" not in x] == list(OBSERVATION_KEYS)
+    spec = so100_action_spec()
+    assert list(spec.shape) == k["action_shape"] and spec.dtype.name == k["action_dtype"]
+    for (lo, hi), smin, smax in zip(k["action_ranges_2dp"], spec.minimum, spec.maximum):
+        assert round(float(smin), 2) == lo and round(float(smax), 2) == hi
+    assert spec.minimum[0] == np.float32(-np.pi) and spec.maximum[1] == np.float32(3.14158)
+    # five random-action steps from a settled reset all give reward 0.000
+    o = Oracle(blobs["f64"])
+    o.env_config(seed=0, env_id=0)
+    o.env_reset()
+    for s in k["random_steps"]:
+        _, rew, disc, st = o.env_step(s["action"])
+        assert rew == s["reward"] == 0.0 and disc == 1.0 and st == 1
+
+
+def test_time_limit_table(golden):
+    for t, step in golden["time_limit_table"]["last_step"].items():
+        assert scenes.time_limit_last_step(float(t)) == step
+
+
+def test_time_limit_gives_last_then_first(blobs):
+    o = Oracle(blobs["f64"])
+    o.env_config(seed=1, env_id=5, last_step=3, settle_max_substeps=50)
+    o.env_reset()
+    out = [o.env_step(np.zeros(6)) for _ in range(3)]
+    assert [x[3] for x in out] == [1, 1, 2]
+    assert out[2][2] == 1.0                              # time-limit termination keeps discount 1.0
+    obs, rew, disc, st = o.env_step(np.zeros(6))         # step after LAST: auto-reset, FIRST
+    assert st == 0
+
+
+def test_compile_constants(blobs):
+    meta, m = blobs["meta"], blobfmt.unpack(blobs["f64"])
+    # SURVEY.md Appendix A "derived constants"
+    np.testing.assert_allclose(meta["M0_diag"][:6], [0.13148961, 0.12508802, 0.10887202, 0.10115972, 0.10004333, 0.10002769], atol=5e-9)
+    assert (int(m["nq"][0]), int(m["nv"][0]), int(m["nu"][0]), int(m["nbody"][0]), int(m["ngeom"][0])) == (20, 18, 6, 13, 83)
+    names = meta["geom_names"]
+    counts = dict(zip(names, m["geom_vertnum"]))
+    for n, c in dict(Base=150, Rotation_Pitch=400, Upper_Arm=421, Lower_Arm=516, Wrist_Pitch_Roll=525, Fixed_Jaw_Collision_1=16,
+                     Fixed_Jaw_Collision_2=221, Moving_Jaw_Collision_1=12, Moving_Jaw_Collision_2=8, Moving_Jaw_Collision_3=187).items():
+        assert counts[n] == c, n
+    assert [counts[f"object/coacd_part_00{i}"] for i in range(4)] == [106, 1080, 498, 1021]
+    assert sum(c for n, c in counts.items() if n.startswith("container/")) == 7609
+    assert abs(m["body_mass"][11] - 0.0427) < 5e-4 and abs(m["body_mass"][12] - 0.127) < 1e-3     # proxy masses
+    # contact filter: Base<->Rotation_Pitch excluded, parent-child arm pairs filtered, static-static filtered
+    pairs = {(names[a], names[b]) for a, b in m["pair_geom"].reshape(-1, 2)}
+    assert ("Base", "Rotation_Pitch") not in pairs and ("Rotation_Pitch", "Upper_Arm") not in pairs
+    assert ("Base", "Upper_Arm") in pairs and ("Rotation_Pitch", "table_surface") in pairs
+    assert ("floor", "table_surface") not in pairs and ("table_surface", "banana") not in pairs
+    assert ("fixed_jaw_pad_1", "moving_jaw_pad_1") not in pairs          # Fixed_Jaw is the parent of Moving_Jaw
+    assert ("table_surface", "object/coacd_part_000") in pairs and ("object/coacd_part_000", "container/coacd_part_000") in pairs
+
+
+def test_blob_roundtrip(blobs):
+    m = blobfmt.unpack(blobs["f32"])
+    again = blobfmt.unpack(blobfmt.pack(m, np.float32))
+    assert set(m) == set(again) and all(np.array_equal(m[k], again[k]) for k in m)
+
+
+def test_sat_truth_table_from_reference_code(golden):
+    cases = golden["sat_cases"]["overlap_cases"]
+    assert len(cases) >= 400
+    for c in cases:
+        assert overlap_oobb(c["box0"], c["box1"]) == c["overlap"]
+
+
+def test_reward_gate_and_overlap(blobs):
+    m = blobfmt.unpack(blobs["f64"])
+    o = Oracle(blobs["f64"])
+    q = np.zeros(20); q[9] = 1; q[16] = 1
+    q[13:16] = [-0.25, 0.0, 0.4226]                      # bowl on the table
+    box = m["task_box_pos"]                              # overlap box centre in the bowl frame
+    q[6:9] = q[13:16] + box - m["body_ipos"].reshape(-1, 3)[11]   # banana COM on the box centre
+    o.set_state(q, np.zeros(18), None)
+    assert o.reward() == 1.0
+    v = np.zeros(18); v[6] = 1e-3                        # linear speed >= 1e-3 gates the reward off (>=)
+    o.set_state(q, v, None); assert o.reward() == 0.0
+    v[6] = 0.99e-3
+    o.set_state(q, v, None); assert o.reward() == 1.0
+    v[:] = 0; v[9] = 5.0                                 # angular velocity is not looked at
+    o.set_state(q, v, None); assert o.reward() == 1.0
+    q2 = q.copy(); q2[6] += 0.5
+    o.set_state(q2, np.zeros(18), None); assert o.reward() == 0.0
+
+
+def test_rng_is_counter_based_and_in_range():
+    u = [rng_uniform(1, 2, 3, d) for d in range(64)]
+    assert all(0.0 <= x < 1.0 for x in u) and len(set(u)) > 60
+    assert rng_uniform(1, 2, 3, 4) == rng_uniform(1, 2, 3, 4)
+    assert rng_uniform(1, 2, 3, 4) != rng_uniform(1, 3, 3, 4)
+    assert all(float(np.float32(x)) == x for x in u)      # 24-bit uniforms are exact in f32
