@@ -986,17 +986,36 @@ void euler(orc_sim* s) {
   s->warm = s->qacc;
 }
 
-void substeps(orc_sim* s, int nsub, bool freeze_arm) {
+// mj_checkPos/Vel/Acc: NaN or |x| > mjMAXVAL (1e10) => divergence; MuJoCo resets the data (qpos0), and
+// dm_control with raise_exception_on_physics_error=False (so101_sim/task_suite.py:153) ends the episode
+// with reward 0 / discount 0.
+bool diverged_state(orc_sim* s) {
+  const Model& m = s->m;
+  bool bad = false;
+  for (real x : s->qpos) bad = bad || !(std::fabs(x) <= 1e10);
+  for (real x : s->qvel) bad = bad || !(std::fabs(x) <= 1e10);
+  for (real x : s->qacc) bad = bad || !(std::fabs(x) <= 1e10);
+  if (bad) {
+    std::fill(s->qpos.begin(), s->qpos.end(), 0.0); std::fill(s->qvel.begin(), s->qvel.end(), 0.0);
+    std::fill(s->warm.begin(), s->warm.end(), 0.0); std::fill(s->qacc.begin(), s->qacc.end(), 0.0);
+    for (int f = 0; f < m.nfree; f++) s->qpos[m.body_qposadr[m.free_body[f]] + 3] = 1;
+  }
+  return bad;
+}
+
+bool substeps(orc_sim* s, int nsub, bool freeze_arm) {
   const Model& m = s->m;
   std::vector<real> q0, v0;
   if (freeze_arm) { q0.assign(s->qpos.begin(), s->qpos.begin() + m.narm); v0.assign(s->qvel.begin(), s->qvel.begin() + m.narm); }
   for (int k = 0; k < nsub; k++) {
     forward(s, freeze_arm);
     euler(s);
+    if (diverged_state(s)) return true;
     if (freeze_arm) {   // dm_control JointStaticIsolator: non-prop joints restored after every step
       std::copy(q0.begin(), q0.end(), s->qpos.begin()); std::copy(v0.begin(), v0.end(), s->qvel.begin());
     }
   }
+  return false;
 }
 
 // ================================================================ reward (so100_hand_over.py:238-275)
@@ -1226,13 +1245,13 @@ void orc_env_step(orc_sim* s, const double* action, double* obs, double* rew, do
     return;
   }
   for (int k = 0; k < 6; k++) { s->ctrl[k] = action[k] + s->cfg.offsets[k]; s->cmd[k] = s->ctrl[k]; }
-  substeps(s, 10, false);
+  bool diverged = substeps(s, 10, false);
   s->step_count++;
   // delay ring (50 physics steps = 5 control steps): read the value of step k-5, then store step k
   for (int k = 0; k < 6; k++) { s->delayed[k] = s->ring[s->ring_head][k]; s->ring[s->ring_head][k] = s->qpos[k]; }
   s->ring_head = (s->ring_head + 1) % 5;
-  real r = reward(s);
-  bool success = r >= 1.0, timeout = s->step_count >= s->cfg.last_step;
+  real r = diverged ? 0.0 : reward(s);
+  bool success = r >= 1.0 || diverged, timeout = s->step_count >= s->cfg.last_step;
   *rew = r; *disc = success ? 0.0 : 1.0; *st = (success || timeout) ? 2 : 1;
   s->ep_return += r;
   env_obs(s, obs);

@@ -388,6 +388,7 @@ DEV void support(const DevModel* m, const GeomW& G, const float* dir, float* out
       if (d > best) { best = d; bi = i; }
     }
     wave_argmax(best, bi);
+    bi = (bi >= 0 && bi < G.vnum) ? bi : 0;     // a non-finite direction (diverged state) must not index out of range
     loc[0] = x[bi]; loc[1] = y[bi]; loc[2] = z[bi];
   } else if (G.type == G_BOX) {
 #pragma unroll
@@ -543,6 +544,7 @@ DEV bool mpr_penetration(const DevModel* m, const GeomW& G1, const GeomW& G2, fl
         cross3(t, v1.v, v2.v); b[3] = dot3(t, d);
         sum = b[1] + b[2] + b[3];
       }
+      if (!(fabsf(sum) > 1e-30f)) { b[0] = 0.f; b[1] = b[2] = b[3] = 1.f; sum = 3.f; }   // degenerate portal: centroid
       float inv = 1.f / sum;
 #pragma unroll
       for (int i = 0; i < 3; i++) {
@@ -825,21 +827,23 @@ DEV void make_constraints(const DevModel* m, EnvLDS& L) {
 #pragma unroll
           for (int k = 0; k <= j; k++) A[j][k] += mi * dot3(ul[j], ul[k]) + dot3(ua[j], Iua[k]);
       } else if (d >= 0 && c.armslot >= 0) {
+        // rows are streamed through this contact's slot of the LDS pool (private to the lane) to keep
+        // the register footprint small: J row -> B row = Minv J^T -> A block from the stored rows
         ArmCon& ac = L.armcon[c.armslot];
-        float J[6][NARM], Bm[6][NARM];
 #pragma unroll
         for (int j = 0; j < 6; j++) {
-          arm_jac_row(L, d, c.pos, &c.frame[3 * (j % 3)], j >= 3, J[j]);
+          float Jr[NARM];
+          arm_jac_row(L, d, c.pos, &c.frame[3 * (j % 3)], j >= 3, Jr);
+          float vj = 0.f;
 #pragma unroll
           for (int q = 0; q < NARM; q++) {
             float v = 0.f;
 #pragma unroll
-            for (int s = 0; s < NARM; s++) v += L.Minv[q][s] * J[j][s];
-            Bm[j][q] = v;
+            for (int s = 0; s < NARM; s++) v += L.Minv[q][s] * Jr[s];
+            ac.B[j][q] = sgn * v;
+            ac.J[j][q] = sgn * Jr[q];
+            vj += Jr[q] * L.qvel[q];
           }
-          float vj = 0.f;
-#pragma unroll
-          for (int q = 0; q < NARM; q++) { vj += J[j][q] * L.qvel[q]; ac.J[j][q] = sgn * J[j][q]; ac.B[j][q] = sgn * Bm[j][q]; }
           vel[j] += sgn * vj;
         }
 #pragma unroll
@@ -848,7 +852,7 @@ DEV void make_constraints(const DevModel* m, EnvLDS& L) {
           for (int k = 0; k <= j; k++) {
             float v = 0.f;
 #pragma unroll
-            for (int q = 0; q < NARM; q++) v += J[j][q] * Bm[k][q];
+            for (int q = 0; q < NARM; q++) v += ac.J[j][q] * ac.B[k][q];   // sgn^2 = 1
             A[j][k] += v;
           }
       }
@@ -967,326 +971,21 @@ DEV bool qcqp(float* res, const float* A /*5x5 full*/, const float* b, const flo
   return la != 0.f;
 }
 
-// acceleration of body `d` projected on the 6 rows of contact c (signed for side)
-DEV void contact_jacc(const EnvLDS& L, const Contact& c, float* jv /*6*/, bool use_warm, const float* warm_arm, const float (*warm_free)[6]) {
-#pragma unroll
-  for (int j = 0; j < 6; j++) jv[j] = 0.f;
-#pragma unroll
-  for (int side = 0; side < 2; side++) {
-    int d = side == 0 ? c.d1 : c.d2;
-    float sgn = side == 0 ? -1.f : 1.f;
-    if (d >= NARM) {
-      int f = d - NARM;
-      const float* acc = use_warm ? warm_free[f] : L.facc[f];
-      float r[3] = {c.pos[0] - L.xipos[d][0], c.pos[1] - L.xipos[d][1], c.pos[2] - L.xipos[d][2]};
-      float al[3] = {acc[0], acc[1], acc[2]}, aa[3] = {acc[3], acc[4], acc[5]};
-      float t[3]; cross3(t, aa, r);           // (r x u).alpha = u.(alpha x r)
-      float pl[3] = {al[0] + t[0], al[1] + t[1], al[2] + t[2]};
-#pragma unroll
-      for (int j = 0; j < 3; j++) { jv[j] += sgn * dot3(&c.frame[3 * j], pl); jv[3 + j] += sgn * dot3(&c.frame[3 * j], aa); }
-    } else if (d >= 0 && c.armslot >= 0) {
-      const ArmCon& ac = L.armcon[c.armslot];
-      const float* acc = use_warm ? warm_arm : L.qacc_arm;
-#pragma unroll
-      for (int j = 0; j < 6; j++) {
-        float v = 0.f;
-#pragma unroll
-        for (int q = 0; q < NARM; q++) v += ac.J[j][q] * acc[q];     // sign already folded into J
-        jv[j] += v;
-      }
-    }
-  }
-}
-
-// apply a force change df[6] of contact c to the accelerations (uniform; lanes < NARM / lane 0 write)
-DEV void contact_apply(EnvLDS& L, const Contact& c, const float* df) {
-  int lane = wave_lane();
-  float F[3], T0[3];
-#pragma unroll
-  for (int i = 0; i < 3; i++) {
-    F[i] = c.frame[i] * df[0] + c.frame[3 + i] * df[1] + c.frame[6 + i] * df[2];
-    T0[i] = c.frame[i] * df[3] + c.frame[3 + i] * df[4] + c.frame[6 + i] * df[5];
-  }
-#pragma unroll
-  for (int side = 0; side < 2; side++) {
-    int d = side == 0 ? c.d1 : c.d2;
-    float sgn = side == 0 ? -1.f : 1.f;
-    if (d >= NARM) {
-      int f = d - NARM;
-      float r[3] = {c.pos[0] - L.xipos[d][0], c.pos[1] - L.xipos[d][1], c.pos[2] - L.xipos[d][2]};
-      float T[3]; cross3(T, r, F);
-      T[0] += T0[0]; T[1] += T0[1]; T[2] += T0[2];
-      float da[3]; symvec3(da, L.fIinv[f], T);
-      float mi = L.fminv[f];
-      if (lane < 3) L.facc[f][lane] += sgn * mi * F[lane];
-      else if (lane < 6) L.facc[f][lane] += sgn * da[lane - 3];
-    } else if (d >= 0 && c.armslot >= 0) {
-      const ArmCon& ac = L.armcon[c.armslot];
-      if (lane < NARM) {
-        float v = 0.f;
-#pragma unroll
-        for (int j = 0; j < 6; j++) v += ac.B[j][lane] * df[j];
-        L.qacc_arm[lane] += v;
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------ PGS (velocity space, rows in MuJoCo order)
-DEV void solve_pgs(const DevModel* m, EnvLDS& L, int max_iter, float tolerance) {
-  int lane = wave_lane();
-  int nrow = L.nrow, ncon = L.ncon;
-  if (lane == 0) L.iters = 0;
-  if (nrow + ncon == 0) { wave_sync(); return; }
-  // ---- warm start: forces from the previous qacc (mj_constraintUpdate), kept iff the dual cost is negative
-  {
-    // previous qacc in solver coordinates
-    float warm_arm[NARM], warm_free[NFREE][6];
-#pragma unroll
-    for (int d = 0; d < NARM; d++) warm_arm[d] = L.warm[d];
-#pragma unroll
-    for (int f = 0; f < NFREE; f++) {
-      int b = NARM + f;
-      const float* wq = &L.warm[NARM + 6 * f];
-      float wb[3] = {wq[3], wq[4], wq[5]}, alp[3];
-      matvec3(alp, L.xmat[b], wb);
-      float r[3] = {L.xipos[b][0] - L.xpos[b][0], L.xipos[b][1] - L.xpos[b][1], L.xipos[b][2] - L.xpos[b][2]};
-      float ww[3] = {L.fvel[f][3], L.fvel[f][4], L.fvel[f][5]};
-      float t1[3], t2[3];
-      cross3(t1, alp, r); cross3(t2, ww, r); cross3(t2, ww, t2);
-#pragma unroll
-      for (int i = 0; i < 3; i++) { warm_free[f][i] = wq[i] + t1[i] + t2[i]; warm_free[f][3 + i] = alp[i]; }
-    }
-    if (lane < nrow) {
-      Row1& r = L.row[lane];
-      float jar = r.sign * L.warm[r.dof] - r.aref;
-      float D = 1.f / r.R, f = -D * jar;
-      if (r.floss > 0.f) f = fminf(fmaxf(f, -r.floss), r.floss);
-      else f = jar < 0.f ? f : 0.f;
-      r.f = f;
-    }
-    if (lane < ncon) {
-      Contact& c = L.con[lane];
-      float jar[6];
-      contact_jacc(L, c, jar, true, warm_arm, warm_free);
-      const float Rj[6] = {c.R[0], c.R[1], c.R[1], c.R[2], c.R[3], c.R[3]};
-      const float fr[5] = {c.fric[0], c.fric[0], c.fric[1], c.fric[2], c.fric[2]};
-      int dim = c.dim;
-#pragma unroll
-      for (int j = 0; j < 6; j++) jar[j] -= c.aref[j];
-      float mu = c.mu, U[6], T = 0.f;
-      U[0] = jar[0] * mu;
-#pragma unroll
-      for (int j = 1; j < 6; j++) { U[j] = (j < dim) ? jar[j] * fr[j - 1] : 0.f; T += U[j] * U[j]; }
-      T = sqrtf(T);
-      float N = U[0], fo[6];
-      if ((N >= mu * T) || (T <= 0.f && N >= 0.f)) {
-#pragma unroll
-        for (int j = 0; j < 6; j++) fo[j] = 0.f;
-      } else if ((mu * N + T <= 0.f) || (T <= 0.f && N < 0.f)) {
-#pragma unroll
-        for (int j = 0; j < 6; j++) fo[j] = (j < dim) ? -jar[j] / Rj[j] : 0.f;
-      } else {
-        float Dm = (1.f / Rj[0]) / fmaxf(mu * mu * (1.f + mu * mu), MINVAL_F), NmT = N - mu * T;
-        fo[0] = -Dm * NmT * mu;
-#pragma unroll
-        for (int j = 1; j < 6; j++) fo[j] = (j < dim) ? -fo[0] / T * U[j] * fr[j - 1] : 0.f;
-      }
-#pragma unroll
-      for (int j = 0; j < 6; j++) c.f[j] = fo[j];
-    }
-    wave_sync();
-    // dual cost  sum f.(0.5*(A f) + b) with A f evaluated through the accelerations the forces produce
-    if (lane < NARM) L.scratch[lane] = L.qacc_arm[lane];
-    if (lane >= 32 && lane < 32 + 6 * NFREE) L.scratch[8 + lane - 32] = L.facc[(lane - 32) / 6][(lane - 32) % 6];
-    wave_sync();
-    for (int k = 0; k < nrow; k++) {
-      float f = L.row[k].f, sg = L.row[k].sign; int d = L.row[k].dof;
-      if (lane < NARM) L.qacc_arm[lane] += L.Minv[lane][d] * sg * f;
-    }
-    wave_sync();
-    for (int k = 0; k < ncon; k++) {
-      float df[6];
-#pragma unroll
-      for (int j = 0; j < 6; j++) df[j] = L.con[k].f[j];
-      contact_apply(L, L.con[k], df);
-      wave_sync();
-    }
-    // now acc = smooth + Minv J^T f ;  A f = J(acc - smooth) + R f ;  b = J smooth - aref
-    float cost = 0.f;
-    if (lane < nrow) {
-      Row1& r = L.row[lane];
-      float jn = r.sign * L.qacc_arm[r.dof], js = r.sign * L.scratch[r.dof];
-      cost += r.f * (0.5f * (jn - js + r.R * r.f) + js - r.aref);
-    }
-    wave_sync();
-    float jn6[6] = {0, 0, 0, 0, 0, 0};
-    if (lane < ncon) contact_jacc(L, L.con[lane], jn6, false, nullptr, nullptr);
-    wave_sync();
-    // swap smooth accelerations back in to evaluate J*smooth, keep the warm ones in registers
-    float keep_arm = lane < NARM ? L.qacc_arm[lane] : 0.f;
-    float keep_free = (lane >= 32 && lane < 32 + 6 * NFREE) ? L.facc[(lane - 32) / 6][(lane - 32) % 6] : 0.f;
-    wave_sync();
-    if (lane < NARM) L.qacc_arm[lane] = L.scratch[lane];
-    if (lane >= 32 && lane < 32 + 6 * NFREE) L.facc[(lane - 32) / 6][(lane - 32) % 6] = L.scratch[8 + lane - 32];
-    wave_sync();
-    if (lane < ncon) {
-      Contact& c = L.con[lane];
-      float js6[6];
-      contact_jacc(L, c, js6, false, nullptr, nullptr);
-      const float Rj[6] = {c.R[0], c.R[1], c.R[1], c.R[2], c.R[3], c.R[3]};
-#pragma unroll
-      for (int j = 0; j < 6; j++) if (j < c.dim) cost += c.f[j] * (0.5f * (jn6[j] - js6[j] + Rj[j] * c.f[j]) + js6[j] - c.aref[j]);
-    }
-    cost = wave_sum_f(cost);
-    wave_sync();
-    if (cost > 0.f) {       // worse than zero forces: cold start (accelerations are already the smooth ones)
-      if (lane < nrow) L.row[lane].f = 0.f;
-      if (lane < ncon) {
-#pragma unroll
-        for (int j = 0; j < 6; j++) L.con[lane].f[j] = 0.f;
-      }
-    } else {
-      if (lane < NARM) L.qacc_arm[lane] = keep_arm;
-      if (lane >= 32 && lane < 32 + 6 * NFREE) L.facc[(lane - 32) / 6][(lane - 32) % 6] = keep_free;
-    }
-    wave_sync();
-  }
-  // ---- main iteration
-  float scale = 1.f / (m->meaninertia * (float)NV);
-  int it = 0;
-  for (; it < max_iter; it++) {
-    float improvement = 0.f;
-    for (int k = 0; k < nrow; k++) {
-      Row1& r = L.row[k];
-      int d = r.dof; float sg = r.sign, fold = r.f;
-      float res = sg * L.qacc_arm[d] - r.aref + r.R * fold;
-      float Add = 1.f / r.Ainv;
-      float fnew = fold - res * r.Ainv;
-      if (r.floss > 0.f) fnew = fminf(fmaxf(fnew, -r.floss), r.floss);
-      else if (fnew < 0.f) fnew = 0.f;
-      float df = fnew - fold;
-      float change = df * (0.5f * Add * df + res);
-      if (change > 1e-10f) { df = 0.f; change = 0.f; fnew = fold; }
-      improvement -= change;
-      wave_sync();
-      if (lane < NARM) L.qacc_arm[lane] += L.Minv[lane][d] * sg * df;
-      if (lane == 0) r.f = fnew;
-      wave_sync();
-    }
-    for (int k = 0; k < ncon; k++) {
-      Contact& c = L.con[k];
-      int dim = c.dim;
-      if (dim == 0) continue;
-      float res[6], old[6], f[6];
-      contact_jacc(L, c, res, false, nullptr, nullptr);
-      const float Rj[6] = {c.R[0], c.R[1], c.R[1], c.R[2], c.R[3], c.R[3]};
-      const float fr[5] = {c.fric[0], c.fric[0], c.fric[1], c.fric[2], c.fric[2]};
-      float A[6][6];
-#pragma unroll
-      for (int j = 0; j < 6; j++)
-#pragma unroll
-        for (int q = 0; q <= j; q++) { float v = c.A[j * (j + 1) / 2 + q]; A[j][q] = v; A[q][j] = v; }
-#pragma unroll
-      for (int j = 0; j < 6; j++) { old[j] = c.f[j]; f[j] = old[j]; res[j] = (j < dim) ? res[j] - c.aref[j] + Rj[j] * old[j] : 0.f; }
-      // normal / ray update
-      if (f[0] < MINVAL_F) {
-        f[0] -= res[0] / A[0][0];
-        if (f[0] < 0.f) f[0] = 0.f;
-#pragma unroll
-        for (int j = 1; j < 6; j++) f[j] = 0.f;
-      } else {
-        float denom = 0.f, vr = 0.f;
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-          float v1 = 0.f;
-#pragma unroll
-          for (int q = 0; q < 6; q++) v1 += A[j][q] * f[q];
-          denom += f[j] * v1; vr += f[j] * res[j];
-        }
-        if (denom >= MINVAL_F) {
-          float x = -vr / denom;
-          if (f[0] + x * f[0] < 0.f) x = -1.f;
-#pragma unroll
-          for (int j = 0; j < 6; j++) f[j] += x * old[j];
-        }
-      }
-      // friction update with the normal fixed
-      if (f[0] >= MINVAL_F && dim > 1) {
-        float bc[5], v[5];
-#pragma unroll
-        for (int j = 0; j < 5; j++) {
-          float b = res[j + 1];
-#pragma unroll
-          for (int q = 0; q < 5; q++) b -= A[j + 1][q + 1] * old[q + 1];
-          b += A[j + 1][0] * (f[0] - old[0]);
-          bc[j] = (j + 1 < dim) ? b : 0.f;
-        }
-        // unconstrained minimum through the precomputed inverse
-        float ssq = 0.f;
-#pragma unroll
-        for (int j = 0; j < 5; j++) {
-          float s = 0.f;
-#pragma unroll
-          for (int q = 0; q < 5; q++) s -= c.Ai[tri(j, q)] * bc[q];
-          v[j] = (j + 1 < dim) ? s : 0.f;
-          ssq += (v[j] / fr[j]) * (v[j] / fr[j]);
-        }
-        if (ssq - f[0] * f[0] >= 1e-10f) {
-          // outside the cone: Newton iteration on the multiplier (mju_QCQP)
-          float Ac[25];
-#pragma unroll
-          for (int j = 0; j < 5; j++)
-#pragma unroll
-            for (int q = 0; q < 5; q++) Ac[5 * j + q] = A[j + 1][q + 1];
-          bool active = qcqp(v, Ac, bc, fr, f[0], dim - 1);
-          if (active) {
-            float s2 = 0.f;
-#pragma unroll
-            for (int j = 0; j < 5; j++) s2 += (v[j] / fr[j]) * (v[j] / fr[j]);
-            float sc = sqrtf(f[0] * f[0] / fmaxf(MINVAL_F, s2));
-#pragma unroll
-            for (int j = 0; j < 5; j++) v[j] *= sc;
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < 5; j++) f[j + 1] = v[j];
-      }
-      float df[6], change = 0.f;
-#pragma unroll
-      for (int j = 0; j < 6; j++) df[j] = f[j] - old[j];
-#pragma unroll
-      for (int j = 0; j < 6; j++) {
-        float v1 = 0.f;
-#pragma unroll
-        for (int q = 0; q < 6; q++) v1 += A[j][q] * df[q];
-        change += df[j] * (0.5f * v1 + res[j]);
-      }
-      if (change > 1e-10f) {
-#pragma unroll
-        for (int j = 0; j < 6; j++) { df[j] = 0.f; f[j] = old[j]; }
-        change = 0.f;
-      }
-      improvement -= change;
-      wave_sync();
-      contact_apply(L, c, df);
-      if (lane < 6) c.f[lane] = f[0] * (lane == 0) + f[1] * (lane == 1) + f[2] * (lane == 2) + f[3] * (lane == 3) + f[4] * (lane == 4) + f[5] * (lane == 5);
-      wave_sync();
-    }
-    if (improvement * scale < tolerance) { it++; break; }
-  }
-  if (lane == 0) L.iters = it;
-  wave_sync();
-}
+#include "so101_solver.hpp"
 
 // ------------------------------------------------------------------ forward + Euler
-DEV void forward(const DevModel* m, EnvLDS& L, int max_iter, float tolerance) {
+// `phases` is a profiling aid (env SO101_DEBUG_PHASES, default all): bit0 collision, bit1 constraint rows + solve,
+// bit2 solve iterations.  Production runs always execute every stage.
+DEV void forward(const DevModel* m, EnvLDS& L, int max_iter, float tolerance, int phases = 7) {
   kinematics(m, L);
   crba_arm(m, L);
   smooth_dynamics(m, L);
-  collision(m, L);
-  make_constraints(m, L);
-  solve_pgs(m, L, max_iter, tolerance);
+  if (phases & 1) collision(m, L);
+  else { if (wave_lane() == 0) { L.ncand = 0; L.ncon = 0; L.narmcon = 0; } wave_sync(); }
+  if (phases & 2) {
+    make_constraints(m, L);
+    solve_pgs(m, L, (phases & 4) ? max_iter : 0, tolerance);
+  }
   // back to MuJoCo's generalized accelerations
   int lane = wave_lane();
   if (lane < NARM) L.qacc[lane] = L.qacc_arm[lane];
@@ -1324,14 +1023,35 @@ DEV void euler(const DevModel* m, EnvLDS& L) {
   wave_sync();
 }
 
-DEV void substep(const DevModel* m, EnvLDS& L, int max_iter, float tolerance, bool freeze_arm) {
-  forward(m, L, max_iter, tolerance);
+// mj_checkPos / mj_checkVel / mj_checkAcc: a NaN or |x| > 1e10 anywhere in the state means the simulation
+// diverged; MuJoCo resets the data to qpos0, dm_control (raise_exception_on_physics_error=False,
+// so101_sim/task_suite.py:153) ends the episode with reward 0 and discount 0.  Returns true when diverged.
+DEV bool check_divergence(EnvLDS& L) {
+  int lane = wave_lane();
+  bool bad = false;
+  if (lane < NQ) { float x = L.qpos[lane]; bad = bad || !(fabsf(x) <= 1e10f); }
+  if (lane < NV) { float x = L.qvel[lane], y = L.qacc[lane]; bad = bad || !(fabsf(x) <= 1e10f) || !(fabsf(y) <= 1e10f); }
+  bool any = wave_ballot(bad) != 0ull;
+  if (any) {
+    wave_sync();
+    if (lane < NQ) L.qpos[lane] = (lane == NARM + 3 || lane == NARM + 10) ? 1.f : 0.f;
+    if (lane < NV) { L.qvel[lane] = 0.f; L.warm[lane] = 0.f; L.qacc[lane] = 0.f; }
+    if (lane == 0) L.overflow |= 8;
+    wave_sync();
+  }
+  return any;
+}
+
+DEV bool substep(const DevModel* m, EnvLDS& L, int max_iter, float tolerance, bool freeze_arm, int phases = 7) {
+  forward(m, L, max_iter, tolerance, phases);
   euler(m, L);
+  if (check_divergence(L)) return true;
   if (freeze_arm) {   // dm_control JointStaticIsolator: non-prop joints restored after every step
     int lane = wave_lane();
     if (lane < NARM) { L.qpos[lane] = L.arm0_q[lane]; L.qvel[lane] = L.arm0_v[lane]; }
     wave_sync();
   }
+  return false;
 }
 
 // ------------------------------------------------------------------ reward (uniform): so100_hand_over.py:238-275

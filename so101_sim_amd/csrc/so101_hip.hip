@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -116,6 +117,8 @@ StepParams make_params(const so101_sim* s) {
   P.tolerance = s->cfg.solver_tolerance >= 0.f ? s->cfg.solver_tolerance : s->hm.tolerance;
   P.settle_max = s->cfg.settle_max_substeps; P.terminate_on_success = s->cfg.terminate_on_success;
   P.n_envs = s->n_envs; P.seed = s->seed; P.env_id_base = s->cfg.env_id_base;
+  const char* ph = getenv("SO101_DEBUG_PHASES");      // profiling aid for so101_physics only
+  P.phases = ph ? atoi(ph) : 7;
   return P;
 }
 

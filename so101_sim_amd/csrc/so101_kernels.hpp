@@ -152,7 +152,8 @@ __global__ void __launch_bounds__(64) k_step(const DevModel* m, StepParams P, De
   // before_step: ctrl = action + homing offsets, unclamped (so100_task.py:266-287)
   if (lane < NU) L.ctrl[lane] = action[(size_t)e * NU + lane] + P.action_offset[lane];
   wave_sync();
-  for (int s = 0; s < P.n_substeps; s++) substep(m, L, P.iterations, P.tolerance, false);
+  bool diverged = false;
+  for (int s = 0; s < P.n_substeps && !diverged; s++) diverged = substep(m, L, P.iterations, P.tolerance, false);
   kinematics(m, L);     // position-dependent quantities of the post-step state (legacy step2/step1 order)
   // joints_pos delay line: read the value of control step k-5, then store step k
   int slot = (sc - 1) % 5;
@@ -164,8 +165,9 @@ __global__ void __launch_bounds__(64) k_step(const DevModel* m, StepParams P, De
     obs[(size_t)e * 18 + 6 + lane] = L.qpos[lane];
     obs[(size_t)e * 18 + 12 + lane] = L.ctrl[lane];
   }
-  float r = task_reward(m, L);
-  bool success = P.terminate_on_success && r >= 1.f, timeout = sc >= P.last_step;
+  float r = diverged ? 0.f : task_reward(m, L);
+  // physics error (dm_control): reward 0, discount 0, episode terminates
+  bool success = (P.terminate_on_success && r >= 1.f) || diverged, timeout = sc >= P.last_step;
   store_state(L, B, e, N);
   store_diag(L, diag, e);
   if (lane == 0) {
@@ -182,7 +184,7 @@ __global__ void __launch_bounds__(64) k_physics(const DevModel* m, StepParams P,
   load_state(L, B, e, P.n_envs);
   if (lane < NARM) { L.arm0_q[lane] = L.qpos[lane]; L.arm0_v[lane] = L.qvel[lane]; }
   wave_sync();
-  for (int s = 0; s < nsub; s++) substep(m, L, P.iterations, P.tolerance, freeze != 0);
+  for (int s = 0; s < nsub; s++) substep(m, L, P.iterations, P.tolerance, freeze != 0, P.phases);
   store_state(L, B, e, P.n_envs);
   store_diag(L, diag, e);
 }

@@ -64,7 +64,7 @@ struct DevModel {
 // Per-env launch parameters that are not part of the model.
 struct StepParams {
   float action_offset[NU];
-  int last_step, n_substeps, iterations, settle_max, terminate_on_success, n_envs;
+  int last_step, n_substeps, iterations, settle_max, terminate_on_success, n_envs, phases;
   float tolerance;
   unsigned long long seed, env_id_base;
 };

@@ -1,0 +1,383 @@
+// PGS constraint solve, island-parallel.
+//
+// The rows of one env split into at most three independent "islands" (arm, object, container; a contact
+// between two dynamic bodies merges their islands).  Gauss-Seidel over a block-diagonal system
+// decouples exactly, so each island is swept by ONE LANE in MuJoCo's row order, with the island's
+// accelerations held in that lane's registers: the iteration loop has no barrier and no shared writes.
+// Lanes 0..2 own the islands rooted at (arm, object, container); the wave reconverges once per iteration
+// for the termination test (sum of cost improvements, MuJoCo's rule).
+//
+// Velocity-space form: the dual residual  A f + b  of a block is evaluated as  J·acc − aref + R f  with
+// acc = qacc_smooth + M⁻¹Jᵀf carried along; the iterates equal those of MuJoCo's explicit-A PGS.
+#pragma once
+
+struct Acc { float arm[NARM]; float fr[NFREE][6]; };
+
+DEV void acc_load(const EnvLDS& L, Acc& a) {
+#pragma unroll
+  for (int q = 0; q < NARM; q++) a.arm[q] = L.qacc_arm[q];
+#pragma unroll
+  for (int f = 0; f < NFREE; f++)
+#pragma unroll
+    for (int i = 0; i < 6; i++) a.fr[f][i] = L.facc[f][i];
+}
+
+// island group of a dynamic-body index: arm links -> 0, free body f -> 1+f, static -> -1
+DEV int body_group(int d) { return d < 0 ? -1 : (d < NARM ? 0 : d - NARM + 1); }
+
+// J·acc for the 6 rows of contact c (sign of each side folded in)
+DEV void jacc_reg(const EnvLDS& L, const Contact& c, const Acc& a, float* jv) {
+#pragma unroll
+  for (int j = 0; j < 6; j++) jv[j] = 0.f;
+#pragma unroll
+  for (int side = 0; side < 2; side++) {
+    int d = side == 0 ? c.d1 : c.d2;
+    float sgn = side == 0 ? -1.f : 1.f;
+    if (d >= NARM) {
+      bool f1 = d > NARM;
+      float al[3], aa[3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) { al[i] = f1 ? a.fr[1][i] : a.fr[0][i]; aa[i] = f1 ? a.fr[1][3 + i] : a.fr[0][3 + i]; }
+      float r[3] = {c.pos[0] - L.xipos[d][0], c.pos[1] - L.xipos[d][1], c.pos[2] - L.xipos[d][2]};
+      float t[3]; cross3(t, aa, r);
+      float pl[3] = {al[0] + t[0], al[1] + t[1], al[2] + t[2]};
+#pragma unroll
+      for (int j = 0; j < 3; j++) { jv[j] += sgn * dot3(&c.frame[3 * j], pl); jv[3 + j] += sgn * dot3(&c.frame[3 * j], aa); }
+    } else if (d >= 0 && c.armslot >= 0) {
+      const ArmCon& ac = L.armcon[c.armslot];
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < NARM; q++) v += ac.J[j][q] * a.arm[q];
+        jv[j] += v;
+      }
+    }
+  }
+}
+
+// acc += M⁻¹ Jᵀ df for contact c
+DEV void apply_reg(const EnvLDS& L, const Contact& c, const float* df, Acc& a) {
+  float F[3], T0[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    F[i] = c.frame[i] * df[0] + c.frame[3 + i] * df[1] + c.frame[6 + i] * df[2];
+    T0[i] = c.frame[i] * df[3] + c.frame[3 + i] * df[4] + c.frame[6 + i] * df[5];
+  }
+#pragma unroll
+  for (int side = 0; side < 2; side++) {
+    int d = side == 0 ? c.d1 : c.d2;
+    float sgn = side == 0 ? -1.f : 1.f;
+    if (d >= NARM) {
+      int f = d - NARM;
+      float r[3] = {c.pos[0] - L.xipos[d][0], c.pos[1] - L.xipos[d][1], c.pos[2] - L.xipos[d][2]};
+      float T[3]; cross3(T, r, F);
+      T[0] += T0[0]; T[1] += T0[1]; T[2] += T0[2];
+      float da[3]; symvec3(da, L.fIinv[f], T);
+      float mi = sgn * L.fminv[f];
+      float s0 = f == 0 ? 1.f : 0.f, s1 = 1.f - s0;
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        a.fr[0][i] += s0 * mi * F[i]; a.fr[0][3 + i] += s0 * sgn * da[i];
+        a.fr[1][i] += s1 * mi * F[i]; a.fr[1][3 + i] += s1 * sgn * da[i];
+      }
+    } else if (d >= 0 && c.armslot >= 0) {
+      const ArmCon& ac = L.armcon[c.armslot];
+#pragma unroll
+      for (int q = 0; q < NARM; q++) {
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < 6; j++) v += ac.B[j][q] * df[j];
+        a.arm[q] += v;
+      }
+    }
+  }
+}
+
+DEV float arm_get(const Acc& a, int d) {
+  float v = a.arm[0];
+#pragma unroll
+  for (int q = 1; q < NARM; q++) v = (d == q) ? a.arm[q] : v;
+  return v;
+}
+
+// one PGS update of scalar row r (dof frictionloss / joint limit); returns the cost decrease
+DEV float row_update(const EnvLDS& L, Row1& r, Acc& a) {
+  int d = r.dof; float sg = r.sign, fold = r.f;
+  float res = sg * arm_get(a, d) - r.aref + r.R * fold;
+  float fnew = fold - res * r.Ainv;
+  if (r.floss > 0.f) fnew = fminf(fmaxf(fnew, -r.floss), r.floss);
+  else if (fnew < 0.f) fnew = 0.f;
+  float df = fnew - fold;
+  float change = df * (0.5f * df / r.Ainv + res);
+  if (change > 1e-10f) return 0.f;
+#pragma unroll
+  for (int q = 0; q < NARM; q++) a.arm[q] += L.Minv[q][d] * sg * df;
+  r.f = fnew;
+  return -change;
+}
+
+// one PGS update of an elliptic contact block; returns the cost decrease
+DEV float contact_update(const EnvLDS& L, Contact& c, Acc& a) {
+  int dim = c.dim;
+  if (dim == 0) return 0.f;
+  float res[6], old[6], f[6];
+  jacc_reg(L, c, a, res);
+  const float Rj[6] = {c.R[0], c.R[1], c.R[1], c.R[2], c.R[3], c.R[3]};
+  const float fr[5] = {c.fric[0], c.fric[0], c.fric[1], c.fric[2], c.fric[2]};
+  float A[6][6];
+#pragma unroll
+  for (int j = 0; j < 6; j++)
+#pragma unroll
+    for (int q = 0; q <= j; q++) { float v = c.A[j * (j + 1) / 2 + q]; A[j][q] = v; A[q][j] = v; }
+#pragma unroll
+  for (int j = 0; j < 6; j++) { old[j] = c.f[j]; f[j] = old[j]; res[j] = (j < dim) ? res[j] - c.aref[j] + Rj[j] * old[j] : 0.f; }
+  // normal / ray update
+  if (f[0] < MINVAL_F) {
+    f[0] -= res[0] / A[0][0];
+    if (f[0] < 0.f) f[0] = 0.f;
+#pragma unroll
+    for (int j = 1; j < 6; j++) f[j] = 0.f;
+  } else {
+    float denom = 0.f, vr = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      float v1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 6; q++) v1 += A[j][q] * f[q];
+      denom += f[j] * v1; vr += f[j] * res[j];
+    }
+    if (denom >= MINVAL_F) {
+      float x = -vr / denom;
+      if (f[0] + x * f[0] < 0.f) x = -1.f;
+#pragma unroll
+      for (int j = 0; j < 6; j++) f[j] += x * old[j];
+    }
+  }
+  // friction update with the normal fixed
+  if (f[0] >= MINVAL_F && dim > 1) {
+    float bc[5], v[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      float b = res[j + 1];
+#pragma unroll
+      for (int q = 0; q < 5; q++) b -= A[j + 1][q + 1] * old[q + 1];
+      b += A[j + 1][0] * (f[0] - old[0]);
+      bc[j] = (j + 1 < dim) ? b : 0.f;
+    }
+    float ssq = 0.f;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 5; q++) s -= c.Ai[tri(j, q)] * bc[q];
+      v[j] = (j + 1 < dim) ? s : 0.f;
+      ssq += (v[j] / fr[j]) * (v[j] / fr[j]);
+    }
+    if (ssq - f[0] * f[0] >= 1e-10f) {
+      float Ac[25];
+#pragma unroll
+      for (int j = 0; j < 5; j++)
+#pragma unroll
+        for (int q = 0; q < 5; q++) Ac[5 * j + q] = A[j + 1][q + 1];
+      bool active = qcqp(v, Ac, bc, fr, f[0], dim - 1);
+      if (active) {
+        float s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 5; j++) s2 += (v[j] / fr[j]) * (v[j] / fr[j]);
+        float sc = sqrtf(f[0] * f[0] / fmaxf(MINVAL_F, s2));
+#pragma unroll
+        for (int j = 0; j < 5; j++) v[j] *= sc;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 5; j++) f[j + 1] = v[j];
+  }
+  float df[6], change = 0.f;
+#pragma unroll
+  for (int j = 0; j < 6; j++) df[j] = f[j] - old[j];
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    float v1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 6; q++) v1 += A[j][q] * df[q];
+    change += df[j] * (0.5f * v1 + res[j]);
+  }
+  if (change > 1e-10f) return 0.f;      // cost went up: keep the old forces
+  apply_reg(L, c, df, a);
+#pragma unroll
+  for (int j = 0; j < 6; j++) c.f[j] = f[j];
+  return -change;
+}
+
+DEV void solve_pgs(const DevModel* m, EnvLDS& L, int max_iter, float tolerance) {
+  int lane = wave_lane();
+  int nrow = L.nrow, ncon = L.ncon;
+  if (lane == 0) L.iters = 0;
+  if (nrow + ncon == 0) { wave_sync(); return; }
+  // ---- islands (uniform): union the dynamic bodies each contact couples
+  int root[3] = {0, 1, 2};
+  for (int k = 0; k < ncon; k++) {
+    int g1 = body_group(L.con[k].d1), g2 = body_group(L.con[k].d2);
+    if (g1 >= 0 && g2 >= 0) {
+      int r1 = g1 == 0 ? root[0] : (g1 == 1 ? root[1] : root[2]);
+      int r2 = g2 == 0 ? root[0] : (g2 == 1 ? root[1] : root[2]);
+      int lo = r1 < r2 ? r1 : r2, hi = r1 < r2 ? r2 : r1;
+#pragma unroll
+      for (int i = 0; i < 3; i++) if (root[i] == hi) root[i] = lo;
+    }
+  }
+  bool owner = lane < 3 && (lane == 0 ? root[0] == 0 : (lane == 1 ? root[1] == 1 : root[2] == 2));
+  auto island_of = [&](const Contact& c) {
+    int g = body_group(c.d1 >= 0 ? c.d1 : c.d2);
+    return g == 0 ? root[0] : (g == 1 ? root[1] : root[2]);
+  };
+  Acc smooth; acc_load(L, smooth);          // uniform copy of the unconstrained accelerations
+  // ---- warm start: forces from the previous qacc through the primal->force map (lane = row / contact)
+  {
+    Acc w;
+#pragma unroll
+    for (int d = 0; d < NARM; d++) w.arm[d] = L.warm[d];
+#pragma unroll
+    for (int f = 0; f < NFREE; f++) {
+      int b = NARM + f;
+      const float* wq = &L.warm[NARM + 6 * f];
+      float wb[3] = {wq[3], wq[4], wq[5]}, alp[3];
+      matvec3(alp, L.xmat[b], wb);
+      float r[3] = {L.xipos[b][0] - L.xpos[b][0], L.xipos[b][1] - L.xpos[b][1], L.xipos[b][2] - L.xpos[b][2]};
+      float ww[3] = {L.fvel[f][3], L.fvel[f][4], L.fvel[f][5]};
+      float t1[3], t2[3];
+      cross3(t1, alp, r); cross3(t2, ww, r); cross3(t2, ww, t2);
+#pragma unroll
+      for (int i = 0; i < 3; i++) { w.fr[f][i] = wq[i] + t1[i] + t2[i]; w.fr[f][3 + i] = alp[i]; }
+    }
+    if (lane < nrow) {
+      Row1& r = L.row[lane];
+      float jar = r.sign * L.warm[r.dof] - r.aref;
+      float f = -jar / r.R;
+      if (r.floss > 0.f) f = fminf(fmaxf(f, -r.floss), r.floss);
+      else f = jar < 0.f ? f : 0.f;
+      r.f = f;
+    }
+    if (lane < ncon) {
+      Contact& c = L.con[lane];
+      float jar[6];
+      jacc_reg(L, c, w, jar);
+      const float Rj[6] = {c.R[0], c.R[1], c.R[1], c.R[2], c.R[3], c.R[3]};
+      const float fr[5] = {c.fric[0], c.fric[0], c.fric[1], c.fric[2], c.fric[2]};
+      int dim = c.dim;
+#pragma unroll
+      for (int j = 0; j < 6; j++) jar[j] -= c.aref[j];
+      float mu = c.mu, U[6], T = 0.f;
+      U[0] = jar[0] * mu;
+#pragma unroll
+      for (int j = 1; j < 6; j++) { U[j] = (j < dim) ? jar[j] * fr[j - 1] : 0.f; T += U[j] * U[j]; }
+      T = sqrtf(T);
+      float N = U[0], fo[6];
+      if ((N >= mu * T) || (T <= 0.f && N >= 0.f)) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) fo[j] = 0.f;
+      } else if ((mu * N + T <= 0.f) || (T <= 0.f && N < 0.f)) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) fo[j] = (j < dim) ? -jar[j] / Rj[j] : 0.f;
+      } else {
+        float Dm = (1.f / Rj[0]) / fmaxf(mu * mu * (1.f + mu * mu), MINVAL_F), NmT = N - mu * T;
+        fo[0] = -Dm * NmT * mu;
+#pragma unroll
+        for (int j = 1; j < 6; j++) fo[j] = (j < dim) ? -fo[0] / T * U[j] * fr[j - 1] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 6; j++) c.f[j] = fo[j];
+    }
+  }
+  wave_sync();
+  // ---- accelerations produced by the warm forces: each island owner applies its own rows
+  Acc a = smooth;
+  if (owner) {
+    if (lane == 0) {
+      for (int k = 0; k < nrow; k++) {
+        const Row1& r = L.row[k];
+#pragma unroll
+        for (int q = 0; q < NARM; q++) a.arm[q] += L.Minv[q][r.dof] * r.sign * r.f;
+      }
+    }
+    for (int k = 0; k < ncon; k++) {
+      const Contact& c = L.con[k];
+      if (island_of(c) != lane) continue;
+      float df[6];
+#pragma unroll
+      for (int j = 0; j < 6; j++) df[j] = c.f[j];
+      apply_reg(L, c, df, a);
+    }
+    // publish the bodies this island owns: scratch[0..5] arm, [8..13] object, [16..21] container
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+      int rg = g == 0 ? root[0] : (g == 1 ? root[1] : root[2]);
+      if (rg == lane) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) L.scratch[8 * g + i] = g == 0 ? a.arm[i] : a.fr[g - 1][i];
+      }
+    }
+  }
+  wave_sync();
+  // ---- dual cost  sum f.(0.5 (A f) + b),  A f = J (acc_w - smooth) + R f,  b = J smooth - aref
+  float cost = 0.f;
+  {
+    Acc aw;
+#pragma unroll
+    for (int i = 0; i < 6; i++) { aw.arm[i] = L.scratch[i]; aw.fr[0][i] = L.scratch[8 + i]; aw.fr[1][i] = L.scratch[16 + i]; }
+    if (lane < nrow) {
+      const Row1& r = L.row[lane];
+      float jn = r.sign * L.scratch[r.dof], js = r.sign * L.qacc_arm[r.dof];
+      cost += r.f * (0.5f * (jn - js + r.R * r.f) + js - r.aref);
+    }
+    if (lane < ncon) {
+      const Contact& c = L.con[lane];
+      float jn6[6], js6[6];
+      jacc_reg(L, c, aw, jn6); jacc_reg(L, c, smooth, js6);
+      const float Rj[6] = {c.R[0], c.R[1], c.R[1], c.R[2], c.R[3], c.R[3]};
+#pragma unroll
+      for (int j = 0; j < 6; j++) if (j < c.dim) cost += c.f[j] * (0.5f * (jn6[j] - js6[j] + Rj[j] * c.f[j]) + js6[j] - c.aref[j]);
+    }
+  }
+  cost = wave_sum_f(cost);
+  if (cost > 0.f) {             // worse than zero forces: cold start
+    if (lane < nrow) L.row[lane].f = 0.f;
+    if (lane < ncon) {
+#pragma unroll
+      for (int j = 0; j < 6; j++) L.con[lane].f[j] = 0.f;
+    }
+    a = smooth;
+  }
+  wave_sync();
+  // ---- main iteration: island owners sweep their rows, no barrier inside
+  float scale = 1.f / (m->meaninertia * (float)NV);
+  int it = 0;
+  for (; it < max_iter; it++) {
+    float improvement = 0.f;
+    if (owner) {
+      if (lane == 0) for (int k = 0; k < nrow; k++) improvement += row_update(L, L.row[k], a);
+      for (int k = 0; k < ncon; k++) {
+        Contact& c = L.con[k];
+        if (island_of(c) != lane) continue;
+        improvement += contact_update(L, c, a);
+      }
+    }
+    improvement = wave_sum_f(improvement);
+    if (improvement * scale < tolerance) { it++; break; }
+  }
+  // ---- publish the constrained accelerations
+  wave_sync();
+  if (owner) {
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+      int rg = g == 0 ? root[0] : (g == 1 ? root[1] : root[2]);
+      if (rg == lane) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) { if (g == 0) L.qacc_arm[i] = a.arm[i]; else L.facc[g - 1][i] = a.fr[g - 1][i]; }
+      }
+    }
+  }
+  if (lane == 0) L.iters = it;
+  wave_sync();
+}

@@ -51,6 +51,12 @@ def load_library(path: str | None = None) -> C.CDLL:
         raise RuntimeError(
             f"{path} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback for the step path.")
+    # PyTorch bundles its own HIP runtime; it must be the first one the process loads, otherwise this
+    # library binds /opt/rocm's copy and the two runtimes do not see each other's device state.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(path)
     vp = C.c_void_p
     L.so101_version.restype = C.c_int

@@ -20,6 +20,10 @@ KAT_PROPS = np.array([2.65129794e-01, 4.09270959e-03, 4.21711098e-01, 9.99246834
                       -2.17988678e-01, -3.96717335e-02, 4.22621829e-01, 9.99999456e-01, -5.82714664e-04, -8.65621822e-04, -8.25292623e-06])
 
 
+def _arm_geom(g):
+    return 1 <= g <= 18        # geom ids: 0 floor, 1 Base, 2-18 arm links/pads, 19-25 table + static props, 26+ free props
+
+
 def valid_arm_states(blob64, n, seed=0, spread=0.6):
     """Random arm configurations/velocities whose geoms touch nothing (checked with the oracle)."""
     rng = np.random.RandomState(seed)
@@ -29,8 +33,7 @@ def valid_arm_states(blob64, n, seed=0, spread=0.6):
         q = np.concatenate([rng.uniform(-spread, spread, 6) * [1, 0.6, 1, 1, 1, 0.5] + [0, -0.3, 0.6, 0.3, 0, 0.3], KAT_PROPS])
         o.set_state(q, np.zeros(18), None)
         o.forward()
-        names_ok = all(c["geom1"] >= 19 for c in o.contacts())       # only table/prop contacts (geom ids >= 19)
-        if names_ok:
+        if not any(_arm_geom(c["geom1"]) or _arm_geom(c["geom2"]) for c in o.contacts()):   # arm touches nothing
             Q.append(q)
             V.append(np.concatenate([rng.uniform(-1.5, 1.5, 6), np.zeros(12)]))
     return np.array(Q).T, np.array(V).T
@@ -99,7 +102,7 @@ def check_control_step(make_sim, blobs, n=4, seed=3, iterations=100):
         o.set_ctrl(CT[:, e])
         o.substeps(10)
         qo, vo, _ = o.get_state()
-        arm_contact = any(c["geom1"] < 19 for c in o.contacts())
+        arm_contact = any(_arm_geom(c["geom1"]) or _arm_geom(c["geom2"]) for c in o.contacts())
         tol_q, tol_v = (2e-4, 5e-2) if arm_contact else (2e-5, 5e-3)
         assert np.abs(q1[:6, e] - qo[:6]).max() <= max(tol_q, 2e-6 * np.abs(qo[:6]).max()), e
         assert np.abs(v1[:6, e] - vo[:6]).max() <= max(tol_v, 2e-5 * np.abs(vo[:6]).max()), e
@@ -184,3 +187,28 @@ def check_env_semantics(make_sim, blobs, n=2, settle=30, steps=8, last_step=7, s
         elif t == last_step + 1:
             assert np.all(st == 0)                                             # auto-reset: FIRST
             assert np.all(obs[:, 0:12] == 0)
+
+
+def check_divergence_handling(make_sim, blobs):
+    """A non-finite / exploded state ends the episode like a dm_control physics error: LAST, reward 0, discount 0,
+    then the next step auto-resets (SURVEY.md section 5 'failure detection'); the kernels must survive NaNs."""
+    n = 2
+    sim = make_sim(n, seed=2, settle_max_substeps=5, solver_iterations=5)
+    Q = np.tile(np.concatenate([np.zeros(6), KAT_PROPS])[:, None], (1, n))
+    V = np.zeros((18, n))
+    V[2, 0] = np.nan            # env 0 poisoned, env 1 healthy
+    sim.set_state(Q, V, np.zeros((6, n)), np.zeros((18, n)))
+    sim.begin_episode()
+    obs, rew, disc, st = sim.step(np.zeros((n, 6), dtype=np.float32))
+    assert (rew[0], disc[0], st[0]) == (0.0, 0.0, 2)
+    assert (rew[1], disc[1], st[1]) == (0.0, 1.0, 1)
+    q, v, _ = sim.get_state()
+    assert np.all(np.isfinite(q)) and np.all(np.isfinite(v))
+    o = Oracle(blobs["f64"])
+    o.env_config(seed=2, env_id=0, settle_max_substeps=5)
+    o.set_state(Q[:, 0], V[:, 0], np.zeros(18))
+    o.env_begin()
+    _, orew, odisc, ost = o.env_step(np.zeros(6))
+    assert (orew, odisc, ost) == (0.0, 0.0, 2)
+    obs, rew, disc, st = sim.step(np.zeros((n, 6), dtype=np.float32))
+    assert st[0] == 0 and st[1] == 1          # env 0 auto-reset -> FIRST

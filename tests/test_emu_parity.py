@@ -32,3 +32,7 @@ def test_reward_bitexact(make_sim, blobs):
 
 def test_env_semantics(make_sim, blobs):
     pc.check_env_semantics(make_sim, blobs, n=1, settle=10, steps=8, last_step=7, iterations=10)
+
+
+def test_divergence_handling(make_sim, blobs):
+    pc.check_divergence_handling(make_sim, blobs)

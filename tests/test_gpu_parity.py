@@ -109,3 +109,7 @@ def test_properties_at_benchmark_size(make_sim, blobs):
     assert np.all(d[:, 4] == 0), "contact/candidate overflow at benchmark size"
     ep = sim._get(sim.ep_return)
     np.testing.assert_array_equal(ep, total.astype(np.float32))
+
+
+def test_divergence_handling(make_sim, blobs):
+    pc.check_divergence_handling(make_sim, blobs)
