@@ -426,30 +426,33 @@ void mdsupport(const orc_sim* s, int g1, int g2, const real* dir, const real* or
 
 inline bool isz(real x) { return std::fabs(x) < 1e-10; }   // CCD_EPS-style zero test
 
-// squared distance of the origin to triangle (x0,B,C) with witness (libccd ccdVec3PointTriDist2 for P=0)
-real origin_tri_dist2(const real* x0, const real* B, const real* C, real* wit) {
+// squared distance of the origin to triangle (x0,B,C): closest point `wit` and its barycentric weights `bw`
+// (libccd ccdVec3PointTriDist2 for P=0, extended with the weights)
+real origin_tri_dist2(const real* x0, const real* B, const real* C, real* wit, real* bw) {
   real d1[3], d2[3], a[3];
   for (int k = 0; k < 3; k++) { d1[k] = B[k] - x0[k]; d2[k] = C[k] - x0[k]; a[k] = x0[k]; }
-  real u = dot3(a, a), v = dot3(d1, d1), w = dot3(d2, d2), p = dot3(a, d1), q = dot3(a, d2), r = dot3(d1, d2);
+  real v = dot3(d1, d1), w = dot3(d2, d2), p = dot3(a, d1), q = dot3(a, d2), r = dot3(d1, d2);
   real den = w * v - r * r, sp = -1, tp = -1;
   if (!isz(den)) { sp = (q * r - w * p) / den; tp = (-sp * r - q) / w; }
-  auto seg = [&](const real* P0, const real* P1, real* wt) {   // origin to segment
+  auto seg = [&](const real* P0, const real* P1, real* wt, real* tout) {   // origin to segment
     real dd[3] = {P1[0] - P0[0], P1[1] - P0[1], P1[2] - P0[2]};
     real t = -dot3(P0, dd) / std::max(dot3(dd, dd), MINVAL);
     t = std::min(std::max(t, 0.0), 1.0);
     for (int k = 0; k < 3; k++) wt[k] = P0[k] + t * dd[k];
+    *tout = t;
     return dot3(wt, wt);
   };
   if ((isz(sp) || sp > 0) && (isz(sp - 1) || sp < 1) && (isz(tp) || tp > 0) && (isz(tp - 1) || tp < 1) &&
       (isz(tp + sp - 1) || tp + sp < 1)) {
     for (int k = 0; k < 3; k++) wit[k] = x0[k] + sp * d1[k] + tp * d2[k];
+    bw[0] = 1 - sp - tp; bw[1] = sp; bw[2] = tp;
     return dot3(wit, wit);
   }
-  real w1[3], w2[3], w3[3];
-  real e1 = seg(x0, B, w1), e2 = seg(x0, C, w2), e3 = seg(B, C, w3);
-  real best = e1; std::memcpy(wit, w1, sizeof w1);
-  if (e2 < best) { best = e2; std::memcpy(wit, w2, sizeof w2); }
-  if (e3 < best) { best = e3; std::memcpy(wit, w3, sizeof w3); }
+  real w1[3], w2[3], w3[3], t1, t2, t3;
+  real e1 = seg(x0, B, w1, &t1), e2 = seg(x0, C, w2, &t2), e3 = seg(B, C, w3, &t3);
+  real best = e1; std::memcpy(wit, w1, sizeof w1); bw[0] = 1 - t1; bw[1] = t1; bw[2] = 0;
+  if (e2 < best) { best = e2; std::memcpy(wit, w2, sizeof w2); bw[0] = 1 - t2; bw[1] = 0; bw[2] = t2; }
+  if (e3 < best) { best = e3; std::memcpy(wit, w3, sizeof w3); bw[0] = 0; bw[1] = 1 - t3; bw[2] = t3; }
   return best;
 }
 
@@ -543,31 +546,17 @@ bool mpr_penetration(const orc_sim* s, int g1, int g2, real* depth, real* dir, r
     portal_dir(d);
     mdsupport(s, g1, g2, d, org, &v4);
     if (reach_tol(v4, d) || it > m.mpr_iter) {
-      real pd[3];
-      real d2 = origin_tri_dist2(v1.v, v2.v, v3.v, pd);
+      real pd[3], bw[3];
+      real d2 = origin_tri_dist2(v1.v, v2.v, v3.v, pd, bw);
       *depth = std::sqrt(d2);
       if (isz(pd[0]) && isz(pd[1]) && isz(pd[2])) { *depth = 0; for (int k = 0; k < 3; k++) dir[k] = d[k]; }
       else { for (int k = 0; k < 3; k++) dir[k] = pd[k]; normalize3(dir); }
-      // position (libccd findPos): barycentric weights of the origin ray within the portal
-      real b[4], t[3];
-      cross3(t, v1.v, v2.v); b[0] = dot3(t, v3.v);
-      cross3(t, v3.v, v2.v); b[1] = dot3(t, v0.v);
-      cross3(t, v0.v, v1.v); b[2] = dot3(t, v3.v);
-      cross3(t, v2.v, v1.v); b[3] = dot3(t, v0.v);
-      real sum = b[0] + b[1] + b[2] + b[3];
-      if (isz(sum) || sum < 0) {
-        b[0] = 0;
-        cross3(t, v2.v, v3.v); b[1] = dot3(t, d);
-        cross3(t, v3.v, v1.v); b[2] = dot3(t, d);
-        cross3(t, v1.v, v2.v); b[3] = dot3(t, d);
-        sum = b[1] + b[2] + b[3];
-      }
-      real inv = 1.0 / sum;
-      const MV* vs[4] = {&v0, &v1, &v2, &v3};
+      // contact position: midpoint of the two witness points of the closest point on the portal (the witness
+      // pair GJK/EPA reports; libccd's origin-ray weights are path dependent for deep penetrations)
       for (int k = 0; k < 3; k++) {
-        real p1 = 0, p2 = 0;
-        for (int i = 0; i < 4; i++) { p1 += b[i] * vs[i]->a[k]; p2 += b[i] * vs[i]->b[k]; }
-        pos[k] = 0.5 * (p1 + p2) * inv + org[k];
+        real p1 = bw[0] * v1.a[k] + bw[1] * v2.a[k] + bw[2] * v3.a[k];
+        real p2 = bw[0] * v1.b[k] + bw[1] * v2.b[k] + bw[2] * v3.b[k];
+        pos[k] = 0.5 * (p1 + p2) + org[k];
       }
       return true;
     }

@@ -1,0 +1,33 @@
+"""Runs random-action steps on the GPU, snapshots every env's state each step and saves the state/action that
+precede the first divergence flags (diag word 4 & 8) so they can be replayed against the oracle offline."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from so101_sim_amd.model import scenes
+from tests.simharness import ArraySim
+
+raw32, _ = scenes.load_blob("banana", "f32")
+N = 4096
+s = ArraySim(raw32, N, backend="gpu", seed=1, solver_iterations=int(os.environ.get("ITERS", "100")), settle_max_substeps=200, last_step=500)
+s.reset()
+lo = np.array([-np.pi, -3.14158, -3.14158, -3.14158, -3.14158, 0.0], dtype=np.float32)
+hi = np.array([np.pi, 3.14158, 3.14158, 3.14158, 3.14158, 0.08], dtype=np.float32)
+rng = np.random.RandomState(2)
+saved = []
+stats = []
+for t in range(25):
+    q0, v0, w0 = s.get_state()
+    c0 = s._get(s.ctrl)
+    act = rng.uniform(lo, hi, size=(N, 6)).astype(np.float32)
+    obs, rew, disc, st = s.step(act)
+    d = s.get_diag()
+    bad = np.where((d[:, 4] & 8) != 0)[0]
+    stats.append((t, len(bad), int((d[:, 4] & 4 != 0).sum()), int((d[:, 4] & 2 != 0).sum()), int((d[:, 4] & 1 != 0).sum()), float(d[:, 0].mean()), int(d[:, 0].max()), float(d[:, 3].mean()), int(d[:, 3].max())))
+    for e in bad[:4]:
+        if st[e] == 2:
+            saved.append(dict(t=t, env=int(e), qpos=q0[:, e], qvel=v0[:, e], warm=w0[:, e], action=act[e], ctrl=c0[:, e]))
+for x in stats:
+    print("t=%d diverged=%d armpool_ovf=%d con_ovf=%d cand_ovf=%d ncon mean %.1f max %d ncand mean %.1f max %d" % x)
+os.makedirs("gpurun_out", exist_ok=True)
+np.save("gpurun_out/diverged.npy", np.array(saved, dtype=object), allow_pickle=True)
+print("saved", len(saved))

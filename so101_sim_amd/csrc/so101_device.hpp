@@ -337,10 +337,14 @@ DEV void smooth_dynamics(const DevModel* m, EnvLDS& L) {
     float g[3]; cross3(g, ww, Iw_);
     g[0] = -g[0]; g[1] = -g[1]; g[2] = -g[2];
     float alp[3]; symvec3(alp, L.fIinv[f], g);
+    // Solver coordinates: (a~, alpha) with a~ = qacc_lin + alpha x r, i.e. the COM acceleration WITHOUT the
+    // centripetal term w x (w x r).  J*qacc in MuJoCo's generalized coordinates (which neglects Jdot*qvel)
+    // is then e.(a~ + alpha x (p - com)) exactly, and force updates stay (1/m, Iinv).
+    float cen[3]; cross3(cen, ww, wr);
 #pragma unroll
     for (int i = 0; i < 3; i++) {
       L.fvel[f][i] = qv[i] + wr[i]; L.fvel[f][3 + i] = ww[i];
-      L.facc[f][i] = m->grav[i]; L.facc[f][3 + i] = alp[i];
+      L.facc[f][i] = m->grav[i] - cen[i]; L.facc[f][3 + i] = alp[i];
     }
   }
   wave_sync();
@@ -421,15 +425,18 @@ DEV void mdsupport(const DevModel* m, const GeomW& G1, const GeomW& G2, const fl
 
 DEV bool isz(float x) { return fabsf(x) < EPS_F; }
 
-DEV float seg_origin(const float* P0, const float* P1, float* wt) {
+// origin to segment P0-P1: squared distance, closest point and the parameter t (weight of P1)
+DEV float seg_origin(const float* P0, const float* P1, float* wt, float* tout) {
   float dd[3] = {P1[0] - P0[0], P1[1] - P0[1], P1[2] - P0[2]};
   float t = -dot3(P0, dd) / fmaxf(dot3(dd, dd), 1e-30f);
   t = fminf(fmaxf(t, 0.f), 1.f);
   wt[0] = P0[0] + t * dd[0]; wt[1] = P0[1] + t * dd[1]; wt[2] = P0[2] + t * dd[2];
+  *tout = t;
   return dot3(wt, wt);
 }
 
-DEV float origin_tri_dist2(const float* x0, const float* B, const float* C, float* wit) {
+// squared distance of the origin to triangle (x0,B,C); wit = closest point, bw = its barycentric weights
+DEV float origin_tri_dist2(const float* x0, const float* B, const float* C, float* wit, float* bw) {
   float d1[3] = {B[0] - x0[0], B[1] - x0[1], B[2] - x0[2]}, d2[3] = {C[0] - x0[0], C[1] - x0[1], C[2] - x0[2]};
   float v = dot3(d1, d1), w = dot3(d2, d2), p = dot3(x0, d1), q = dot3(x0, d2), r = dot3(d1, d2);
   float den = w * v - r * r, sp = -1.f, tp = -1.f;
@@ -437,13 +444,14 @@ DEV float origin_tri_dist2(const float* x0, const float* B, const float* C, floa
   if ((isz(sp) || sp > 0.f) && (isz(sp - 1.f) || sp < 1.f) && (isz(tp) || tp > 0.f) && (isz(tp - 1.f) || tp < 1.f) &&
       (isz(tp + sp - 1.f) || tp + sp < 1.f)) {
     wit[0] = x0[0] + sp * d1[0] + tp * d2[0]; wit[1] = x0[1] + sp * d1[1] + tp * d2[1]; wit[2] = x0[2] + sp * d1[2] + tp * d2[2];
+    bw[0] = 1.f - sp - tp; bw[1] = sp; bw[2] = tp;
     return dot3(wit, wit);
   }
-  float w1[3], w2[3], w3[3];
-  float e1 = seg_origin(x0, B, w1), e2 = seg_origin(x0, C, w2), e3 = seg_origin(B, C, w3);
-  float best = e1; wit[0] = w1[0]; wit[1] = w1[1]; wit[2] = w1[2];
-  if (e2 < best) { best = e2; wit[0] = w2[0]; wit[1] = w2[1]; wit[2] = w2[2]; }
-  if (e3 < best) { best = e3; wit[0] = w3[0]; wit[1] = w3[1]; wit[2] = w3[2]; }
+  float w1[3], w2[3], w3[3], t1, t2, t3;
+  float e1 = seg_origin(x0, B, w1, &t1), e2 = seg_origin(x0, C, w2, &t2), e3 = seg_origin(B, C, w3, &t3);
+  float best = e1; wit[0] = w1[0]; wit[1] = w1[1]; wit[2] = w1[2]; bw[0] = 1.f - t1; bw[1] = t1; bw[2] = 0.f;
+  if (e2 < best) { best = e2; wit[0] = w2[0]; wit[1] = w2[1]; wit[2] = w2[2]; bw[0] = 1.f - t2; bw[1] = 0.f; bw[2] = t2; }
+  if (e3 < best) { best = e3; wit[0] = w3[0]; wit[1] = w3[1]; wit[2] = w3[2]; bw[0] = 0.f; bw[1] = 1.f - t3; bw[2] = t3; }
   return best;
 }
 
@@ -526,31 +534,18 @@ DEV bool mpr_penetration(const DevModel* m, const GeomW& G1, const GeomW& G2, fl
       if (!(isz(dv4) || dv4 > 0.f)) return false;     // cannot encapsule origin
       if (reached || it > 100) return false;
     } else if (reached || it > m->mpr_iter) {
-      float pd[3];
-      float d2 = origin_tri_dist2(v1.v, v2.v, v3.v, pd);
+      float pd[3], bw[3];
+      float d2 = origin_tri_dist2(v1.v, v2.v, v3.v, pd, bw);
       *depth = sqrtf(d2);
       if (isz(pd[0]) && isz(pd[1]) && isz(pd[2])) { *depth = 0.f; dir[0] = d[0]; dir[1] = d[1]; dir[2] = d[2]; }
       else { dir[0] = pd[0]; dir[1] = pd[1]; dir[2] = pd[2]; normalize3(dir); }
-      float b[4], t[3];
-      cross3(t, v1.v, v2.v); b[0] = dot3(t, v3.v);
-      cross3(t, v3.v, v2.v); b[1] = dot3(t, v0.v);
-      cross3(t, v0.v, v1.v); b[2] = dot3(t, v3.v);
-      cross3(t, v2.v, v1.v); b[3] = dot3(t, v0.v);
-      float sum = b[0] + b[1] + b[2] + b[3];
-      if (isz(sum) || sum < 0.f) {
-        b[0] = 0.f;
-        cross3(t, v2.v, v3.v); b[1] = dot3(t, d);
-        cross3(t, v3.v, v1.v); b[2] = dot3(t, d);
-        cross3(t, v1.v, v2.v); b[3] = dot3(t, d);
-        sum = b[1] + b[2] + b[3];
-      }
-      if (!(fabsf(sum) > 1e-30f)) { b[0] = 0.f; b[1] = b[2] = b[3] = 1.f; sum = 3.f; }   // degenerate portal: centroid
-      float inv = 1.f / sum;
+      // contact position: midpoint of the two witness points of the closest point on the portal (the witness pair
+      // GJK/EPA reports); libccd's origin-ray weights are path dependent for deep penetrations
 #pragma unroll
       for (int i = 0; i < 3; i++) {
-        float p1 = b[0] * v0.a[i] + b[1] * v1.a[i] + b[2] * v2.a[i] + b[3] * v3.a[i];
-        float p2 = b[0] * v0.b[i] + b[1] * v1.b[i] + b[2] * v2.b[i] + b[3] * v3.b[i];
-        pos[i] = 0.5f * (p1 + p2) * inv + org[i];
+        float p1 = bw[0] * v1.a[i] + bw[1] * v2.a[i] + bw[2] * v3.a[i];
+        float p2 = bw[0] * v1.b[i] + bw[1] * v2.b[i] + bw[2] * v3.b[i];
+        pos[i] = 0.5f * (p1 + p2) + org[i];
       }
       return true;
     }
@@ -826,35 +821,43 @@ DEV void make_constraints(const DevModel* m, EnvLDS& L) {
         for (int j = 0; j < 6; j++)
 #pragma unroll
           for (int k = 0; k <= j; k++) A[j][k] += mi * dot3(ul[j], ul[k]) + dot3(ua[j], Iua[k]);
-      } else if (d >= 0 && c.armslot >= 0) {
-        // rows are streamed through this contact's slot of the LDS pool (private to the lane) to keep
-        // the register footprint small: J row -> B row = Minv J^T -> A block from the stored rows
-        ArmCon& ac = L.armcon[c.armslot];
+      }
+    }
+    if (c.armslot >= 0) {
+      // Arm part, ONCE per contact: J = J(link of geom2) - J(link of geom1) in the 6 arm dofs (either side may
+      // be static or a free body; for arm-arm self-collision both contribute).  Rows are streamed through this
+      // contact's slot of the LDS pool (private to the lane) to keep the register footprint small.
+      ArmCon& ac = L.armcon[c.armslot];
+      int l1 = (c.d1 >= 0 && c.d1 < NARM) ? c.d1 : -1, l2 = (c.d2 >= 0 && c.d2 < NARM) ? c.d2 : -1;
 #pragma unroll
-        for (int j = 0; j < 6; j++) {
-          float Jr[NARM];
-          arm_jac_row(L, d, c.pos, &c.frame[3 * (j % 3)], j >= 3, Jr);
-          float vj = 0.f;
+      for (int j = 0; j < 6; j++) {
+        float Jr[NARM], J1[NARM];
+        arm_jac_row(L, l2, c.pos, &c.frame[3 * (j % 3)], j >= 3, Jr);      // link -1 gives a zero row
+        arm_jac_row(L, l1, c.pos, &c.frame[3 * (j % 3)], j >= 3, J1);
 #pragma unroll
-          for (int q = 0; q < NARM; q++) {
-            float v = 0.f;
+        for (int q = 0; q < NARM; q++) Jr[q] -= J1[q];
+        float vj = 0.f;
 #pragma unroll
-            for (int s = 0; s < NARM; s++) v += L.Minv[q][s] * Jr[s];
-            ac.B[j][q] = sgn * v;
-            ac.J[j][q] = sgn * Jr[q];
-            vj += Jr[q] * L.qvel[q];
-          }
-          vel[j] += sgn * vj;
+        for (int q = 0; q < NARM; q++) { ac.J[j][q] = Jr[q]; vj += Jr[q] * L.qvel[q]; }
+        vel[j] += vj;
+      }
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        float Bk[NARM];                    // column k of Minv J^T
+#pragma unroll
+        for (int q = 0; q < NARM; q++) {
+          float v = 0.f;
+#pragma unroll
+          for (int s = 0; s < NARM; s++) v += L.Minv[q][s] * ac.J[k][s];
+          Bk[q] = v;
         }
 #pragma unroll
-        for (int j = 0; j < 6; j++)
+        for (int j = k; j < 6; j++) {
+          float v = 0.f;
 #pragma unroll
-          for (int k = 0; k <= j; k++) {
-            float v = 0.f;
-#pragma unroll
-            for (int q = 0; q < NARM; q++) v += ac.J[j][q] * ac.B[k][q];   // sgn^2 = 1
-            A[j][k] += v;
-          }
+          for (int q = 0; q < NARM; q++) v += ac.J[j][q] * Bk[q];
+          A[j][k] += v;
+        }
       }
     }
     const float Rj[6] = {c.R[0], c.R[1], c.R[1], c.R[2], c.R[3], c.R[3]};
@@ -997,7 +1000,7 @@ DEV void forward(const DevModel* m, EnvLDS& L, int max_iter, float tolerance, in
     cross3(t1, al, r); cross3(t2, ww, r); cross3(t2, ww, t2);
     matTvec3(ab, L.xmat[b], al);
 #pragma unroll
-    for (int i = 0; i < 3; i++) { L.qacc[NARM + 6 * f + i] = L.facc[f][i] - t1[i] - t2[i]; L.qacc[NARM + 6 * f + 3 + i] = ab[i]; }
+    for (int i = 0; i < 3; i++) { L.qacc[NARM + 6 * f + i] = L.facc[f][i] - t1[i]; L.qacc[NARM + 6 * f + 3 + i] = ab[i]; }
   }
   wave_sync();
 }

@@ -56,7 +56,7 @@ DEV void twist_to_qacc(EnvLDS& L) {
     cross3(t1, al, r); cross3(t2, ww, r); cross3(t2, ww, t2);
     matTvec3(ab, L.xmat[b], al);
 #pragma unroll
-    for (int i = 0; i < 3; i++) { L.qacc[NARM + 6 * f + i] = L.facc[f][i] - t1[i] - t2[i]; L.qacc[NARM + 6 * f + 3 + i] = ab[i]; }
+    for (int i = 0; i < 3; i++) { L.qacc[NARM + 6 * f + i] = L.facc[f][i] - t1[i]; L.qacc[NARM + 6 * f + 3 + i] = ab[i]; }
   }
   wave_sync();
 }

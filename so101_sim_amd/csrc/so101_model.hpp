@@ -14,9 +14,9 @@
 #define NV (NARM + 6 * NFREE)
 #define NU 6
 #define MAXGEOM 96
-#define MAXCAND 128
+#define MAXCAND 256
 #define MAXCON 32
-#define MAXARMCON 16
+#define MAXARMCON MAXCON
 #define MAXROW1 (2 * NARM)
 
 enum { G_PLANE = 0, G_SPHERE = 1, G_CAPSULE = 2, G_CYLINDER = 3, G_BOX = 4, G_MESH = 5 };
@@ -81,8 +81,8 @@ struct Contact {
   float mu, pad;
 };
 
-struct ArmCon {                // rows of an arm-link contact in joint space
-  float J[6][NARM], B[6][NARM];
+struct ArmCon {                // rows of an arm-link contact in joint space: J(link of geom2) - J(link of geom1)
+  float J[6][NARM];
 };
 
 struct Row1 {                  // scalar rows: dof frictionloss and joint limits

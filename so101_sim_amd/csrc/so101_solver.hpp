@@ -43,15 +43,16 @@ DEV void jacc_reg(const EnvLDS& L, const Contact& c, const Acc& a, float* jv) {
       float pl[3] = {al[0] + t[0], al[1] + t[1], al[2] + t[2]};
 #pragma unroll
       for (int j = 0; j < 3; j++) { jv[j] += sgn * dot3(&c.frame[3 * j], pl); jv[3 + j] += sgn * dot3(&c.frame[3 * j], aa); }
-    } else if (d >= 0 && c.armslot >= 0) {
-      const ArmCon& ac = L.armcon[c.armslot];
+    }
+  }
+  if (c.armslot >= 0) {            // arm part once: the stored rows already hold J(link2) - J(link1)
+    const ArmCon& ac = L.armcon[c.armslot];
 #pragma unroll
-      for (int j = 0; j < 6; j++) {
-        float v = 0.f;
+    for (int j = 0; j < 6; j++) {
+      float v = 0.f;
 #pragma unroll
-        for (int q = 0; q < NARM; q++) v += ac.J[j][q] * a.arm[q];
-        jv[j] += v;
-      }
+      for (int q = 0; q < NARM; q++) v += ac.J[j][q] * a.arm[q];
+      jv[j] += v;
     }
   }
 }
@@ -81,15 +82,24 @@ DEV void apply_reg(const EnvLDS& L, const Contact& c, const float* df, Acc& a) {
         a.fr[0][i] += s0 * mi * F[i]; a.fr[0][3 + i] += s0 * sgn * da[i];
         a.fr[1][i] += s1 * mi * F[i]; a.fr[1][3 + i] += s1 * sgn * da[i];
       }
-    } else if (d >= 0 && c.armslot >= 0) {
-      const ArmCon& ac = L.armcon[c.armslot];
+    }
+  }
+  if (c.armslot >= 0) {            // arm: qacc += Minv (J^T df)
+    const ArmCon& ac = L.armcon[c.armslot];
+    float g[NARM];
 #pragma unroll
-      for (int q = 0; q < NARM; q++) {
-        float v = 0.f;
+    for (int q = 0; q < NARM; q++) {
+      float v = 0.f;
 #pragma unroll
-        for (int j = 0; j < 6; j++) v += ac.B[j][q] * df[j];
-        a.arm[q] += v;
-      }
+      for (int j = 0; j < 6; j++) v += ac.J[j][q] * df[j];
+      g[q] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < NARM; q++) {
+      float v = 0.f;
+#pragma unroll
+      for (int s = 0; s < NARM; s++) v += L.Minv[q][s] * g[s];
+      a.arm[q] += v;
     }
   }
 }
@@ -249,7 +259,7 @@ DEV void solve_pgs(const DevModel* m, EnvLDS& L, int max_iter, float tolerance) 
       float t1[3], t2[3];
       cross3(t1, alp, r); cross3(t2, ww, r); cross3(t2, ww, t2);
 #pragma unroll
-      for (int i = 0; i < 3; i++) { w.fr[f][i] = wq[i] + t1[i] + t2[i]; w.fr[f][3 + i] = alp[i]; }
+      for (int i = 0; i < 3; i++) { w.fr[f][i] = wq[i] + t1[i]; w.fr[f][3 + i] = alp[i]; }
     }
     if (lane < nrow) {
       Row1& r = L.row[lane];

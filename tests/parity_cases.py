@@ -161,8 +161,10 @@ def check_env_semantics(make_sim, blobs, n=2, settle=30, steps=8, last_step=7, s
         o.env_config(seed=seed, env_id=100 + e, last_step=last_step, settle_max_substeps=settle)
         o.env_reset()
         qo, vo, _ = o.get_state()
-        # identical RNG draws: placement equal to f32 rounding before settle drift accumulates
-        assert np.abs(q0[:, e] - qo).max() < 5e-5, (e, np.abs(q0[:, e] - qo).max())
+        # identical RNG draws + same settle.  An object spawned inside the static post is ejected (a chaotic
+        # transient: SURVEY.md section 9 item 8), so the bound is loose there and tight otherwise.
+        ejected = abs(qo[8] - 0.4217) > 2e-3 or np.abs(vo[6:]).max() > 0.05
+        assert np.abs(q0[:, e] - qo).max() < (0.2 if ejected else 2e-4), (e, np.abs(q0[:, e] - qo).max())
         assert np.all(q0[:6, e] == 0)
         oracles.append(o)
     rng = np.random.RandomState(seed)
@@ -187,6 +189,46 @@ def check_env_semantics(make_sim, blobs, n=2, settle=30, steps=8, last_step=7, s
         elif t == last_step + 1:
             assert np.all(st == 0)                                             # auto-reset: FIRST
             assert np.all(obs[:, 0:12] == 0)
+
+
+def check_contact_rich(make_sim, blobs, golden, count=4, verbose=False):
+    """Arm self-collision / arm-table / arm-prop contact states (20-30 simultaneous contacts, captured from a
+    random-action rollout): same contact set as the oracle and the same constrained acceleration.
+    Tolerance: contact sets equal up to contacts shallower than 2e-6 m; qacc within 2% of max|qacc|
+    (both solvers stop at the 100-iteration cap, far from converged, with fp32 vs fp64 iterates)."""
+    states = golden["contact_rich_states"]["states"][:count]
+    n = len(states)
+    Q = np.array([s["qpos"] for s in states]).T
+    V = np.array([s["qvel"] for s in states]).T
+    W = np.array([s["warm"] for s in states]).T
+    A = np.array([s["action"] for s in states]).T
+    sim = make_sim(n)
+    sim.set_state(Q, V, A, W)
+    dbg = sim.debug_forward()
+    worst, seen_arm_arm = 0.0, False
+    for e in range(n):
+        o = Oracle(blobs["f64"])
+        o.set_state(Q[:, e], V[:, e], W[:, e])
+        o.set_ctrl(A[:, e])
+        o.forward()
+        a, _ = o.qacc()
+        d = dbg[e]
+        assert d["overflow"] == 0
+        mine = {(c["geom1"], c["geom2"]): c for c in d["contacts"]}
+        ref = {(c["geom1"], c["geom2"]): c for c in o.contacts()}
+        for k in set(mine) ^ set(ref):
+            c = mine.get(k) or ref.get(k)
+            assert abs(c["dist"]) < 2e-6, (e, k, c["dist"])          # only grazing contacts may differ
+        for k in set(mine) & set(ref):
+            assert abs(mine[k]["dist"] - ref[k]["dist"]) <= 5e-6 + 1e-4 * abs(ref[k]["dist"]), (e, k)
+        seen_arm_arm = seen_arm_arm or any(_arm_geom(g1) and _arm_geom(g2) for g1, g2 in ref)
+        err = np.abs(d["qacc"] - a).max() / np.abs(a).max()
+        worst = max(worst, err)
+        if verbose:
+            print(e, "ncon", len(ref), "qacc rel err", err)
+        assert err <= 2e-2, (e, err)
+    assert seen_arm_arm, "fixture must contain arm-arm contacts"
+    return worst
 
 
 def check_divergence_handling(make_sim, blobs):

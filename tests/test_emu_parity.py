@@ -36,3 +36,7 @@ def test_env_semantics(make_sim, blobs):
 
 def test_divergence_handling(make_sim, blobs):
     pc.check_divergence_handling(make_sim, blobs)
+
+
+def test_contact_rich_states(make_sim, blobs, golden):
+    pc.check_contact_rich(make_sim, blobs, golden, count=4)

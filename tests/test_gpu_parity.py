@@ -113,3 +113,7 @@ def test_properties_at_benchmark_size(make_sim, blobs):
 
 def test_divergence_handling(make_sim, blobs):
     pc.check_divergence_handling(make_sim, blobs)
+
+
+def test_contact_rich_states(make_sim, blobs, golden):
+    pc.check_contact_rich(make_sim, blobs, golden, count=12)
