@@ -26,7 +26,11 @@ def needs_build() -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or needs_build():
+        # -fno-hip-fp32-correctly-rounded-divide-sqrt: v_rcp/v_sqrt based fp32 division and sqrt (<= ~2.5 ulp)
+        # instead of the 10-15 instruction IEEE expansions; the solver is VALU-issue bound and full of both
+        # (profiles/README.md).  Parity tolerances in tests/parity_cases.py are stated for this build.
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-fno-hip-fp32-correctly-rounded-divide-sqrt",
                "-o", LIB, os.path.join(CSRC, "so101_hip.hip")]
         if verbose:
             cmd.append("-Rpass-analysis=kernel-resource-usage")

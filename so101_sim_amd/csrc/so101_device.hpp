@@ -262,7 +262,13 @@ DEV void crba_arm(const DevModel* m, EnvLDS& L) {
       x[i] = v / Lc[i][i];
     }
 #pragma unroll
-    for (int i = 0; i < NARM; i++) { L.Minv[i][lane] = x[i]; L.Marm[i][lane] = Mfull[i][lane]; }
+    for (int i = 0; i < NARM; i++) L.Minv[i][lane] = x[i];
+  }
+  if (lane == 0) {          // constant indices only: a lane-indexed read would push Mfull into scratch memory
+#pragma unroll
+    for (int i = 0; i < NARM; i++)
+#pragma unroll
+      for (int j = 0; j < NARM; j++) L.Marm[i][j] = Mfull[i][j];
   }
   wave_sync();
 }
@@ -385,15 +391,19 @@ DEV void support(const DevModel* m, const GeomW& G, const float* dir, float* out
   float loc[3] = {0.f, 0.f, 0.f};
   if (G.type == G_MESH) {
     int lane = wave_lane();
-    float best = -3.0e38f; int bi = 0x7fffffff;
+    // each lane scans vertices lane, lane+64, ... (coalesced SoA loads) and keeps its best vertex in registers;
+    // the wave-level argmax then broadcasts the winner with v_readlane (no second memory access, and a
+    // non-finite direction of a diverged state can never index out of range)
+    float best = -3.0e38f, bx = 0.f, by = 0.f, bz = 0.f; int bi = 0x7fffffff;
     const float* x = m->vx + G.vadr; const float* y = m->vy + G.vadr; const float* z = m->vz + G.vadr;
+#pragma unroll 4
     for (int i = lane; i < G.vnum; i += WAVE) {
-      float d = x[i] * dl[0] + y[i] * dl[1] + z[i] * dl[2];
-      if (d > best) { best = d; bi = i; }
+      float X = x[i], Y = y[i], Z = z[i];
+      float d = X * dl[0] + Y * dl[1] + Z * dl[2];
+      if (d > best) { best = d; bi = i; bx = X; by = Y; bz = Z; }
     }
-    wave_argmax(best, bi);
-    bi = (bi >= 0 && bi < G.vnum) ? bi : 0;     // a non-finite direction (diverged state) must not index out of range
-    loc[0] = x[bi]; loc[1] = y[bi]; loc[2] = z[bi];
+    wave_argmax3(best, bi, bx, by, bz);
+    loc[0] = bx; loc[1] = by; loc[2] = bz;
   } else if (G.type == G_BOX) {
 #pragma unroll
     for (int i = 0; i < 3; i++) loc[i] = dl[i] >= 0.f ? G.size[i] : -G.size[i];
@@ -871,107 +881,56 @@ DEV void make_constraints(const DevModel* m, EnvLDS& L) {
     for (int j = 0; j < 6; j++)
 #pragma unroll
       for (int k = 0; k <= j; k++) c.A[j * (j + 1) / 2 + k] = A[j][k];
-    // inverse of the friction block (rows 1..dim-1), via Cholesky; rows >= dim are decoupled (identity)
-    float Lf[5][5], Inv[5][5];
-    int nf = dim - 1;
+    // Spectral form of the friction block for the cone QCQP (mju_QCQP): with D = diag(mu_j) the scaled block
+    // D Ac D = Q diag(lam) Q^T is decomposed ONCE per substep (cyclic Jacobi, lane = contact); every Newton step
+    // on the cone multiplier inside the PGS sweep is then O(5) instead of a 5x5 Cholesky factorisation.  Rows
+    // >= dim are decoupled (identity).
+    {
+      const float fr5[5] = {c.fric[0], c.fric[0], c.fric[1], c.fric[2], c.fric[2]};
+      int nf = dim - 1;
+      float S[5][5], Qm[5][5];
 #pragma unroll
-    for (int j = 0; j < 5; j++) {
-      float dj = (j < nf) ? A[j + 1][j + 1] : 1.f;
+      for (int i = 0; i < 5; i++)
 #pragma unroll
-      for (int k = 0; k < j; k++) dj -= Lf[j][k] * Lf[j][k];
-      dj = sqrtf(fmaxf(dj, 1e-30f));
-      Lf[j][j] = dj;
+        for (int k = 0; k < 5; k++) {
+          float aik = i >= k ? A[i + 1][k + 1] : A[k + 1][i + 1];        // only the lower triangle of A is filled
+          S[i][k] = (i < nf && k < nf) ? aik * fr5[i] * fr5[k] : (i == k ? 1.f : 0.f);
+          Qm[i][k] = i == k ? 1.f : 0.f;
+        }
+      for (int sweep = 0; sweep < 6; sweep++) {
 #pragma unroll
-      for (int i = j + 1; i < 5; i++) {
-        float v = (i < nf && j < nf) ? A[i + 1][j + 1] : 0.f;
+        for (int p = 0; p < 4; p++)
 #pragma unroll
-        for (int k = 0; k < j; k++) v -= Lf[i][k] * Lf[j][k];
-        Lf[i][j] = v / dj;
+          for (int q = p + 1; q < 5; q++) {
+            float apq = S[p][q];
+            if (fabsf(apq) > 1e-30f) {
+              float app = S[p][p], aqq = S[q][q];
+              float tau = (aqq - app) / (2.f * apq);
+              float t = (tau >= 0.f ? 1.f : -1.f) / (fabsf(tau) + sqrtf(1.f + tau * tau));
+              float cs = 1.f / sqrtf(1.f + t * t), sn = t * cs;
+#pragma unroll
+              for (int k = 0; k < 5; k++) {
+                if (k != p && k != q) {
+                  float skp = S[k][p], skq = S[k][q];
+                  float np_ = cs * skp - sn * skq, nq_ = sn * skp + cs * skq;
+                  S[k][p] = np_; S[p][k] = np_; S[k][q] = nq_; S[q][k] = nq_;
+                }
+                float qkp = Qm[k][p], qkq = Qm[k][q];
+                Qm[k][p] = cs * qkp - sn * qkq; Qm[k][q] = sn * qkp + cs * qkq;
+              }
+              S[p][p] = app - t * apq; S[q][q] = aqq + t * apq; S[p][q] = 0.f; S[q][p] = 0.f;
+            }
+          }
       }
-    }
-#pragma unroll
-    for (int col = 0; col < 5; col++) {
-      float y[5];
 #pragma unroll
       for (int i = 0; i < 5; i++) {
-        float v = (i == col) ? 1.f : 0.f;
+        c.lam[i] = fmaxf(S[i][i], 1e-30f);
 #pragma unroll
-        for (int k = 0; k < i; k++) v -= Lf[i][k] * y[k];
-        y[i] = v / Lf[i][i];
-      }
-#pragma unroll
-      for (int i = 4; i >= 0; i--) {
-        float v = y[i];
-#pragma unroll
-        for (int k = i + 1; k < 5; k++) v -= Lf[k][i] * Inv[k][col];
-        Inv[i][col] = v / Lf[i][i];
+        for (int k = 0; k < 5; k++) c.Q[5 * i + k] = Qm[i][k];
       }
     }
-#pragma unroll
-    for (int j = 0; j < 5; j++)
-#pragma unroll
-      for (int k = 0; k <= j; k++) c.Ai[j * (j + 1) / 2 + k] = Inv[j][k];
   }
   wave_sync();
-}
-
-// ------------------------------------------------------------------ QCQP (uniform): min 0.5 x'Ax + b'x s.t. sum (x_i/d_i)^2 <= r^2
-DEV bool qcqp(float* res, const float* A /*5x5 full*/, const float* b, const float* dd, float r, int n) {
-  float As[5][5], bs[5], y[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < 5; i++) {
-    bs[i] = i < n ? b[i] * dd[i] : 0.f;
-#pragma unroll
-    for (int j = 0; j < 5; j++) As[i][j] = (i < n && j < n) ? A[5 * i + j] * dd[i] * dd[j] : (i == j ? 1.f : 0.f);
-  }
-  float la = 0.f;
-  for (int iter = 0; iter < 20; iter++) {
-    float P[5][5];
-    bool ok = true;
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-      float v = As[j][j] + (j < n ? la : 0.f);
-#pragma unroll
-      for (int k = 0; k < j; k++) v -= P[j][k] * P[j][k];
-      if (v < MINVAL_F) ok = false;
-      v = sqrtf(fmaxf(v, 1e-30f));
-      P[j][j] = v;
-#pragma unroll
-      for (int i = j + 1; i < 5; i++) {
-        float w = As[i][j];
-#pragma unroll
-        for (int k = 0; k < j; k++) w -= P[i][k] * P[j][k];
-        P[i][j] = w / v;
-      }
-    }
-    if (!ok) {
-#pragma unroll
-      for (int i = 0; i < 5; i++) res[i] = 0.f;
-      return false;
-    }
-    float t[5], z[5];
-#pragma unroll
-    for (int i = 0; i < 5; i++) { float v = -bs[i]; _Pragma("unroll") for (int k = 0; k < i; k++) v -= P[i][k] * t[k]; t[i] = v / P[i][i]; }
-#pragma unroll
-    for (int i = 4; i >= 0; i--) { float v = t[i]; _Pragma("unroll") for (int k = i + 1; k < 5; k++) v -= P[k][i] * y[k]; y[i] = v / P[i][i]; }
-    float val = -r * r;
-#pragma unroll
-    for (int i = 0; i < 5; i++) if (i < n) val += y[i] * y[i];
-    if (val < 1e-10f) break;
-#pragma unroll
-    for (int i = 0; i < 5; i++) { float v = (i < n) ? y[i] : 0.f; _Pragma("unroll") for (int k = 0; k < i; k++) v -= P[i][k] * t[k]; t[i] = v / P[i][i]; }
-#pragma unroll
-    for (int i = 4; i >= 0; i--) { float v = t[i]; _Pragma("unroll") for (int k = i + 1; k < 5; k++) v -= P[k][i] * z[k]; z[i] = v / P[i][i]; }
-    float deriv = 0.f;
-#pragma unroll
-    for (int i = 0; i < 5; i++) if (i < n) deriv += -2.f * y[i] * z[i];
-    float delta = -val / deriv;
-    if (delta < 1e-10f) break;
-    la += delta;
-  }
-#pragma unroll
-  for (int i = 0; i < 5; i++) res[i] = (i < n) ? y[i] * dd[i] : 0.f;
-  return la != 0.f;
 }
 
 #include "so101_solver.hpp"

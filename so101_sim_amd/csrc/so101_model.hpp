@@ -77,7 +77,7 @@ struct Contact {
   float R[4];                 // normal, tangential, torsional, rolling
   float aref[6], f[6];
   float A[21];                // diagonal block of AR = J Minv J^T + R, packed lower triangle
-  float Ai[15];               // inverse of the friction block, packed lower triangle
+  float Q[25], lam[5];        // eigen-decomposition D Ac D = Q diag(lam) Q^T of the mu-scaled friction block
   float mu, pad;
 };
 

@@ -175,30 +175,47 @@ DEV float contact_update(const EnvLDS& L, Contact& c, Acc& a) {
       b += A[j + 1][0] * (f[0] - old[0]);
       bc[j] = (j + 1 < dim) ? b : 0.f;
     }
-    float ssq = 0.f;
+    // mju_QCQP: min 0.5 v'Ac v + bc'v  s.t.  sum (v_j/mu_j)^2 <= fn^2.  In the scaled variable y = v/mu and the
+    // eigenbasis of D Ac D (c.Q, c.lam, built once per substep) the stationarity condition (D Ac D + la I) y = -D bc
+    // reads z_i = -g_i / (lam_i + la); the Newton iteration on the multiplier la is MuJoCo's
+    // (val = |y|^2 - r^2, deriv = -2 y'(P^-1)y) evaluated in O(5).  la = 0 is the unconstrained minimum.
+    float g[5], z[5], r2 = f[0] * f[0], la = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 5; j++) s += c.Q[5 * j + i] * (bc[j] * fr[j]);
+      g[i] = s;
+    }
+    for (int iter = 0; iter < 20; iter++) {
+      float val = -r2, deriv = 0.f;
+#pragma unroll
+      for (int i = 0; i < 5; i++) {
+        float inv = 1.f / (c.lam[i] + la);
+        z[i] = -g[i] * inv;
+        val += z[i] * z[i];
+        deriv -= 2.f * z[i] * z[i] * inv;
+      }
+      // fp64 MuJoCo stops at val < 1e-10 / delta < 1e-10; in fp32 the thresholds sit at the rounding level of val
+      if (val <= (la == 0.f ? 1e-10f : 2e-6f * r2)) break;
+      float delta = -val / deriv;
+      if (!(delta > 1e-6f * la)) break;
+      la += delta;
+    }
 #pragma unroll
     for (int j = 0; j < 5; j++) {
       float s = 0.f;
 #pragma unroll
-      for (int q = 0; q < 5; q++) s -= c.Ai[tri(j, q)] * bc[q];
-      v[j] = (j + 1 < dim) ? s : 0.f;
-      ssq += (v[j] / fr[j]) * (v[j] / fr[j]);
+      for (int i = 0; i < 5; i++) s += c.Q[5 * j + i] * z[i];
+      v[j] = (j + 1 < dim) ? s * fr[j] : 0.f;
     }
-    if (ssq - f[0] * f[0] >= 1e-10f) {
-      float Ac[25];
+    if (la != 0.f) {          // constraint active: put v exactly on the cone (no drift)
+      float s2 = 0.f;
 #pragma unroll
-      for (int j = 0; j < 5; j++)
+      for (int j = 0; j < 5; j++) s2 += (v[j] / fr[j]) * (v[j] / fr[j]);
+      float sc = sqrtf(r2 / fmaxf(MINVAL_F, s2));
 #pragma unroll
-        for (int q = 0; q < 5; q++) Ac[5 * j + q] = A[j + 1][q + 1];
-      bool active = qcqp(v, Ac, bc, fr, f[0], dim - 1);
-      if (active) {
-        float s2 = 0.f;
-#pragma unroll
-        for (int j = 0; j < 5; j++) s2 += (v[j] / fr[j]) * (v[j] / fr[j]);
-        float sc = sqrtf(f[0] * f[0] / fmaxf(MINVAL_F, s2));
-#pragma unroll
-        for (int j = 0; j < 5; j++) v[j] *= sc;
-      }
+      for (int j = 0; j < 5; j++) v[j] *= sc;
     }
 #pragma unroll
     for (int j = 0; j < 5; j++) f[j + 1] = v[j];
@@ -360,24 +377,7 @@ DEV void solve_pgs(const DevModel* m, EnvLDS& L, int max_iter, float tolerance) 
     a = smooth;
   }
   wave_sync();
-  // ---- main iteration: island owners sweep their rows, no barrier inside
-  float scale = 1.f / (m->meaninertia * (float)NV);
-  int it = 0;
-  for (; it < max_iter; it++) {
-    float improvement = 0.f;
-    if (owner) {
-      if (lane == 0) for (int k = 0; k < nrow; k++) improvement += row_update(L, L.row[k], a);
-      for (int k = 0; k < ncon; k++) {
-        Contact& c = L.con[k];
-        if (island_of(c) != lane) continue;
-        improvement += contact_update(L, c, a);
-      }
-    }
-    improvement = wave_sum_f(improvement);
-    if (improvement * scale < tolerance) { it++; break; }
-  }
-  // ---- publish the constrained accelerations
-  wave_sync();
+  // ---- publish the starting accelerations (warm or smooth): L.qacc_arm / L.facc are the shared island state
   if (owner) {
 #pragma unroll
     for (int g = 0; g < 3; g++) {
@@ -388,6 +388,71 @@ DEV void solve_pgs(const DevModel* m, EnvLDS& L, int max_iter, float tolerance) 
       }
     }
   }
+  wave_sync();
+  // ---- main iteration, lane = constraint block.  Lane k < MAXCON keeps contact k (A block, friction-block
+  // inverse, frame, aref, R, forces) in REGISTERS for the whole solve; lane 32+r keeps scalar row r.  A sweep
+  // runs in turns: at turn t every lane whose block is the t-th of its island (MuJoCo order: scalar rows, then
+  // contacts) updates at once — islands advance in parallel, blocks of one island stay sequential, so the
+  // iterates are those of the plain Gauss-Seidel sweep.  Only the island accelerations travel through LDS.
+  bool has_con = lane < ncon, has_row = lane >= 32 && lane - 32 < nrow;
+  Contact creg;
+  Row1 rreg;
+  if (has_con) creg = L.con[lane];
+  if (has_row) rreg = L.row[lane - 32];
+  int myroot = has_con ? island_of(creg) : (has_row ? root[0] : -1);
+  unsigned long long below = (1ull << lane) - 1ull;
+  unsigned long long mk0 = wave_ballot(has_con && myroot == 0), mk1 = wave_ballot(has_con && myroot == 1),
+                     mk2 = wave_ballot(has_con && myroot == 2);
+  int rows_in0 = root[0] == 0 ? nrow : 0, rows_in1 = root[0] == 1 ? nrow : 0, rows_in2 = root[0] == 2 ? nrow : 0;
+  int mypos = -1;
+  if (has_row) mypos = lane - 32;
+  if (has_con) {
+    unsigned long long mine = myroot == 0 ? mk0 : (myroot == 1 ? mk1 : mk2);
+    mypos = (myroot == root[0] ? nrow : 0) + __popcll(mine & below);
+  }
+  int len0 = rows_in0 + __popcll(mk0), len1 = rows_in1 + __popcll(mk1), len2 = rows_in2 + __popcll(mk2);
+  int turns = len0 > len1 ? len0 : len1;
+  turns = turns > len2 ? turns : len2;
+  float scale = 1.f / (m->meaninertia * (float)NV);
+  int it = 0;
+  for (; it < max_iter; it++) {
+    float improvement = 0.f;
+    for (int t = 0; t < turns; t++) {
+      if (has_row && mypos == t) {
+        Acc b;
+#pragma unroll
+        for (int q = 0; q < NARM; q++) b.arm[q] = L.qacc_arm[q];
+        improvement += row_update(L, rreg, b);
+#pragma unroll
+        for (int q = 0; q < NARM; q++) L.qacc_arm[q] = b.arm[q];
+      }
+      if (has_con && mypos == t) {
+        Acc b;
+        acc_load(L, b);
+        improvement += contact_update(L, creg, b);
+        if (creg.armslot >= 0) {
+#pragma unroll
+          for (int q = 0; q < NARM; q++) L.qacc_arm[q] = b.arm[q];
+        }
+#pragma unroll
+        for (int f = 0; f < NFREE; f++) {
+          if (creg.d1 == NARM + f || creg.d2 == NARM + f) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) L.facc[f][i] = b.fr[f][i];
+          }
+        }
+      }
+      wave_sync();
+    }
+    improvement = wave_sum_f(improvement);
+    if (improvement * scale < tolerance) { it++; break; }
+  }
+  // forces back to LDS (diagnostics / debug dump); accelerations are already there
+  if (has_con) {
+#pragma unroll
+    for (int j = 0; j < 6; j++) L.con[lane].f[j] = creg.f[j];
+  }
+  if (has_row) L.row[lane - 32].f = rreg.f;
   if (lane == 0) L.iters = it;
   wave_sync();
 }

@@ -1,5 +1,8 @@
 // Wave-level primitives for gfx950 (64-lane wavefronts).  One environment == one wavefront == one
 // 64-thread workgroup, so "wave" and "block" coincide and __syncthreads() is a single-wave barrier.
+//
+// Reductions use DPP (data-parallel primitives: the cross-lane operand is fetched inside the VALU, no LDS
+// crossbar round trip as with ds_bpermute/__shfl) and v_readlane for the final broadcast.
 #ifndef SO101_WAVE_HPP_
 #define SO101_WAVE_HPP_
 #include <hip/hip_runtime.h>
@@ -9,22 +12,46 @@
 __device__ __forceinline__ int wave_lane() { return threadIdx.x; }
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
 
-// DPP row/bank operations keep reductions in the VALU (no LDS crossbar round trip).
-template <int CTRL>
+// DPP controls (GFX9 encoding)
+#define DPP_QUAD_XOR1 0xB1        // quad_perm [1,0,3,2]
+#define DPP_QUAD_XOR2 0x4E        // quad_perm [2,3,0,1]
+#define DPP_ROW_HALF_MIRROR 0x141
+#define DPP_ROW_MIRROR 0x140
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+
+template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ float dpp_f(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+  int x = __builtin_bit_cast(int, v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
 }
 
+// all-lanes max: butterflies inside each row of 16, then row broadcasts; lane 63 ends with the total
 __device__ __forceinline__ float wave_max_f(float v) {
-  v = fmaxf(v, __shfl_xor(v, 32));
-  v = fmaxf(v, __shfl_xor(v, 16));
-  v = fmaxf(v, __shfl_xor(v, 8));
-  v = fmaxf(v, __shfl_xor(v, 4));
-  v = fmaxf(v, __shfl_xor(v, 2));
-  v = fmaxf(v, __shfl_xor(v, 1));
-  return v;
+  v = fmaxf(v, dpp_f<DPP_QUAD_XOR1>(v));
+  v = fmaxf(v, dpp_f<DPP_QUAD_XOR2>(v));
+  v = fmaxf(v, dpp_f<DPP_ROW_HALF_MIRROR>(v));
+  v = fmaxf(v, dpp_f<DPP_ROW_MIRROR>(v));
+  v = fmaxf(v, dpp_f<DPP_ROW_BCAST15, 0xA>(v));
+  v = fmaxf(v, dpp_f<DPP_ROW_BCAST31, 0xC>(v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+__device__ __forceinline__ int wave_min_i(int v) {
+  v = min(v, dpp_i<DPP_QUAD_XOR1>(v));
+  v = min(v, dpp_i<DPP_QUAD_XOR2>(v));
+  v = min(v, dpp_i<DPP_ROW_HALF_MIRROR>(v));
+  v = min(v, dpp_i<DPP_ROW_MIRROR>(v));
+  v = min(v, dpp_i<DPP_ROW_BCAST15, 0xA>(v));
+  v = min(v, dpp_i<DPP_ROW_BCAST31, 0xC>(v));
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// all-lanes sum with a fixed xor-butterfly order (the emulation harness reproduces the same order)
 __device__ __forceinline__ float wave_sum_f(float v) {
   v += __shfl_xor(v, 32);
   v += __shfl_xor(v, 16);
@@ -49,13 +76,22 @@ __device__ __forceinline__ int wave_bcast_i(int v, int src) { return __shfl(v, s
 __device__ __forceinline__ void wave_argmax(float& val, int& idx) {
   float mx = wave_max_f(val);
   int cand = (val == mx) ? idx : 0x7fffffff;
-  cand = min(cand, __shfl_xor(cand, 32));
-  cand = min(cand, __shfl_xor(cand, 16));
-  cand = min(cand, __shfl_xor(cand, 8));
-  cand = min(cand, __shfl_xor(cand, 4));
-  cand = min(cand, __shfl_xor(cand, 2));
-  cand = min(cand, __shfl_xor(cand, 1));
+  idx = wave_min_i(cand);
   val = mx;
-  idx = cand;
+}
+
+// argmax that also carries a 3-vector payload held by each lane (the winning lane's payload is broadcast
+// with v_readlane, no memory access): used by the hull support function
+__device__ __forceinline__ void wave_argmax3(float& val, int& idx, float& x, float& y, float& z) {
+  float mx = wave_max_f(val);
+  int cand = (val == mx) ? idx : 0x7fffffff;
+  int best = wave_min_i(cand);
+  unsigned long long who = __ballot(cand == best);
+  int src = who ? (int)__builtin_ctzll(who) : 0;
+  x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), src));
+  y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y), src));
+  z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, z), src));
+  val = mx;
+  idx = best;
 }
 #endif  // SO101_WAVE_HPP_

@@ -32,4 +32,22 @@ inline void wave_argmax(float& val, int& idx) {
   int b = 0x7fffffff; for (int i = 0; i < 64; i++) if (emu_xchg_f[i] == m) b = std::min(b, emu_xchg_i[i]);
   __syncthreads(); val = m; idx = b;
 }
+inline int wave_min_i(int v) {
+  emu_xchg_i[threadIdx.x] = v; __syncthreads();
+  int m = emu_xchg_i[0]; for (int i = 1; i < 64; i++) m = std::min(m, emu_xchg_i[i]);
+  __syncthreads(); return m;
+}
+inline void wave_argmax3(float& val, int& idx, float& x, float& y, float& z) {
+  static float px[64], py[64], pz[64];
+  emu_xchg_f[threadIdx.x] = val; emu_xchg_i[threadIdx.x] = idx; px[threadIdx.x] = x; py[threadIdx.x] = y; pz[threadIdx.x] = z;
+  __syncthreads();
+  float m = emu_xchg_f[0]; for (int i = 1; i < 64; i++) m = std::fmax(m, emu_xchg_f[i]);
+  int b = 0x7fffffff, src = 0;
+  for (int i = 0; i < 64; i++) if (emu_xchg_f[i] == m) b = std::min(b, emu_xchg_i[i]);
+  bool found = false;
+  for (int i = 0; i < 64 && !found; i++) if (((emu_xchg_f[i] == m) ? emu_xchg_i[i] : 0x7fffffff) == b) { src = i; found = true; }
+  float ox = px[src], oy = py[src], oz = pz[src];
+  __syncthreads();
+  val = m; idx = b; x = ox; y = oy; z = oz;
+}
 #endif
