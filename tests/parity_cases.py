@@ -163,7 +163,7 @@ def check_env_semantics(make_sim, blobs, n=2, settle=30, steps=8, last_step=7, s
         qo, vo, _ = o.get_state()
         # identical RNG draws + same settle.  An object spawned inside the static post is ejected (a chaotic
         # transient: SURVEY.md section 9 item 8), so the bound is loose there and tight otherwise.
-        ejected = abs(qo[8] - 0.4217) > 2e-3 or np.abs(vo[6:]).max() > 0.05
+        ejected = abs(qo[8] - 0.4217) > 2e-3 or np.abs(vo[6:]).max() > 5e-3      # still moving when the budget ran out
         # (the settle is a dynamic transient of drops/impacts: fp32 vs fp64 drift of a few mm over hundreds of substeps)
         assert np.abs(q0[:, e] - qo).max() < (0.2 if ejected else 5e-3), (e, np.abs(q0[:, e] - qo).max())
         assert np.all(q0[:6, e] == 0)
