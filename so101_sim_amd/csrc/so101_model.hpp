@@ -96,10 +96,13 @@ struct EnvLDS {
   float fminv[NFREE], fIinv[NFREE][6], fvel[NFREE][6], facc[NFREE][6];   // COM-twist coordinates
   float tau[NARM], bias[NARM], qacc[NV], qacc_arm[NARM];
   float arm0_q[NARM], arm0_v[NARM];
-  float aabb[MAXGEOM][6];
-  unsigned short cand[MAXCAND][2];
+  // collision-phase scratch (geom boxes, broadphase candidates) shares storage with the arm-contact Jacobian
+  // pool: the pool is first written by make_constraints(), after collision() has consumed boxes and candidates
+  union {
+    struct { float aabb[MAXGEOM][6]; unsigned short cand[MAXCAND][2]; };
+    ArmCon armcon[MAXARMCON];
+  };
   Contact con[MAXCON];
-  ArmCon armcon[MAXARMCON];
   Row1 row[MAXROW1];
   int ncand, ncon, nrow, narmcon, iters, overflow;
   float scratch[64];
