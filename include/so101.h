@@ -33,6 +33,8 @@ extern "C" {
 #define SO101_ABI_VERSION 1
 #define SO101_OBS_DIM 18      /* joints_pos(6, delayed) | undelayed_joints_pos(6) | commanded_joints_pos(6) */
 #define SO101_ACT_DIM 6
+#define SO101_SOLVER_PGS 0
+#define SO101_SOLVER_NEWTON 1
 #define SO101_RING_DEPTH 5    /* joints_pos delay: 0.1 s = 5 control steps (so100_task.py:81,196-198) */
 
 typedef enum {
@@ -69,6 +71,9 @@ typedef struct {
   int32_t settle_max_substeps; /* PropPlacer settle budget, 1000 = 2.0 s (so100_hand_over.py:222-229) */
   int32_t terminate_on_success; /* SO100Task terminate_episode (so100_task.py:120,297-302) */
   uint64_t env_id_base;    /* global index of env 0 of this handle (multi-GPU sharding) */
+  int32_t solver;          /* SO101_SOLVER_NEWTON (default: the reference's scene sets no <option solver>, so MuJoCo's
+                              default Newton applies) or SO101_SOLVER_PGS (the solver BASELINE.json's north_star names) */
+  int32_t reserved;
 } so101_config;
 
 int so101_version(void);

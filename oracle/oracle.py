@@ -45,6 +45,9 @@ def lib():
             getattr(L, n).argtypes = [C.c_void_p]
         L.orc_set_solver.argtypes = [C.c_void_p, C.c_int, C.c_double]
         L.orc_set_collision.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_solver_type.argtypes = [C.c_void_p, C.c_int]
+        L.orc_ls_evals.restype = C.c_int
+        L.orc_ls_evals.argtypes = [C.c_void_p]
         L.orc_set_state.argtypes = [C.c_void_p, dp, dp, dp]
         L.orc_get_state.argtypes = [C.c_void_p, dp, dp, dp]
         L.orc_set_ctrl.argtypes = [C.c_void_p, dp]
@@ -112,6 +115,9 @@ class Oracle:
 
     def set_solver(self, iterations=0, tolerance=-1.0):
         self.L.orc_set_solver(self.h, int(iterations), float(tolerance))
+
+    def set_solver_type(self, newton: bool):
+        self.L.orc_set_solver_type(self.h, int(bool(newton)))
 
     def set_collision(self, enable: bool):
         self.L.orc_set_collision(self.h, int(enable))

@@ -160,6 +160,8 @@ struct orc_sim {
   std::vector<real> J, efc_pos, efc_D, efc_R, efc_aref, efc_force, efc_floss, efc_b, AR;
   std::vector<int> efc_type, efc_id, efc_dim;
   int iterations; real tolerance; bool collide = true;
+  int solver = 1;              // 1 = Newton (mujoco default; the reference scene sets no solver), 0 = PGS (north_star)
+  int ls_evals = 0;
   // env layer
   orc_env_cfg cfg{};
   int step_count = 0; uint64_t episode = 0; bool need_reset = true; real ep_return = 0;
@@ -938,6 +940,157 @@ void solve_pgs(orc_sim* s) {
   }
 }
 
+
+// ================================================================ Newton solver (mj_solNewton restated)
+// Primal problem:  min_a  0.5 (a - a_s)' M (a - a_s) + sum_i s_i( (J a - aref)_i ),  a_s = qacc_smooth.
+// Row costs s_i (mj_constraintUpdate): quadratic 0.5 D r^2 when active; dof frictionloss is Huber-like (quadratic
+// inside |r| < R*floss, linear outside); elliptic contacts have three zones in (N, T) = (mu*r0, |mu_k r_k|):
+// top (N >= mu T) free, bottom (mu N + T <= 0) fully quadratic, middle 0.5*Dm*(N - mu T)^2.
+struct RowEval { real cost, g1, g2; };    // cost and its first/second derivative along a line
+
+// cost, force (= -ds/dr) and, if Hc != nullptr, the dim x dim Hessian d2s/dr2 of one constraint block at r = jar
+real block_cost(const orc_sim* s, int i, const real* jar, real* force, real* Hc) {
+  int tp = s->efc_type[i], dim = s->efc_dim[i];
+  if (Hc) for (int k = 0; k < dim * dim; k++) Hc[k] = 0;
+  if (tp == C_FRICTION) {
+    real D = s->efc_D[i], R = s->efc_R[i], fl = s->efc_floss[i], rf = R * fl, r = jar[0];
+    if (r <= -rf) { force[0] = fl; return fl * (-0.5 * rf - r); }
+    if (r >= rf) { force[0] = -fl; return fl * (-0.5 * rf + r); }
+    force[0] = -D * r; if (Hc) Hc[0] = D; return 0.5 * D * r * r;
+  }
+  if (tp == C_LIMIT || dim == 1) {
+    real D = s->efc_D[i], r = jar[0];
+    if (r < 0) { force[0] = -D * r; if (Hc) Hc[0] = D; return 0.5 * D * r * r; }
+    force[0] = 0; return 0;
+  }
+  const Contact& c = s->con[s->efc_id[i]];
+  real mu = c.mu, U[6];
+  U[0] = jar[0] * mu;
+  real T = 0;
+  for (int j = 1; j < dim; j++) { U[j] = jar[j] * c.friction[j - 1]; T += U[j] * U[j]; }
+  T = std::sqrt(T);
+  real N = U[0];
+  if ((N >= mu * T) || (T <= 0 && N >= 0)) { for (int j = 0; j < dim; j++) force[j] = 0; return 0; }        // top
+  if ((mu * N + T <= 0) || (T <= 0 && N < 0)) {                                                              // bottom
+    real cost = 0;
+    for (int j = 0; j < dim; j++) { real D = s->efc_D[i + j]; force[j] = -D * jar[j]; cost += 0.5 * D * jar[j] * jar[j]; if (Hc) Hc[j * dim + j] = D; }
+    return cost;
+  }
+  real Dm = s->efc_D[i] / std::max(mu * mu * (1 + mu * mu), MINVAL), sN = N - mu * T;                        // middle
+  force[0] = -Dm * sN * mu;
+  for (int j = 1; j < dim; j++) force[j] = -force[0] / T * U[j] * c.friction[j - 1];
+  if (Hc) {
+    // d2/dr2 of 0.5*Dm*(mu r0 - mu T)^2 with T = |mu_k r_k|
+    Hc[0] = Dm * mu * mu;
+    for (int k = 1; k < dim; k++) {
+      real mk = c.friction[k - 1];
+      Hc[k] = Hc[k * dim] = -Dm * mu * mu * U[k] * mk / T;
+      for (int l = 1; l < dim; l++) {
+        real ml = c.friction[l - 1];
+        Hc[k * dim + l] = Dm * mu * mu * mk * ml * U[k] * U[l] / (T * T)
+                          - Dm * sN * mu * mk * ml * ((k == l ? 1.0 : 0.0) / T - U[k] * U[l] / (T * T * T));
+      }
+    }
+  }
+  return 0.5 * Dm * sN * sN;
+}
+
+void solve_newton(orc_sim* s) {
+  const Model& m = s->m;
+  int nv = m.nv, n = s->nefc;
+  s->solver_iter = 0; s->ls_evals = 0;
+  s->qacc = s->qacc_smooth;
+  if (n == 0) return;
+  const real* J = s->J.data();
+  std::vector<real> qfrc_smooth(nv, 0);      // M a_s
+  for (int r = 0; r < nv; r++) for (int c = 0; c < nv; c++) qfrc_smooth[r] += s->M[r * nv + c] * s->qacc_smooth[c];
+  std::vector<real> jar(n), force(n), Ma(nv), grad(nv), search(nv), jv(n), H(nv * nv), Mv(nv);
+  auto total_cost = [&](const std::vector<real>& a, bool want_grad_hess) {
+    for (int r = 0; r < nv; r++) { Ma[r] = 0; for (int c = 0; c < nv; c++) Ma[r] += s->M[r * nv + c] * a[c]; }
+    real cost = 0;
+    for (int r = 0; r < nv; r++) cost += 0.5 * (Ma[r] - qfrc_smooth[r]) * (a[r] - s->qacc_smooth[r]);
+    for (int i = 0; i < n; i++) { real v = -s->efc_aref[i]; for (int d = 0; d < nv; d++) v += J[(size_t)i * nv + d] * a[d]; jar[i] = v; }
+    if (want_grad_hess) for (int k = 0; k < nv * nv; k++) H[k] = s->M[k];
+    int i = 0;
+    while (i < n) {
+      int dim = s->efc_dim[i];
+      real Hc[36];
+      cost += block_cost(s, i, &jar[i], &force[i], want_grad_hess ? Hc : nullptr);
+      if (want_grad_hess)
+        for (int j = 0; j < dim; j++) for (int k = 0; k < dim; k++) {
+          real h = Hc[j * dim + k];
+          if (h == 0) continue;
+          for (int a_ = 0; a_ < nv; a_++) { real ja = J[(size_t)(i + j) * nv + a_]; if (ja == 0) continue; for (int b_ = 0; b_ < nv; b_++) H[a_ * nv + b_] += ja * h * J[(size_t)(i + k) * nv + b_]; }
+        }
+      i += dim;
+    }
+    if (want_grad_hess)
+      for (int r = 0; r < nv; r++) { real g = Ma[r] - qfrc_smooth[r]; for (int i2 = 0; i2 < n; i2++) g -= J[(size_t)i2 * nv + r] * force[i2]; grad[r] = g; }
+    return cost;
+  };
+  // warm start: the better of qacc_warmstart and qacc_smooth
+  std::vector<real> a = s->warm;
+  real cw = total_cost(a, false), cs = total_cost(s->qacc_smooth, false);
+  if (!(cw < cs)) a = s->qacc_smooth;
+  real scale = 1 / (m.meaninertia * std::max(1, nv));
+  real cost = total_cost(a, true);
+  for (int iter = 0; iter < s->iterations; iter++) {
+    // search = -H^-1 grad (Cholesky)
+    std::vector<real> Lc(H);
+    for (int j = 0; j < nv; j++) {
+      for (int k = 0; k < j; k++) for (int i = j; i < nv; i++) Lc[i * nv + j] -= Lc[i * nv + k] * Lc[j * nv + k];
+      real d = std::sqrt(std::max(Lc[j * nv + j], MINVAL));
+      for (int i = j; i < nv; i++) Lc[i * nv + j] /= d;
+    }
+    std::vector<real> y(nv);
+    for (int i = 0; i < nv; i++) { real v = -grad[i]; for (int k = 0; k < i; k++) v -= Lc[i * nv + k] * y[k]; y[i] = v / Lc[i * nv + i]; }
+    for (int i = nv - 1; i >= 0; i--) { real v = y[i]; for (int k = i + 1; k < nv; k++) v -= Lc[k * nv + i] * search[k]; search[i] = v / Lc[i * nv + i]; }
+    // exact line search on phi(alpha) = cost(a + alpha*search): safeguarded Newton on phi'
+    for (int i = 0; i < n; i++) { real v = 0; for (int d = 0; d < nv; d++) v += J[(size_t)i * nv + d] * search[d]; jv[i] = v; }
+    for (int r = 0; r < nv; r++) { Mv[r] = 0; for (int c = 0; c < nv; c++) Mv[r] += s->M[r * nv + c] * search[c]; }
+    real q1 = 0, q2 = 0;                       // Gauss part: phi_g = c0 + q1 alpha + 0.5 q2 alpha^2
+    for (int r = 0; r < nv; r++) { q1 += search[r] * (Ma[r] - qfrc_smooth[r]); q2 += search[r] * Mv[r]; }
+    std::vector<real> jar0(jar);
+    auto dphi = [&](real alpha, real* d2) {
+      s->ls_evals++;
+      real d1 = q1 + q2 * alpha; *d2 = q2;
+      int i = 0;
+      while (i < n) {
+        int dim = s->efc_dim[i];
+        real r6[6], f6[6], Hc[36];
+        for (int j = 0; j < dim; j++) r6[j] = jar0[i + j] + alpha * jv[i + j];
+        block_cost(s, i, r6, f6, Hc);
+        for (int j = 0; j < dim; j++) { d1 -= f6[j] * jv[i + j]; for (int k = 0; k < dim; k++) *d2 += jv[i + j] * Hc[j * dim + k] * jv[i + k]; }
+        i += dim;
+      }
+      return d1;
+    };
+    real lo = 0, hi = -1, alpha = 0, d2, d1 = dphi(0, &d2), d10 = std::fabs(d1);
+    if (d1 < 0) {
+      for (int ls = 0; ls < 60; ls++) {
+        real step = -d1 / std::max(d2, MINVAL), cand = alpha + step;
+        if (hi > 0 && (cand <= lo || cand >= hi)) cand = 0.5 * (lo + hi);
+        alpha = cand;
+        d1 = dphi(alpha, &d2);
+        if (std::fabs(d1) <= 1e-12 * std::max(d10, MINVAL)) break;
+        if (d1 < 0) lo = alpha; else hi = alpha;
+        if (hi > 0 && hi - lo < 1e-15 * std::max(1.0, hi)) break;
+      }
+    }
+    for (int r = 0; r < nv; r++) a[r] += alpha * search[r];
+    real newcost = total_cost(a, true);
+    real improvement = scale * (cost - newcost), gnorm = 0;
+    for (int r = 0; r < nv; r++) gnorm += grad[r] * grad[r];
+    gnorm = scale * std::sqrt(gnorm);
+    cost = newcost;
+    s->solver_iter = iter + 1;
+    if (improvement < s->tolerance || gnorm < s->tolerance) break;
+  }
+  s->qacc = a;
+  total_cost(a, false);
+  s->efc_force = force;
+}
+
 void forward(orc_sim* s, bool freeze_arm) {
   const Model& m = s->m;
   int nv = m.nv;
@@ -953,7 +1106,7 @@ void forward(orc_sim* s, bool freeze_arm) {
   }
   collision(s);
   make_constraints(s, freeze_arm);
-  solve_pgs(s);
+  if (s->solver == 1) solve_newton(s); else solve_pgs(s);
 }
 
 void euler(orc_sim* s) {
@@ -1174,6 +1327,8 @@ int orc_nv(const orc_sim* s) { return s->m.nv; }
 int orc_nu(const orc_sim* s) { return s->m.nu; }
 void orc_set_solver(orc_sim* s, int it, double tol) { if (it > 0) s->iterations = it; if (tol >= 0) s->tolerance = tol; }
 void orc_set_collision(orc_sim* s, int e) { s->collide = e != 0; }
+void orc_set_solver_type(orc_sim* s, int t) { s->solver = t; }
+int orc_ls_evals(const orc_sim* s) { return s->ls_evals; }
 void orc_set_state(orc_sim* s, const double* q, const double* v, const double* w) {
   if (q) std::copy(q, q + s->m.nq, s->qpos.begin());
   if (v) std::copy(v, v + s->m.nv, s->qvel.begin());

@@ -42,6 +42,9 @@ int orc_nu(const orc_sim*);
 // solver knobs: iterations<=0 keeps the model's (100), tolerance<0 keeps the model's (1e-8)
 void orc_set_solver(orc_sim*, int iterations, double tolerance);
 void orc_set_collision(orc_sim*, int enable);
+// 0 = PGS (default; BASELINE north_star), 1 = Newton (mujoco's default solver, mj_solNewton restated)
+void orc_set_solver_type(orc_sim*, int type);
+int orc_ls_evals(const orc_sim*);
 
 // state access (one env)
 void orc_set_state(orc_sim*, const double* qpos, const double* qvel, const double* warm);

@@ -742,7 +742,8 @@ DEV void arm_jac_row(const EnvLDS& L, int link, const float* p, const float* u, 
   }
 }
 
-DEV void make_constraints(const DevModel* m, EnvLDS& L) {
+// pgs_data: also build what only PGS needs (diagonal block of A, spectral form of its friction block)
+DEV void make_constraints(const DevModel* m, EnvLDS& L, bool pgs_data = true) {
   int lane = wave_lane();
   // ---- scalar rows: frictionloss (dof order) then active joint limits (joint order) — lane 0 builds the list
   if (lane == 0) {
@@ -827,10 +828,12 @@ DEV void make_constraints(const DevModel* m, EnvLDS& L) {
           vel[j] += sgn * (dot3(ul[j], &L.fvel[f][0]) + dot3(ua[j], &L.fvel[f][3]));
         }
         float mi = L.fminv[f];
+        if (pgs_data) {
 #pragma unroll
-        for (int j = 0; j < 6; j++)
+          for (int j = 0; j < 6; j++)
 #pragma unroll
-          for (int k = 0; k <= j; k++) A[j][k] += mi * dot3(ul[j], ul[k]) + dot3(ua[j], Iua[k]);
+            for (int k = 0; k <= j; k++) A[j][k] += mi * dot3(ul[j], ul[k]) + dot3(ua[j], Iua[k]);
+        }
       }
     }
     if (c.armslot >= 0) {
@@ -852,7 +855,7 @@ DEV void make_constraints(const DevModel* m, EnvLDS& L) {
         vel[j] += vj;
       }
 #pragma unroll
-      for (int k = 0; k < 6; k++) {
+      for (int k = 0; k < (pgs_data ? 6 : 0); k++) {
         float Bk[NARM];                    // column k of Minv J^T
 #pragma unroll
         for (int q = 0; q < NARM; q++) {
@@ -881,6 +884,7 @@ DEV void make_constraints(const DevModel* m, EnvLDS& L) {
     for (int j = 0; j < 6; j++)
 #pragma unroll
       for (int k = 0; k <= j; k++) c.A[j * (j + 1) / 2 + k] = A[j][k];
+    if (pgs_data)
     // Spectral form of the friction block for the cone QCQP (mju_QCQP): with D = diag(mu_j) the scaled block
     // D Ac D = Q diag(lam) Q^T is decomposed ONCE per substep (cyclic Jacobi, lane = contact); every Newton step
     // on the cone multiplier inside the PGS sweep is then O(5) instead of a 5x5 Cholesky factorisation.  Rows
@@ -934,19 +938,21 @@ DEV void make_constraints(const DevModel* m, EnvLDS& L) {
 }
 
 #include "so101_solver.hpp"
+#include "so101_newton.hpp"
 
 // ------------------------------------------------------------------ forward + Euler
 // `phases` is a profiling aid (env SO101_DEBUG_PHASES, default all): bit0 collision, bit1 constraint rows + solve,
 // bit2 solve iterations.  Production runs always execute every stage.
-DEV void forward(const DevModel* m, EnvLDS& L, int max_iter, float tolerance, int phases = 7) {
+DEV void forward(const DevModel* m, EnvLDS& L, int max_iter, float tolerance, int phases = 7, int solver = 0) {
   kinematics(m, L);
   crba_arm(m, L);
   smooth_dynamics(m, L);
   if (phases & 1) collision(m, L);
   else { if (wave_lane() == 0) { L.ncand = 0; L.ncon = 0; L.narmcon = 0; } wave_sync(); }
   if (phases & 2) {
-    make_constraints(m, L);
-    solve_pgs(m, L, (phases & 4) ? max_iter : 0, tolerance);
+    make_constraints(m, L, solver == 0);
+    if (solver == 1) solve_newton(m, L, (phases & 4) ? max_iter : 0, tolerance);
+    else solve_pgs(m, L, (phases & 4) ? max_iter : 0, tolerance);
   }
   // back to MuJoCo's generalized accelerations
   int lane = wave_lane();
@@ -1004,8 +1010,8 @@ DEV bool check_divergence(EnvLDS& L) {
   return any;
 }
 
-DEV bool substep(const DevModel* m, EnvLDS& L, int max_iter, float tolerance, bool freeze_arm, int phases = 7) {
-  forward(m, L, max_iter, tolerance, phases);
+DEV bool substep(const DevModel* m, EnvLDS& L, int max_iter, float tolerance, bool freeze_arm, int phases = 7, int solver = 0) {
+  forward(m, L, max_iter, tolerance, phases, solver);
   euler(m, L);
   if (check_divergence(L)) return true;
   if (freeze_arm) {   // dm_control JointStaticIsolator: non-prop joints restored after every step

@@ -116,7 +116,7 @@ StepParams make_params(const so101_sim* s) {
   P.iterations = s->cfg.solver_iterations > 0 ? s->cfg.solver_iterations : s->hm.iterations;
   P.tolerance = s->cfg.solver_tolerance >= 0.f ? s->cfg.solver_tolerance : s->hm.tolerance;
   P.settle_max = s->cfg.settle_max_substeps; P.terminate_on_success = s->cfg.terminate_on_success;
-  P.n_envs = s->n_envs; P.seed = s->seed; P.env_id_base = s->cfg.env_id_base;
+  P.n_envs = s->n_envs; P.seed = s->seed; P.env_id_base = s->cfg.env_id_base; P.solver = s->cfg.solver;
   const char* ph = getenv("SO101_DEBUG_PHASES");      // profiling aid for so101_physics only
   P.phases = ph ? atoi(ph) : 7;
   return P;
@@ -261,7 +261,7 @@ int so101_default_config(so101_config* cfg) {
   if (!cfg) return SO101_ERR_ARG;
   memset(cfg, 0, sizeof *cfg);
   cfg->last_step = 1 << 30; cfg->n_substeps = 10; cfg->solver_iterations = 0; cfg->solver_tolerance = -1.f;
-  cfg->settle_max_substeps = 1000; cfg->terminate_on_success = 1; cfg->env_id_base = 0;
+  cfg->settle_max_substeps = 1000; cfg->terminate_on_success = 1; cfg->env_id_base = 0; cfg->solver = SO101_SOLVER_NEWTON;
   return SO101_OK;
 }
 
@@ -300,6 +300,7 @@ void so101_destroy(so101_sim* s) {
 int so101_configure(so101_sim* s, const so101_config* cfg) {
   if (!s || !cfg) return SO101_ERR_ARG;
   if (cfg->n_substeps <= 0 || cfg->settle_max_substeps < 0) { s->err = "so101_configure: bad substep counts"; return SO101_ERR_ARG; }
+  if (cfg->solver != SO101_SOLVER_PGS && cfg->solver != SO101_SOLVER_NEWTON) { s->err = "so101_configure: unknown solver"; return SO101_ERR_ARG; }
   s->cfg = *cfg;
   return SO101_OK;
 }

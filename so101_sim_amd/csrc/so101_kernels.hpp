@@ -93,7 +93,7 @@ DEV void env_reset(const DevModel* m, EnvLDS& L, const StepParams& P, const DevB
   }
   // settle: arm restored after every substep; stop when |qvel|<1e-3 and |qacc|<1e-2 over the prop dofs
   for (int k = 0; k < P.settle_max; k++) {
-    substep(m, L, P.iterations, P.tolerance, true);
+    substep(m, L, P.iterations, P.tolerance, true, 7, P.solver);
     float mv = 0.f, ma = 0.f;
     if (lane >= NARM && lane < NV) { mv = fabsf(L.qvel[lane]); ma = fabsf(L.qacc[lane]); }
     mv = wave_max_f(mv); ma = wave_max_f(ma);
@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(64, 2) k_step(const DevModel* m, StepParams P,
   if (lane < NU) L.ctrl[lane] = action[(size_t)e * NU + lane] + P.action_offset[lane];
   wave_sync();
   bool diverged = false;
-  for (int s = 0; s < P.n_substeps && !diverged; s++) diverged = substep(m, L, P.iterations, P.tolerance, false);
+  for (int s = 0; s < P.n_substeps && !diverged; s++) diverged = substep(m, L, P.iterations, P.tolerance, false, 7, P.solver);
   kinematics(m, L);     // position-dependent quantities of the post-step state (legacy step2/step1 order)
   // joints_pos delay line: read the value of control step k-5, then store step k
   int slot = (sc - 1) % 5;
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(64, 2) k_physics(const DevModel* m, StepParams
   load_state(L, B, e, P.n_envs);
   if (lane < NARM) { L.arm0_q[lane] = L.qpos[lane]; L.arm0_v[lane] = L.qvel[lane]; }
   wave_sync();
-  for (int s = 0; s < nsub; s++) substep(m, L, P.iterations, P.tolerance, freeze != 0, P.phases);
+  for (int s = 0; s < nsub; s++) substep(m, L, P.iterations, P.tolerance, freeze != 0, P.phases, P.solver);
   store_state(L, B, e, P.n_envs);
   store_diag(L, diag, e);
 }
@@ -216,8 +216,8 @@ __global__ void __launch_bounds__(64) k_debug_forward(const DevModel* m, StepPar
   if (lane < 24) o[DBG_XPOS + lane] = L.xpos[lane / 3][lane % 3];
   wave_sync();
   collision(m, L);
-  make_constraints(m, L);
-  solve_pgs(m, L, P.iterations, P.tolerance);
+  make_constraints(m, L, P.solver == 0);
+  if (P.solver == 1) solve_newton(m, L, P.iterations, P.tolerance); else solve_pgs(m, L, P.iterations, P.tolerance);
   twist_to_qacc(L);
   if (lane < NV) o[DBG_QACC + lane] = L.qacc[lane];
   if (lane == 0) {

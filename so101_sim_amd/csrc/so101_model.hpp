@@ -18,6 +18,7 @@
 #define MAXCON 32
 #define MAXARMCON MAXCON
 #define MAXROW1 (2 * NARM)
+#define NVS NV                    // solver coordinates: arm qacc | object twist | container twist
 
 enum { G_PLANE = 0, G_SPHERE = 1, G_CAPSULE = 2, G_CYLINDER = 3, G_BOX = 4, G_MESH = 5 };
 
@@ -64,7 +65,7 @@ struct DevModel {
 // Per-env launch parameters that are not part of the model.
 struct StepParams {
   float action_offset[NU];
-  int last_step, n_substeps, iterations, settle_max, terminate_on_success, n_envs, phases;
+  int last_step, n_substeps, iterations, settle_max, terminate_on_success, n_envs, phases, solver;
   float tolerance;
   unsigned long long seed, env_id_base;
 };
@@ -89,6 +90,15 @@ struct Row1 {                  // scalar rows: dof frictionloss and joint limits
   int dof; float sign, R, aref, f, floss, Ainv, pad;
 };
 
+struct NewtonScratch {          // working set of solve_newton()
+  float H[NVS][NVS + 1];
+  float x[NVS], xs[NVS], xw[NVS], tmp[NVS], mxd[NVS], grad[NVS], search[NVS];
+  float Jst[6][12], Wst[6][12], Hst[6][6];
+  float jtf[MAXCON][12];
+  float rowf[MAXROW1], rowh[MAXROW1];
+  int zone[MAXCON];
+};
+
 struct EnvLDS {
   float qpos[NQ], qvel[NV], ctrl[NU], warm[NV];
   float xpos[NDYN][3], xmat[NDYN][9], xipos[NDYN][3], axis[NARM][3], Iw[NDYN][6];
@@ -104,6 +114,7 @@ struct EnvLDS {
   };
   Contact con[MAXCON];
   Row1 row[MAXROW1];
+  NewtonScratch nw;
   int ncand, ncon, nrow, narmcon, iters, overflow;
   float scratch[64];
 };

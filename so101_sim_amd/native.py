@@ -11,6 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libso101_hip.so")
 
+SOLVER_PGS, SOLVER_NEWTON = 0, 1
 OBS_DIM = 18
 ACT_DIM = 6
 RING_DEPTH = 5
@@ -37,7 +38,7 @@ class Config(C.Structure):
     _fields_ = [("action_offset", C.c_float * ACT_DIM), ("last_step", C.c_int32), ("n_substeps", C.c_int32),
                 ("solver_iterations", C.c_int32), ("solver_tolerance", C.c_float),
                 ("settle_max_substeps", C.c_int32), ("terminate_on_success", C.c_int32),
-                ("env_id_base", C.c_uint64)]
+                ("env_id_base", C.c_uint64), ("solver", C.c_int32), ("reserved", C.c_int32)]
 
 
 _libs: dict[str, C.CDLL] = {}
