@@ -92,7 +92,7 @@ struct Row1 {                  // scalar rows: dof frictionloss and joint limits
 
 struct NewtonScratch {          // working set of solve_newton()
   float H[NVS][NVS + 1];
-  float x[NVS], xs[NVS], xw[NVS], tmp[NVS], mxd[NVS], grad[NVS], search[NVS];
+  float x[NVS], xs[NVS], xw[NVS], tmp[NVS], mxd[NVS], grad[NVS], search[NVS], mxs[NVS];
   float Jst[6][12], Wst[6][12], Hst[6][6];
   float jtf[MAXCON][12];
   float rowf[MAXROW1], rowh[MAXROW1];

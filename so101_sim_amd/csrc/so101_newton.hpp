@@ -93,14 +93,16 @@ DEV float contact_jentry(const EnvLDS& L, const Contact& c, int g, int j, int q)
   if (g == 0) return L.armcon[c.armslot].J[j][q];
   int d = NARM + g - 1;
   float sgn = (c.d2 == d) ? 1.f : -1.f;
-  const float* u = &c.frame[3 * (j % 3)];
+  int jj = j % 3, qq = q % 3;
+  float u0 = c.frame[3 * jj], u1 = c.frame[3 * jj + 1], u2 = c.frame[3 * jj + 2];
+  float uq = qq == 0 ? u0 : (qq == 1 ? u1 : u2);           // selects, never a lane-indexed register array
   if (j < 3) {
-    if (q < 3) return sgn * u[q];
-    float r[3] = {c.pos[0] - L.xipos[d][0], c.pos[1] - L.xipos[d][1], c.pos[2] - L.xipos[d][2]}, t[3];
-    cross3(t, r, u);
-    return sgn * t[q - 3];
+    if (q < 3) return sgn * uq;
+    float r0 = c.pos[0] - L.xipos[d][0], r1 = c.pos[1] - L.xipos[d][1], r2 = c.pos[2] - L.xipos[d][2];
+    float t0 = r1 * u2 - r2 * u1, t1 = r2 * u0 - r0 * u2, t2 = r0 * u1 - r1 * u0;      // r x u
+    return sgn * (qq == 0 ? t0 : (qq == 1 ? t1 : t2));
   }
-  return q < 3 ? 0.f : sgn * u[q - 3];
+  return q < 3 ? 0.f : sgn * uq;
 }
 
 // M * v in solver coordinates, element `lane` (lane < NVS)
@@ -229,7 +231,7 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
         else if (i >= 3 && j >= 3) {
           const float* I = L.Iw[NARM + f];
           int p = i - 3, q = j - 3;
-          v = p == q ? I[p] : ((p + q == 1) ? I[3] : ((p + q == 2) ? I[4] : I[5]));
+          v = I[p == q ? p : p + q + 2];        // packed xx yy zz xy xz yz: (0,1)->3, (0,2)->4, (1,2)->5
         }
       }
       W.H[a][b] = v;
@@ -274,9 +276,16 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
       }
       wave_sync();
     }
-    // ---- Cholesky H = L L' (in place, lower), then search = -H^-1 grad
+    // ---- symmetric diagonal scaling  H~ = S H S, S = diag(H)^-1/2 : translational (mass ~ 4e-2) and rotational
+    // (inertia ~ 1e-5) coordinates differ by ~1e3 in scale, which puts cond(H) near 1/eps_fp32; after scaling the
+    // fp32 Cholesky is safe.  Solve H~ y = -S g, search = S y.
+    if (lane < NVS) W.mxs[lane] = 1.f / sqrtf(fmaxf(W.H[lane][lane], 1e-30f));
+    wave_sync();
+    for (int e = lane; e < NVS * NVS; e += WAVE) { int a = e / NVS, b = e % NVS; W.H[a][b] *= W.mxs[a] * W.mxs[b]; }
+    wave_sync();
+    // ---- Cholesky H~ = L L' (in place, lower), then the two triangular solves
     for (int j = 0; j < NVS; j++) {
-      float d = sqrtf(fmaxf(W.H[j][j], 1e-30f));
+      float d = sqrtf(fmaxf(W.H[j][j], 1e-7f));       // pivot floor: H~ has unit diagonal
       wave_sync();
       if (lane >= j && lane < NVS) W.H[lane][j] = (lane == j) ? d : W.H[lane][j] / d;
       wave_sync();
@@ -287,7 +296,7 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
       }
       wave_sync();
     }
-    if (lane < NVS) W.tmp[lane] = -W.grad[lane];
+    if (lane < NVS) W.tmp[lane] = -W.grad[lane] * W.mxs[lane];
     wave_sync();
     for (int i = 0; i < NVS; i++) {          // forward substitution, column oriented
       float yi = W.tmp[i] / W.H[i][i];
@@ -303,6 +312,7 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
       else if (lane < i) W.tmp[lane] -= W.H[i][lane] * xi;
       wave_sync();
     }
+    if (lane < NVS) W.tmp[lane] *= W.mxs[lane];
     if (lane < NVS) W.search[lane] = W.tmp[lane];
     wave_sync();
     // ---- exact line search: phi'(alpha) = 0 by safeguarded Newton
@@ -345,6 +355,7 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
     if (lane < NVS) W.x[lane] += alpha * W.search[lane];
     wave_sync();
     float newcost = eval_cost(W.x, true);
+
     float gp = lane < NVS ? W.grad[lane] * W.grad[lane] : 0.f;       // gradient of the previous point (cheap proxy)
     float gnorm = scale * sqrtf(wave_sum_f(gp));
     float improvement = scale * (cost - newcost);
