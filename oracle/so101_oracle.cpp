@@ -458,12 +458,36 @@ real origin_tri_dist2(const real* x0, const real* B, const real* C, real* wit, r
   return best;
 }
 
+// Interior point of a geom for the MPR origin ray: for primitives the point closest to `target` (the other geom's
+// centre) pulled slightly inside, so the ray follows the local penetration direction (with the fixed
+// centre of the large flat table box MPR's depth is erratic; EPA in mujoco >= 3.3 has no such dependence).
+void interior_point(const orc_sim* s, int g, const real* target, real* out) {
+  const Model& m = s->m;
+  int tp = m.geom_type[g];
+  if (tp == G_MESH || tp == G_SPHERE || tp == G_PLANE) { geom_center(s, g, out); return; }
+  const real* R = &s->gmat[9 * g]; const real* P = &s->gpos[3 * g]; const real* sz = &m.geom_size[3 * g];
+  real rel[3] = {target[0] - P[0], target[1] - P[1], target[2] - P[2]}, t[3];
+  mulmatTvec3(t, R, rel);
+  if (tp == G_BOX) {
+    for (int i = 0; i < 3; i++) { real lim = sz[i] - std::min(1e-3, 0.5 * sz[i]); t[i] = std::min(std::max(t[i], -lim), lim); }
+  } else if (tp == G_CYLINDER) {
+    real rmax = sz[0] - std::min(1e-3, 0.5 * sz[0]), rho = std::sqrt(t[0] * t[0] + t[1] * t[1]);
+    if (rho > rmax) { real sc = rmax / rho; t[0] *= sc; t[1] *= sc; }
+    real lim = sz[1] - std::min(1e-3, 0.5 * sz[1]);
+    t[2] = std::min(std::max(t[2], -lim), lim);
+  } else { t[0] = 0; t[1] = 0; t[2] = std::min(std::max(t[2], -sz[1]), sz[1]); }
+  real w[3]; mulmatvec3(w, R, t);
+  for (int k = 0; k < 3; k++) out[k] = P[k] + w[k];
+}
+
 // MPR penetration (libccd ccdMPRPenetration restated).  Returns true when the geoms intersect and
 // fills depth, dir (from g1 into g2) and pos (world).
 bool mpr_penetration(const orc_sim* s, int g1, int g2, real* depth, real* dir, real* pos) {
   const Model& m = s->m;
-  real org[3]; geom_center(s, g1, org);       // work in a frame centred on geom1 (conditioning only)
-  real c1[3] = {0, 0, 0}, c2[3]; geom_center(s, g2, c2);
+  real org[3], c1[3] = {0, 0, 0}, c2[3], cdef2[3];
+  geom_center(s, g2, cdef2);
+  interior_point(s, g1, cdef2, org);          // work in a frame centred on geom1's interior point
+  interior_point(s, g2, org, c2);
   for (int k = 0; k < 3; k++) c2[k] -= org[k];
   MV v0, v1, v2, v3, v4;
   for (int k = 0; k < 3; k++) { v0.a[k] = c1[k]; v0.b[k] = c2[k]; v0.v[k] = c1[k] - c2[k]; }

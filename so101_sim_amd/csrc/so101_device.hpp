@@ -467,12 +467,38 @@ DEV float origin_tri_dist2(const float* x0, const float* B, const float* C, floa
 
 #define MVCOPY(dst, src) do { _Pragma("unroll") for (int _i = 0; _i < 3; _i++) { (dst).v[_i] = (src).v[_i]; (dst).a[_i] = (src).a[_i]; (dst).b[_i] = (src).b[_i]; } } while (0)
 
+// Interior point of a geom for the MPR origin ray.  For primitives it is the point of the primitive closest to
+// `target` (the other geom's centre), pulled slightly inside, so that the ray follows the local penetration
+// direction: with the fixed geometric centre of a large flat box (the 1.0 x 0.8 m table top) the ray is nearly
+// parallel to the contact face and MPR's depth estimate becomes erratic (EPA, which mujoco >= 3.3 uses, has no such
+// dependence).  Hulls keep their centre of mass.
+DEV void interior_point(const GeomW& G, const float* target, float* out) {
+  if (G.type == G_MESH || G.type == G_SPHERE || G.type == G_PLANE) { out[0] = G.c[0]; out[1] = G.c[1]; out[2] = G.c[2]; return; }
+  float rel[3] = {target[0] - G.p[0], target[1] - G.p[1], target[2] - G.p[2]}, t[3];
+  matTvec3(t, G.R, rel);
+  if (G.type == G_BOX) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) { float lim = G.size[i] - fminf(1e-3f, 0.5f * G.size[i]); t[i] = fminf(fmaxf(t[i], -lim), lim); }
+  } else if (G.type == G_CYLINDER) {
+    float rmax = G.size[0] - fminf(1e-3f, 0.5f * G.size[0]), rho = sqrtf(t[0] * t[0] + t[1] * t[1]);
+    if (rho > rmax) { float sc = rmax / rho; t[0] *= sc; t[1] *= sc; }
+    float lim = G.size[1] - fminf(1e-3f, 0.5f * G.size[1]);
+    t[2] = fminf(fmaxf(t[2], -lim), lim);
+  } else {            // capsule: closest point of the axis segment
+    t[0] = 0.f; t[1] = 0.f; t[2] = fminf(fmaxf(t[2], -G.size[1]), G.size[1]);
+  }
+  float w[3]; matvec3(w, G.R, t);
+  out[0] = G.p[0] + w[0]; out[1] = G.p[1] + w[1]; out[2] = G.p[2] + w[2];
+}
+
 // MPR penetration query (XenoCollide / libccd ccdMPRPenetration).  Entirely wave-uniform control flow.
 DEV bool mpr_penetration(const DevModel* m, const GeomW& G1, const GeomW& G2, float* depth, float* dir, float* pos) {
-  float org[3] = {G1.c[0], G1.c[1], G1.c[2]};
+  float org[3], c2[3];
+  interior_point(G1, G2.c, org);
+  interior_point(G2, org, c2);
   MV v0, v1, v2, v3, v4;
 #pragma unroll
-  for (int i = 0; i < 3; i++) { v0.a[i] = 0.f; v0.b[i] = G2.c[i] - org[i]; v0.v[i] = -v0.b[i]; }
+  for (int i = 0; i < 3; i++) { v0.a[i] = 0.f; v0.b[i] = c2[i] - org[i]; v0.v[i] = -v0.b[i]; }
   if (isz(v0.v[0]) && isz(v0.v[1]) && isz(v0.v[2])) v0.v[0] += 1e-5f;
   float d[3] = {-v0.v[0], -v0.v[1], -v0.v[2]};
   normalize3(d);
