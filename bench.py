@@ -44,7 +44,7 @@ def cpu_baseline(seconds_budget: float = 20.0):
         steps += 1
     dt = time.perf_counter() - t0
     return {"value": steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"1 env: reset (settle) + {steps} random-action control steps, fp64 oracle, PGS 100 it, {dt:.1f} s"}
+            "sample": f"1 env: reset (settle) + {steps} random-action control steps, fp64 oracle, Newton solver, {dt:.1f} s"}
 
 
 def main():
@@ -53,7 +53,10 @@ def main():
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
-    ap.add_argument("--solver-iterations", type=int, default=0, help="PGS cap; 0 = model default (100)")
+    ap.add_argument("--solver", choices=("newton", "pgs"), default="newton",
+                    help="newton = MuJoCo's default, which the reference scene uses (it sets no <option solver>)")
+    ap.add_argument("--no-prefetch", action="store_true", help="settle auto-resets inside the step call")
+    ap.add_argument("--solver-iterations", type=int, default=0, help="iteration cap; 0 = model default (100)")
     ap.add_argument("--solver-tolerance", type=float, default=-1.0, help="<0 = model default (1e-8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -78,7 +81,8 @@ def main():
     os.chdir("/tmp")          # calibration offsets OFF (reference looks the JSON up relative to the CWD)
     env = task_suite.create_task_env("SO100HandOverBanana", time_limit=10.0, random_state=0, n_envs=N,
                                      device=dev, env_id_base=rank * N, solver_iterations=args.solver_iterations,
-                                     solver_tolerance=args.solver_tolerance)
+                                     solver_tolerance=args.solver_tolerance, solver=args.solver,
+                                     prefetch_resets=not args.no_prefetch)
     os.chdir(cwd)
     spec = env.action_spec()
     lo = torch.tensor(spec.minimum, device=dev)
@@ -135,7 +139,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "SO100HandOverBanana, 4096 lock-step envs per GPU, proprioceptive obs, uniform random actions, 500-step episodes with auto-reset+settle (BASELINE.json configs[1])",
                        "envs_per_gpu": N, "global_envs": world * N, "substeps_per_step": 10,
-                       "solver": "PGS", "solver_iterations": args.solver_iterations or 100,
+                       "solver": args.solver, "reset_prefetch": not args.no_prefetch, "solver_iterations": args.solver_iterations or 100,
                        "solver_tolerance": args.solver_tolerance if args.solver_tolerance >= 0 else 1e-8,
                        "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

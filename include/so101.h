@@ -73,7 +73,9 @@ typedef struct {
   uint64_t env_id_base;    /* global index of env 0 of this handle (multi-GPU sharding) */
   int32_t solver;          /* SO101_SOLVER_NEWTON (default: the reference's scene sets no <option solver>, so MuJoCo's
                               default Newton applies) or SO101_SOLVER_PGS (the solver BASELINE.json's north_star names) */
-  int32_t reserved;
+  int32_t prefetch_resets; /* 1 (default): settle the next episode's initial state of every env ahead of time on an
+                              internal low-priority stream, so that auto-resets inside so101_step cost a copy;
+                              0: always settle inside the call.  Results are identical either way. */
 } so101_config;
 
 int so101_version(void);

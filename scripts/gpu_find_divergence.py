@@ -15,7 +15,9 @@ hi = np.array([np.pi, 3.14158, 3.14158, 3.14158, 3.14158, 0.08], dtype=np.float3
 rng = np.random.RandomState(2)
 saved = []
 stats = []
-for t in range(25):
+hist = []
+HIST = int(os.environ.get('HIST', '8'))
+for t in range(int(os.environ.get("STEPS", "25"))):
     q0, v0, w0 = s.get_state()
     c0 = s._get(s.ctrl)
     act = rng.uniform(lo, hi, size=(N, 6)).astype(np.float32)
@@ -23,9 +25,12 @@ for t in range(25):
     d = s.get_diag()
     bad = np.where((d[:, 4] & 8) != 0)[0]
     stats.append((t, len(bad), int((d[:, 4] & 4 != 0).sum()), int((d[:, 4] & 2 != 0).sum()), int((d[:, 4] & 1 != 0).sum()), float(d[:, 0].mean()), int(d[:, 0].max()), float(d[:, 3].mean()), int(d[:, 3].max())))
+    hist.append((t, q0, v0, w0, c0, act))
+    hist = hist[-HIST:]
     for e in bad[:4]:
         if st[e] == 2:
-            saved.append(dict(t=t, env=int(e), qpos=q0[:, e], qvel=v0[:, e], warm=w0[:, e], action=act[e], ctrl=c0[:, e]))
+            saved.append(dict(t=t, env=int(e), qpos=q0[:, e], qvel=v0[:, e], warm=w0[:, e], action=act[e], ctrl=c0[:, e],
+                              hist=[dict(t=h[0], qpos=h[1][:, e].copy(), qvel=h[2][:, e].copy(), warm=h[3][:, e].copy(), ctrl=h[4][:, e].copy(), action=h[5][e].copy()) for h in hist]))
 for x in stats:
     print("t=%d diverged=%d armpool_ovf=%d con_ovf=%d cand_ovf=%d ncon mean %.1f max %d ncand mean %.1f max %d" % x)
 os.makedirs("gpurun_out", exist_ok=True)

@@ -87,6 +87,12 @@ struct so101_sim {
   bool bound = false;
   unsigned char* need_reset = nullptr;
   int* diag = nullptr;
+  // reset prefetch: cache of settled initial states, filled by k_prepare on a low-priority side stream
+  PrepBuffers prep{};
+  hipStream_t prep_stream = nullptr;
+  hipEvent_t prep_done = nullptr, main_ev = nullptr;
+  bool prep_pending = false;
+  int prep_waves = 0;
   std::string err;
 };
 
@@ -250,6 +256,27 @@ int build_model(so101_sim* s, const BlobView& b) {
   return SO101_OK;
 }
 
+// Launches k_prepare behind whatever `stream` holds now, unless the previous one is still running (it picks up
+// every env whose next episode is missing, so skipping a launch only delays the refill).
+void launch_prepare(so101_sim* s, hipStream_t stream) {
+  if (!s->cfg.prefetch_resets || !s->prep_stream) return;
+  if (s->prep_pending) {
+    if (hipEventQuery(s->prep_done) != hipSuccess) { (void)hipGetLastError(); return; }
+    s->prep_pending = false;
+  }
+  if (hipEventRecord(s->main_ev, stream) != hipSuccess) return;
+  if (hipStreamWaitEvent(s->prep_stream, s->main_ev, 0) != hipSuccess) return;
+  if (hipMemsetAsync(s->prep.cursor, 0, sizeof(int), s->prep_stream) != hipSuccess) return;
+  hipLaunchKernelGGL(k_prepare, dim3(s->prep_waves), dim3(64), 0, s->prep_stream, s->dm, make_params(s), s->buf, s->prep);
+  if (hipEventRecord(s->prep_done, s->prep_stream) == hipSuccess) s->prep_pending = true;
+}
+
+bool drain_prepare(so101_sim* s) {
+  if (!s->prep_stream) return true;
+  s->prep_pending = false;
+  return hip_ok(s, hipStreamSynchronize(s->prep_stream), "hipStreamSynchronize(prepare)");
+}
+
 }  // namespace
 
 extern "C" {
@@ -262,6 +289,7 @@ int so101_default_config(so101_config* cfg) {
   memset(cfg, 0, sizeof *cfg);
   cfg->last_step = 1 << 30; cfg->n_substeps = 10; cfg->solver_iterations = 0; cfg->solver_tolerance = -1.f;
   cfg->settle_max_substeps = 1000; cfg->terminate_on_success = 1; cfg->env_id_base = 0; cfg->solver = SO101_SOLVER_NEWTON;
+  cfg->prefetch_resets = 1;
   return SO101_OK;
 }
 
@@ -286,6 +314,25 @@ int so101_create(const void* blob, size_t bytes, int n_envs, int device, uint64_
     if (!hip_ok(s, hipMalloc(&p, sizeof(int) * SO101_DIAG_DIM * (size_t)n_envs), "hipMalloc(diag)")) rc = SO101_ERR_HIP;
     else { s->owned.push_back(p); s->diag = (int*)p; if (!hip_ok(s, hipMemset(p, 0, sizeof(int) * SO101_DIAG_DIM * (size_t)n_envs), "hipMemset")) rc = SO101_ERR_HIP; }
   }
+  if (rc == SO101_OK) {
+    size_t n = (size_t)n_envs;
+    void *q = nullptr, *v = nullptr, *w = nullptr, *t = nullptr, *c = nullptr;
+    bool ok = hip_ok(s, hipMalloc(&q, sizeof(float) * NQ * n), "hipMalloc(prep)") && hip_ok(s, hipMalloc(&v, sizeof(float) * NV * n), "hipMalloc(prep)") &&
+              hip_ok(s, hipMalloc(&w, sizeof(float) * NV * n), "hipMalloc(prep)") && hip_ok(s, hipMalloc(&t, sizeof(int) * n), "hipMalloc(prep)") &&
+              hip_ok(s, hipMalloc(&c, sizeof(int)), "hipMalloc(prep)");
+    for (void* p : {q, v, w, t, c}) if (p) s->owned.push_back(p);
+    ok = ok && hip_ok(s, hipMemset(t, 0xFF, sizeof(int) * n), "hipMemset(prep)");
+    int lo = 0, hi = 0;
+    ok = ok && hip_ok(s, hipDeviceGetStreamPriorityRange(&lo, &hi), "hipDeviceGetStreamPriorityRange") &&
+         hip_ok(s, hipStreamCreateWithPriority(&s->prep_stream, hipStreamNonBlocking, lo), "hipStreamCreateWithPriority") &&
+         hip_ok(s, hipEventCreateWithFlags(&s->prep_done, hipEventDisableTiming), "hipEventCreate") &&
+         hip_ok(s, hipEventCreateWithFlags(&s->main_ev, hipEventDisableTiming), "hipEventCreate");
+    if (ok) {
+      s->prep = PrepBuffers{(float*)q, (float*)v, (float*)w, (int*)t, (int*)c};
+      // one wave per CU at most: the refill runs beside the stepping kernels, it must not crowd them out
+      s->prep_waves = n_envs < 256 ? n_envs : 256;
+    } else rc = SO101_ERR_HIP;
+  }
   if (rc != SO101_OK) { g_create_error = s->err; so101_destroy(s); return rc; }
   *out = s;
   return SO101_OK;
@@ -293,6 +340,9 @@ int so101_create(const void* blob, size_t bytes, int n_envs, int device, uint64_
 
 void so101_destroy(so101_sim* s) {
   if (!s) return;
+  if (s->prep_stream) { (void)hipStreamSynchronize(s->prep_stream); (void)hipStreamDestroy(s->prep_stream); }
+  if (s->prep_done) (void)hipEventDestroy(s->prep_done);
+  if (s->main_ev) (void)hipEventDestroy(s->main_ev);
   for (void* p : s->owned) (void)hipFree(p);
   delete s;
 }
@@ -301,6 +351,9 @@ int so101_configure(so101_sim* s, const so101_config* cfg) {
   if (!s || !cfg) return SO101_ERR_ARG;
   if (cfg->n_substeps <= 0 || cfg->settle_max_substeps < 0) { s->err = "so101_configure: bad substep counts"; return SO101_ERR_ARG; }
   if (cfg->solver != SO101_SOLVER_PGS && cfg->solver != SO101_SOLVER_NEWTON) { s->err = "so101_configure: unknown solver"; return SO101_ERR_ARG; }
+  // cached initial states were settled under the old configuration
+  if (!drain_prepare(s)) return SO101_ERR_HIP;
+  if (s->prep.tag && !hip_ok(s, hipMemset(s->prep.tag, 0xFF, sizeof(int) * (size_t)s->n_envs), "hipMemset(prep)")) return SO101_ERR_HIP;
   s->cfg = *cfg;
   return SO101_OK;
 }
@@ -321,8 +374,9 @@ int so101_bind_state(so101_sim* s, const so101_buffers* b) {
 
 int so101_reset(so101_sim* s, const uint8_t* mask, void* stream) {
   REQUIRE_BOUND(s);
-  hipLaunchKernelGGL(k_reset, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, make_params(s), s->buf, mask, s->need_reset, s->diag);
+  hipLaunchKernelGGL(k_reset, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, make_params(s), s->buf, s->prep, mask, s->need_reset, s->diag);
   LAUNCH_CHECK(s, "k_reset");
+  launch_prepare(s, (hipStream_t)stream);
   return SO101_OK;
 }
 
@@ -336,9 +390,10 @@ int so101_begin_episode(so101_sim* s, void* stream) {
 int so101_step(so101_sim* s, const float* action, float* obs, float* reward, float* discount, uint8_t* step_type, void* stream) {
   REQUIRE_BOUND(s);
   if (!action || !obs || !reward || !discount || !step_type) { s->err = "so101_step: NULL argument"; return SO101_ERR_ARG; }
-  hipLaunchKernelGGL(k_step, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, make_params(s), s->buf, action, obs, reward,
+  hipLaunchKernelGGL(k_step, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, make_params(s), s->buf, s->prep, action, obs, reward,
                      discount, step_type, s->need_reset, s->diag);
   LAUNCH_CHECK(s, "k_step");
+  launch_prepare(s, (hipStream_t)stream);
   return SO101_OK;
 }
 

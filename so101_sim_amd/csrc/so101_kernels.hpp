@@ -7,6 +7,17 @@ struct DevBuffers {
   int *step_count, *episode;
 };
 
+// Library-owned cache of settled initial states.  The settled state of an episode is a pure function of
+// (seed, global env id, episode index, config), so it can be computed ahead of time: k_prepare() fills the
+// cache on a side stream while the envs are stepping and env_reset() consumes an entry when its tag matches the
+// episode that is about to start; otherwise env_reset() settles in place.  Either way the result is the same
+// bits, only the time at which the work is done differs.
+struct PrepBuffers {
+  float *qpos, *qvel, *warm;   // [NQ|NV|NV][n_envs]
+  int *tag;                    // episode index the entry belongs to, -1 = empty
+  int *cursor;                 // work-queue head of k_prepare
+};
+
 // debug dump layout (floats) of so101_debug_forward
 #define DBG_M 0          // 36  arm mass matrix
 #define DBG_MINV 36      // 36
@@ -61,12 +72,11 @@ DEV void twist_to_qacc(EnvLDS& L) {
   wave_sync();
 }
 
-// env.reset(): SO100Task.initialize_episode + SO100HandOver placers + settle (so100_task.py:304-320,
-// so100_hand_over.py:208-229,320-323).  Leaves the settled state in LDS and the delay line in HBM.
-DEV void env_reset(const DevModel* m, EnvLDS& L, const StepParams& P, const DevBuffers& B, int e) {
-  int lane = wave_lane(), N = P.n_envs;
+// env.reset(), part 1: SO100Task.initialize_episode + SO100HandOver placers + settle (so100_task.py:304-320,
+// so100_hand_over.py:208-229,320-323).  Leaves the settled state of `episode` in LDS; touches no HBM state.
+DEV void env_settle(const DevModel* m, EnvLDS& L, const StepParams& P, int e, unsigned int episode) {
+  int lane = wave_lane();
   unsigned long long env_id = P.env_id_base + (unsigned long long)e;
-  unsigned int episode = (unsigned int)B.episode[e];
   if (lane < NQ) L.qpos[lane] = 0.f;
   if (lane < NV) { L.qvel[lane] = 0.f; L.warm[lane] = 0.f; }
   if (lane < NU) L.ctrl[lane] = m->home_ctrl[lane] + P.action_offset[lane];
@@ -99,22 +109,65 @@ DEV void env_reset(const DevModel* m, EnvLDS& L, const StepParams& P, const DevB
     mv = wave_max_f(mv); ma = wave_max_f(ma);
     if (mv < 1e-3f && ma < 1e-2f) break;
   }
-  // delay line padded with the reset value (task_suite.py:154 INITIAL_VALUE)
+}
+
+// env.reset(): takes the settled state of the next episode from the cache or computes it, then starts the
+// episode: delay line padded with the reset value (task_suite.py:154 INITIAL_VALUE), counters cleared.
+DEV void env_reset(const DevModel* m, EnvLDS& L, const StepParams& P, const DevBuffers& B, const PrepBuffers& C, int e) {
+  int lane = wave_lane(), N = P.n_envs;
+  unsigned int episode = (unsigned int)B.episode[e];
+  bool cached = C.tag && __atomic_load_n(&C.tag[e], __ATOMIC_ACQUIRE) == (int)episode;
+  if (cached) {
+    if (lane < NQ) L.qpos[lane] = C.qpos[(size_t)lane * N + e];
+    if (lane < NV) { L.qvel[lane] = C.qvel[(size_t)lane * N + e]; L.warm[lane] = C.warm[(size_t)lane * N + e]; }
+    if (lane < NU) L.ctrl[lane] = m->home_ctrl[lane] + P.action_offset[lane];
+    if (lane == 0) { L.ncon = 0; L.nrow = 0; L.iters = 0; L.ncand = 0; }
+    wave_sync();
+  } else {
+    env_settle(m, L, P, e, episode);
+  }
   if (lane < NARM) {
     for (int r = 0; r < 5; r++) B.ring[((size_t)r * NARM + lane) * N + e] = L.qpos[lane];
   }
-  if (lane == 0) { B.step_count[e] = 0; B.ep_return[e] = 0.f; B.episode[e] = (int)(episode + 1u); }
+  // the cache entry has been read completely before the episode counter tells k_prepare() to refill it
+  __threadfence();
+  wave_sync();
+  if (lane == 0) { B.step_count[e] = 0; B.ep_return[e] = 0.f; __atomic_store_n(&B.episode[e], (int)(episode + 1u), __ATOMIC_RELEASE); }
+}
+
+// Fills the cache for every env whose next episode is not in it yet.  A few persistent waves pull env indices
+// from a queue so that the stepping kernels keep most of the machine.
+__global__ void __launch_bounds__(64, 2) k_prepare(const DevModel* m, StepParams P, DevBuffers B, PrepBuffers C) {
+  __shared__ EnvLDS L;
+  int lane = wave_lane(), N = P.n_envs;
+  for (;;) {
+    int e = 0;
+    if (lane == 0) e = atomicAdd(C.cursor, 1);
+    e = wave_bcast_i(e, 0);
+    if (e >= N) break;
+    int target = __atomic_load_n(&B.episode[e], __ATOMIC_ACQUIRE);
+    if (__atomic_load_n(&C.tag[e], __ATOMIC_ACQUIRE) == target) continue;
+    if (lane == 0) L.overflow = 0;
+    env_settle(m, L, P, e, (unsigned int)target);
+    wave_sync();
+    if (lane < NQ) C.qpos[(size_t)lane * N + e] = L.qpos[lane];
+    if (lane < NV) { C.qvel[(size_t)lane * N + e] = L.qvel[lane]; C.warm[(size_t)lane * N + e] = L.warm[lane]; }
+    __threadfence();
+    wave_sync();
+    if (lane == 0) __atomic_store_n(&C.tag[e], target, __ATOMIC_RELEASE);
+    wave_sync();
+  }
 }
 
 // __launch_bounds__(64, 2): two waves per SIMD => at most 256 VGPRs; measured 234 -> 204 ms per control step on
 // the 4096-env random-action workload against the unconstrained allocation (256 VGPR + 75 AGPR, one wave per SIMD).
-__global__ void __launch_bounds__(64, 2) k_reset(const DevModel* m, StepParams P, DevBuffers B, const unsigned char* mask,
+__global__ void __launch_bounds__(64, 2) k_reset(const DevModel* m, StepParams P, DevBuffers B, PrepBuffers C, const unsigned char* mask,
                                               unsigned char* need_reset, int* diag) {
   __shared__ EnvLDS L;
   int e = blockIdx.x;
   if (mask && !mask[e]) return;
   if (wave_lane() == 0) L.overflow = 0;
-  env_reset(m, L, P, B, e);
+  env_reset(m, L, P, B, C, e);
   store_state(L, B, e, P.n_envs);
   store_diag(L, diag, e);
   if (wave_lane() == 0) need_reset[e] = 0;
@@ -130,7 +183,7 @@ __global__ void __launch_bounds__(64) k_begin(const DevModel* m, StepParams P, D
   if (lane == 0) { B.step_count[e] = 0; B.ep_return[e] = 0.f; need_reset[e] = 0; }
 }
 
-__global__ void __launch_bounds__(64, 2) k_step(const DevModel* m, StepParams P, DevBuffers B, const float* action, float* obs,
+__global__ void __launch_bounds__(64, 2) k_step(const DevModel* m, StepParams P, DevBuffers B, PrepBuffers C, const float* action, float* obs,
                                              float* reward, float* discount, unsigned char* step_type,
                                              unsigned char* need_reset, int* diag) {
   __shared__ EnvLDS L;
@@ -138,7 +191,7 @@ __global__ void __launch_bounds__(64, 2) k_step(const DevModel* m, StepParams P,
   if (need_reset[e]) {
     // dm_control auto-reset: the call after LAST resets and reports FIRST; the action is ignored
     if (lane == 0) L.overflow = 0;
-    env_reset(m, L, P, B, e);
+    env_reset(m, L, P, B, C, e);
     store_state(L, B, e, N);
     store_diag(L, diag, e);
     if (lane < NARM) {

@@ -98,7 +98,8 @@ class _PhysicsView:
 class BatchedEnvironment:
     def __init__(self, task: SO100HandOverTask, n_envs: int = 1, time_limit: float = float("inf"),
                  random_state=None, device=None, env_id_base: int = 0, solver_iterations: int = 0,
-                 solver_tolerance: float = -1.0, settle_max_substeps: int = 1000):
+                 solver_tolerance: float = -1.0, settle_max_substeps: int = 1000, solver: str = "newton",
+                 prefetch_resets: bool = True):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("so101_sim_amd needs a ROCm GPU (MI355X): the step path has no CPU fallback")
@@ -133,7 +134,9 @@ class BatchedEnvironment:
         self.sim.configure(action_offset=[float(x) for x in task.calibration.homing_offsets], last_step=last,
                            n_substeps=nsub, solver_iterations=int(solver_iterations),
                            solver_tolerance=float(solver_tolerance), settle_max_substeps=int(settle_max_substeps),
-                           terminate_on_success=int(task.terminate_episode), env_id_base=int(env_id_base))
+                           terminate_on_success=int(task.terminate_episode), env_id_base=int(env_id_base),
+                           solver={"newton": native.SOLVER_NEWTON, "pgs": native.SOLVER_PGS}[str(solver).lower()],
+                           prefetch_resets=int(bool(prefetch_resets)))
         self.physics = _PhysicsView(self)
         self._physics = self.physics
 

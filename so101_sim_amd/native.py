@@ -38,7 +38,7 @@ class Config(C.Structure):
     _fields_ = [("action_offset", C.c_float * ACT_DIM), ("last_step", C.c_int32), ("n_substeps", C.c_int32),
                 ("solver_iterations", C.c_int32), ("solver_tolerance", C.c_float),
                 ("settle_max_substeps", C.c_int32), ("terminate_on_success", C.c_int32),
-                ("env_id_base", C.c_uint64), ("solver", C.c_int32), ("reserved", C.c_int32)]
+                ("env_id_base", C.c_uint64), ("solver", C.c_int32), ("prefetch_resets", C.c_int32)]
 
 
 _libs: dict[str, C.CDLL] = {}

@@ -84,7 +84,8 @@ def create_task_env(
     Unknown `task_name` raises ValueError listing the names; kwargs that the task constructor does not
     name explicitly are silently dropped (task_suite.py:134-144) — for `SO100HandOver`, whose signature
     is `(object_name, reward_based_on_overlap=True, **kwargs)`, that is everything except those two.
-    Batched extension: `n_envs`, `device`, `solver_iterations`, `solver_tolerance`, `env_id_base` are
+    Batched extension: `n_envs`, `device`, `solver` ("newton" | "pgs"), `solver_iterations`, `solver_tolerance`,
+    `settle_max_substeps`, `prefetch_resets`, `env_id_base` are
     consumed here and never reach the task.
     """
     if task_name not in TASK_FACTORIES:
@@ -93,7 +94,8 @@ def create_task_env(
             f" {list(TASK_FACTORIES.keys())}"
         )
     n_envs = int(kwargs.pop("n_envs", 1))
-    env_kwargs = {k: kwargs.pop(k) for k in ("device", "solver_iterations", "solver_tolerance", "env_id_base", "settle_max_substeps")
+    env_kwargs = {k: kwargs.pop(k) for k in ("device", "solver_iterations", "solver_tolerance", "env_id_base", "settle_max_substeps", "solver",
+                                                 "prefetch_resets")
                   if k in kwargs}
 
     task_class, task_kwargs = TASK_FACTORIES[task_name]

@@ -192,6 +192,23 @@ def check_env_semantics(make_sim, blobs, n=2, settle=30, steps=8, last_step=7, s
             assert np.all(obs[:, 0:12] == 0)
 
 
+def check_prefetch_identical(make_sim, n=3, settle=25, steps=9, last_step=3, seed=5):
+    """The reset prefetch (k_prepare + cache) changes when an episode's initial state is settled, never its value:
+    rollouts across several auto-resets are bit-identical with prefetch_resets=0 and =1."""
+    out = []
+    for prefetch in (0, 1):
+        sim = make_sim(n, seed=seed, settle_max_substeps=settle, last_step=last_step, prefetch_resets=prefetch)
+        sim.reset()
+        rng = np.random.RandomState(seed)
+        trace = [np.concatenate([a.ravel() for a in sim.get_state()])]
+        for t in range(steps):
+            obs, rew, disc, st = sim.step(rng.uniform(-0.4, 0.4, size=(n, 6)).astype(np.float32))
+            trace.append(np.concatenate([obs.ravel(), rew, disc, st.astype(np.float32)] + [a.ravel() for a in sim.get_state()]))
+        out.append(trace)
+    for a, b in zip(*out):
+        np.testing.assert_array_equal(a, b)
+
+
 def check_contact_rich(make_sim, blobs, golden, count=4, verbose=False):
     """Arm self-collision / arm-table / arm-prop contact states (20-30 simultaneous contacts, captured from a
     random-action rollout): same contact set as the oracle and the same constrained acceleration.

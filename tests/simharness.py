@@ -52,6 +52,9 @@ class ArraySim:
         p = self.ptr
         self.sim.bind(p(self.qpos), p(self.qvel), p(self.ctrl), p(self.warm), p(self.ring), p(self.ep_return),
                       p(self.step_count), p(self.episode))
+        if backend == "emu":
+            # launches are synchronous in the emulator: a prefetch would settle every env after every call
+            cfg.setdefault("prefetch_resets", 0)
         if cfg:
             self.sim.configure(**cfg)
 

@@ -40,3 +40,7 @@ def test_divergence_handling(make_sim, blobs):
 
 def test_contact_rich_states(make_sim, blobs, golden):
     pc.check_contact_rich(make_sim, blobs, golden, count=4)
+
+
+def test_reset_prefetch_is_bit_identical(make_sim):
+    pc.check_prefetch_identical(make_sim, n=2, settle=8, steps=7, last_step=2)

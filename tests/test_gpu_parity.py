@@ -43,6 +43,10 @@ def test_env_semantics(make_sim, blobs):
     pc.check_env_semantics(make_sim, blobs, n=4, settle=200, steps=9, last_step=7, iterations=50)
 
 
+def test_reset_prefetch_is_bit_identical(make_sim):
+    pc.check_prefetch_identical(make_sim, n=64, settle=300, steps=14, last_step=3)
+
+
 def test_full_settle_matches_oracle(make_sim, blobs):
     """reset with the reference's full 1000-substep settle budget: rest pose vs oracle, KAT-2 heights."""
     from oracle.oracle import Oracle
