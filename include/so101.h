@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SO101_ABI_VERSION 1
+#define SO101_ABI_VERSION 2
 #define SO101_OBS_DIM 18      /* joints_pos(6, delayed) | undelayed_joints_pos(6) | commanded_joints_pos(6) */
 #define SO101_ACT_DIM 6
 #define SO101_SOLVER_PGS 0
@@ -76,6 +76,9 @@ typedef struct {
   int32_t prefetch_resets; /* 1 (default): settle the next episode's initial state of every env ahead of time on an
                               internal low-priority stream, so that auto-resets inside so101_step cost a copy;
                               0: always settle inside the call.  Results are identical either way. */
+  int32_t pipeline;        /* 1 (default): so101_step runs every substep as narrowphase (one wavefront per candidate pair)
+                              + solve (one wavefront per env) launches; 0: one fused launch, one wavefront per env. */
+  int32_t reserved;
 } so101_config;
 
 int so101_version(void);
@@ -127,7 +130,9 @@ int so101_reward(so101_sim* sim, float* reward, void* hip_stream);
 int so101_get_returns(so101_sim* sim, float* out, void* hip_stream);
 
 /* Diagnostics of the most recent substep, per env: [N][SO101_DIAG_DIM] int32
- *   0 ncon, 1 nefc, 2 solver iterations, 3 broadphase candidates, 4 overflow flags. */
+ *   0 ncon, 1 nefc, 2 solver iterations, 3 broadphase candidates, 4 overflow flags,
+ *   5 collision time, 6 constraint+solver time, 7 whole-call time of this env's wavefront (10 ns ticks, summed over
+ *   the substeps of the last call). */
 #define SO101_DIAG_DIM 8
 int so101_get_diag(so101_sim* sim, int32_t* out, void* hip_stream);
 
@@ -135,6 +140,11 @@ int so101_get_diag(so101_sim* sim, int32_t* out, void* hip_stream);
  * out is [N][SO101_DEBUG_DIM] float32; layout documented in csrc/so101_device.hpp (DBG_*). */
 #define SO101_DEBUG_DIM 1024
 int so101_debug_forward(so101_sim* sim, float* out, void* hip_stream);
+
+/* Diagnostics of the pipelined step's last narrowphase launch (device buffers, any may be NULL):
+ * ncand[N] (count | overflow << 16), cand[N][256] (geom1 | geom2 << 16), ticks[N][256] (10 ns per candidate),
+ * conres[N][256][8] (dist, normal, position, valid). */
+int so101_debug_candidates(so101_sim* sim, int32_t* ncand, uint32_t* cand, uint32_t* ticks, float* conres, void* hip_stream);
 
 const char* so101_last_error(const so101_sim* sim);
 

@@ -1,0 +1,35 @@
+"""Per-candidate narrowphase time (k_narrow's ticks buffer) on the bench workload: distribution and the slowest pairs."""
+import os, sys, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from so101_sim_amd.model import scenes
+from tests.simharness import ArraySim
+raw32, meta = scenes.load_blob("banana", "f32")
+gn = meta["geom_names"]
+N = 4096
+s = ArraySim(raw32, N, backend="gpu", seed=0, settle_max_substeps=300, last_step=100000, prefetch_resets=0)
+s.reset()
+lo = np.array([-np.pi, -3.14158, -3.14158, -3.14158, -3.14158, 0.0], dtype=np.float32)
+hi = np.array([np.pi, 3.14158, 3.14158, 3.14158, 3.14158, 0.08], dtype=np.float32)
+rng = np.random.RandomState(2)
+for t in range(30):
+    s.step(rng.uniform(lo, hi, size=(N, 6)).astype(np.float32))
+dev = s.dev
+nc = torch.zeros(N, dtype=torch.int32, device=dev); cand = torch.zeros(N, 256, dtype=torch.int32, device=dev)
+tk = torch.zeros(N, 256, dtype=torch.int32, device=dev); cr = torch.zeros(N, 256, 8, device=dev)
+s.sim.debug_candidates(nc.data_ptr(), cand.data_ptr(), tk.data_ptr(), cr.data_ptr())
+torch.cuda.synchronize()
+nc = (nc.cpu().numpy() & 0xffff); cand = cand.cpu().numpy(); tk = tk.cpu().numpy(); cr = cr.cpu().numpy()
+mask = np.arange(256)[None, :] < nc[:, None]
+t = tk[mask] * 1e-2          # us
+print("candidates", mask.sum(), "sum %.1f ms, mean %.2f us, p50 %.2f p90 %.2f p99 %.2f max %.1f" % (t.sum() * 1e-3, t.mean(), *np.percentile(t, [50, 90, 99]), t.max()))
+print("sum/2048 waves = %.3f ms" % (t.sum() * 1e-3 / 2048))
+hit = cr[..., 7][mask] != 0
+print("hit fraction %.2f; mean us hit %.2f miss %.2f" % (hit.mean(), t[hit].mean(), t[~hit].mean()))
+c = cand[mask]; g1 = c & 0xffff; g2 = (c >> 16) & 0xffff
+agg = collections.defaultdict(lambda: [0, 0.0])
+for a, b, x in zip(g1, g2, t):
+    k = (gn[a].split("/")[0] if "/" in gn[a] else gn[a], gn[b].split("/")[0] if "/" in gn[b] else gn[b])
+    agg[k][0] += 1; agg[k][1] += x
+for k, (n, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
+    print("  %-50s n %6d  total %.1f ms  mean %.2f us" % (k, n, tot * 1e-3, tot / n))

@@ -359,34 +359,67 @@ DEV void smooth_dynamics(const DevModel* m, EnvLDS& L) {
 // ------------------------------------------------------------------ geometry
 struct GeomW { int type, vadr, vnum; float size[3], R[9], p[3], c[3]; };
 
-DEV void load_geom(const DevModel* m, const EnvLDS& L, int g, GeomW& G) {
-  G.type = m->geom_type[g]; G.vadr = m->geom_vertadr[g]; G.vnum = m->geom_vertnum[g];
-  const float* gp = m->geom_pos + 3 * g; const float* gm = m->geom_mat + 9 * g;
-  const float* gc = m->geom_center + 3 * g;
+// xp/xm: world position and orientation of the geom's dynamic body (ignored for static geoms)
+DEV void load_geom_at(const DevModel* m, int g, const float* xp, const float* xm, GeomW& G) {
+  g = wave_uniform_i(g);
+  G.type = ldc(ldc(&m->geom_type) + g); G.vadr = ldc(ldc(&m->geom_vertadr) + g); G.vnum = ldc(ldc(&m->geom_vertnum) + g);
+  const float* gp = ldc(&m->geom_pos) + 3 * g; const float* gm = ldc(&m->geom_mat) + 9 * g;
+  const float* gc = ldc(&m->geom_center) + 3 * g; const float* gs = ldc(&m->geom_size) + 3 * g;
 #pragma unroll
-  for (int i = 0; i < 3; i++) G.size[i] = m->geom_size[3 * g + i];
-  int d = m->geom_dyn[g];
-  float lp[3] = {gp[0], gp[1], gp[2]}, lm[9], lc[3] = {gc[0], gc[1], gc[2]};
+  for (int i = 0; i < 3; i++) G.size[i] = ldc(gs + i);
+  int d = ldc(ldc(&m->geom_dyn) + g);
+  float lp[3] = {ldc(gp), ldc(gp + 1), ldc(gp + 2)}, lm[9], lc[3] = {ldc(gc), ldc(gc + 1), ldc(gc + 2)};
 #pragma unroll
-  for (int i = 0; i < 9; i++) lm[i] = gm[i];
-  if (d < 0) {
+  for (int i = 0; i < 9; i++) lm[i] = ldc(gm + i);
+  // static geoms go through the same arithmetic with an identity pose (exact: 1*a + 0*b + 0*c == a), so that the
+  // geom stays in registers instead of becoming a stack object selected by the branch
+  float X[9], P0[3];
 #pragma unroll
-    for (int i = 0; i < 9; i++) G.R[i] = lm[i];
+  for (int i = 0; i < 9; i++) X[i] = d < 0 ? (i % 4 == 0 ? 1.f : 0.f) : xm[i];
 #pragma unroll
-    for (int i = 0; i < 3; i++) G.p[i] = lp[i];
-  } else {
-    float t[3]; matvec3(t, L.xmat[d], lp);
+  for (int i = 0; i < 3; i++) P0[i] = d < 0 ? 0.f : xp[i];
+  float t[3]; matvec3(t, X, lp);
 #pragma unroll
-    for (int i = 0; i < 3; i++) G.p[i] = L.xpos[d][i] + t[i];
-    matmul3(G.R, L.xmat[d], lm);
-  }
+  for (int i = 0; i < 3; i++) G.p[i] = P0[i] + t[i];
+  matmul3(G.R, X, lm);
   float cw[3]; matvec3(cw, G.R, lc);
 #pragma unroll
   for (int i = 0; i < 3; i++) G.c[i] = G.p[i] + cw[i];
 }
 
+DEV void load_geom(const DevModel* m, const EnvLDS& L, int g, GeomW& G) {
+  g = wave_uniform_i(g);
+  int d = ldc(ldc(&m->geom_dyn) + g);
+  load_geom_at(m, g, L.xpos[d < 0 ? 0 : d], L.xmat[d < 0 ? 0 : d], G);
+}
+
+// Hull vertices of one geom held in registers for the duration of a narrowphase query: lane l keeps vertices
+// l, l+64, ... (HULL_K of them; 64 * 8 = 512 covers all but four hulls of the SO100 scenes, the rest of those is scanned in memory).  An MPR
+// query evaluates ~20-30 support points per geom; reading the hull once instead of once per support call removes
+// the vertex traffic (205 -> ~10 vector loads per candidate pair).  Only k_narrow can afford the registers; the fused
+// kernels use NoCache and scan memory.  Both variants visit the vertices in the same order with the same
+// arithmetic, so they return the same vertex.
+#define HULL_K 8
+struct HullCache { float x[HULL_K], y[HULL_K], z[HULL_K]; };
+struct NoCache {};
+
+DEV void hull_load(const DevModel* m, const GeomW& G, HullCache& H) {
+  if (G.type != G_MESH) return;
+  int lane = wave_lane();
+  const float* x = ldc(&m->vx) + G.vadr; const float* y = ldc(&m->vy) + G.vadr; const float* z = ldc(&m->vz) + G.vadr;
+#pragma unroll
+  for (int j = 0; j < HULL_K; j++) {
+    if (WAVE * j >= G.vnum) break;
+    int i = lane + WAVE * j;
+    bool v = i < G.vnum;
+    H.x[j] = v ? x[i] : 0.f; H.y[j] = v ? y[i] : 0.f; H.z[j] = v ? z[i] : 0.f;
+  }
+}
+DEV void hull_load(const DevModel*, const GeomW&, NoCache&) {}
+
 // support point (world) of G in world direction dir; wave-parallel over hull vertices for meshes
-DEV void support(const DevModel* m, const GeomW& G, const float* dir, float* out) {
+template <class Cache>
+DEV void support(const DevModel* m, const GeomW& G, const float* dir, float* out, const Cache& H) {
   float dl[3]; matTvec3(dl, G.R, dir);
   float loc[3] = {0.f, 0.f, 0.f};
   if (G.type == G_MESH) {
@@ -395,9 +428,21 @@ DEV void support(const DevModel* m, const GeomW& G, const float* dir, float* out
     // the wave-level argmax then broadcasts the winner with v_readlane (no second memory access, and a
     // non-finite direction of a diverged state can never index out of range)
     float best = -3.0e38f, bx = 0.f, by = 0.f, bz = 0.f; int bi = 0x7fffffff;
-    const float* x = m->vx + G.vadr; const float* y = m->vy + G.vadr; const float* z = m->vz + G.vadr;
+    const float* x = ldc(&m->vx) + G.vadr; const float* y = ldc(&m->vy) + G.vadr; const float* z = ldc(&m->vz) + G.vadr;
+    int first = lane;
+    if constexpr (sizeof(Cache) >= sizeof(HullCache)) {
+#pragma unroll
+      for (int j = 0; j < HULL_K; j++) {
+        if (WAVE * j >= G.vnum) break;
+        int i = lane + WAVE * j;
+        float X = H.x[j], Y = H.y[j], Z = H.z[j];
+        float d = X * dl[0] + Y * dl[1] + Z * dl[2];
+        if (i < G.vnum && d > best) { best = d; bi = i; bx = X; by = Y; bz = Z; }
+      }
+      first = lane + WAVE * HULL_K;
+    }
 #pragma unroll 4
-    for (int i = lane; i < G.vnum; i += WAVE) {
+    for (int i = first; i < G.vnum; i += WAVE) {
       float X = x[i], Y = y[i], Z = z[i];
       float d = X * dl[0] + Y * dl[1] + Z * dl[2];
       if (d > best) { best = d; bi = i; bx = X; by = Y; bz = Z; }
@@ -425,10 +470,12 @@ DEV void support(const DevModel* m, const GeomW& G, const float* dir, float* out
 
 struct MV { float v[3], a[3], b[3]; };
 
-DEV void mdsupport(const DevModel* m, const GeomW& G1, const GeomW& G2, const float* dir, const float* org, MV& o) {
+template <class Cache>
+DEV void mdsupport(const DevModel* m, const GeomW& G1, const GeomW& G2, const float* dir, const float* org, MV& o,
+                   const Cache& H1, const Cache& H2) {
   float nd[3] = {-dir[0], -dir[1], -dir[2]};
-  support(m, G1, dir, o.a);
-  support(m, G2, nd, o.b);
+  support(m, G1, dir, o.a, H1);
+  support(m, G2, nd, o.b, H2);
 #pragma unroll
   for (int i = 0; i < 3; i++) { o.a[i] -= org[i]; o.b[i] -= org[i]; o.v[i] = o.a[i] - o.b[i]; }
 }
@@ -492,7 +539,10 @@ DEV void interior_point(const GeomW& G, const float* target, float* out) {
 }
 
 // MPR penetration query (XenoCollide / libccd ccdMPRPenetration).  Entirely wave-uniform control flow.
-DEV bool mpr_penetration(const DevModel* m, const GeomW& G1, const GeomW& G2, float* depth, float* dir, float* pos) {
+template <class Cache>
+DEV bool mpr_penetration(const DevModel* m, const GeomW& G1, const GeomW& G2, float* depth, float* dir, float* pos,
+                         const Cache& H1, const Cache& H2) {
+  const float mpr_tol = ldc(&m->mpr_tol); const int mpr_iter = ldc(&m->mpr_iter);
   float org[3], c2[3];
   interior_point(G1, G2.c, org);
   interior_point(G2, org, c2);
@@ -502,7 +552,7 @@ DEV bool mpr_penetration(const DevModel* m, const GeomW& G1, const GeomW& G2, fl
   if (isz(v0.v[0]) && isz(v0.v[1]) && isz(v0.v[2])) v0.v[0] += 1e-5f;
   float d[3] = {-v0.v[0], -v0.v[1], -v0.v[2]};
   normalize3(d);
-  mdsupport(m, G1, G2, d, org, v1);
+  mdsupport(m, G1, G2, d, org, v1, H1, H2);
   float dt = dot3(v1.v, d);
   if (isz(dt) || dt < 0.f) return false;
   cross3(d, v0.v, v1.v);
@@ -520,7 +570,7 @@ DEV bool mpr_penetration(const DevModel* m, const GeomW& G1, const GeomW& G2, fl
     return true;
   }
   normalize3(d);
-  mdsupport(m, G1, G2, d, org, v2);
+  mdsupport(m, G1, G2, d, org, v2, H1, H2);
   dt = dot3(v2.v, d);
   if (isz(dt) || dt < 0.f) return false;
   float va[3], vb[3];
@@ -533,7 +583,7 @@ DEV bool mpr_penetration(const DevModel* m, const GeomW& G1, const GeomW& G2, fl
   }
   bool have3 = false;
   for (int guard = 0; guard < 100 && !have3; guard++) {
-    mdsupport(m, G1, G2, d, org, v3);
+    mdsupport(m, G1, G2, d, org, v3, H1, H2);
     dt = dot3(v3.v, d);
     if (isz(dt) || dt < 0.f) return false;
     bool cont = false;
@@ -562,14 +612,14 @@ DEV bool mpr_penetration(const DevModel* m, const GeomW& G1, const GeomW& G2, fl
       dt = dot3(d, v1.v);
       if (isz(dt) || dt > 0.f) { inside = true; it = -1; continue; }   // portal encapsules origin: start penetration phase
     }
-    mdsupport(m, G1, G2, d, org, v4);
+    mdsupport(m, G1, G2, d, org, v4, H1, H2);
     float dv1 = dot3(v1.v, d), dv2 = dot3(v2.v, d), dv3 = dot3(v3.v, d), dv4 = dot3(v4.v, d);
     float dm = fminf(fminf(dv4 - dv1, dv4 - dv2), dv4 - dv3);
-    bool reached = isz(dm - m->mpr_tol) || dm < m->mpr_tol;
+    bool reached = isz(dm - mpr_tol) || dm < mpr_tol;
     if (!inside) {
       if (!(isz(dv4) || dv4 > 0.f)) return false;     // cannot encapsule origin
       if (reached || it > 100) return false;
-    } else if (reached || it > m->mpr_iter) {
+    } else if (reached || it > mpr_iter) {
       float pd[3], bw[3];
       float d2 = origin_tri_dist2(v1.v, v2.v, v3.v, pd, bw);
       *depth = sqrtf(d2);
@@ -610,9 +660,10 @@ DEV void make_frame(float* fr) {
 }
 
 // ------------------------------------------------------------------ collision driver
-DEV void collision(const DevModel* m, EnvLDS& L) {
+// Broadphase: world boxes of all geoms, then the statically filtered pair list is tested lane-parallel; survivors
+// are appended to L.cand in pair order.
+DEV void broadphase(const DevModel* m, EnvLDS& L) {
   int lane = wave_lane();
-  // world boxes of all geoms (lane-parallel)
   for (int g = lane; g < m->ngeom; g += WAVE) {
     const float* ab = m->geom_aabb + 6 * g;
     const float* gp = m->geom_pos + 3 * g; const float* gm = m->geom_mat + 9 * g;
@@ -642,7 +693,6 @@ DEV void collision(const DevModel* m, EnvLDS& L) {
   }
   if (lane == 0) { L.ncand = 0; L.ncon = 0; L.narmcon = 0; }
   wave_sync();
-  // broadphase: lanes stride the static pair list; survivors appended in pair order
   int base = 0;
   for (int p0 = 0; p0 < m->npair; p0 += WAVE) {
     int p = p0 + lane;
@@ -670,52 +720,65 @@ DEV void collision(const DevModel* m, EnvLDS& L) {
   }
   if (lane == 0) { L.ncand = base < MAXCAND ? base : MAXCAND; if (base > MAXCAND) L.overflow |= 1; }
   wave_sync();
-  // narrowphase: uniform loop over candidates
+}
+
+// Narrowphase of one candidate pair (geom types ordered): penetration distance (<0), normal geom1 -> geom2, position.
+template <class Cache>
+DEV bool narrow_pair(const DevModel* m, const GeomW& G1, const GeomW& G2, float* dist, float* nrm, float* pos) {
+  Cache H1, H2;
+  hull_load(m, G1, H1); hull_load(m, G2, H2);
+  if (G1.type == G_PLANE) {
+    nrm[0] = G1.R[2]; nrm[1] = G1.R[5]; nrm[2] = G1.R[8];
+    float nn[3] = {-nrm[0], -nrm[1], -nrm[2]}, sp[3];
+    support(m, G2, nn, sp, H2);
+    float t[3] = {sp[0] - G1.p[0], sp[1] - G1.p[1], sp[2] - G1.p[2]};
+    *dist = dot3(t, nrm);
+#pragma unroll
+    for (int i = 0; i < 3; i++) pos[i] = sp[i] - 0.5f * *dist * nrm[i];
+    return *dist < 0.f;
+  }
+  float depth;
+  bool ok = mpr_penetration(m, G1, G2, &depth, nrm, pos, H1, H2);
+  *dist = -depth;
+  return ok && depth > 0.f;
+}
+
+// Contact record of an accepted pair (one lane): frame, body indices, mixed friction / solref / solimp
+DEV void contact_init(const DevModel* m, Contact& c, int g1, int g2, float dist, const float* nrm, const float* pos) {
+  c.dist = dist;
+  float fr[9] = {nrm[0], nrm[1], nrm[2], 0, 0, 0, 0, 0, 0};
+  make_frame(fr);
+#pragma unroll
+  for (int i = 0; i < 9; i++) c.frame[i] = fr[i];
+#pragma unroll
+  for (int i = 0; i < 3; i++) c.pos[i] = pos[i];
+  c.d1 = m->geom_dyn[g1]; c.d2 = m->geom_dyn[g2]; c.g1 = g1; c.g2 = g2;
+  int cd1 = m->geom_condim[g1], cd2 = m->geom_condim[g2];
+  c.dim = cd1 > cd2 ? cd1 : cd2;
+#pragma unroll
+  for (int i = 0; i < 3; i++) c.fric[i] = fmaxf(m->geom_friction[3 * g1 + i], m->geom_friction[3 * g2 + i]);
+  // solref / solimp mixed with equal weights (solmix = 1 on every geom of these scenes); stash in aref/f
+  c.aref[0] = 0.5f * (m->geom_solref[2 * g1] + m->geom_solref[2 * g2]);
+  c.aref[1] = 0.5f * (m->geom_solref[2 * g1 + 1] + m->geom_solref[2 * g2 + 1]);
+#pragma unroll
+  for (int i = 0; i < 5; i++) c.f[i] = 0.5f * (m->geom_solimp[5 * g1 + i] + m->geom_solimp[5 * g2 + i]);
+  c.armslot = -1;
+}
+
+// Fused collision stage: the wave walks its own candidate list.  (The pipelined step hands the candidates to
+// k_narrow instead, one wavefront per candidate.)
+DEV void collision(const DevModel* m, EnvLDS& L) {
+  int lane = wave_lane();
+  broadphase(m, L);
   int ncand = L.ncand, ncon = 0;
   for (int k = 0; k < ncand; k++) {
     int g1 = L.cand[k][0], g2 = L.cand[k][1];
     GeomW G1, G2;
     load_geom(m, L, g1, G1); load_geom(m, L, g2, G2);
     float dist, nrm[3], pos[3];
-    bool ok;
-    if (G1.type == G_PLANE) {
-      nrm[0] = G1.R[2]; nrm[1] = G1.R[5]; nrm[2] = G1.R[8];
-      float nn[3] = {-nrm[0], -nrm[1], -nrm[2]}, sp[3];
-      support(m, G2, nn, sp);
-      float t[3] = {sp[0] - G1.p[0], sp[1] - G1.p[1], sp[2] - G1.p[2]};
-      dist = dot3(t, nrm);
-      ok = dist < 0.f;
-#pragma unroll
-      for (int i = 0; i < 3; i++) pos[i] = sp[i] - 0.5f * dist * nrm[i];
-    } else {
-      float depth;
-      ok = mpr_penetration(m, G1, G2, &depth, nrm, pos);
-      ok = ok && depth > 0.f;
-      dist = -depth;
-    }
-    if (!ok) continue;
+    if (!narrow_pair<NoCache>(m, G1, G2, &dist, nrm, pos)) continue;
     if (ncon >= MAXCON) { if (lane == 0) L.overflow |= 2; break; }
-    if (lane == 0) {
-      Contact& c = L.con[ncon];
-      c.dist = dist;
-      float fr[9] = {nrm[0], nrm[1], nrm[2], 0, 0, 0, 0, 0, 0};
-      make_frame(fr);
-#pragma unroll
-      for (int i = 0; i < 9; i++) c.frame[i] = fr[i];
-#pragma unroll
-      for (int i = 0; i < 3; i++) c.pos[i] = pos[i];
-      c.d1 = m->geom_dyn[g1]; c.d2 = m->geom_dyn[g2]; c.g1 = g1; c.g2 = g2;
-      int cd1 = m->geom_condim[g1], cd2 = m->geom_condim[g2];
-      c.dim = cd1 > cd2 ? cd1 : cd2;
-#pragma unroll
-      for (int i = 0; i < 3; i++) c.fric[i] = fmaxf(m->geom_friction[3 * g1 + i], m->geom_friction[3 * g2 + i]);
-      // solref / solimp mixed with equal weights (solmix = 1 on every geom of these scenes); stash in aref/f
-      c.aref[0] = 0.5f * (m->geom_solref[2 * g1] + m->geom_solref[2 * g2]);
-      c.aref[1] = 0.5f * (m->geom_solref[2 * g1 + 1] + m->geom_solref[2 * g2 + 1]);
-#pragma unroll
-      for (int i = 0; i < 5; i++) c.f[i] = 0.5f * (m->geom_solimp[5 * g1 + i] + m->geom_solimp[5 * g2 + i]);
-      c.armslot = -1;
-    }
+    if (lane == 0) contact_init(m, L.con[ncon], g1, g2, dist, nrm, pos);
     ncon++;
   }
   if (lane == 0) L.ncon = ncon;
@@ -969,18 +1032,19 @@ DEV void make_constraints(const DevModel* m, EnvLDS& L, bool pgs_data = true) {
 // ------------------------------------------------------------------ forward + Euler
 // `phases` is a profiling aid (env SO101_DEBUG_PHASES, default all): bit0 collision, bit1 constraint rows + solve,
 // bit2 solve iterations.  Production runs always execute every stage.
-DEV void forward(const DevModel* m, EnvLDS& L, int max_iter, float tolerance, int phases = 7, int solver = 0) {
+DEV void forward_smooth(const DevModel* m, EnvLDS& L) {
   kinematics(m, L);
   crba_arm(m, L);
   smooth_dynamics(m, L);
-  if (phases & 1) collision(m, L);
-  else { if (wave_lane() == 0) { L.ncand = 0; L.ncon = 0; L.narmcon = 0; } wave_sync(); }
+}
+
+// constraint rows + solve for the contacts in L.con, then back to MuJoCo's generalized accelerations
+DEV void forward_constrained(const DevModel* m, EnvLDS& L, int max_iter, float tolerance, int phases, int solver) {
   if (phases & 2) {
     make_constraints(m, L, solver == 0);
     if (solver == 1) solve_newton(m, L, (phases & 4) ? max_iter : 0, tolerance);
     else solve_pgs(m, L, (phases & 4) ? max_iter : 0, tolerance);
   }
-  // back to MuJoCo's generalized accelerations
   int lane = wave_lane();
   if (lane < NARM) L.qacc[lane] = L.qacc_arm[lane];
   if (lane >= 32 && lane < 32 + NFREE) {
@@ -994,6 +1058,17 @@ DEV void forward(const DevModel* m, EnvLDS& L, int max_iter, float tolerance, in
     for (int i = 0; i < 3; i++) { L.qacc[NARM + 6 * f + i] = L.facc[f][i] - t1[i]; L.qacc[NARM + 6 * f + 3 + i] = ab[i]; }
   }
   wave_sync();
+}
+
+DEV void forward(const DevModel* m, EnvLDS& L, int max_iter, float tolerance, int phases = 7, int solver = 0) {
+  forward_smooth(m, L);
+  // stage clocks (100 MHz s_memrealtime ticks) accumulate per env into the diagnostics
+  unsigned long long t0 = wall_clock64();
+  if (phases & 1) collision(m, L);
+  else { if (wave_lane() == 0) { L.ncand = 0; L.ncon = 0; L.narmcon = 0; } wave_sync(); }
+  unsigned long long t1 = wall_clock64();
+  forward_constrained(m, L, max_iter, tolerance, phases, solver);
+  if (wave_lane() == 0) { L.t_collision += (unsigned int)(t1 - t0); L.t_solve += (unsigned int)(wall_clock64() - t1); }
 }
 
 DEV void euler(const DevModel* m, EnvLDS& L) {

@@ -93,6 +93,8 @@ struct so101_sim {
   hipEvent_t prep_done = nullptr, main_ev = nullptr;
   bool prep_pending = false;
   int prep_waves = 0;
+  PipeBuffers pipe{};          // scratch of the pipelined step
+  int narrow_waves = 0;
   std::string err;
 };
 
@@ -289,7 +291,7 @@ int so101_default_config(so101_config* cfg) {
   memset(cfg, 0, sizeof *cfg);
   cfg->last_step = 1 << 30; cfg->n_substeps = 10; cfg->solver_iterations = 0; cfg->solver_tolerance = -1.f;
   cfg->settle_max_substeps = 1000; cfg->terminate_on_success = 1; cfg->env_id_base = 0; cfg->solver = SO101_SOLVER_NEWTON;
-  cfg->prefetch_resets = 1;
+  cfg->prefetch_resets = 1; cfg->pipeline = 1;
   return SO101_OK;
 }
 
@@ -331,6 +333,23 @@ int so101_create(const void* blob, size_t bytes, int n_envs, int device, uint64_
       s->prep = PrepBuffers{(float*)q, (float*)v, (float*)w, (int*)t, (int*)c};
       // one wave per CU at most: the refill runs beside the stepping kernels, it must not crowd them out
       s->prep_waves = n_envs < 256 ? n_envs : 256;
+    } else rc = SO101_ERR_HIP;
+  }
+  if (rc == SO101_OK) {
+    size_t n = (size_t)n_envs;
+    void *po = nullptr, *ca = nullptr, *nc = nullptr, *wk = nullptr, *ct = nullptr, *cr = nullptr, *ac = nullptr, *tk = nullptr;
+    bool ok = hip_ok(s, hipMalloc(&po, sizeof(float) * NDYN * 12 * n), "hipMalloc(pipe)") && hip_ok(s, hipMalloc(&ca, sizeof(int) * MAXCAND * n), "hipMalloc(pipe)") &&
+              hip_ok(s, hipMalloc(&nc, sizeof(int) * n), "hipMalloc(pipe)") && hip_ok(s, hipMalloc(&wk, sizeof(int) * 2 * MAXCAND * n), "hipMalloc(pipe)") &&
+              hip_ok(s, hipMalloc(&ct, sizeof(int) * 2 * MAXSUB), "hipMalloc(pipe)") && hip_ok(s, hipMalloc(&cr, sizeof(float) * 8 * MAXCAND * n), "hipMalloc(pipe)") &&
+              hip_ok(s, hipMalloc(&ac, n), "hipMalloc(pipe)") && hip_ok(s, hipMalloc(&tk, sizeof(int) * MAXCAND * n), "hipMalloc(pipe)");
+    for (void* p : {po, ca, nc, wk, ct, cr, ac, tk}) if (p) s->owned.push_back(p);
+    ok = ok && hip_ok(s, hipMemset(nc, 0, sizeof(int) * n), "hipMemset(pipe)") && hip_ok(s, hipMemset(ac, 0, n), "hipMemset(pipe)");
+    if (ok) {
+      s->pipe = PipeBuffers{(float*)po, (unsigned int*)ca, (int*)nc, (unsigned int*)wk, (int*)ct, (float*)cr, (unsigned char*)ac, (unsigned int*)tk};
+      // persistent narrowphase waves: about the mean number of candidate pairs per env, capped at what fills
+      // 256 CUs (the waves pull work items until the list is empty, so the count only has to cover the machine)
+      size_t want = n * 16;
+      s->narrow_waves = (int)(want < 4096 ? want : 4096);
     } else rc = SO101_ERR_HIP;
   }
   if (rc != SO101_OK) { g_create_error = s->err; so101_destroy(s); return rc; }
@@ -390,6 +409,22 @@ int so101_begin_episode(so101_sim* s, void* stream) {
 int so101_step(so101_sim* s, const float* action, float* obs, float* reward, float* discount, uint8_t* step_type, void* stream) {
   REQUIRE_BOUND(s);
   if (!action || !obs || !reward || !discount || !step_type) { s->err = "so101_step: NULL argument"; return SO101_ERR_ARG; }
+  if (s->cfg.pipeline && s->cfg.n_substeps <= MAXSUB) {
+    hipStream_t st = (hipStream_t)stream;
+    StepParams P = make_params(s);
+    if (!hip_ok(s, hipMemsetAsync(s->pipe.counters, 0, sizeof(int) * 2 * MAXSUB, st), "hipMemsetAsync(pipe)")) return SO101_ERR_HIP;
+    hipLaunchKernelGGL(k_pipe_begin, dim3(s->n_envs), dim3(64), 0, st, s->dm, P, s->buf, s->prep, s->pipe, action, obs, reward, discount,
+                       step_type, s->need_reset, s->diag);
+    LAUNCH_CHECK(s, "k_pipe_begin");
+    for (int k = 0; k < P.n_substeps; k++) {
+      hipLaunchKernelGGL(k_narrow, dim3(s->narrow_waves), dim3(64), 0, st, s->dm, s->n_envs, s->pipe, k);
+      hipLaunchKernelGGL(k_pipe_solve, dim3(s->n_envs), dim3(64), 0, st, s->dm, P, s->buf, s->pipe, k, (int)(k == P.n_substeps - 1), obs, reward,
+                         discount, step_type, s->need_reset, s->diag);
+    }
+    LAUNCH_CHECK(s, "k_pipe_solve");
+    launch_prepare(s, st);
+    return SO101_OK;
+  }
   hipLaunchKernelGGL(k_step, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, make_params(s), s->buf, s->prep, action, obs, reward,
                      discount, step_type, s->need_reset, s->diag);
   LAUNCH_CHECK(s, "k_step");
@@ -434,6 +469,18 @@ int so101_debug_forward(so101_sim* s, float* out, void* stream) {
   hipLaunchKernelGGL(k_debug_forward, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, make_params(s), s->buf, out);
   LAUNCH_CHECK(s, "k_debug_forward");
   return SO101_OK;
+}
+
+int so101_debug_candidates(so101_sim* s, int32_t* ncand, uint32_t* cand, uint32_t* ticks, float* conres, void* stream) {
+  if (!s) return SO101_ERR_ARG;
+  size_t n = (size_t)s->n_envs;
+  hipStream_t st = (hipStream_t)stream;
+  bool ok = true;
+  if (ncand) ok = ok && hip_ok(s, hipMemcpyAsync(ncand, s->pipe.ncand, sizeof(int) * n, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync(debug)");
+  if (cand) ok = ok && hip_ok(s, hipMemcpyAsync(cand, s->pipe.cand, sizeof(int) * MAXCAND * n, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync(debug)");
+  if (ticks) ok = ok && hip_ok(s, hipMemcpyAsync(ticks, s->pipe.ticks, sizeof(int) * MAXCAND * n, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync(debug)");
+  if (conres) ok = ok && hip_ok(s, hipMemcpyAsync(conres, s->pipe.conres, sizeof(float) * 8 * MAXCAND * n, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync(debug)");
+  return ok ? SO101_OK : SO101_ERR_HIP;
 }
 
 const char* so101_last_error(const so101_sim* s) { return s ? s->err.c_str() : g_create_error.c_str(); }

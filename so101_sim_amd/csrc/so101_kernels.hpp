@@ -36,7 +36,7 @@ DEV void load_state(EnvLDS& L, const DevBuffers& B, int e, int N) {
   if (lane < NQ) L.qpos[lane] = B.qpos[(size_t)lane * N + e];
   if (lane < NV) { L.qvel[lane] = B.qvel[(size_t)lane * N + e]; L.warm[lane] = B.warm[(size_t)lane * N + e]; }
   if (lane < NU) L.ctrl[lane] = B.ctrl[(size_t)lane * N + e];
-  if (lane == 0) L.overflow = 0;
+  if (lane == 0) { L.overflow = 0; L.t_collision = 0; L.t_solve = 0; L.t_begin = (unsigned int)wall_clock64(); }
   wave_sync();
 }
 
@@ -53,6 +53,8 @@ DEV void store_diag(const EnvLDS& L, int* diag, int e) {
     for (int k = 0; k < L.ncon; k++) nefc += L.con[k].dim;
     diag[8 * e + 0] = L.ncon; diag[8 * e + 1] = nefc; diag[8 * e + 2] = L.iters; diag[8 * e + 3] = L.ncand;
     diag[8 * e + 4] = L.overflow;
+    diag[8 * e + 5] = (int)L.t_collision; diag[8 * e + 6] = (int)L.t_solve;
+    diag[8 * e + 7] = (int)((unsigned int)wall_clock64() - L.t_begin);
   }
 }
 
@@ -143,11 +145,11 @@ __global__ void __launch_bounds__(64, 2) k_prepare(const DevModel* m, StepParams
   for (;;) {
     int e = 0;
     if (lane == 0) e = atomicAdd(C.cursor, 1);
-    e = wave_bcast_i(e, 0);
+    e = wave_uniform_i(e);
     if (e >= N) break;
     int target = __atomic_load_n(&B.episode[e], __ATOMIC_ACQUIRE);
     if (__atomic_load_n(&C.tag[e], __ATOMIC_ACQUIRE) == target) continue;
-    if (lane == 0) L.overflow = 0;
+    if (lane == 0) { L.overflow = 0; L.t_collision = 0; L.t_solve = 0; }
     env_settle(m, L, P, e, (unsigned int)target);
     wave_sync();
     if (lane < NQ) C.qpos[(size_t)lane * N + e] = L.qpos[lane];
@@ -166,7 +168,7 @@ __global__ void __launch_bounds__(64, 2) k_reset(const DevModel* m, StepParams P
   __shared__ EnvLDS L;
   int e = blockIdx.x;
   if (mask && !mask[e]) return;
-  if (wave_lane() == 0) L.overflow = 0;
+  if (wave_lane() == 0) { L.overflow = 0; L.t_collision = 0; L.t_solve = 0; L.t_begin = (unsigned int)wall_clock64(); }
   env_reset(m, L, P, B, C, e);
   store_state(L, B, e, P.n_envs);
   store_diag(L, diag, e);
@@ -190,7 +192,7 @@ __global__ void __launch_bounds__(64, 2) k_step(const DevModel* m, StepParams P,
   int e = blockIdx.x, lane = wave_lane(), N = P.n_envs;
   if (need_reset[e]) {
     // dm_control auto-reset: the call after LAST resets and reports FIRST; the action is ignored
-    if (lane == 0) L.overflow = 0;
+    if (lane == 0) { L.overflow = 0; L.t_collision = 0; L.t_solve = 0; L.t_begin = (unsigned int)wall_clock64(); }
     env_reset(m, L, P, B, C, e);
     store_state(L, B, e, N);
     store_diag(L, diag, e);
@@ -232,6 +234,8 @@ __global__ void __launch_bounds__(64, 2) k_step(const DevModel* m, StepParams P,
     B.step_count[e] = sc; B.ep_return[e] += r;
   }
 }
+
+#include "so101_pipeline.hpp"
 
 __global__ void __launch_bounds__(64, 2) k_physics(const DevModel* m, StepParams P, DevBuffers B, int nsub, int freeze, int* diag) {
   __shared__ EnvLDS L;

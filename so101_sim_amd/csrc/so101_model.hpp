@@ -116,5 +116,6 @@ struct EnvLDS {
   Row1 row[MAXROW1];
   NewtonScratch nw;
   int ncand, ncon, nrow, narmcon, iters, overflow;
+  unsigned int t_collision, t_solve, t_begin;   // stage clocks, 10 ns ticks
   float scratch[64];
 };

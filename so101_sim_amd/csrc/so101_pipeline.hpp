@@ -1,0 +1,187 @@
+// Pipelined control step: the narrowphase leaves the env's wavefront.
+//
+// In the fused k_step one wavefront walks its env's candidate pairs one after the other, so a launch lasts as long
+// as its most crowded env (props inside each other: 100+ candidate pairs against a mean of 16).  Here every substep
+// is two launches:
+//   k_narrow      one wavefront per CANDIDATE PAIR of the whole batch (persistent waves pulling from a work list),
+//                 needs no LDS and half the registers of the fused kernel -> the machine stays full and balanced;
+//   k_pipe_solve  one wavefront per env: smooth dynamics, gathers its contacts in candidate order, constraint rows,
+//                 solver, Euler step, and the broadphase of the NEXT substep (which refills the work list).
+// k_pipe_begin does the per-call prologue (auto-reset, before_step, first broadphase).  State makes a round trip
+// through HBM per substep (~300 B/env) plus body poses, candidates and contact records (~1 KB/env).
+// All stages call the same device functions as the fused path; contact order (= candidate order) is preserved.
+#pragma once
+
+#define MAXSUB 32
+
+struct PipeBuffers {
+  float* pose;            // [N][NDYN][12] xpos, xmat of the dynamic bodies
+  unsigned int* cand;     // [N][MAXCAND]  geom1 | geom2 << 16, in pair-list order
+  int* ncand;             // [N]           count | broadphase overflow flag << 16
+  unsigned int* work;     // [2][N*MAXCAND] env * MAXCAND + k, double buffered over substeps
+  int* counters;          // [MAXSUB][2]   work items, cursor
+  float* conres;          // [N][MAXCAND][8] dist, normal, position, valid
+  unsigned char* active;  // [N] 0 not stepping in this call (auto-reset), 1 stepping, 2 diverged
+  unsigned int* ticks;    // [N][MAXCAND] narrowphase time of each candidate of the last substep (10 ns ticks), diagnostics
+};
+
+// hands the candidates in L.cand (and the poses the narrowphase needs) to substep s
+DEV void publish_candidates(const EnvLDS& L, const PipeBuffers& W, int e, int N, int s) {
+  int lane = wave_lane(), ncand = L.ncand;
+  for (int i = lane; i < NDYN * 12; i += WAVE) {
+    int b = i / 12, j = i % 12;
+    W.pose[(size_t)e * (NDYN * 12) + i] = j < 3 ? L.xpos[b][j] : L.xmat[b][j - 3];
+  }
+  int base = 0;
+  if (lane == 0) {
+    base = ncand ? atomicAdd(&W.counters[2 * s], ncand) : 0;
+    W.ncand[e] = ncand | ((L.overflow & 1) << 16);
+  }
+  base = wave_bcast_i(base, 0);
+  unsigned int* list = W.work + (size_t)(s & 1) * N * MAXCAND;
+  for (int k = lane; k < ncand; k += WAVE) {
+    unsigned int w = (unsigned int)e * MAXCAND + k;
+    W.cand[w] = (unsigned int)L.cand[k][0] | ((unsigned int)L.cand[k][1] << 16);
+    list[base + k] = w;
+  }
+}
+
+// contacts of this env for the current substep, in candidate order, truncated at MAXCON like the fused loop
+DEV void gather_contacts(const DevModel* m, EnvLDS& L, const PipeBuffers& W, int e) {
+  int lane = wave_lane();
+  int info = W.ncand[e], ncand = info & 0xffff, ncon = 0;
+  for (int k0 = 0; k0 < ncand; k0 += WAVE) {
+    int k = k0 + lane;
+    size_t w = (size_t)e * MAXCAND + k;
+    bool valid = k < ncand && W.conres[w * 8 + 7] != 0.f;
+    unsigned long long mask = wave_ballot(valid);
+    int idx = ncon + wave_prefix(mask);
+    if (valid && idx < MAXCON) {
+      const float* r = W.conres + w * 8;
+      unsigned int c = W.cand[w];
+      float nrm[3] = {r[1], r[2], r[3]}, pos[3] = {r[4], r[5], r[6]};
+      contact_init(m, L.con[idx], (int)(c & 0xffffu), (int)(c >> 16), r[0], nrm, pos);
+    }
+    ncon += __popcll(mask);
+  }
+  if (lane == 0) {
+    L.ncand = ncand; L.narmcon = 0;
+    L.overflow |= info >> 16;
+    if (ncon > MAXCON) L.overflow |= 2;
+    L.ncon = ncon > MAXCON ? MAXCON : ncon;
+  }
+  wave_sync();
+}
+
+__global__ void __launch_bounds__(64, 2) k_pipe_begin(const DevModel* m, StepParams P, DevBuffers B, PrepBuffers C, PipeBuffers W,
+                                                   const float* action, float* obs, float* reward, float* discount,
+                                                   unsigned char* step_type, unsigned char* need_reset, int* diag) {
+  __shared__ EnvLDS L;
+  int e = blockIdx.x, lane = wave_lane(), N = P.n_envs;
+  if (need_reset[e]) {
+    // dm_control auto-reset: the call after LAST resets and reports FIRST; the action is ignored
+    if (lane == 0) { L.overflow = 0; L.t_collision = 0; L.t_solve = 0; L.t_begin = (unsigned int)wall_clock64(); }
+    env_reset(m, L, P, B, C, e);
+    store_state(L, B, e, N);
+    store_diag(L, diag, e);
+    if (lane < NARM) {
+      obs[(size_t)e * 18 + lane] = L.qpos[lane];
+      obs[(size_t)e * 18 + 6 + lane] = L.qpos[lane];
+      obs[(size_t)e * 18 + 12 + lane] = L.ctrl[lane];
+    }
+    if (lane == 0) { reward[e] = 0.f; discount[e] = 1.f; step_type[e] = 0; need_reset[e] = 0; W.active[e] = 0; W.ncand[e] = 0; }
+    return;
+  }
+  load_state(L, B, e, N);
+  // before_step: ctrl = action + homing offsets, unclamped (so100_task.py:266-287)
+  if (lane < NU) { float c = action[(size_t)e * NU + lane] + P.action_offset[lane]; L.ctrl[lane] = c; B.ctrl[(size_t)lane * N + e] = c; }
+  wave_sync();
+  kinematics(m, L);
+  broadphase(m, L);
+  publish_candidates(L, W, e, N, 0);
+  if (lane == 0) W.active[e] = 1;
+}
+
+// One wavefront per candidate pair.  No LDS; the two geoms live in registers.
+__global__ void __launch_bounds__(64, 2) k_narrow(const DevModel* m, int N, PipeBuffers W, int s) {
+  int lane = wave_lane();
+  int nwork = W.counters[2 * s];
+  const unsigned int* list = W.work + (size_t)(s & 1) * N * MAXCAND;
+  for (;;) {
+    int i = 0;
+    if (lane == 0) i = atomicAdd(&W.counters[2 * s + 1], 1);
+    i = wave_uniform_i(i);
+    if (i >= nwork) break;
+    unsigned long long t0 = wall_clock64();
+    unsigned int w = (unsigned int)wave_uniform_i((int)list[i]), c = (unsigned int)wave_uniform_i((int)W.cand[w]);
+    int e = (int)(w / MAXCAND), g1 = (int)(c & 0xffffu), g2 = (int)(c >> 16);
+    const float* pose = W.pose + (size_t)e * (NDYN * 12);
+    int d1 = ldc(ldc(&m->geom_dyn) + g1), d2 = ldc(ldc(&m->geom_dyn) + g2);
+    const float* p1 = pose + 12 * (d1 < 0 ? 0 : d1); const float* p2 = pose + 12 * (d2 < 0 ? 0 : d2);
+    GeomW G1, G2;
+    load_geom_at(m, g1, p1, p1 + 3, G1); load_geom_at(m, g2, p2, p2 + 3, G2);
+    float dist, nrm[3], pos[3];
+    bool ok = narrow_pair<HullCache>(m, G1, G2, &dist, nrm, pos);
+    if (lane == 0) {
+      float* r = W.conres + (size_t)w * 8;
+      r[0] = dist; r[1] = nrm[0]; r[2] = nrm[1]; r[3] = nrm[2]; r[4] = pos[0]; r[5] = pos[1]; r[6] = pos[2]; r[7] = ok ? 1.f : 0.f;
+      W.ticks[w] = (unsigned int)(wall_clock64() - t0);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(64, 2) k_pipe_solve(const DevModel* m, StepParams P, DevBuffers B, PipeBuffers W, int s, int last,
+                                                   float* obs, float* reward, float* discount, unsigned char* step_type,
+                                                   unsigned char* need_reset, int* diag) {
+  __shared__ EnvLDS L;
+  int e = blockIdx.x, lane = wave_lane(), N = P.n_envs;
+  int act = W.active[e];
+  if (act == 0) return;
+  int sc = B.step_count[e] + 1;
+  load_state(L, B, e, N);
+  bool diverged = act == 2;
+  if (!diverged) {
+    forward_smooth(m, L);
+    gather_contacts(m, L, W, e);
+    unsigned long long t1 = wall_clock64();
+    forward_constrained(m, L, P.iterations, P.tolerance, 7, P.solver);
+    if (lane == 0) L.t_solve += (unsigned int)(wall_clock64() - t1);
+    euler(m, L);
+    diverged = check_divergence(L);
+    if (diverged && lane == 0) W.active[e] = 2;
+  } else {
+    if (lane == 0) { L.ncon = 0; L.nrow = 0; L.iters = 0; L.ncand = 0; L.overflow = 8; }
+    wave_sync();
+  }
+  if (!last) {
+    store_state(L, B, e, N);
+    if (!diverged) {
+      kinematics(m, L);
+      broadphase(m, L);
+      publish_candidates(L, W, e, N, s + 1);
+    } else if (lane == 0) W.ncand[e] = 0;
+    return;
+  }
+  kinematics(m, L);     // position-dependent quantities of the post-step state (legacy step2/step1 order)
+  // joints_pos delay line: read the value of control step k-5, then store step k
+  int slot = (sc - 1) % 5;
+  if (lane < NARM) {
+    size_t ri = ((size_t)slot * NARM + lane) * N + e;
+    float delayed = B.ring[ri];
+    B.ring[ri] = L.qpos[lane];
+    obs[(size_t)e * 18 + lane] = delayed;
+    obs[(size_t)e * 18 + 6 + lane] = L.qpos[lane];
+    obs[(size_t)e * 18 + 12 + lane] = L.ctrl[lane];
+  }
+  float r = diverged ? 0.f : task_reward(m, L);
+  // physics error (dm_control): reward 0, discount 0, episode terminates
+  bool success = (P.terminate_on_success && r >= 1.f) || diverged, timeout = sc >= P.last_step;
+  store_state(L, B, e, N);
+  store_diag(L, diag, e);
+  if (lane == 0) {
+    reward[e] = r; discount[e] = success ? 0.f : 1.f;
+    unsigned char st = (success || timeout) ? 2 : 1;
+    step_type[e] = st; need_reset[e] = st == 2;
+    B.step_count[e] = sc; B.ep_return[e] += r;
+  }
+}

@@ -69,6 +69,15 @@ __device__ __forceinline__ int wave_prefix(unsigned long long mask) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
 }
 
+// Load from memory that no kernel ever writes (the model tables): the constant address space lets the compiler use
+// scalar loads (s_load, SGPR result, scalar branches on it) whenever the address is wave-uniform, even in kernels
+// that also store to global memory.
+template <class T>
+__device__ __forceinline__ T ldc(const T* p) { return *(const __attribute__((address_space(4))) T*)(unsigned long long)p; }
+
+// tells the compiler that v is the same in every lane (keeps it in an SGPR: scalar loads, scalar branches)
+__device__ __forceinline__ int wave_uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 __device__ __forceinline__ float wave_bcast_f(float v, int src) { return __shfl(v, src); }
 __device__ __forceinline__ int wave_bcast_i(int v, int src) { return __shfl(v, src); }
 

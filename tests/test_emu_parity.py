@@ -43,4 +43,8 @@ def test_contact_rich_states(make_sim, blobs, golden):
 
 
 def test_reset_prefetch_is_bit_identical(make_sim):
-    pc.check_prefetch_identical(make_sim, n=2, settle=8, steps=7, last_step=2)
+    pc.check_prefetch_identical(make_sim, n=1, settle=4, steps=4, last_step=1)
+
+
+def test_pipelined_step_matches_fused(make_sim, golden):
+    pc.check_pipeline_identical(make_sim, golden, n=1, steps=1, settle=3)

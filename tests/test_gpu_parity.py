@@ -20,7 +20,7 @@ def test_native_library_is_the_hip_build():
     import os
     from so101_sim_amd import native
     assert os.path.exists(native.LIB_PATH)
-    assert native.load_library().so101_version() == 1
+    assert native.load_library().so101_version() == 2
 
 
 def test_forward_stages(make_sim, blobs):
@@ -45,6 +45,10 @@ def test_env_semantics(make_sim, blobs):
 
 def test_reset_prefetch_is_bit_identical(make_sim):
     pc.check_prefetch_identical(make_sim, n=64, settle=300, steps=14, last_step=3)
+
+
+def test_pipelined_step_matches_fused(make_sim, golden):
+    pc.check_pipeline_identical(make_sim, golden, n=8, steps=6)
 
 
 def test_full_settle_matches_oracle(make_sim, blobs):
