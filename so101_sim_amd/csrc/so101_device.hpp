@@ -694,13 +694,16 @@ DEV void broadphase(const DevModel* m, EnvLDS& L) {
   if (lane == 0) { L.ncand = 0; L.ncon = 0; L.narmcon = 0; }
   wave_sync();
   int base = 0;
-  for (int p0 = 0; p0 < m->npair; p0 += WAVE) {
+  const unsigned int* pairs = ldc(&m->pair_packed);
+  const int npair = ldc(&m->npair);
+#pragma unroll 4
+  for (int p0 = 0; p0 < npair; p0 += WAVE) {
     int p = p0 + lane;
     bool hit = false; int g1 = 0, g2 = 0;
-    if (p < m->npair) {
-      g1 = m->pair[2 * p]; g2 = m->pair[2 * p + 1];
-      if (m->geom_type[g1] > m->geom_type[g2]) { int t = g1; g1 = g2; g2 = t; }
-      if (m->geom_type[g1] == G_PLANE) {
+    if (p < npair) {
+      unsigned int w = pairs[p];
+      g1 = (int)(w & 0xffu); g2 = (int)((w >> 8) & 0xffu);
+      if (w >> 16) {
         // plane: test the lowest corner of the other box against the plane
         const float* gm = m->geom_mat + 9 * g1; const float* gp = m->geom_pos + 3 * g1;
         float n[3] = {gm[2], gm[5], gm[8]}, low = 0.f;

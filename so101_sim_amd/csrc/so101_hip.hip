@@ -243,12 +243,19 @@ int build_model(so101_sim* s, const BlobView& b) {
   std::vector<float> vx(nvert), vy(nvert), vz(nvert);
   for (int i = 0; i < nvert; i++) { vx[i] = mv[3 * i]; vy[i] = mv[3 * i + 1]; vz[i] = mv[3 * i + 2]; }
   auto pairs = b.I("pair_geom");
+  // broadphase pair list, one word per pair: geom1 | geom2 << 8 | (geom1 is a plane) << 16, geom types ordered
+  std::vector<unsigned int> packed(M.npair);
+  for (int k = 0; k < M.npair; k++) {
+    int g1 = pairs[2 * k], g2 = pairs[2 * k + 1];
+    if (gtype[g1] > gtype[g2]) std::swap(g1, g2);
+    packed[k] = (unsigned int)g1 | ((unsigned int)g2 << 8) | ((gtype[g1] == G_PLANE ? 1u : 0u) << 16);
+  }
   bool ok = upload(s, gtype, &M.geom_type) && upload(s, gdyn, &M.geom_dyn) && upload(s, gcondim, &M.geom_condim) &&
             upload(s, gva, &M.geom_vertadr) && upload(s, gvn, &M.geom_vertnum) && upload(s, gp, &M.geom_pos) &&
             upload(s, gm, &M.geom_mat) && upload(s, gsize, &M.geom_size) && upload(s, gfr, &M.geom_friction) &&
             upload(s, gsr, &M.geom_solref) && upload(s, gsi, &M.geom_solimp) && upload(s, gctr, &M.geom_center) &&
             upload(s, gaabb, &M.geom_aabb) && upload(s, vx, &M.vx) && upload(s, vy, &M.vy) && upload(s, vz, &M.vz) &&
-            upload(s, pairs, &M.pair);
+            upload(s, pairs, &M.pair) && upload(s, packed, &M.pair_packed);
   if (!ok) return SO101_ERR_HIP;
   void* dm = nullptr;
   if (!hip_ok(s, hipMalloc(&dm, sizeof(DevModel)), "hipMalloc(DevModel)")) return SO101_ERR_HIP;

@@ -60,6 +60,7 @@ struct DevModel {
   const float* vy;
   const float* vz;
   const int* pair;            // [npair][2] statically filtered candidate geom pairs, sorted
+  const unsigned int* pair_packed;   // [npair] geom1 | geom2 << 8 | plane flag << 16 (types ordered), same order
 };
 
 // Per-env launch parameters that are not part of the model.
