@@ -39,12 +39,13 @@ def cpu_baseline(seconds_budget: float = 20.0):
     t0 = time.perf_counter()
     o.env_reset()
     steps = 0
-    while time.perf_counter() - t0 < seconds_budget and steps < 500:
+    while time.perf_counter() - t0 < seconds_budget:          # episodes follow each other through the auto-reset
         o.env_step(rng.uniform(lo, hi))
         steps += 1
     dt = time.perf_counter() - t0
     return {"value": steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"1 env: reset (settle) + {steps} random-action control steps, fp64 oracle, Newton solver, {dt:.1f} s"}
+            "sample": f"1 env, {steps} env.step calls with uniform random actions in {dt:.1f} s (500-step episodes, auto-reset + settle "
+                      "included), fp64 oracle, Newton solver"}
 
 
 def main():
@@ -56,6 +57,7 @@ def main():
     ap.add_argument("--solver", choices=("newton", "pgs"), default="newton",
                     help="newton = MuJoCo's default, which the reference scene uses (it sets no <option solver>)")
     ap.add_argument("--no-prefetch", action="store_true", help="settle auto-resets inside the step call")
+    ap.add_argument("--fused", action="store_true", help="one fused k_step launch per control step instead of the pipeline")
     ap.add_argument("--solver-iterations", type=int, default=0, help="iteration cap; 0 = model default (100)")
     ap.add_argument("--solver-tolerance", type=float, default=-1.0, help="<0 = model default (1e-8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -84,6 +86,8 @@ def main():
                                      solver_tolerance=args.solver_tolerance, solver=args.solver,
                                      prefetch_resets=not args.no_prefetch)
     os.chdir(cwd)
+    if args.fused:
+        env.sim.configure(pipeline=0)
     spec = env.action_spec()
     lo = torch.tensor(spec.minimum, device=dev)
     hi = torch.tensor(spec.maximum, device=dev)
@@ -108,7 +112,9 @@ def main():
     if distributed:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ev[0].elapsed_time(ev[1]) / args.steps     # k_step average launch duration on its stream
+    # device time of one control step on the stream the kernels are launched on (torch's current stream, which
+    # so101_step receives): 1 + 2*substeps launches with the pipelined step, one k_step launch with --fused
+    kernel_ms = ev[0].elapsed_time(ev[1]) / args.steps
 
     # logging-only exchange: episode returns all-gathered over RCCL/xGMI (not in the timed region)
     returns = env.episode_returns()
@@ -127,10 +133,12 @@ def main():
         value = world * N * args.steps / elapsed
         achieved = ALGO_BYTES_PER_ENV_STEP * N / (kernel_ms * 1e-3) / 1e9
         traffic = None
+        # HBM bytes per control step from the committed PMC passes (FETCH_SIZE x2 per the gfx950 note in
+        # MI355X_MICROARCH.md + WRITE_SIZE, summed over the launches of one step); not measured live
         prof = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(prof):
+        if os.path.exists(prof) and not args.fused:
             try:
-                traffic = json.load(open(prof)).get("hbm_bytes_per_launch")
+                traffic = json.load(open(prof)).get("hbm_bytes_per_step")
             except Exception:
                 traffic = None
         out = {
@@ -139,13 +147,15 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "SO100HandOverBanana, 4096 lock-step envs per GPU, proprioceptive obs, uniform random actions, 500-step episodes with auto-reset+settle (BASELINE.json configs[1])",
                        "envs_per_gpu": N, "global_envs": world * N, "substeps_per_step": 10,
-                       "solver": args.solver, "reset_prefetch": not args.no_prefetch, "solver_iterations": args.solver_iterations or 100,
+                       "solver": args.solver, "reset_prefetch": not args.no_prefetch, "pipeline": not args.fused, "solver_iterations": args.solver_iterations or 100,
                        "solver_tolerance": args.solver_tolerance if args.solver_tolerance >= 0 else 1e-8,
                        "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_step", "kernel_ms": kernel_ms,
-                         "note": "algorithmic bytes = 620 B/env-step x envs per launch; the path is VALU/LDS-bound, not HBM-bound (DESIGN.md)"},
+                         "kernel": "k_step" if args.fused else "k_pipe_begin + substeps x (k_narrow + k_pipe_solve)",
+                         "kernel_ms": kernel_ms, "launches_per_step": 1 if args.fused else 21,
+                         "note": "per control step: algorithmic bytes = 620 B/env-step x envs, time = device time of the step's "
+                                 "launch chain; the path is latency/VALU-bound, not HBM-bound (DESIGN.md section 6)"},
             "diag_mean": {"ncon": diag[0], "nefc": diag[1], "solver_iter": diag[2], "broadphase_candidates": diag[3]},
             "mean_episode_return": mean_return,
         }

@@ -78,7 +78,9 @@ typedef struct {
                               0: always settle inside the call.  Results are identical either way. */
   int32_t pipeline;        /* 1 (default): so101_step runs every substep as narrowphase (one wavefront per candidate pair)
                               + solve (one wavefront per env) launches; 0: one fused launch, one wavefront per env. */
-  int32_t reserved;
+  int32_t groups;          /* pipelined step: number of env groups whose launch chains run on separate internal streams
+                              (default 1, max 8; measured slower than 1 on MI355X at 4096 envs: 17.6 vs 13.3 ms per step with 4);
+                              results do not depend on it */
 } so101_config;
 
 int so101_version(void);
@@ -144,6 +146,10 @@ int so101_debug_forward(so101_sim* sim, float* out, void* hip_stream);
 /* Diagnostics of the pipelined step's last narrowphase launch (device buffers, any may be NULL):
  * ncand[N] (count | overflow << 16), cand[N][256] (geom1 | geom2 << 16), ticks[N][256] (10 ns per candidate),
  * conres[N][256][8] (dist, normal, position, valid). */
+/* Stage clocks of k_pipe_solve's second-to-last substep: stage[N][8] = smooth dynamics, contact gather, constraint
+ * rows, solver, integrate, next broadphase (10 ns ticks), ncon, solver iterations. */
+int so101_debug_stages(so101_sim* sim, uint32_t* stage, void* hip_stream);
+
 int so101_debug_candidates(so101_sim* sim, int32_t* ncand, uint32_t* cand, uint32_t* ticks, float* conres, void* hip_stream);
 
 const char* so101_last_error(const so101_sim* sim);

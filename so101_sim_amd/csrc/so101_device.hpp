@@ -1041,13 +1041,8 @@ DEV void forward_smooth(const DevModel* m, EnvLDS& L) {
   smooth_dynamics(m, L);
 }
 
-// constraint rows + solve for the contacts in L.con, then back to MuJoCo's generalized accelerations
-DEV void forward_constrained(const DevModel* m, EnvLDS& L, int max_iter, float tolerance, int phases, int solver) {
-  if (phases & 2) {
-    make_constraints(m, L, solver == 0);
-    if (solver == 1) solve_newton(m, L, (phases & 4) ? max_iter : 0, tolerance);
-    else solve_pgs(m, L, (phases & 4) ? max_iter : 0, tolerance);
-  }
+// solver coordinates -> MuJoCo's generalized accelerations
+DEV void forward_accelerations(EnvLDS& L) {
   int lane = wave_lane();
   if (lane < NARM) L.qacc[lane] = L.qacc_arm[lane];
   if (lane >= 32 && lane < 32 + NFREE) {
@@ -1061,6 +1056,17 @@ DEV void forward_constrained(const DevModel* m, EnvLDS& L, int max_iter, float t
     for (int i = 0; i < 3; i++) { L.qacc[NARM + 6 * f + i] = L.facc[f][i] - t1[i]; L.qacc[NARM + 6 * f + 3 + i] = ab[i]; }
   }
   wave_sync();
+}
+
+
+// constraint rows + solve for the contacts in L.con, then back to MuJoCo's generalized accelerations
+DEV void forward_constrained(const DevModel* m, EnvLDS& L, int max_iter, float tolerance, int phases, int solver) {
+  if (phases & 2) {
+    make_constraints(m, L, solver == 0);
+    if (solver == 1) solve_newton(m, L, (phases & 4) ? max_iter : 0, tolerance);
+    else solve_pgs(m, L, (phases & 4) ? max_iter : 0, tolerance);
+  }
+  forward_accelerations(L);
 }
 
 DEV void forward(const DevModel* m, EnvLDS& L, int max_iter, float tolerance, int phases = 7, int solver = 0) {

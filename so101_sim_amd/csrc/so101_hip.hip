@@ -93,8 +93,11 @@ struct so101_sim {
   hipEvent_t prep_done = nullptr, main_ev = nullptr;
   bool prep_pending = false;
   int prep_waves = 0;
-  PipeBuffers pipe{};          // scratch of the pipelined step
-  int narrow_waves = 0;
+  PipeBuffers pipe{};          // scratch of the pipelined step (group 0's view; the groups differ in work/counters)
+  static constexpr int MAXGROUPS = 8;
+  hipStream_t group_stream[MAXGROUPS] = {};
+  hipEvent_t group_done[MAXGROUPS] = {};
+  hipEvent_t step_begin = nullptr;
   std::string err;
 };
 
@@ -298,7 +301,7 @@ int so101_default_config(so101_config* cfg) {
   memset(cfg, 0, sizeof *cfg);
   cfg->last_step = 1 << 30; cfg->n_substeps = 10; cfg->solver_iterations = 0; cfg->solver_tolerance = -1.f;
   cfg->settle_max_substeps = 1000; cfg->terminate_on_success = 1; cfg->env_id_base = 0; cfg->solver = SO101_SOLVER_NEWTON;
-  cfg->prefetch_resets = 1; cfg->pipeline = 1;
+  cfg->prefetch_resets = 1; cfg->pipeline = 1; cfg->groups = 1;
   return SO101_OK;
 }
 
@@ -344,19 +347,21 @@ int so101_create(const void* blob, size_t bytes, int n_envs, int device, uint64_
   }
   if (rc == SO101_OK) {
     size_t n = (size_t)n_envs;
-    void *po = nullptr, *ca = nullptr, *nc = nullptr, *wk = nullptr, *ct = nullptr, *cr = nullptr, *ac = nullptr, *tk = nullptr;
+    void *po = nullptr, *ca = nullptr, *nc = nullptr, *wk = nullptr, *ct = nullptr, *cr = nullptr, *ac = nullptr, *tk = nullptr, *sg = nullptr;
     bool ok = hip_ok(s, hipMalloc(&po, sizeof(float) * NDYN * 12 * n), "hipMalloc(pipe)") && hip_ok(s, hipMalloc(&ca, sizeof(int) * MAXCAND * n), "hipMalloc(pipe)") &&
               hip_ok(s, hipMalloc(&nc, sizeof(int) * n), "hipMalloc(pipe)") && hip_ok(s, hipMalloc(&wk, sizeof(int) * 2 * MAXCAND * n), "hipMalloc(pipe)") &&
-              hip_ok(s, hipMalloc(&ct, sizeof(int) * 2 * MAXSUB), "hipMalloc(pipe)") && hip_ok(s, hipMalloc(&cr, sizeof(float) * 8 * MAXCAND * n), "hipMalloc(pipe)") &&
-              hip_ok(s, hipMalloc(&ac, n), "hipMalloc(pipe)") && hip_ok(s, hipMalloc(&tk, sizeof(int) * MAXCAND * n), "hipMalloc(pipe)");
-    for (void* p : {po, ca, nc, wk, ct, cr, ac, tk}) if (p) s->owned.push_back(p);
+              hip_ok(s, hipMalloc(&ct, sizeof(int) * 2 * MAXSUB * so101_sim::MAXGROUPS), "hipMalloc(pipe)") && hip_ok(s, hipMalloc(&cr, sizeof(float) * 8 * MAXCAND * n), "hipMalloc(pipe)") &&
+              hip_ok(s, hipMalloc(&ac, n), "hipMalloc(pipe)") && hip_ok(s, hipMalloc(&tk, sizeof(int) * MAXCAND * n), "hipMalloc(pipe)") &&
+              hip_ok(s, hipMalloc(&sg, sizeof(int) * 8 * n), "hipMalloc(pipe)");
+    for (void* p : {po, ca, nc, wk, ct, cr, ac, tk, sg}) if (p) s->owned.push_back(p);
     ok = ok && hip_ok(s, hipMemset(nc, 0, sizeof(int) * n), "hipMemset(pipe)") && hip_ok(s, hipMemset(ac, 0, n), "hipMemset(pipe)");
     if (ok) {
-      s->pipe = PipeBuffers{(float*)po, (unsigned int*)ca, (int*)nc, (unsigned int*)wk, (int*)ct, (float*)cr, (unsigned char*)ac, (unsigned int*)tk};
-      // persistent narrowphase waves: about the mean number of candidate pairs per env, capped at what fills
-      // 256 CUs (the waves pull work items until the list is empty, so the count only has to cover the machine)
-      size_t want = n * 16;
-      s->narrow_waves = (int)(want < 4096 ? want : 4096);
+      s->pipe = PipeBuffers{(float*)po, (unsigned int*)ca, (int*)nc, (unsigned int*)wk, (int*)ct, (float*)cr, (unsigned char*)ac, (unsigned int*)sg, 0u, (unsigned int*)tk};
+      for (int g = 0; g < so101_sim::MAXGROUPS && ok; g++)
+        ok = hip_ok(s, hipStreamCreateWithFlags(&s->group_stream[g], hipStreamNonBlocking), "hipStreamCreate") &&
+             hip_ok(s, hipEventCreateWithFlags(&s->group_done[g], hipEventDisableTiming), "hipEventCreate");
+      ok = ok && hip_ok(s, hipEventCreateWithFlags(&s->step_begin, hipEventDisableTiming), "hipEventCreate");
+      if (!ok) rc = SO101_ERR_HIP;
     } else rc = SO101_ERR_HIP;
   }
   if (rc != SO101_OK) { g_create_error = s->err; so101_destroy(s); return rc; }
@@ -367,6 +372,11 @@ int so101_create(const void* blob, size_t bytes, int n_envs, int device, uint64_
 void so101_destroy(so101_sim* s) {
   if (!s) return;
   if (s->prep_stream) { (void)hipStreamSynchronize(s->prep_stream); (void)hipStreamDestroy(s->prep_stream); }
+  for (int g = 0; g < so101_sim::MAXGROUPS; g++) {
+    if (s->group_stream[g]) { (void)hipStreamSynchronize(s->group_stream[g]); (void)hipStreamDestroy(s->group_stream[g]); }
+    if (s->group_done[g]) (void)hipEventDestroy(s->group_done[g]);
+  }
+  if (s->step_begin) (void)hipEventDestroy(s->step_begin);
   if (s->prep_done) (void)hipEventDestroy(s->prep_done);
   if (s->main_ev) (void)hipEventDestroy(s->main_ev);
   for (void* p : s->owned) (void)hipFree(p);
@@ -419,16 +429,34 @@ int so101_step(so101_sim* s, const float* action, float* obs, float* reward, flo
   if (s->cfg.pipeline && s->cfg.n_substeps <= MAXSUB) {
     hipStream_t st = (hipStream_t)stream;
     StepParams P = make_params(s);
-    if (!hip_ok(s, hipMemsetAsync(s->pipe.counters, 0, sizeof(int) * 2 * MAXSUB, st), "hipMemsetAsync(pipe)")) return SO101_ERR_HIP;
-    hipLaunchKernelGGL(k_pipe_begin, dim3(s->n_envs), dim3(64), 0, st, s->dm, P, s->buf, s->prep, s->pipe, action, obs, reward, discount,
-                       step_type, s->need_reset, s->diag);
-    LAUNCH_CHECK(s, "k_pipe_begin");
-    for (int k = 0; k < P.n_substeps; k++) {
-      hipLaunchKernelGGL(k_narrow, dim3(s->narrow_waves), dim3(64), 0, st, s->dm, s->n_envs, s->pipe, k);
-      hipLaunchKernelGGL(k_pipe_solve, dim3(s->n_envs), dim3(64), 0, st, s->dm, P, s->buf, s->pipe, k, (int)(k == P.n_substeps - 1), obs, reward,
-                         discount, step_type, s->need_reset, s->diag);
+    int G = s->cfg.groups < 1 ? 1 : (s->cfg.groups > so101_sim::MAXGROUPS ? so101_sim::MAXGROUPS : s->cfg.groups);
+    if (G > s->n_envs) G = s->n_envs;
+    if (!hip_ok(s, hipEventRecord(s->step_begin, st), "hipEventRecord")) return SO101_ERR_HIP;
+    int per = (s->n_envs + G - 1) / G;
+    for (int g = 0; g < G; g++) {
+      int e0 = g * per, ng = s->n_envs - e0 < per ? s->n_envs - e0 : per;
+      if (ng <= 0) break;
+      hipStream_t gs = G == 1 ? st : s->group_stream[g];
+      PipeBuffers W = s->pipe;
+      W.counters = s->pipe.counters + 2 * MAXSUB * g;
+      W.work = s->pipe.work + (size_t)2 * MAXCAND * e0;
+      W.work_cap = (unsigned int)ng * MAXCAND;
+      // persistent narrowphase waves: about the mean number of candidate pairs per env, capped at what fills
+      // 256 CUs (the waves pull work items until the list is empty, so the count only has to cover the machine)
+      int nw = ng * 16 < 4096 ? ng * 16 : 4096;
+      if (G > 1 && !hip_ok(s, hipStreamWaitEvent(gs, s->step_begin, 0), "hipStreamWaitEvent")) return SO101_ERR_HIP;
+      if (!hip_ok(s, hipMemsetAsync(W.counters, 0, sizeof(int) * 2 * MAXSUB, gs), "hipMemsetAsync(pipe)")) return SO101_ERR_HIP;
+      hipLaunchKernelGGL(k_pipe_begin, dim3(ng), dim3(64), 0, gs, s->dm, P, s->buf, s->prep, W, action, obs, reward, discount,
+                         step_type, s->need_reset, s->diag, e0);
+      for (int k = 0; k < P.n_substeps; k++) {
+        hipLaunchKernelGGL(k_narrow, dim3(nw), dim3(64), 0, gs, s->dm, s->n_envs, W, k);
+        hipLaunchKernelGGL(k_pipe_solve, dim3(ng), dim3(64), 0, gs, s->dm, P, s->buf, W, k, (int)(k == P.n_substeps - 1), obs, reward,
+                           discount, step_type, s->need_reset, s->diag, e0);
+      }
+      LAUNCH_CHECK(s, "k_pipe_solve");
+      if (G > 1 && !(hip_ok(s, hipEventRecord(s->group_done[g], gs), "hipEventRecord") &&
+                     hip_ok(s, hipStreamWaitEvent(st, s->group_done[g], 0), "hipStreamWaitEvent"))) return SO101_ERR_HIP;
     }
-    LAUNCH_CHECK(s, "k_pipe_solve");
     launch_prepare(s, st);
     return SO101_OK;
   }
@@ -476,6 +504,11 @@ int so101_debug_forward(so101_sim* s, float* out, void* stream) {
   hipLaunchKernelGGL(k_debug_forward, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, make_params(s), s->buf, out);
   LAUNCH_CHECK(s, "k_debug_forward");
   return SO101_OK;
+}
+
+int so101_debug_stages(so101_sim* s, uint32_t* stage, void* stream) {
+  if (!s || !stage) return SO101_ERR_ARG;
+  return hip_ok(s, hipMemcpyAsync(stage, s->pipe.stage, sizeof(int) * 8 * (size_t)s->n_envs, hipMemcpyDeviceToDevice, (hipStream_t)stream), "hipMemcpyAsync(debug)") ? SO101_OK : SO101_ERR_HIP;
 }
 
 int so101_debug_candidates(so101_sim* s, int32_t* ncand, uint32_t* cand, uint32_t* ticks, float* conres, void* stream) {

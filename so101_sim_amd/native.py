@@ -24,7 +24,7 @@ DBG = dict(M=0, MINV=36, BIAS=72, SMOOTH=78, QACC=96, COUNTS=114, XPOS=120, CON=
 EXPORTS = (
     "so101_version", "so101_max_contacts", "so101_create", "so101_destroy", "so101_default_config",
     "so101_configure", "so101_bind_state", "so101_reset", "so101_begin_episode", "so101_step", "so101_physics", "so101_reward",
-    "so101_get_returns", "so101_get_diag", "so101_debug_forward", "so101_debug_candidates", "so101_last_error",
+    "so101_get_returns", "so101_get_diag", "so101_debug_forward", "so101_debug_candidates", "so101_debug_stages", "so101_last_error",
 )
 
 
@@ -39,7 +39,7 @@ class Config(C.Structure):
                 ("solver_iterations", C.c_int32), ("solver_tolerance", C.c_float),
                 ("settle_max_substeps", C.c_int32), ("terminate_on_success", C.c_int32),
                 ("env_id_base", C.c_uint64), ("solver", C.c_int32), ("prefetch_resets", C.c_int32), ("pipeline", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("groups", C.c_int32)]
 
 
 _libs: dict[str, C.CDLL] = {}
@@ -78,6 +78,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.so101_get_diag.argtypes = [vp, vp, vp]
     L.so101_debug_forward.argtypes = [vp, vp, vp]
     L.so101_debug_candidates.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.so101_debug_stages.argtypes = [vp, vp, vp]
     L.so101_last_error.restype = C.c_char_p
     L.so101_last_error.argtypes = [vp]
     _libs[path] = L
@@ -153,6 +154,9 @@ class Sim:
 
     def debug_candidates(self, ncand=None, cand=None, ticks=None, conres=None, stream=0):
         self._check(self.L.so101_debug_candidates(self.h, ncand, cand, ticks, conres, stream), "so101_debug_candidates")
+
+    def debug_stages(self, out, stream=0):
+        self._check(self.L.so101_debug_stages(self.h, out, stream), "so101_debug_stages")
 
     def debug_forward(self, out, stream=0):
         self._check(self.L.so101_debug_forward(self.h, out, stream), "so101_debug_forward")
