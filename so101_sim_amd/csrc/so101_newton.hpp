@@ -283,37 +283,44 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
     wave_sync();
     for (int e = lane; e < NVS * NVS; e += WAVE) { int a = e / NVS, b = e % NVS; W.H[a][b] *= W.mxs[a] * W.mxs[b]; }
     wave_sync();
-    // ---- Cholesky H~ = L L' (in place, lower), then the two triangular solves
+    // ---- Cholesky H~ = L L' and the two triangular solves, register resident: lane i < NVS owns row i of H~ (and
+    // of L), the pivot row is broadcast with v_readlane.  No LDS traffic and no barriers inside the factorisation
+    // (the LDS version spent ~130 barrier rounds per Newton iteration here).
+    float h[NVS];
+#pragma unroll
+    for (int b = 0; b < NVS; b++) h[b] = lane < NVS ? W.H[lane][b] : 0.f;
+#pragma unroll
     for (int j = 0; j < NVS; j++) {
-      float d = sqrtf(fmaxf(W.H[j][j], 1e-7f));       // pivot floor: H~ has unit diagonal
-      wave_sync();
-      if (lane >= j && lane < NVS) W.H[lane][j] = (lane == j) ? d : W.H[lane][j] / d;
-      wave_sync();
-      int rem = NVS - j - 1;
-      for (int t = lane; t < rem * rem; t += WAVE) {
-        int i = j + 1 + t / rem, k = j + 1 + t % rem;
-        if (k <= i) W.H[i][k] -= W.H[i][j] * W.H[k][j];
-      }
-      wave_sync();
+      float d = sqrtf(fmaxf(wave_get_f(h[j], j), 1e-7f));       // pivot floor: H~ has unit diagonal
+      float l = (lane == j) ? d : h[j] / d;
+      h[j] = l;
+#pragma unroll
+      for (int k = j + 1; k < NVS; k++) h[k] -= l * wave_get_f(l, k);     // rows i < k hold unused upper entries
     }
-    if (lane < NVS) W.tmp[lane] = -W.grad[lane] * W.mxs[lane];
+    float y = lane < NVS ? -W.grad[lane] * W.mxs[lane] : 0.f;
+#pragma unroll
+    for (int i = 0; i < NVS; i++) {          // forward substitution L y = b
+      float yi = wave_get_f(y, i) / wave_get_f(h[i], i);
+      if (lane == i) y = yi;
+      else if (lane > i) y -= h[i] * yi;
+    }
+    // backward substitution needs column `lane` of L: one transposed round trip through LDS
     wave_sync();
-    for (int i = 0; i < NVS; i++) {          // forward substitution, column oriented
-      float yi = W.tmp[i] / W.H[i][i];
-      wave_sync();
-      if (lane == i) W.tmp[i] = yi;
-      else if (lane > i && lane < NVS) W.tmp[lane] -= W.H[lane][i] * yi;
-      wave_sync();
+    if (lane < NVS) {
+#pragma unroll
+      for (int b = 0; b < NVS; b++) W.H[lane][b] = h[b];
     }
-    for (int i = NVS - 1; i >= 0; i--) {     // backward substitution with L'
-      float xi = W.tmp[i] / W.H[i][i];
-      wave_sync();
-      if (lane == i) W.tmp[i] = xi;
-      else if (lane < i) W.tmp[lane] -= W.H[i][lane] * xi;
-      wave_sync();
+    wave_sync();
+    float t[NVS];
+#pragma unroll
+    for (int i = 0; i < NVS; i++) t[i] = lane < NVS ? W.H[i][lane] : 0.f;
+#pragma unroll
+    for (int i = NVS - 1; i >= 0; i--) {     // L' x = y
+      float xi = wave_get_f(y, i) / wave_get_f(h[i], i);
+      if (lane == i) y = xi;
+      else if (lane < i) y -= t[i] * xi;
     }
-    if (lane < NVS) W.tmp[lane] *= W.mxs[lane];
-    if (lane < NVS) W.search[lane] = W.tmp[lane];
+    if (lane < NVS) { float sv = y * W.mxs[lane]; W.tmp[lane] = sv; W.search[lane] = sv; }
     wave_sync();
     // ---- exact line search: phi'(alpha) = 0 by safeguarded Newton
     float jv[6] = {0, 0, 0, 0, 0, 0}, jar0[6];

@@ -78,6 +78,9 @@ __device__ __forceinline__ T ldc(const T* p) { return *(const __attribute__((add
 // tells the compiler that v is the same in every lane (keeps it in an SGPR: scalar loads, scalar branches)
 __device__ __forceinline__ int wave_uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// value of lane `src` (wave-uniform src): v_readlane, the result lives in an SGPR
+__device__ __forceinline__ float wave_get_f(float v, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); }
+
 __device__ __forceinline__ float wave_bcast_f(float v, int src) { return __shfl(v, src); }
 __device__ __forceinline__ int wave_bcast_i(int v, int src) { return __shfl(v, src); }
 

@@ -27,6 +27,7 @@ inline int wave_prefix(unsigned long long mask) { return __builtin_popcountll(ma
 // readfirstlane: every lane gets lane 0's value
 inline int wave_uniform_i(int v) { emu_xchg_i[threadIdx.x] = v; __syncthreads(); int r = emu_xchg_i[0]; __syncthreads(); return r; }
 template <class T> inline T ldc(const T* p) { return *p; }
+inline float wave_get_f(float v, int src) { emu_xchg_f[threadIdx.x] = v; __syncthreads(); float r = emu_xchg_f[src]; __syncthreads(); return r; }
 inline float wave_bcast_f(float v, int src) { emu_xchg_f[threadIdx.x] = v; __syncthreads(); float r = emu_xchg_f[src]; __syncthreads(); return r; }
 inline int wave_bcast_i(int v, int src) { emu_xchg_i[threadIdx.x] = v; __syncthreads(); int r = emu_xchg_i[src]; __syncthreads(); return r; }
 inline void wave_argmax(float& val, int& idx) {
