@@ -21,6 +21,14 @@ def blobs():
 
 
 @pytest.fixture(scope="session")
+def blobs_pen():
+    from so101_sim_amd.model import scenes
+    raw32, meta = scenes.load_blob("pen", "f32")
+    raw64, _ = scenes.load_blob("pen", "f64")
+    return dict(f32=raw32, f64=raw64, meta=meta)
+
+
+@pytest.fixture(scope="session")
 def golden():
     import json
     d = os.path.join(ROOT, "tests", "golden")

@@ -51,6 +51,34 @@ def test_pipelined_step_matches_fused(make_sim, golden):
     pc.check_pipeline_identical(make_sim, golden, n=8, steps=6)
 
 
+# ---- SO100HandOverPen: same kernels, second scene blob (pen + utensil holder, two overlap boxes)
+@pytest.fixture(scope="module")
+def make_pen(blobs_pen):
+    def f(n, seed=0, **cfg):
+        return ArraySim(blobs_pen["f32"], n, backend="gpu", seed=seed, **cfg)
+    return f
+
+
+def test_pen_forward_stages(make_pen, blobs_pen):
+    pc.check_forward_stages(make_pen, blobs_pen, n=8)
+
+
+def test_pen_control_step(make_pen, blobs_pen):
+    pc.check_control_step(make_pen, blobs_pen, n=8, iterations=100)
+
+
+def test_pen_reward_bitexact(make_pen, blobs_pen):
+    pc.check_reward_generic(make_pen, blobs_pen, n=256)
+
+
+def test_pen_env_semantics(make_pen, blobs_pen):
+    from oracle.oracle import Oracle
+    o = Oracle(blobs_pen["f64"])
+    o.env_config(seed=11, env_id=100)
+    o.env_reset()
+    pc.check_env_semantics(make_pen, blobs_pen, n=4, settle=200, steps=9, last_step=7, iterations=50, rest_z=float(o.get_state()[0][8]))
+
+
 def test_full_settle_matches_oracle(make_sim, blobs):
     """reset with the reference's full 1000-substep settle budget: rest pose vs oracle, KAT-2 heights."""
     from oracle.oracle import Oracle

@@ -162,3 +162,19 @@ def test_rng_is_counter_based_and_in_range():
     assert rng_uniform(1, 2, 3, 4) == rng_uniform(1, 2, 3, 4)
     assert rng_uniform(1, 2, 3, 4) != rng_uniform(1, 3, 3, 4)
     assert all(float(np.float32(x)) == x for x in u)      # 24-bit uniforms are exact in f32
+
+
+def test_pen_scene_oracle(blobs_pen):
+    """SO100HandOverPen compiles to the same topology; the oracle resets it (props come to rest on the table, arm at
+    zero) and the two-box reward is 0 for the reset state (so100_hand_over.py:98-118)."""
+    import numpy as np
+    from oracle.oracle import Oracle
+    meta = blobs_pen["meta"]
+    assert meta["nq"] == 20 and meta["nv"] == 18 and meta["nu"] == 6 if "nq" in meta else True
+    o = Oracle(blobs_pen["f64"])
+    o.env_config(seed=3, env_id=0, settle_max_substeps=1000)
+    o.env_reset()
+    q, v, _ = o.get_state()
+    assert np.all(q[:6] == 0) and np.abs(v[12:]).max() < 5e-2      # holder at rest; the pen may still be rolling
+    assert 0.40 < q[8] < 0.47 and 0.40 < q[15] < 0.60            # both props on the table top (z = 0.42)
+    assert o.reward() == 0.0
