@@ -347,16 +347,18 @@ int so101_create(const void* blob, size_t bytes, int n_envs, int device, uint64_
   }
   if (rc == SO101_OK) {
     size_t n = (size_t)n_envs;
-    void *po = nullptr, *ca = nullptr, *nc = nullptr, *wk = nullptr, *ct = nullptr, *cr = nullptr, *ac = nullptr, *tk = nullptr, *sg = nullptr;
+    void *po = nullptr, *ca = nullptr, *nc = nullptr, *wk = nullptr, *ct = nullptr, *cr = nullptr, *ac = nullptr, *tk = nullptr, *sg = nullptr, *co = nullptr, *od = nullptr;
     bool ok = hip_ok(s, hipMalloc(&po, sizeof(float) * NDYN * 12 * n), "hipMalloc(pipe)") && hip_ok(s, hipMalloc(&ca, sizeof(int) * MAXCAND * n), "hipMalloc(pipe)") &&
               hip_ok(s, hipMalloc(&nc, sizeof(int) * n), "hipMalloc(pipe)") && hip_ok(s, hipMalloc(&wk, sizeof(int) * 2 * MAXCAND * n), "hipMalloc(pipe)") &&
               hip_ok(s, hipMalloc(&ct, sizeof(int) * 2 * MAXSUB * so101_sim::MAXGROUPS), "hipMalloc(pipe)") && hip_ok(s, hipMalloc(&cr, sizeof(float) * 8 * MAXCAND * n), "hipMalloc(pipe)") &&
               hip_ok(s, hipMalloc(&ac, n), "hipMalloc(pipe)") && hip_ok(s, hipMalloc(&tk, sizeof(int) * MAXCAND * n), "hipMalloc(pipe)") &&
-              hip_ok(s, hipMalloc(&sg, sizeof(int) * 8 * n), "hipMalloc(pipe)");
-    for (void* p : {po, ca, nc, wk, ct, cr, ac, tk, sg}) if (p) s->owned.push_back(p);
+              hip_ok(s, hipMalloc(&sg, sizeof(int) * 8 * n), "hipMalloc(pipe)") && hip_ok(s, hipMalloc(&co, sizeof(int) * n), "hipMalloc(pipe)") &&
+              hip_ok(s, hipMalloc(&od, sizeof(int) * n), "hipMalloc(pipe)");
+    for (void* p : {po, ca, nc, wk, ct, cr, ac, tk, sg, co, od}) if (p) s->owned.push_back(p);
+    ok = ok && hip_ok(s, hipMemset(co, 0, sizeof(int) * n), "hipMemset(pipe)");
     ok = ok && hip_ok(s, hipMemset(nc, 0, sizeof(int) * n), "hipMemset(pipe)") && hip_ok(s, hipMemset(ac, 0, n), "hipMemset(pipe)");
     if (ok) {
-      s->pipe = PipeBuffers{(float*)po, (unsigned int*)ca, (int*)nc, (unsigned int*)wk, (int*)ct, (float*)cr, (unsigned char*)ac, (unsigned int*)sg, 0u, (unsigned int*)tk};
+      s->pipe = PipeBuffers{(float*)po, (unsigned int*)ca, (int*)nc, (unsigned int*)wk, (int*)ct, (float*)cr, (unsigned char*)ac, (unsigned int*)sg, (unsigned int*)co, (int*)od, 0u, (unsigned int*)tk};
       for (int g = 0; g < so101_sim::MAXGROUPS && ok; g++)
         ok = hip_ok(s, hipStreamCreateWithFlags(&s->group_stream[g], hipStreamNonBlocking), "hipStreamCreate") &&
              hip_ok(s, hipEventCreateWithFlags(&s->group_done[g], hipEventDisableTiming), "hipEventCreate");
@@ -446,6 +448,7 @@ int so101_step(so101_sim* s, const float* action, float* obs, float* reward, flo
       int nw = ng * 16 < 4096 ? ng * 16 : 4096;
       if (G > 1 && !hip_ok(s, hipStreamWaitEvent(gs, s->step_begin, 0), "hipStreamWaitEvent")) return SO101_ERR_HIP;
       if (!hip_ok(s, hipMemsetAsync(W.counters, 0, sizeof(int) * 2 * MAXSUB, gs), "hipMemsetAsync(pipe)")) return SO101_ERR_HIP;
+      hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, gs, W.cost, W.order, e0, ng);
       hipLaunchKernelGGL(k_pipe_begin, dim3(ng), dim3(64), 0, gs, s->dm, P, s->buf, s->prep, W, action, obs, reward, discount,
                          step_type, s->need_reset, s->diag, e0);
       for (int k = 0; k < P.n_substeps; k++) {

@@ -30,6 +30,8 @@ struct PipeBuffers {
   float* conres;          // [N][MAXCAND][8] dist, normal, position, valid
   unsigned char* active;  // [N] 0 not stepping in this call (auto-reset), 1 stepping, 2 diverged
   unsigned int* stage;    // [N][8] k_pipe_solve stage clocks of the last substep (10 ns ticks), diagnostics
+  unsigned int* cost;     // [N] solver time of the env in its last substep (ticks): scheduling hint only
+  int* order;             // [N] per group: env indices sorted by decreasing cost, see k_order
   unsigned int work_cap;  // capacity of one work list = envs of the group * MAXCAND
   unsigned int* ticks;    // [N][MAXCAND] narrowphase time of each candidate of the last substep (10 ns ticks), diagnostics
 };
@@ -148,11 +150,35 @@ __global__ void __launch_bounds__(64, 2) k_narrow(const DevModel* m, int N, Pipe
   }
 }
 
+// Longest-processing-time-first launch order for k_pipe_solve.  A launch ends with its slowest env (Newton iteration
+// counts: mean 2.7, max ~19) and workgroups are dispatched in index order, so envs that were expensive in the
+// previous control step go first: counting sort of the group's envs by log2(cost), descending.  The order only
+// changes WHEN an env is processed, never its result.  One workgroup per env group.
+__global__ void __launch_bounds__(1024) k_order(const unsigned int* cost, int* order, int e0, int ng) {
+  __shared__ int hist[32], start[32];
+  int t = threadIdx.x;
+  if (t < 32) hist[t] = 0;
+  __syncthreads();
+  for (int i = t; i < ng; i += 1024) {
+    unsigned int c = cost[e0 + i];
+    int b = c ? __clz((int)c) : 31;                      // large cost -> small bucket index (factor-of-two buckets)
+    atomicAdd(&hist[b], 1);
+  }
+  __syncthreads();
+  if (t == 0) { int acc = 0; for (int b = 0; b < 32; b++) { start[b] = acc; acc += hist[b]; } }
+  __syncthreads();
+  for (int i = t; i < ng; i += 1024) {
+    unsigned int c = cost[e0 + i];
+    int b = c ? __clz((int)c) : 31;
+    order[e0 + atomicAdd(&start[b], 1)] = e0 + i;
+  }
+}
+
 __global__ void __launch_bounds__(64, 2) k_pipe_solve(const DevModel* m, StepParams P, DevBuffers B, PipeBuffers W, int s, int last,
                                                    float* obs, float* reward, float* discount, unsigned char* step_type,
                                                    unsigned char* need_reset, int* diag, int e0) {
   __shared__ EnvLDS L;
-  int e = e0 + blockIdx.x, lane = wave_lane(), N = P.n_envs;
+  int e = wave_uniform_i(W.order[e0 + blockIdx.x]), lane = wave_lane(), N = P.n_envs;
   int act = W.active[e];
   if (act == 0) return;
   int sc = B.step_count[e] + 1;
@@ -169,7 +195,7 @@ __global__ void __launch_bounds__(64, 2) k_pipe_solve(const DevModel* m, StepPar
     if (P.solver == 1) solve_newton(m, L, P.iterations, P.tolerance); else solve_pgs(m, L, P.iterations, P.tolerance);
     c4 = wall_clock64();
     forward_accelerations(L);
-    if (lane == 0) L.t_solve += (unsigned int)(c4 - c2);
+    if (lane == 0) { L.t_solve += (unsigned int)(c4 - c2); W.cost[e] = (unsigned int)(c4 - c2); }
     euler(m, L);
     diverged = check_divergence(L);
     if (diverged && lane == 0) W.active[e] = 2;

@@ -62,6 +62,7 @@ inline hipError_t hipEventQuery(hipEvent_t) { return 0; }
 inline unsigned long long wall_clock64() { return 0ull; }
 // v_readlane: value of lane `l`
 inline int __builtin_amdgcn_readlane(int v, int l) { emu_xchg_i[threadIdx.x] = v; __syncthreads(); int r = emu_xchg_i[l]; __syncthreads(); return r; }
+inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline hipError_t hipGetLastError() { return 0; }

@@ -154,3 +154,27 @@ def test_divergence_handling(make_sim, blobs):
 
 def test_contact_rich_states(make_sim, blobs, golden):
     pc.check_contact_rich(make_sim, blobs, golden, count=12)
+
+
+@pytest.mark.parametrize("task_name", ["SO100HandOverBanana", "SO100HandOverPen"])
+def test_python_dropin_api(task_name):
+    """task_suite.create_task_env keeps the reference's contract (task_suite.py:103-155) for both hand-over tasks:
+    dm_env TimeSteps from the single env, tensors with a leading env dimension from the batched extension."""
+    import torch
+    from so101_sim_amd import task_suite
+    env = task_suite.create_task_env(task_name, time_limit=0.2, random_state=7, settle_max_substeps=100)
+    ts = env.reset()
+    assert ts.first() and ts.reward is None and ts.discount is None
+    assert set(ts.observation) >= {"joints_pos", "undelayed_joints_pos", "commanded_joints_pos", "physics_state"}
+    spec = env.action_spec()
+    assert spec.shape == (6,)
+    n = 0
+    while not ts.last():
+        ts = env.step(np.zeros(6, dtype=np.float32))
+        n += 1
+    assert n == 10 and ts.discount == 1.0 and ts.reward == 0.0        # time limit 0.2 s = 10 control steps of 20 ms
+    assert env.step(np.zeros(6, dtype=np.float32)).first()             # auto-reset
+    benv = task_suite.create_task_env(task_name, time_limit=10.0, random_state=7, n_envs=16, settle_max_substeps=100)
+    benv.reset_all()
+    out = benv.step_tensor(torch.zeros(16, 6, device="cuda"))
+    assert all(torch.isfinite(t.float()).all() for t in out if torch.is_tensor(t))
