@@ -301,7 +301,7 @@ int so101_default_config(so101_config* cfg) {
   memset(cfg, 0, sizeof *cfg);
   cfg->last_step = 1 << 30; cfg->n_substeps = 10; cfg->solver_iterations = 0; cfg->solver_tolerance = -1.f;
   cfg->settle_max_substeps = 1000; cfg->terminate_on_success = 1; cfg->env_id_base = 0; cfg->solver = SO101_SOLVER_NEWTON;
-  cfg->prefetch_resets = 1; cfg->pipeline = 1; cfg->groups = 1;
+  cfg->prefetch_resets = 1; cfg->pipeline = 1; cfg->groups = 2;
   return SO101_OK;
 }
 
@@ -431,13 +431,19 @@ int so101_step(so101_sim* s, const float* action, float* obs, float* reward, flo
   if (s->cfg.pipeline && s->cfg.n_substeps <= MAXSUB) {
     hipStream_t st = (hipStream_t)stream;
     StepParams P = make_params(s);
-    int G = s->cfg.groups < 1 ? 1 : (s->cfg.groups > so101_sim::MAXGROUPS ? so101_sim::MAXGROUPS : s->cfg.groups);
-    if (G > s->n_envs) G = s->n_envs;
-    if (!hip_ok(s, hipEventRecord(s->step_begin, st), "hipEventRecord")) return SO101_ERR_HIP;
-    int per = (s->n_envs + G - 1) / G;
+    int G = s->cfg.groups < 1 ? 1 : (s->cfg.groups > 3 ? 3 : s->cfg.groups);
+    int n = s->n_envs;
+    if (n < 64) G = 1;
+    // slices of the cost-sorted env order: [0, n/32) expensive, [n/32, n/4) middle (G = 3 only), rest cheap
+    int bounds[4] = {0, n, n, n};
+    if (G == 2) { bounds[1] = n / 32; bounds[2] = n; }
+    if (G == 3) { bounds[1] = n / 32; bounds[2] = n / 4; bounds[3] = n; }
+    hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, s->pipe.cost, s->pipe.order, 0, n);
+    LAUNCH_CHECK(s, "k_order");
+    if (G > 1 && !hip_ok(s, hipEventRecord(s->step_begin, st), "hipEventRecord")) return SO101_ERR_HIP;
     for (int g = 0; g < G; g++) {
-      int e0 = g * per, ng = s->n_envs - e0 < per ? s->n_envs - e0 : per;
-      if (ng <= 0) break;
+      int e0 = bounds[g], ng = bounds[g + 1] - bounds[g];
+      if (ng <= 0) continue;
       hipStream_t gs = G == 1 ? st : s->group_stream[g];
       PipeBuffers W = s->pipe;
       W.counters = s->pipe.counters + 2 * MAXSUB * g;
@@ -448,7 +454,6 @@ int so101_step(so101_sim* s, const float* action, float* obs, float* reward, flo
       int nw = ng * 16 < 4096 ? ng * 16 : 4096;
       if (G > 1 && !hip_ok(s, hipStreamWaitEvent(gs, s->step_begin, 0), "hipStreamWaitEvent")) return SO101_ERR_HIP;
       if (!hip_ok(s, hipMemsetAsync(W.counters, 0, sizeof(int) * 2 * MAXSUB, gs), "hipMemsetAsync(pipe)")) return SO101_ERR_HIP;
-      hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, gs, W.cost, W.order, e0, ng);
       hipLaunchKernelGGL(k_pipe_begin, dim3(ng), dim3(64), 0, gs, s->dm, P, s->buf, s->prep, W, action, obs, reward, discount,
                          step_type, s->need_reset, s->diag, e0);
       for (int k = 0; k < P.n_substeps; k++) {

@@ -12,11 +12,12 @@
 // All stages call the same device functions as the fused path; contact order (= candidate order) is preserved.
 //
 // Env groups: a launch ends when its slowest env does (a Newton solve that needs 15 iterations instead of 3), and
-// the next launch of the chain cannot start before that.  The batch is therefore cut into groups whose chains run
-// on separate streams; the tail of one group's launch is filled by the other groups' kernels.  Every group has its
-// own work lists and counters, everything else is indexed by the global env index.  (Measured on MI355X, 4096 envs:
-// 4 groups 17.6 ms per control step against 13.3 ms with one - the co-resident kernels slow each other more than the
-// filled tails win - so the default is one group; the knob stays for larger batches.)
+// the next launch of the chain cannot start before that.  k_order sorts the envs by the solver time of their previous
+// control step; with `groups` > 1 the sorted order is cut into slices - the few expensive envs (first 1/32 of the
+// batch), optionally a middle slice, and the rest - whose launch chains run on separate streams.  The cheap slice's
+// launches then have no stragglers, and the expensive slice's long chain overlaps them on a few CUs.  Every group has
+// its own work lists and counters; everything else is indexed by the global env index.  Results never depend on
+// the grouping (each env is advanced by the same code on the same data).
 #pragma once
 
 #define MAXSUB 32
@@ -88,7 +89,7 @@ __global__ void __launch_bounds__(64, 2) k_pipe_begin(const DevModel* m, StepPar
                                                    const float* action, float* obs, float* reward, float* discount,
                                                    unsigned char* step_type, unsigned char* need_reset, int* diag, int e0) {
   __shared__ EnvLDS L;
-  int e = e0 + blockIdx.x, lane = wave_lane(), N = P.n_envs;
+  int e = wave_uniform_i(W.order[e0 + blockIdx.x]), lane = wave_lane(), N = P.n_envs;
   if (need_reset[e]) {
     // dm_control auto-reset: the call after LAST resets and reports FIRST; the action is ignored
     if (lane == 0) { L.overflow = 0; L.t_collision = 0; L.t_solve = 0; L.t_begin = (unsigned int)wall_clock64(); }
@@ -153,8 +154,8 @@ __global__ void __launch_bounds__(64, 2) k_narrow(const DevModel* m, int N, Pipe
 // Longest-processing-time-first launch order for k_pipe_solve.  A launch ends with its slowest env (Newton iteration
 // counts: mean 2.7, max ~19) and workgroups are dispatched in index order, so envs that were expensive in the
 // previous control step go first: counting sort of the group's envs by log2(cost), descending.  The order only
-// changes WHEN an env is processed, never its result.  One workgroup per env group.
-__global__ void __launch_bounds__(1024) k_order(const unsigned int* cost, int* order, int e0, int ng) {
+// changes WHEN an env is processed, never its result.  One workgroup for the whole batch.
+__global__ void __launch_bounds__(1024) k_order(const unsigned int* cost, int* order, int e0, int ng) {   // e0 = 0, ng = N
   __shared__ int hist[32], start[32];
   int t = threadIdx.x;
   if (t < 32) hist[t] = 0;
