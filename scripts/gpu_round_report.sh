@@ -20,9 +20,9 @@ tot = collections.defaultdict(float); cnt = collections.defaultdict(set)
 for f in glob.glob('/tmp/prof_pmc/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name'].split('(')[0]
-        if k in ('k_pipe_begin', 'k_narrow', 'k_pipe_solve') and r['Counter_Name'] == '$c':
+        if k in ('k_order', 'k_pipe_begin', 'k_narrow', 'k_pipe_solve') and r['Counter_Name'] == '$c':
             tot[k] += float(r['Counter_Value']); cnt[k].add(r['Dispatch_Id'])
-steps = max(1, len(cnt['k_pipe_begin']))
+steps = max(1, len(cnt['k_order']))          # one k_order per control step (k_pipe_begin: one per env slice)
 out = {k: {'dispatches': len(cnt[k]), 'KB_per_dispatch': tot[k] / max(1, len(cnt[k])), 'KB_per_step': tot[k] / steps} for k in tot}
 out['steps'] = steps
 print('$c', json.dumps(out))
