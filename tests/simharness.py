@@ -55,6 +55,9 @@ class ArraySim:
         if backend == "emu":
             # launches are synchronous in the emulator: a prefetch would settle every env after every call
             cfg.setdefault("prefetch_resets", 0)
+            # the pipelined step is ~20 launches of 64 (k_order: 1024) OS threads per block here; the emulator runs the
+            # fused step unless a test asks for the pipeline (test_pipelined_step_matches_fused does)
+            cfg.setdefault("pipeline", 0)
         if cfg:
             self.sim.configure(**cfg)
 
