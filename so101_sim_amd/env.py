@@ -51,7 +51,9 @@ class SO100HandOverTask:
         if object_name not in scenes.HANDOVER_CONFIGS:
             raise ValueError(f"Invalid object name: {object_name}, must be one of {scenes.HANDOVER_CONFIGS.keys()}")
         if not reward_based_on_overlap:
-            raise NotImplementedError("contact+distance reward mode (so100_hand_over.py:277-318) is not built yet")
+            raise NotImplementedError(
+                "contact+distance reward mode (so100_hand_over.py:277-318) is not built: in the reference that branch looks up "
+                "a body 'so100/hand_link' which scene_pbr.xml does not define, so it raises there as well")
         self.object_name = object_name
         self.control_timestep = float(kwargs.pop("control_timestep", DEFAULT_CONTROL_TIMESTEP))
         self.cameras = tuple(kwargs.pop("cameras", ()))
