@@ -129,7 +129,8 @@ __global__ void __launch_bounds__(64, 2) k_narrow(const DevModel* m, int N, Pipe
     if (i0 >= nwork) break;
     unsigned int wl = 0, cl = 0;
     if (lane < NARROW_CHUNK && i0 + lane < nwork) { wl = list[i0 + lane]; cl = W.cand[wl]; }
-#pragma unroll
+    // not unrolled: four inlined copies of the MPR query are ~130 KB of code, more than the instruction cache holds
+#pragma unroll 1
     for (int j = 0; j < NARROW_CHUNK; j++) {
       if (i0 + j >= nwork) break;
       unsigned long long t0 = wall_clock64();
