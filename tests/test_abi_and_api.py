@@ -99,3 +99,20 @@ def test_shard_ranges_partition_the_envs():
         spans = [shard_range(n, w, r) for r in range(w)]
         assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def test_lerobot_packaging_format():
+    """so101_lerobot_wrapper.py:77-122: keys, dtypes, the 0.1 s timestamp quirk, zero action on reset; batched shapes."""
+    import numpy as np
+    import torch
+    from so101_sim_amd import lerobot
+    o = lerobot.to_lerobot_format(np.arange(6, dtype=np.float64), None, 0, 3)
+    assert set(o) == {"observation.state", "action", "timestamp", "frame_index", "episode_index", "index", "task_index", "task"}
+    assert o["observation.state"].dtype == torch.float32 and o["observation.state"].shape == (6,)
+    assert torch.equal(o["action"], torch.zeros(6)) and o["timestamp"].item() == 0.0 and o["episode_index"].item() == 3
+    o = lerobot.to_lerobot_format(np.zeros(6), np.ones(6), 7, 0)
+    assert abs(o["timestamp"].item() - 0.7) < 1e-6 and o["frame_index"].item() == 7 and o["index"].item() == 7
+    assert o["frame_index"].dtype == torch.long and o["task"] == "SO100 manipulation task" and o["task_index"].item() == 0
+    b = lerobot.to_lerobot_format(np.zeros((5, 6)), None, 2, 1, n_envs=5)
+    assert b["observation.state"].shape == (5, 6) and b["action"].shape == (5, 6) and b["frame_index"].shape == (5,)
+    assert torch.all(b["frame_index"] == 2) and torch.allclose(b["timestamp"], torch.full((5,), 0.2))

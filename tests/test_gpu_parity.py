@@ -178,3 +178,24 @@ def test_python_dropin_api(task_name):
     benv.reset_all()
     out = benv.step_tensor(torch.zeros(16, 6, device="cuda"))
     assert all(torch.isfinite(t.float()).all() for t in out if torch.is_tensor(t))
+
+
+def test_lerobot_wrapper_on_gpu():
+    """SO101LeRobotWrapper (so101_lerobot_wrapper.py:60-122) over the batched env: observation.state is the delayed
+    joints_pos of the underlying env, the action is echoed, frame/timestamp count wrapper steps."""
+    import torch
+    from so101_sim_amd.lerobot import SO101LeRobotWrapper
+    w = SO101LeRobotWrapper(time_limit=10.0, n_envs=8, random_state=3, settle_max_substeps=100)
+    o = w.reset()
+    assert o["observation.state"].shape == (8, 6) and torch.all(o["observation.state"] == 0) and torch.all(o["action"] == 0)
+    act = torch.full((8, 6), 0.1)
+    for t in range(1, 8):
+        o = w.step(act)
+        assert torch.all(o["frame_index"] == t) and torch.allclose(o["timestamp"], torch.full((8,), 0.1 * t, device=o["timestamp"].device))
+        assert torch.equal(o["observation.state"], w.env.obs[:, 0:6]) and torch.allclose(o["action"].cpu(), act)
+        if t <= 5:
+            assert torch.all(o["observation.state"] == 0)              # 5-step observation delay
+    assert torch.any(o["observation.state"] != 0)
+    w1 = SO101LeRobotWrapper(time_limit=10.0, n_envs=1, random_state=3, settle_max_substeps=100)
+    ep = w1.collect_episode([np.zeros(6, dtype=np.float32)] * 3)
+    assert len(ep) == 4 and ep[0]["observation.state"].shape == (6,) and ep[3]["frame_index"].item() == 3 and w1.episode_index == 1
