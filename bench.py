@@ -58,6 +58,7 @@ def main():
                     help="newton = MuJoCo's default, which the reference scene uses (it sets no <option solver>)")
     ap.add_argument("--no-prefetch", action="store_true", help="settle auto-resets inside the step call")
     ap.add_argument("--fused", action="store_true", help="one fused k_step launch per control step instead of the pipeline")
+    ap.add_argument("--groups", type=int, default=0, help="env slices of the pipelined step (0 = library default)")
     ap.add_argument("--solver-iterations", type=int, default=0, help="iteration cap; 0 = model default (100)")
     ap.add_argument("--solver-tolerance", type=float, default=-1.0, help="<0 = model default (1e-8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -88,6 +89,8 @@ def main():
     os.chdir(cwd)
     if args.fused:
         env.sim.configure(pipeline=0)
+    if args.groups:
+        env.sim.configure(groups=args.groups)
     spec = env.action_spec()
     lo = torch.tensor(spec.minimum, device=dev)
     hi = torch.tensor(spec.maximum, device=dev)

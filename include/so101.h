@@ -78,9 +78,9 @@ typedef struct {
                               0: always settle inside the call.  Results are identical either way. */
   int32_t pipeline;        /* 1 (default): so101_step runs every substep as narrowphase (one wavefront per candidate pair)
                               + solve (one wavefront per env) launches; 0: one fused launch, one wavefront per env. */
-  int32_t groups;          /* pipelined step: 1 = one launch chain; 2 (default) / 3 = the envs, sorted by the solver time of
-                              their previous step, are cut into expensive (1/32) [/ middle (up to 1/4)] / cheap slices whose
-                              chains run on separate internal streams; results do not depend on it */
+  int32_t groups;          /* pipelined step: the envs, sorted by the solver time of their previous step, are cut into 1, 2
+                              (split at n/2) or 3 (default; n/4 and 5n/8) slices whose launch chains run on separate
+                              internal streams and fill each other's tails; results do not depend on it */
 } so101_config;
 
 int so101_version(void);

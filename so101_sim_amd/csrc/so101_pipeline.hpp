@@ -11,13 +11,14 @@
 // through HBM per substep (~300 B/env) plus body poses, candidates and contact records (~1 KB/env).
 // All stages call the same device functions as the fused path; contact order (= candidate order) is preserved.
 //
-// Env groups: a launch ends when its slowest env does (a Newton solve that needs 15 iterations instead of 3), and
-// the next launch of the chain cannot start before that.  k_order sorts the envs by the solver time of their previous
-// control step; with `groups` > 1 the sorted order is cut into slices - the few expensive envs (first 1/32 of the
-// batch), optionally a middle slice, and the rest - whose launch chains run on separate streams.  The cheap slice's
-// launches then have no stragglers, and the expensive slice's long chain overlaps them on a few CUs.  Every group has
-// its own work lists and counters; everything else is indexed by the global env index.  Results never depend on
-// the grouping (each env is advanced by the same code on the same data).
+// Env slices: a launch ends when its slowest env does (a Newton solve that needs 15 iterations instead of 3), and
+// the next launch of the chain cannot start before that; with ~2.2 rounds of resident waves per launch that tail is
+// about half of every k_pipe_solve.  k_order sorts the envs by the solver time of their previous control step and
+// the sorted order is cut into up to three slices (default: n/4 most expensive, 3n/8, 3n/8) whose launch chains run
+// on separate streams, so that one chain's tail is filled by the other chains' kernels: 365 k -> 452 k env-steps/s
+// at 4096 envs.  Four chains are slower than one (264-276 k).  Every slice has its own work lists and counters;
+// everything else is indexed by the global env index.  Results never depend on the slicing (each env is advanced
+// by the same code on the same data).
 #pragma once
 
 #define MAXSUB 32
