@@ -459,9 +459,10 @@ int so101_step(so101_sim* s, const float* action, float* obs, float* reward, flo
       W.counters = s->pipe.counters + 2 * MAXSUB * g;
       W.work = s->pipe.work + (size_t)2 * MAXCAND * e0;
       W.work_cap = (unsigned int)ng * MAXCAND;
-      // persistent narrowphase waves: about the mean number of candidate pairs per env, capped at what fills
-      // 256 CUs (the waves pull work items until the list is empty, so the count only has to cover the machine)
-      int nw = ng * 16 < 4096 ? ng * 16 : 4096;
+      // persistent narrowphase waves (they pull work items until the list is empty): two per env of the slice, at
+      // most what fills 256 CUs.  Measured with three slices: 2/env 466 k env-steps/s, 1/env 463 k, >= 4/env 451 k -
+      // a smaller narrowphase grid leaves slots to the other chains' solve kernels.
+      int nw = ng * 2 < 4096 ? ng * 2 : 4096;
       if (G > 1 && !hip_ok(s, hipStreamWaitEvent(gs, s->step_begin, 0), "hipStreamWaitEvent")) return SO101_ERR_HIP;
       if (!hip_ok(s, hipMemsetAsync(W.counters, 0, sizeof(int) * 2 * MAXSUB, gs), "hipMemsetAsync(pipe)")) return SO101_ERR_HIP;
       hipLaunchKernelGGL(k_pipe_begin, dim3(ng), dim3(64), 0, gs, s->dm, P, s->buf, s->prep, W, action, obs, reward, discount,
