@@ -116,7 +116,8 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     # device time of one control step on the stream the kernels are launched on (torch's current stream, which
-    # so101_step receives): 1 + 2*substeps launches with the pipelined step, one k_step launch with --fused
+    # so101_step receives and on which the internal slice streams are joined): k_order + per env slice
+    # 1 + 2*substeps launches with the pipelined step, one k_step launch with --fused
     kernel_ms = ev[0].elapsed_time(ev[1]) / args.steps
 
     # logging-only exchange: episode returns all-gathered over RCCL/xGMI (not in the timed region)
@@ -155,8 +156,8 @@ def main():
                        "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_step" if args.fused else "k_pipe_begin + substeps x (k_narrow + k_pipe_solve)",
-                         "kernel_ms": kernel_ms, "launches_per_step": 1 if args.fused else 21,
+                         "kernel": "k_step" if args.fused else "k_order + 3 env slices x (k_pipe_begin + substeps x (k_narrow + k_pipe_solve))",
+                         "kernel_ms": kernel_ms, "launches_per_step": 1 if args.fused else 1 + (args.groups or 3) * 21,
                          "note": "per control step: algorithmic bytes = 620 B/env-step x envs, time = device time of the step's "
                                  "launch chain; the path is latency/VALU-bound, not HBM-bound (DESIGN.md section 6)"},
             "diag_mean": {"ncon": diag[0], "nefc": diag[1], "solver_iter": diag[2], "broadphase_candidates": diag[3]},
