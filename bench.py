@@ -149,7 +149,7 @@ def main():
             "metric": "env_steps_per_sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "SO100HandOverBanana, 4096 lock-step envs per GPU, proprioceptive obs, uniform random actions, 500-step episodes with auto-reset+settle (BASELINE.json configs[1])",
+            "config": {"workload": f"SO100HandOverBanana, {N} lock-step envs per GPU, proprioceptive obs, uniform random actions, 500-step episodes with auto-reset+settle" + (" (BASELINE.json configs[1])" if N == 4096 else ""),
                        "envs_per_gpu": N, "global_envs": world * N, "substeps_per_step": 10,
                        "solver": args.solver, "reset_prefetch": not args.no_prefetch, "pipeline": not args.fused, "solver_iterations": args.solver_iterations or 100,
                        "solver_tolerance": args.solver_tolerance if args.solver_tolerance >= 0 else 1e-8,
