@@ -66,8 +66,8 @@ typedef struct {
   int32_t last_step;       /* control step on which physics.time() >= time_limit first holds
                               (task_suite.py:151; fp64 accumulation replayed on the host) */
   int32_t n_substeps;      /* control_timestep / physics timestep = 10 (task_suite.py:41) */
-  int32_t solver_iterations; /* PGS iteration cap; <=0 keeps the model's (100) */
-  float solver_tolerance;  /* PGS early-exit tolerance; <0 keeps the model's (1e-8) */
+  int32_t solver_iterations; /* solver iteration cap; <=0 keeps the model's (100) */
+  float solver_tolerance;  /* solver early-exit tolerance; <0 keeps the model's (1e-8) */
   int32_t settle_max_substeps; /* PropPlacer settle budget, 1000 = 2.0 s (so100_hand_over.py:222-229) */
   int32_t terminate_on_success; /* SO100Task terminate_episode (so100_task.py:120,297-302) */
   uint64_t env_id_base;    /* global index of env 0 of this handle (multi-GPU sharding) */
