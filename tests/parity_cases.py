@@ -239,11 +239,12 @@ def check_prefetch_identical(make_sim, n=3, settle=25, steps=9, last_step=3, see
         np.testing.assert_array_equal(a, b)
 
 
-def check_pipeline_identical(make_sim, golden, n=4, steps=3, seed=9, settle=20, exact=True):
+def check_pipeline_identical(make_sim, golden, n=4, steps=3, seed=9, settle=20, exact=True, all_reset_last=True):
     """The pipelined step (k_pipe_begin / k_narrow / k_pipe_solve per substep) and the fused k_step run the same device
     functions in the same order: rollouts from contact-rich states, across a time-limit auto-reset, must agree
     (bit for bit when `exact`)."""
-    states = golden["contact_rich_states"]["states"][:n]
+    states = golden["contact_rich_states"]["states"]
+    states = (states * (1 + n // len(states)))[:n]            # tiled: n >= 64 exercises the multi-chain launch
     Q = np.array([s["qpos"] for s in states]).T
     V = np.array([s["qvel"] for s in states]).T
     W = np.array([s["warm"] for s in states]).T
@@ -259,7 +260,10 @@ def check_pipeline_identical(make_sim, golden, n=4, steps=3, seed=9, settle=20, 
         for t in range(steps + 1):
             obs, rew, disc, st = sim.step((A.T + rng.uniform(-0.2, 0.2, size=(n, 6))).astype(np.float32))
             trace.append(np.concatenate([obs.ravel(), rew, disc, st.astype(np.float32)] + [a.ravel() for a in sim.get_state()]))
-        assert np.all(st == 0)                 # the last call was the auto-reset
+        if all_reset_last:
+            assert np.all(st == 0)             # the last call was the auto-reset
+        else:
+            assert np.any(st == 0)             # (envs that ended early, e.g. diverged, are one episode ahead)
         out.append(trace)
     for t, (a, b) in enumerate(zip(*out)):
         if exact:

@@ -51,6 +51,12 @@ def test_pipelined_step_matches_fused(make_sim, golden):
     pc.check_pipeline_identical(make_sim, golden, n=8, steps=6)
 
 
+def test_three_launch_chains_match_fused(make_sim, golden):
+    """n >= 64: so101_step cuts the cost-sorted envs into three slices on separate streams; still bit-identical to the
+    fused single-launch step (different random actions per env, so the slices really differ in cost)."""
+    pc.check_pipeline_identical(make_sim, golden, n=160, steps=5, seed=4, all_reset_last=False)
+
+
 # ---- SO100HandOverPen: same kernels, second scene blob (pen + utensil holder, two overlap boxes)
 @pytest.fixture(scope="module")
 def make_pen(blobs_pen):
