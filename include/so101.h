@@ -18,7 +18,10 @@
  *    so that lanes reading one scalar for consecutive envs coalesce.
  *  - `hip_stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream); calls are
  *    asynchronous with respect to the host.
- *  - a handle is bound to one device and is not thread-safe.
+ *  - a handle is bound to one device (every entry point makes that device current for the duration of the call
+ *    and restores the caller's) and is not thread-safe.
+ *  - bound state buffers must stay allocated until so101_destroy or the next so101_bind_state returns: the reset
+ *    prefetch reads them asynchronously on an internal stream (both calls drain it).
  */
 #ifndef SO101_H_
 #define SO101_H_
@@ -30,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SO101_ABI_VERSION 2
+#define SO101_ABI_VERSION 3
 #define SO101_OBS_DIM 18      /* joints_pos(6, delayed) | undelayed_joints_pos(6) | commanded_joints_pos(6) */
 #define SO101_ACT_DIM 6
 #define SO101_SOLVER_PGS 0
@@ -134,9 +137,22 @@ int so101_get_returns(so101_sim* sim, float* out, void* hip_stream);
 /* Diagnostics of the most recent substep, per env: [N][SO101_DIAG_DIM] int32
  *   0 ncon, 1 nefc, 2 solver iterations, 3 broadphase candidates, 4 overflow flags,
  *   5 collision time, 6 constraint+solver time, 7 whole-call time of this env's wavefront (10 ns ticks, summed over
- *   the substeps of the last call). */
+ *   the substeps of the last call; words 5 and 7 are zero unless the library was built with -DSO101_DEBUG_CLOCKS). */
 #define SO101_DIAG_DIM 8
 int so101_get_diag(so101_sim* sim, int32_t* out, void* hip_stream);
+
+/* Event counters since so101_create (or the last call with clear != 0): out is a DEVICE pointer to
+ * SO101_NEVENTS uint64.  Counter b counts env-steps (b <= 3) or env-resets (b = 4, 5) on which flag b was raised:
+ *   0 broadphase candidate list overflowed (candidates dropped)      1 contact list overflowed (contacts dropped)
+ *   2 arm-contact Jacobian pool overflowed (contacts dropped)        3 physics diverged: NaN or |x| > 1e10 in the
+ *     state (mj_checkPos/Vel/Acc); the episode ends with reward 0 / discount 0 like a dm_control PhysicsError
+ *     (task_suite.py:153 raise_exception_on_physics_error=False)
+ *   4 reset: the container placer's 20 attempts all collided (dm_control's PropPlacer raises RuntimeError there;
+ *     here the last sample is kept and the event is counted)         5 reset: the settle did not converge within
+ *     settle_max_substeps (dm_control warns, examples/so101_rl_breakdown.ipynb:50-55)
+ * The same bits appear per env in diag word 4 for the most recent substep. */
+#define SO101_NEVENTS 8
+int so101_get_events(so101_sim* sim, uint64_t* out, int clear, void* hip_stream);
 
 /* Stage dump of one forward pass (no integration) for parity tests against the oracle:
  * out is [N][SO101_DEBUG_DIM] float32; layout documented in csrc/so101_device.hpp (DBG_*). */
@@ -146,7 +162,7 @@ int so101_debug_forward(so101_sim* sim, float* out, void* hip_stream);
 /* Diagnostics of the pipelined step's last narrowphase launch (device buffers, any may be NULL):
  * ncand[N] (count | overflow << 16), cand[N][256] (geom1 | geom2 << 16), ticks[N][256] (10 ns per candidate),
  * conres[N][256][8] (dist, normal, position, valid). */
-/* Stage clocks of k_pipe_solve's second-to-last substep: stage[N][8] = smooth dynamics, contact gather, constraint
+/* (profiling builds, -DSO101_DEBUG_CLOCKS; zeros otherwise) Stage clocks of k_pipe_solve's second-to-last substep: stage[N][8] = smooth dynamics, contact gather, constraint
  * rows, solver, integrate, next broadphase (10 ns ticks), ncon, solver iterations. */
 int so101_debug_stages(so101_sim* sim, uint32_t* stage, void* hip_stream);
 

@@ -19,6 +19,16 @@
 #include "wave.hpp"
 
 #define DEV __device__ __forceinline__
+// Stage clocks (100 MHz s_memrealtime ticks) for scripts/gpu_*.py: compiled in only with -DSO101_DEBUG_CLOCKS
+// (python -m so101_sim_amd.build --clocks).  Production builds read the clock twice per solve (the scheduling hint
+// of k_order) and nowhere else.
+#ifdef SO101_DEBUG_CLOCKS
+#define SO101_CLOCKS_ON 1
+#define SO101_CLOCK() wall_clock64()
+#else
+#define SO101_CLOCKS_ON 0
+#define SO101_CLOCK() 0ull
+#endif
 #define MINVAL_F 1e-15f
 #define MINIMP_F 1e-4f
 #define MAXIMP_F 0.9999f
@@ -77,6 +87,22 @@ DEV void normquat(float* q) {
   float inv = 1.f / n;
   q[0] *= inv; q[1] *= inv; q[2] *= inv; q[3] *= inv;
 }
+// sin and cos of one angle: Cody-Waite reduction by pi/2 (three constants, exact products through fma) and the
+// cephes minimax polynomials on [-pi/4, pi/4]; <= 2 ulp for |x| < 1e4 rad.  The libm sinf/cosf expand to ~220
+// instructions each (large-argument path), and the kinematics needs six pairs per substep.
+DEV void sincos_f(float x, float* sn, float* cs) {
+  float k = rintf(x * 0.63661977236758134308f);
+  float r = fmaf(-k, 1.57079625129699707031f, x);
+  r = fmaf(-k, 7.54978941586159635335e-08f, r);
+  r = fmaf(-k, 5.39030285815811905290e-15f, r);
+  float z = r * r;
+  float s = fmaf(r * z, fmaf(z, fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f), r);
+  float c = fmaf(z * z, fmaf(z, fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f), fmaf(-0.5f, z, 1.f));
+  int q = (int)k;
+  float s1 = (q & 1) ? c : s, c1 = (q & 1) ? s : c;
+  *sn = (q & 2) ? -s1 : s1;
+  *cs = ((q + 1) & 2) ? -c1 : c1;
+}
 DEV void rotvecquat(float* o, const float* v, const float* q) {
   float m[9]; quat2mat(m, q); matvec3(o, m, v);
 }
@@ -130,7 +156,7 @@ DEV void kinematics(const DevModel* m, EnvLDS& L) {
     float t[3]; matvec3(t, R, m->arm_pos[k]);
     xp[0] += t[0]; xp[1] += t[1]; xp[2] += t[2];
     mulquat(xq, xq, m->arm_quat[k]);
-    float half = 0.5f * L.qpos[k], sn = sinf(half), cs = cosf(half);
+    float sn, cs; sincos_f(0.5f * L.qpos[k], &sn, &cs);
     float jq[4] = {cs, m->arm_axis[k][0] * sn, m->arm_axis[k][1] * sn, m->arm_axis[k][2] * sn};
     mulquat(xq, xq, jq);
     normquat(xq);
@@ -789,6 +815,10 @@ DEV void collision(const DevModel* m, EnvLDS& L) {
 }
 
 // ------------------------------------------------------------------ constraint rows
+// x^power for the solimp sigmoid with a power other than MuJoCo's default 2: ONE out-of-line copy (the inlined
+// ocml powf is ~1100 instructions and impedance() is expanded at three call sites)
+static __device__ __attribute__((noinline)) float impedance_pow(float x, float power) { return powf(x, power); }
+
 DEV float impedance(const float* solimp, float pos) {
   float dmin = fminf(fmaxf(solimp[0], MINIMP_F), MAXIMP_F), dmax = fminf(fmaxf(solimp[1], MINIMP_F), MAXIMP_F);
   float width = fmaxf(solimp[2], 0.f), mid = fminf(fmaxf(solimp[3], MINIMP_F), MAXIMP_F), power = fmaxf(solimp[4], 1.f);
@@ -798,8 +828,9 @@ DEV float impedance(const float* solimp, float pos) {
   if (x <= 0.f) return dmin;
   float y;
   if (power == 1.f) y = x;
-  else if (x <= mid) y = powf(x, power) / powf(mid, power - 1.f);
-  else y = 1.f - powf(1.f - x, power) / powf(1.f - mid, power - 1.f);
+  else if (power == 2.f) y = x <= mid ? x * x / mid : 1.f - (1.f - x) * (1.f - x) / (1.f - mid);
+  else if (x <= mid) y = impedance_pow(x, power) / impedance_pow(mid, power - 1.f);
+  else y = 1.f - impedance_pow(1.f - x, power) / impedance_pow(1.f - mid, power - 1.f);
   return dmin + y * (dmax - dmin);
 }
 
@@ -1033,8 +1064,8 @@ DEV void make_constraints(const DevModel* m, EnvLDS& L, bool pgs_data = true) {
 #include "so101_newton.hpp"
 
 // ------------------------------------------------------------------ forward + Euler
-// `phases` is a profiling aid (env SO101_DEBUG_PHASES, default all): bit0 collision, bit1 constraint rows + solve,
-// bit2 solve iterations.  Production runs always execute every stage.
+// `phases` is a profiling aid of so101_physics (StepParams.phases, 7 = everything): bit0 collision, bit1 constraint
+// rows + solve, bit2 solve iterations.
 DEV void forward_smooth(const DevModel* m, EnvLDS& L) {
   kinematics(m, L);
   crba_arm(m, L);
@@ -1059,25 +1090,28 @@ DEV void forward_accelerations(EnvLDS& L) {
 }
 
 
-// constraint rows + solve for the contacts in L.con, then back to MuJoCo's generalized accelerations
-DEV void forward_constrained(const DevModel* m, EnvLDS& L, int max_iter, float tolerance, int phases, int solver) {
+// constraint rows + solve for the contacts in L.con, then back to MuJoCo's generalized accelerations.
+// SOLVER is a compile-time choice (SO101_SOLVER_NEWTON / SO101_SOLVER_PGS): every kernel exists once per solver, so
+// the Newton kernels carry no PGS code (and no PGS-only constraint data) and vice versa.
+template <int SOLVER>
+DEV void forward_constrained(const DevModel* m, EnvLDS& L, int max_iter, float tolerance, int phases) {
   if (phases & 2) {
-    make_constraints(m, L, solver == 0);
-    if (solver == 1) solve_newton(m, L, (phases & 4) ? max_iter : 0, tolerance);
+    make_constraints(m, L, SOLVER == 0);
+    if constexpr (SOLVER == 1) solve_newton(m, L, (phases & 4) ? max_iter : 0, tolerance);
     else solve_pgs(m, L, (phases & 4) ? max_iter : 0, tolerance);
   }
   forward_accelerations(L);
 }
 
-DEV void forward(const DevModel* m, EnvLDS& L, int max_iter, float tolerance, int phases = 7, int solver = 0) {
+template <int SOLVER>
+DEV void forward(const DevModel* m, EnvLDS& L, int max_iter, float tolerance, int phases = 7) {
   forward_smooth(m, L);
-  // stage clocks (100 MHz s_memrealtime ticks) accumulate per env into the diagnostics
-  unsigned long long t0 = wall_clock64();
+  unsigned long long t0 = SO101_CLOCK();
   if (phases & 1) collision(m, L);
   else { if (wave_lane() == 0) { L.ncand = 0; L.ncon = 0; L.narmcon = 0; } wave_sync(); }
-  unsigned long long t1 = wall_clock64();
-  forward_constrained(m, L, max_iter, tolerance, phases, solver);
-  if (wave_lane() == 0) { L.t_collision += (unsigned int)(t1 - t0); L.t_solve += (unsigned int)(wall_clock64() - t1); }
+  unsigned long long t1 = SO101_CLOCK();
+  forward_constrained<SOLVER>(m, L, max_iter, tolerance, phases);
+  if (SO101_CLOCKS_ON && wave_lane() == 0) { L.t_collision += (unsigned int)(t1 - t0); L.t_solve += (unsigned int)(SO101_CLOCK() - t1); }
 }
 
 DEV void euler(const DevModel* m, EnvLDS& L) {
@@ -1092,7 +1126,8 @@ DEV void euler(const DevModel* m, EnvLDS& L) {
     q[0] += dt * v[0]; q[1] += dt * v[1]; q[2] += dt * v[2];
     float w[3] = {v[3], v[4], v[5]};
     float ang = dt * normalize3(w);
-    float sn = sinf(0.5f * ang), dq[4] = {cosf(0.5f * ang), w[0] * sn, w[1] * sn, w[2] * sn};
+    float sn, cs; sincos_f(0.5f * ang, &sn, &cs);
+    float dq[4] = {cs, w[0] * sn, w[1] * sn, w[2] * sn};
     float qq[4] = {q[3], q[4], q[5], q[6]};
     mulquat(qq, qq, dq);
     normquat(qq);
@@ -1120,8 +1155,9 @@ DEV bool check_divergence(EnvLDS& L) {
   return any;
 }
 
-DEV bool substep(const DevModel* m, EnvLDS& L, int max_iter, float tolerance, bool freeze_arm, int phases = 7, int solver = 0) {
-  forward(m, L, max_iter, tolerance, phases, solver);
+template <int SOLVER>
+DEV bool substep(const DevModel* m, EnvLDS& L, int max_iter, float tolerance, bool freeze_arm, int phases = 7) {
+  forward<SOLVER>(m, L, max_iter, tolerance, phases);
   euler(m, L);
   if (check_divergence(L)) return true;
   if (freeze_arm) {   // dm_control JointStaticIsolator: non-prop joints restored after every step

@@ -2,13 +2,14 @@
 // copy of the model, launch plumbing.  No torch types, no CPU compute path: every entry point that
 // does physics launches a HIP kernel or fails.
 #include "../../include/so101.h"
-#include "so101_kernels.hpp"
+#include "so101_launch.hpp"
 
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -32,12 +33,13 @@ struct BlobView {
       char name[33]; memcpy(name, e, 32); name[32] = 0;
       uint32_t kd, cnt; uint64_t off;
       memcpy(&kd, e + 32, 4); memcpy(&cnt, e + 36, 4); memcpy(&off, e + 40, 8);
-      if (off + (size_t)cnt * 4 > bytes) { err = std::string("truncated blob entry ") + name; return false; }
+      if (off > bytes || (uint64_t)cnt * 4 > bytes - off) { err = std::string("truncated blob entry ") + name; return false; }
       ent[name] = {b + off, cnt};
     }
     return true;
   }
   bool has(const char* n) const { return ent.count(n) != 0; }
+  size_t count(const char* n) const { auto it = ent.find(n); return it == ent.end() ? 0 : it->second.second; }
   std::vector<int> I(const char* n) const {
     std::vector<int> v; auto it = ent.find(n);
     if (it != ent.end()) { v.resize(it->second.second); memcpy(v.data(), it->second.first, 4 * v.size()); }
@@ -98,6 +100,7 @@ struct so101_sim {
   hipStream_t group_stream[MAXGROUPS] = {};
   hipEvent_t group_done[MAXGROUPS] = {};
   hipEvent_t step_begin = nullptr;
+  EventBuffers ev{};           // per-env flag accumulator + global event counters (so101_get_events)
   std::string err;
 };
 
@@ -108,6 +111,19 @@ bool hip_ok(so101_sim* s, hipError_t e, const char* what) {
   s->err = std::string(what) + ": " + hipGetErrorString(e);
   return false;
 }
+
+// Every entry point that touches HIP runs with the handle's device current and restores the caller's device on exit
+// (a handle is bound to one device; streams, events and allocations below belong to it).
+struct DeviceGuard {
+  int prev = -1, dev;
+  bool ok;
+  explicit DeviceGuard(so101_sim* s) : dev(s->device) {
+    ok = hipGetDevice(&prev) == hipSuccess && (prev == dev || hipSetDevice(dev) == hipSuccess);
+    if (!ok) s->err = "hipSetDevice: cannot make the handle's device current";
+  }
+  ~DeviceGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+};
+#define GUARD_DEVICE(s) DeviceGuard guard_(s); if (!guard_.ok) return SO101_ERR_HIP
 
 template <typename T>
 bool upload(so101_sim* s, const std::vector<T>& v, const T** out) {
@@ -128,16 +144,49 @@ StepParams make_params(const so101_sim* s) {
   P.tolerance = s->cfg.solver_tolerance >= 0.f ? s->cfg.solver_tolerance : s->hm.tolerance;
   P.settle_max = s->cfg.settle_max_substeps; P.terminate_on_success = s->cfg.terminate_on_success;
   P.n_envs = s->n_envs; P.seed = s->seed; P.env_id_base = s->cfg.env_id_base; P.solver = s->cfg.solver;
-  const char* ph = getenv("SO101_DEBUG_PHASES");      // profiling aid for so101_physics only
-  P.phases = ph ? atoi(ph) : 7;
+  P.phases = 7;
+#ifdef SO101_DEBUG_CLOCKS
+  if (const char* ph = getenv("SO101_DEBUG_PHASES")) P.phases = atoi(ph);      // profiling builds: stage mask of so101_physics
+#endif
   return P;
 }
 
 int build_model(so101_sim* s, const BlobView& b) {
   auto fail = [&](const std::string& msg) { s->err = msg; return (int)SO101_ERR_MODEL; };
-  const char* need[] = {"nq", "nv", "nu", "nbody", "ngeom", "narm", "nfree", "arm_body", "free_body", "body_parent", "body_pos",
-                        "body_quat", "body_jnttype", "geom_type", "geom_body", "mesh_vert", "pair_geom", "task_object_body"};
-  for (const char* n : need) if (!b.has(n)) return fail(std::string("blob entry missing: ") + n);
+  const char* scalars[] = {"nq", "nv", "nu", "nbody", "ngeom", "narm", "nfree", "npair", "nvert", "opt_iterations", "opt_mpr_iterations",
+                           "task_nbox", "opt_cone_elliptic", "opt_timestep", "opt_impratio", "opt_tolerance", "opt_mpr_tolerance",
+                           "stat_meaninertia", "task_object_body", "task_container_body"};
+  for (const char* n : scalars) if (b.count(n) < 1) return fail(std::string("blob entry missing: ") + n);
+  {
+    // every array the code below indexes, with the element count it relies on: a stale or foreign blob is rejected
+    // here instead of being dereferenced
+    size_t nbody = (size_t)b.I("nbody")[0], ngeom = (size_t)b.I("ngeom")[0], npair = (size_t)b.I("npair")[0], nvert = (size_t)b.I("nvert")[0];
+    size_t nbox = (size_t)b.I("task_nbox")[0];
+    if (nbody > 4096 || ngeom > 4096 || npair > (1u << 24) || nvert > (1u << 24) || nbox > 2) return fail("blob dimensions out of range");
+    struct Need { const char* name; size_t count; };
+    const Need arrays[] = {
+      {"arm_body", NARM}, {"free_body", NFREE}, {"body_parent", nbody}, {"body_jnttype", nbody}, {"body_pos", 3 * nbody}, {"body_quat", 4 * nbody},
+      {"body_ipos", 3 * nbody}, {"body_iquat", 4 * nbody}, {"body_mass", nbody}, {"body_inertia", 3 * nbody}, {"body_invweight0", 2 * nbody},
+      {"body_bvh_aabb", 6 * nbody}, {"opt_gravity", 3}, {"jnt_axis", 3 * NARM}, {"jnt_range", 2 * NARM}, {"dof_armature", NARM},
+      {"dof_frictionloss", NARM}, {"jnt_limited", NARM}, {"dof_invweight0", NV}, {"dof_damping", NARM}, {"jnt_solref", 2 * NARM},
+      {"jnt_solimp", 5 * NARM}, {"dof_solref", 2 * NARM}, {"dof_solimp", 5 * NARM}, {"act_gain", NU}, {"act_bias", 3 * NU},
+      {"act_ctrlrange", 2 * NU}, {"act_forcerange", 2 * NU}, {"act_ctrllimited", NU}, {"act_forcelimited", NU}, {"act_dof", NU},
+      {"task_box_pos", 3 * nbox}, {"task_box_half", 3 * nbox}, {"task_obj_pos_lo", 3}, {"task_obj_pos_hi", 3}, {"task_obj_yaw", 2},
+      {"task_con_pos_lo", 3}, {"task_con_pos_hi", 3}, {"task_home_ctrl", NU}, {"geom_type", ngeom}, {"geom_body", ngeom}, {"geom_condim", ngeom},
+      {"geom_vertadr", ngeom}, {"geom_vertnum", ngeom}, {"geom_pos", 3 * ngeom}, {"geom_quat", 4 * ngeom}, {"geom_size", 3 * ngeom},
+      {"geom_friction", 3 * ngeom}, {"geom_solref", 2 * ngeom}, {"geom_solimp", 5 * ngeom}, {"geom_center", 3 * ngeom}, {"geom_aabb", 6 * ngeom},
+      {"geom_solmix", ngeom}, {"geom_margin", ngeom}, {"geom_gap", ngeom}, {"geom_priority", ngeom}, {"mesh_vert", 3 * nvert}, {"pair_geom", 2 * npair}};
+    for (const Need& a : arrays) if (b.count(a.name) < a.count) return fail(std::string("blob entry missing or too short: ") + a.name);
+    auto in_range = [&](const char* name, size_t limit, bool allow_negative) {
+      for (int v : b.I(name)) if ((v < 0 && !allow_negative) || (v >= 0 && (size_t)v >= limit)) return false;
+      return true;
+    };
+    if (!in_range("arm_body", nbody, false) || !in_range("free_body", nbody, false) || !in_range("body_parent", nbody, false) ||
+        !in_range("geom_body", nbody, false) || !in_range("pair_geom", ngeom, false) || !in_range("task_object_body", nbody, false) ||
+        !in_range("task_container_body", nbody, false)) return fail("blob index array out of range");
+    auto gva = b.I("geom_vertadr"), gvn = b.I("geom_vertnum");
+    for (size_t g = 0; g < ngeom; g++) if (gvn[g] > 0 && (gva[g] < 0 || (size_t)gva[g] + (size_t)gvn[g] > nvert)) return fail("geom vertex range outside mesh_vert");
+  }
   DevModel& M = s->hm;
   int nq = b.I("nq")[0], nv = b.I("nv")[0], nu = b.I("nu")[0], nbody = b.I("nbody")[0], ngeom = b.I("ngeom")[0];
   int narm = b.I("narm")[0], nfree = b.I("nfree")[0];
@@ -270,8 +319,10 @@ int build_model(so101_sim* s, const BlobView& b) {
 
 // Launches k_prepare behind whatever `stream` holds now, unless the previous one is still running (it picks up
 // every env whose next episode is missing, so skipping a launch only delays the refill).
+bool prefetch_on(const so101_sim* s) { return s->cfg.prefetch_resets && s->prep_stream && s->cfg.solver == SO101_SOLVER_NEWTON; }
+
 void launch_prepare(so101_sim* s, hipStream_t stream) {
-  if (!s->cfg.prefetch_resets || !s->prep_stream) return;
+  if (!prefetch_on(s)) return;
   if (s->prep_pending) {
     if (hipEventQuery(s->prep_done) != hipSuccess) { (void)hipGetLastError(); return; }
     s->prep_pending = false;
@@ -279,7 +330,7 @@ void launch_prepare(so101_sim* s, hipStream_t stream) {
   if (hipEventRecord(s->main_ev, stream) != hipSuccess) return;
   if (hipStreamWaitEvent(s->prep_stream, s->main_ev, 0) != hipSuccess) return;
   if (hipMemsetAsync(s->prep.cursor, 0, sizeof(int), s->prep_stream) != hipSuccess) return;
-  hipLaunchKernelGGL(k_prepare, dim3(s->prep_waves), dim3(64), 0, s->prep_stream, s->dm, make_params(s), s->buf, s->prep);
+  so101::launch_prepare(s->prep_waves, s->prep_stream, s->dm, make_params(s), s->buf, s->prep);
   if (hipEventRecord(s->prep_done, s->prep_stream) == hipSuccess) s->prep_pending = true;
 }
 
@@ -287,6 +338,24 @@ bool drain_prepare(so101_sim* s) {
   if (!s->prep_stream) return true;
   s->prep_pending = false;
   return hip_ok(s, hipStreamSynchronize(s->prep_stream), "hipStreamSynchronize(prepare)");
+}
+
+// the cache the kernels see: none when the prefetch is off (PGS, or prefetch_resets = 0)
+PrepBuffers prep_view(const so101_sim* s) {
+  PrepBuffers C = s->prep;
+  if (!prefetch_on(s)) C.tag = nullptr;
+  return C;
+}
+
+template <typename T>
+bool dev_alloc(so101_sim* s, T** out, size_t count, int fill, const char* what) {
+  void* p = nullptr;
+  size_t bytes = sizeof(T) * (count ? count : 1);
+  if (!hip_ok(s, hipMalloc(&p, bytes), what)) return false;
+  s->owned.push_back(p);
+  if (!hip_ok(s, hipMemset(p, fill, bytes), what)) return false;
+  *out = (T*)p;
+  return true;
 }
 
 }  // namespace
@@ -314,57 +383,42 @@ int so101_create(const void* blob, size_t bytes, int n_envs, int device, uint64_
   BlobView b;
   int rc = SO101_OK;
   if (!b.parse(blob, bytes, s->err)) rc = SO101_ERR_MODEL;
-  if (rc == SO101_OK && !hip_ok(s, hipSetDevice(device), "hipSetDevice")) rc = SO101_ERR_HIP;
+  std::unique_ptr<DeviceGuard> guard;
+  if (rc == SO101_OK) { guard.reset(new DeviceGuard(s)); if (!guard->ok) rc = SO101_ERR_HIP; }
   if (rc == SO101_OK) rc = build_model(s, b);
+  size_t n = (size_t)n_envs;
   if (rc == SO101_OK) {
-    void* p = nullptr;
-    if (!hip_ok(s, hipMalloc(&p, n_envs), "hipMalloc(need_reset)")) rc = SO101_ERR_HIP;
-    else { s->owned.push_back(p); s->need_reset = (unsigned char*)p; if (!hip_ok(s, hipMemset(p, 1, n_envs), "hipMemset")) rc = SO101_ERR_HIP; }
+    bool ok = dev_alloc(s, &s->need_reset, n, 1, "hipMalloc(need_reset)") && dev_alloc(s, &s->diag, SO101_DIAG_DIM * n, 0, "hipMalloc(diag)") &&
+              dev_alloc(s, &s->ev.flags, n, 0, "hipMalloc(events)") && dev_alloc(s, &s->ev.events, (size_t)SO101_NEVENTS, 0, "hipMalloc(events)");
+    if (!ok) rc = SO101_ERR_HIP;
   }
   if (rc == SO101_OK) {
-    void* p = nullptr;
-    if (!hip_ok(s, hipMalloc(&p, sizeof(int) * SO101_DIAG_DIM * (size_t)n_envs), "hipMalloc(diag)")) rc = SO101_ERR_HIP;
-    else { s->owned.push_back(p); s->diag = (int*)p; if (!hip_ok(s, hipMemset(p, 0, sizeof(int) * SO101_DIAG_DIM * (size_t)n_envs), "hipMemset")) rc = SO101_ERR_HIP; }
-  }
-  if (rc == SO101_OK) {
-    size_t n = (size_t)n_envs;
-    void *q = nullptr, *v = nullptr, *w = nullptr, *t = nullptr, *c = nullptr;
-    bool ok = hip_ok(s, hipMalloc(&q, sizeof(float) * NQ * n), "hipMalloc(prep)") && hip_ok(s, hipMalloc(&v, sizeof(float) * NV * n), "hipMalloc(prep)") &&
-              hip_ok(s, hipMalloc(&w, sizeof(float) * NV * n), "hipMalloc(prep)") && hip_ok(s, hipMalloc(&t, sizeof(int) * n), "hipMalloc(prep)") &&
-              hip_ok(s, hipMalloc(&c, sizeof(int)), "hipMalloc(prep)");
-    for (void* p : {q, v, w, t, c}) if (p) s->owned.push_back(p);
-    ok = ok && hip_ok(s, hipMemset(t, 0xFF, sizeof(int) * n), "hipMemset(prep)");
+    PrepBuffers& C = s->prep;
+    bool ok = dev_alloc(s, &C.qpos, NQ * n, 0, "hipMalloc(prep)") && dev_alloc(s, &C.qvel, NV * n, 0, "hipMalloc(prep)") &&
+              dev_alloc(s, &C.warm, NV * n, 0, "hipMalloc(prep)") && dev_alloc(s, &C.tag, n, 0xFF, "hipMalloc(prep)") &&
+              dev_alloc(s, &C.cursor, (size_t)1, 0, "hipMalloc(prep)") && dev_alloc(s, &C.flags, n, 0, "hipMalloc(prep)");
     int lo = 0, hi = 0;
     ok = ok && hip_ok(s, hipDeviceGetStreamPriorityRange(&lo, &hi), "hipDeviceGetStreamPriorityRange") &&
          hip_ok(s, hipStreamCreateWithPriority(&s->prep_stream, hipStreamNonBlocking, lo), "hipStreamCreateWithPriority") &&
          hip_ok(s, hipEventCreateWithFlags(&s->prep_done, hipEventDisableTiming), "hipEventCreate") &&
          hip_ok(s, hipEventCreateWithFlags(&s->main_ev, hipEventDisableTiming), "hipEventCreate");
-    if (ok) {
-      s->prep = PrepBuffers{(float*)q, (float*)v, (float*)w, (int*)t, (int*)c};
-      // one wave per CU at most: the refill runs beside the stepping kernels, it must not crowd them out
-      s->prep_waves = n_envs < 256 ? n_envs : 256;
-    } else rc = SO101_ERR_HIP;
+    // one wave per CU at most: the refill runs beside the stepping kernels, it must not crowd them out
+    if (ok) s->prep_waves = n_envs < 256 ? n_envs : 256; else rc = SO101_ERR_HIP;
   }
   if (rc == SO101_OK) {
-    size_t n = (size_t)n_envs;
-    void *po = nullptr, *ca = nullptr, *nc = nullptr, *wk = nullptr, *ct = nullptr, *cr = nullptr, *ac = nullptr, *tk = nullptr, *sg = nullptr, *co = nullptr, *od = nullptr;
-    bool ok = hip_ok(s, hipMalloc(&po, sizeof(float) * NDYN * 12 * n), "hipMalloc(pipe)") && hip_ok(s, hipMalloc(&ca, sizeof(int) * MAXCAND * n), "hipMalloc(pipe)") &&
-              hip_ok(s, hipMalloc(&nc, sizeof(int) * n), "hipMalloc(pipe)") && hip_ok(s, hipMalloc(&wk, sizeof(int) * 2 * MAXCAND * n), "hipMalloc(pipe)") &&
-              hip_ok(s, hipMalloc(&ct, sizeof(int) * 2 * MAXSUB * so101_sim::MAXGROUPS), "hipMalloc(pipe)") && hip_ok(s, hipMalloc(&cr, sizeof(float) * 8 * MAXCAND * n), "hipMalloc(pipe)") &&
-              hip_ok(s, hipMalloc(&ac, n), "hipMalloc(pipe)") && hip_ok(s, hipMalloc(&tk, sizeof(int) * MAXCAND * n), "hipMalloc(pipe)") &&
-              hip_ok(s, hipMalloc(&sg, sizeof(int) * 8 * n), "hipMalloc(pipe)") && hip_ok(s, hipMalloc(&co, sizeof(int) * n), "hipMalloc(pipe)") &&
-              hip_ok(s, hipMalloc(&od, sizeof(int) * n), "hipMalloc(pipe)");
-    for (void* p : {po, ca, nc, wk, ct, cr, ac, tk, sg, co, od}) if (p) s->owned.push_back(p);
-    ok = ok && hip_ok(s, hipMemset(co, 0, sizeof(int) * n), "hipMemset(pipe)");
-    ok = ok && hip_ok(s, hipMemset(nc, 0, sizeof(int) * n), "hipMemset(pipe)") && hip_ok(s, hipMemset(ac, 0, n), "hipMemset(pipe)");
-    if (ok) {
-      s->pipe = PipeBuffers{(float*)po, (unsigned int*)ca, (int*)nc, (unsigned int*)wk, (int*)ct, (float*)cr, (unsigned char*)ac, (unsigned int*)sg, (unsigned int*)co, (int*)od, 0u, (unsigned int*)tk};
-      for (int g = 0; g < so101_sim::MAXGROUPS && ok; g++)
-        ok = hip_ok(s, hipStreamCreateWithFlags(&s->group_stream[g], hipStreamNonBlocking), "hipStreamCreate") &&
-             hip_ok(s, hipEventCreateWithFlags(&s->group_done[g], hipEventDisableTiming), "hipEventCreate");
-      ok = ok && hip_ok(s, hipEventCreateWithFlags(&s->step_begin, hipEventDisableTiming), "hipEventCreate");
-      if (!ok) rc = SO101_ERR_HIP;
-    } else rc = SO101_ERR_HIP;
+    PipeBuffers& W = s->pipe;
+    bool ok = dev_alloc(s, &W.pose, NDYN * 12 * n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.cand, MAXCAND * n, 0, "hipMalloc(pipe)") &&
+              dev_alloc(s, &W.ncand, n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.work, 2 * MAXCAND * n, 0, "hipMalloc(pipe)") &&
+              dev_alloc(s, &W.counters, (size_t)2 * MAXSUB * so101_sim::MAXGROUPS, 0, "hipMalloc(pipe)") &&
+              dev_alloc(s, &W.conres, 8 * MAXCAND * n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.active, n, 0, "hipMalloc(pipe)") &&
+              dev_alloc(s, &W.ticks, MAXCAND * n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.stage, 8 * n, 0, "hipMalloc(pipe)") &&
+              dev_alloc(s, &W.cost, n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.order, n, 0, "hipMalloc(pipe)");
+    W.work_cap = 0u;
+    for (int g = 0; g < so101_sim::MAXGROUPS && ok; g++)
+      ok = hip_ok(s, hipStreamCreateWithFlags(&s->group_stream[g], hipStreamNonBlocking), "hipStreamCreate") &&
+           hip_ok(s, hipEventCreateWithFlags(&s->group_done[g], hipEventDisableTiming), "hipEventCreate");
+    ok = ok && hip_ok(s, hipEventCreateWithFlags(&s->step_begin, hipEventDisableTiming), "hipEventCreate");
+    if (!ok) rc = SO101_ERR_HIP;
   }
   if (rc != SO101_OK) { g_create_error = s->err; so101_destroy(s); return rc; }
   *out = s;
@@ -373,15 +427,18 @@ int so101_create(const void* blob, size_t bytes, int n_envs, int device, uint64_
 
 void so101_destroy(so101_sim* s) {
   if (!s) return;
-  if (s->prep_stream) { (void)hipStreamSynchronize(s->prep_stream); (void)hipStreamDestroy(s->prep_stream); }
-  for (int g = 0; g < so101_sim::MAXGROUPS; g++) {
-    if (s->group_stream[g]) { (void)hipStreamSynchronize(s->group_stream[g]); (void)hipStreamDestroy(s->group_stream[g]); }
-    if (s->group_done[g]) (void)hipEventDestroy(s->group_done[g]);
+  {
+    DeviceGuard guard(s);
+    if (s->prep_stream) { (void)hipStreamSynchronize(s->prep_stream); (void)hipStreamDestroy(s->prep_stream); }
+    for (int g = 0; g < so101_sim::MAXGROUPS; g++) {
+      if (s->group_stream[g]) { (void)hipStreamSynchronize(s->group_stream[g]); (void)hipStreamDestroy(s->group_stream[g]); }
+      if (s->group_done[g]) (void)hipEventDestroy(s->group_done[g]);
+    }
+    if (s->step_begin) (void)hipEventDestroy(s->step_begin);
+    if (s->prep_done) (void)hipEventDestroy(s->prep_done);
+    if (s->main_ev) (void)hipEventDestroy(s->main_ev);
+    for (void* p : s->owned) (void)hipFree(p);
   }
-  if (s->step_begin) (void)hipEventDestroy(s->step_begin);
-  if (s->prep_done) (void)hipEventDestroy(s->prep_done);
-  if (s->main_ev) (void)hipEventDestroy(s->main_ev);
-  for (void* p : s->owned) (void)hipFree(p);
   delete s;
 }
 
@@ -389,6 +446,7 @@ int so101_configure(so101_sim* s, const so101_config* cfg) {
   if (!s || !cfg) return SO101_ERR_ARG;
   if (cfg->n_substeps <= 0 || cfg->settle_max_substeps < 0) { s->err = "so101_configure: bad substep counts"; return SO101_ERR_ARG; }
   if (cfg->solver != SO101_SOLVER_PGS && cfg->solver != SO101_SOLVER_NEWTON) { s->err = "so101_configure: unknown solver"; return SO101_ERR_ARG; }
+  GUARD_DEVICE(s);
   // cached initial states were settled under the old configuration
   if (!drain_prepare(s)) return SO101_ERR_HIP;
   if (s->prep.tag && !hip_ok(s, hipMemset(s->prep.tag, 0xFF, sizeof(int) * (size_t)s->n_envs), "hipMemset(prep)")) return SO101_ERR_HIP;
@@ -401,6 +459,11 @@ int so101_bind_state(so101_sim* s, const so101_buffers* b) {
   if (!b->qpos || !b->qvel || !b->ctrl || !b->warmstart || !b->obs_ring || !b->ep_return || !b->step_count || !b->episode) {
     s->err = "so101_bind_state: NULL buffer"; return SO101_ERR_ARG;
   }
+  GUARD_DEVICE(s);
+  // a prefetch in flight reads the OLD episode buffer: let it finish before the pointers change, and forget what it
+  // cached (the new buffers carry their own episode counters)
+  if (!drain_prepare(s)) return SO101_ERR_HIP;
+  if (s->bound && s->prep.tag && !hip_ok(s, hipMemset(s->prep.tag, 0xFF, sizeof(int) * (size_t)s->n_envs), "hipMemset(prep)")) return SO101_ERR_HIP;
   s->buf.qpos = b->qpos; s->buf.qvel = b->qvel; s->buf.ctrl = b->ctrl; s->buf.warm = b->warmstart; s->buf.ring = b->obs_ring;
   s->buf.ep_return = b->ep_return; s->buf.step_count = b->step_count; s->buf.episode = b->episode;
   s->bound = true;
@@ -412,7 +475,8 @@ int so101_bind_state(so101_sim* s, const so101_buffers* b) {
 
 int so101_reset(so101_sim* s, const uint8_t* mask, void* stream) {
   REQUIRE_BOUND(s);
-  hipLaunchKernelGGL(k_reset, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, make_params(s), s->buf, s->prep, mask, s->need_reset, s->diag);
+  GUARD_DEVICE(s);
+  so101::launch_reset(s->cfg.solver, s->n_envs, (hipStream_t)stream, s->dm, make_params(s), s->buf, prep_view(s), s->ev, mask, s->need_reset, s->diag);
   LAUNCH_CHECK(s, "k_reset");
   launch_prepare(s, (hipStream_t)stream);
   return SO101_OK;
@@ -420,7 +484,8 @@ int so101_reset(so101_sim* s, const uint8_t* mask, void* stream) {
 
 int so101_begin_episode(so101_sim* s, void* stream) {
   REQUIRE_BOUND(s);
-  hipLaunchKernelGGL(k_begin, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, make_params(s), s->buf, s->need_reset);
+  GUARD_DEVICE(s);
+  so101::launch_begin(s->n_envs, (hipStream_t)stream, s->dm, make_params(s), s->buf, s->need_reset);
   LAUNCH_CHECK(s, "k_begin");
   return SO101_OK;
 }
@@ -428,9 +493,13 @@ int so101_begin_episode(so101_sim* s, void* stream) {
 int so101_step(so101_sim* s, const float* action, float* obs, float* reward, float* discount, uint8_t* step_type, void* stream) {
   REQUIRE_BOUND(s);
   if (!action || !obs || !reward || !discount || !step_type) { s->err = "so101_step: NULL argument"; return SO101_ERR_ARG; }
-  if (s->cfg.pipeline && s->cfg.n_substeps <= MAXSUB) {
-    hipStream_t st = (hipStream_t)stream;
-    StepParams P = make_params(s);
+  GUARD_DEVICE(s);
+  hipStream_t st = (hipStream_t)stream;
+  StepParams P = make_params(s);
+  so101::StepIO io{action, obs, reward, discount, step_type};
+  PrepBuffers C = prep_view(s);
+  // the pipelined step is a Newton path; PGS (107 ms per control step at 4096 envs) runs the fused kernel
+  if (s->cfg.pipeline && s->cfg.n_substeps <= MAXSUB && s->cfg.solver == SO101_SOLVER_NEWTON) {
     int G = s->cfg.groups < 1 ? 1 : (s->cfg.groups > 3 ? 3 : s->cfg.groups);
     int n = s->n_envs;
     if (n < 64) G = 1;
@@ -442,13 +511,15 @@ int so101_step(so101_sim* s, const float* action, float* obs, float* reward, flo
     if (G == 2) bounds[1] = n / 2;
     if (G == 3) { bounds[1] = n / 4; bounds[2] = (5 * n) / 8; }
     bounds[G] = n;
-    static const char* dbg_bounds = getenv("SO101_DEBUG_BOUNDS");     // experiment aid: "128,1024" = slice ends
+#ifdef SO101_DEBUG_CLOCKS
+    static const char* dbg_bounds = getenv("SO101_DEBUG_BOUNDS");     // profiling builds: "128,1024" = slice ends
     if (dbg_bounds) {
       G = 0; bounds[0] = 0;
       for (const char* p = dbg_bounds; *p && G < so101_sim::MAXGROUPS - 1;) { int v = atoi(p); if (v > bounds[G] && v < n) bounds[++G] = v; while (*p && *p != ',') p++; if (*p) p++; }
       bounds[++G] = n;
     }
-    hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, s->pipe.cost, s->pipe.order, 0, n);
+#endif
+    so101::launch_order(st, s->pipe.cost, s->pipe.order, n);
     LAUNCH_CHECK(s, "k_order");
     if (G > 1 && !hip_ok(s, hipEventRecord(s->step_begin, st), "hipEventRecord")) return SO101_ERR_HIP;
     for (int g = 0; g < G; g++) {
@@ -465,12 +536,10 @@ int so101_step(so101_sim* s, const float* action, float* obs, float* reward, flo
       int nw = ng * 2 < 4096 ? ng * 2 : 4096;
       if (G > 1 && !hip_ok(s, hipStreamWaitEvent(gs, s->step_begin, 0), "hipStreamWaitEvent")) return SO101_ERR_HIP;
       if (!hip_ok(s, hipMemsetAsync(W.counters, 0, sizeof(int) * 2 * MAXSUB, gs), "hipMemsetAsync(pipe)")) return SO101_ERR_HIP;
-      hipLaunchKernelGGL(k_pipe_begin, dim3(ng), dim3(64), 0, gs, s->dm, P, s->buf, s->prep, W, action, obs, reward, discount,
-                         step_type, s->need_reset, s->diag, e0);
+      so101::launch_pipe_begin(ng, gs, s->dm, P, s->buf, C, s->ev, W, io, s->need_reset, s->diag, e0);
       for (int k = 0; k < P.n_substeps; k++) {
-        hipLaunchKernelGGL(k_narrow, dim3(nw), dim3(64), 0, gs, s->dm, s->n_envs, W, k);
-        hipLaunchKernelGGL(k_pipe_solve, dim3(ng), dim3(64), 0, gs, s->dm, P, s->buf, W, k, (int)(k == P.n_substeps - 1), obs, reward,
-                           discount, step_type, s->need_reset, s->diag, e0);
+        so101::launch_narrow(nw, gs, s->dm, s->n_envs, W, k);
+        so101::launch_pipe_solve(ng, gs, s->dm, P, s->buf, s->ev, W, k, (int)(k == P.n_substeps - 1), io, s->need_reset, s->diag, e0);
       }
       LAUNCH_CHECK(s, "k_pipe_solve");
       if (G > 1 && !(hip_ok(s, hipEventRecord(s->group_done[g], gs), "hipEventRecord") &&
@@ -479,17 +548,17 @@ int so101_step(so101_sim* s, const float* action, float* obs, float* reward, flo
     launch_prepare(s, st);
     return SO101_OK;
   }
-  hipLaunchKernelGGL(k_step, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, make_params(s), s->buf, s->prep, action, obs, reward,
-                     discount, step_type, s->need_reset, s->diag);
+  so101::launch_step(s->cfg.solver, s->n_envs, st, s->dm, P, s->buf, C, s->ev, io, s->need_reset, s->diag);
   LAUNCH_CHECK(s, "k_step");
-  launch_prepare(s, (hipStream_t)stream);
+  launch_prepare(s, st);
   return SO101_OK;
 }
 
 int so101_physics(so101_sim* s, int nsub, int freeze, void* stream) {
   REQUIRE_BOUND(s);
   if (nsub < 0) return SO101_ERR_ARG;
-  hipLaunchKernelGGL(k_physics, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, make_params(s), s->buf, nsub, freeze, s->diag);
+  GUARD_DEVICE(s);
+  so101::launch_physics(s->cfg.solver, s->n_envs, (hipStream_t)stream, s->dm, make_params(s), s->buf, nsub, freeze, s->diag);
   LAUNCH_CHECK(s, "k_physics");
   return SO101_OK;
 }
@@ -497,7 +566,8 @@ int so101_physics(so101_sim* s, int nsub, int freeze, void* stream) {
 int so101_reward(so101_sim* s, float* reward, void* stream) {
   REQUIRE_BOUND(s);
   if (!reward) return SO101_ERR_ARG;
-  hipLaunchKernelGGL(k_reward, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, make_params(s), s->buf, reward);
+  GUARD_DEVICE(s);
+  so101::launch_reward(s->n_envs, (hipStream_t)stream, s->dm, make_params(s), s->buf, reward);
   LAUNCH_CHECK(s, "k_reward");
   return SO101_OK;
 }
@@ -505,6 +575,7 @@ int so101_reward(so101_sim* s, float* reward, void* stream) {
 int so101_get_returns(so101_sim* s, float* out, void* stream) {
   REQUIRE_BOUND(s);
   if (!out) return SO101_ERR_ARG;
+  GUARD_DEVICE(s);
   if (!hip_ok(s, hipMemcpyAsync(out, s->buf.ep_return, sizeof(float) * (size_t)s->n_envs, hipMemcpyDeviceToDevice, (hipStream_t)stream), "hipMemcpyAsync(returns)"))
     return SO101_ERR_HIP;
   return SO101_OK;
@@ -512,26 +583,39 @@ int so101_get_returns(so101_sim* s, float* out, void* stream) {
 
 int so101_get_diag(so101_sim* s, int32_t* out, void* stream) {
   if (!s || !out) return SO101_ERR_ARG;
+  GUARD_DEVICE(s);
   if (!hip_ok(s, hipMemcpyAsync(out, s->diag, sizeof(int) * SO101_DIAG_DIM * (size_t)s->n_envs, hipMemcpyDeviceToDevice, (hipStream_t)stream), "hipMemcpyAsync(diag)"))
     return SO101_ERR_HIP;
+  return SO101_OK;
+}
+
+int so101_get_events(so101_sim* s, uint64_t* out, int clear, void* stream) {
+  if (!s || !out) return SO101_ERR_ARG;
+  GUARD_DEVICE(s);
+  hipStream_t st = (hipStream_t)stream;
+  if (!hip_ok(s, hipMemcpyAsync(out, s->ev.events, sizeof(uint64_t) * SO101_NEVENTS, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync(events)")) return SO101_ERR_HIP;
+  if (clear && !hip_ok(s, hipMemsetAsync(s->ev.events, 0, sizeof(uint64_t) * SO101_NEVENTS, st), "hipMemsetAsync(events)")) return SO101_ERR_HIP;
   return SO101_OK;
 }
 
 int so101_debug_forward(so101_sim* s, float* out, void* stream) {
   REQUIRE_BOUND(s);
   if (!out) return SO101_ERR_ARG;
-  hipLaunchKernelGGL(k_debug_forward, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, make_params(s), s->buf, out);
+  GUARD_DEVICE(s);
+  so101::launch_debug_forward(s->cfg.solver, s->n_envs, (hipStream_t)stream, s->dm, make_params(s), s->buf, out);
   LAUNCH_CHECK(s, "k_debug_forward");
   return SO101_OK;
 }
 
 int so101_debug_stages(so101_sim* s, uint32_t* stage, void* stream) {
   if (!s || !stage) return SO101_ERR_ARG;
+  GUARD_DEVICE(s);
   return hip_ok(s, hipMemcpyAsync(stage, s->pipe.stage, sizeof(int) * 8 * (size_t)s->n_envs, hipMemcpyDeviceToDevice, (hipStream_t)stream), "hipMemcpyAsync(debug)") ? SO101_OK : SO101_ERR_HIP;
 }
 
 int so101_debug_candidates(so101_sim* s, int32_t* ncand, uint32_t* cand, uint32_t* ticks, float* conres, void* stream) {
   if (!s) return SO101_ERR_ARG;
+  GUARD_DEVICE(s);
   size_t n = (size_t)s->n_envs;
   hipStream_t st = (hipStream_t)stream;
   bool ok = true;

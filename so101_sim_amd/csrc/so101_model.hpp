@@ -117,6 +117,66 @@ struct EnvLDS {
   Row1 row[MAXROW1];
   NewtonScratch nw;
   int ncand, ncon, nrow, narmcon, iters, overflow;
-  unsigned int t_collision, t_solve, t_begin;   // stage clocks, 10 ns ticks
+  unsigned int t_collision, t_solve, t_begin;   // stage clocks, 10 ns ticks (SO101_DEBUG_CLOCKS builds)
   float scratch[64];
 };
+
+// Caller-owned per-env state (so101_buffers of include/so101.h), struct-of-arrays with the env index fastest.
+struct DevBuffers {
+  float *qpos, *qvel, *ctrl, *warm, *ring, *ep_return;
+  int *step_count, *episode;
+};
+
+// Library-owned cache of settled initial states.  The settled state of an episode is a pure function of
+// (seed, global env id, episode index, config), so it can be computed ahead of time: k_prepare() fills the
+// cache on a side stream while the envs are stepping and env_reset() consumes an entry when its tag matches the
+// episode that is about to start; otherwise env_reset() settles in place.  Either way the result is the same
+// bits, only the time at which the work is done differs.
+struct PrepBuffers {
+  float *qpos, *qvel, *warm;   // [NQ|NV|NV][n_envs]
+  int *tag;                    // episode index the entry belongs to, -1 = empty
+  int *cursor;                 // work-queue head of k_prepare
+  int *flags;                  // [n_envs] flag word of the settle that produced the entry (placement / settle failures)
+};
+
+// Event accounting (so101_get_events): flags[e] ORs the per-substep flag words of env e within one control step;
+// events[b] counts env-steps (bits 0-3) or env-resets (bits 4-5) on which bit b was set.
+//   bit 0 broadphase candidate overflow, 1 contact overflow (MAXCON), 2 arm-contact pool overflow, 3 physics
+//   diverged (mj_check*: episode ends like a dm_control PhysicsError), 4 container placement rejected 20 times,
+//   5 settle did not converge within its budget
+struct EventBuffers {
+  int* flags;                        // [n_envs]
+  unsigned long long* events;        // [SO101_NEVENTS]
+};
+#define SO101_NEVENTS 8
+
+#define MAXSUB 32
+
+// Scratch of the pipelined step (so101_pipeline.hpp)
+struct PipeBuffers {
+  float* pose;            // [N][NDYN][12] xpos, xmat of the dynamic bodies
+  unsigned int* cand;     // [N][MAXCAND]  geom1 | geom2 << 16, in pair-list order
+  int* ncand;             // [N]           count | broadphase overflow flag << 16
+  unsigned int* work;     // [2][work_cap] env * MAXCAND + k, double buffered over substeps (per env group)
+  int* counters;          // [MAXSUB][2]   work items, cursor
+  float* conres;          // [N][MAXCAND][8] dist, normal, position, valid
+  unsigned char* active;  // [N] 0 not stepping in this call (auto-reset), 1 stepping, 2 diverged
+  unsigned int* stage;    // [N][8] k_pipe_solve stage clocks of the last substep (10 ns ticks; SO101_DEBUG_CLOCKS builds)
+  unsigned int* cost;     // [N] solver time of the env in its last substep (ticks): scheduling hint only
+  int* order;             // [N] per group: env indices sorted by decreasing cost, see k_order
+  unsigned int work_cap;  // capacity of one work list = envs of the group * MAXCAND
+  unsigned int* ticks;    // [N][MAXCAND] narrowphase time of each candidate (10 ns ticks; SO101_DEBUG_CLOCKS builds)
+};
+
+// debug dump layout (floats) of so101_debug_forward
+#define DBG_M 0          // 36  arm mass matrix
+#define DBG_MINV 36      // 36
+#define DBG_BIAS 72      // 6
+#define DBG_SMOOTH 78    // 18  qacc_smooth (generalized)
+#define DBG_QACC 96      // 18  qacc after the solve
+#define DBG_COUNTS 114   // ncon, nrow, iters, ncand, overflow
+#define DBG_XPOS 120     // 8*3 dynamic body positions
+#define DBG_CON 144      // MAXCON * 10: pos3 normal3 dist g1 g2 dim
+#define DBG_FORCE 464    // MAXCON * 6
+#define DBG_ROWF 656     // MAXROW1
+#define DBG_REWARD 672

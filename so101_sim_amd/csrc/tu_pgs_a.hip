@@ -1,0 +1,16 @@
+// Translation unit: PGS instantiations of the fused step and of env.reset().  PGS (the solver BASELINE.json's
+// north_star names) runs the fused path only: the pipelined step and the reset prefetch are Newton kernels.
+#include "so101_kernels.hpp"
+#include "so101_launch.hpp"
+
+namespace so101 {
+void launch_step_pgs(int n_envs, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B, const PrepBuffers& C,
+                     const EventBuffers& E, const StepIO& io, unsigned char* need_reset, int* diag) {
+  hipLaunchKernelGGL(k_step<0>, dim3(n_envs), dim3(64), 0, st, m, P, B, C, E, io.action, io.obs, io.reward, io.discount, io.step_type,
+                     need_reset, diag);
+}
+void launch_reset_pgs(int n_envs, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B, const PrepBuffers& C,
+                      const EventBuffers& E, const unsigned char* mask, unsigned char* need_reset, int* diag) {
+  hipLaunchKernelGGL(k_reset<0>, dim3(n_envs), dim3(64), 0, st, m, P, B, C, E, mask, need_reset, diag);
+}
+}  // namespace so101

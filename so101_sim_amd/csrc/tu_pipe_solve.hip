@@ -1,0 +1,130 @@
+// Translation unit: the per-substep kernels of the pipelined control step (see so101_pipeline.hpp).
+#include "so101_pipeline.hpp"
+#include "so101_launch.hpp"
+
+// One wavefront per candidate pair.  No LDS; the two geoms (and the first 512 vertices of their hulls) live in
+// registers.  Work items are taken NARROW_CHUNK at a time: one atomic and one dependent pair of loads per chunk
+// instead of per item (that chain costs ~3 us, an MPR query on two boxes ~7 us).
+#define NARROW_CHUNK 4
+__global__ void __launch_bounds__(64, 2) k_narrow(const DevModel* m, int N, PipeBuffers W, int s) {
+  int lane = wave_lane();
+  int nwork = W.counters[2 * s];
+  const unsigned int* list = W.work + (size_t)(s & 1) * W.work_cap;
+  for (;;) {
+    int i0 = 0;
+    if (lane == 0) i0 = atomicAdd(&W.counters[2 * s + 1], NARROW_CHUNK);
+    i0 = wave_uniform_i(i0);
+    if (i0 >= nwork) break;
+    unsigned int wl = 0, cl = 0;
+    if (lane < NARROW_CHUNK && i0 + lane < nwork) { wl = list[i0 + lane]; cl = W.cand[wl]; }
+    // not unrolled: four inlined copies of the MPR query are ~130 KB of code, more than the instruction cache holds
+#pragma unroll 1
+    for (int j = 0; j < NARROW_CHUNK; j++) {
+      if (i0 + j >= nwork) break;
+      unsigned long long t0 = SO101_CLOCK();
+      unsigned int w = (unsigned int)__builtin_amdgcn_readlane((int)wl, j), c = (unsigned int)__builtin_amdgcn_readlane((int)cl, j);
+      int e = (int)(w / MAXCAND), g1 = (int)(c & 0xffffu), g2 = (int)(c >> 16);
+      const float* pose = W.pose + (size_t)e * (NDYN * 12);
+      int d1 = ldc(ldc(&m->geom_dyn) + g1), d2 = ldc(ldc(&m->geom_dyn) + g2);
+      const float* p1 = pose + 12 * (d1 < 0 ? 0 : d1); const float* p2 = pose + 12 * (d2 < 0 ? 0 : d2);
+      GeomW G1, G2;
+      load_geom_at(m, g1, p1, p1 + 3, G1); load_geom_at(m, g2, p2, p2 + 3, G2);
+      float dist, nrm[3], pos[3];
+      bool ok = narrow_pair<HullCache>(m, G1, G2, &dist, nrm, pos);
+      if (lane == 0) {
+        float* r = W.conres + (size_t)w * 8;
+        r[0] = dist; r[1] = nrm[0]; r[2] = nrm[1]; r[3] = nrm[2]; r[4] = pos[0]; r[5] = pos[1]; r[6] = pos[2]; r[7] = ok ? 1.f : 0.f;
+        if (SO101_CLOCKS_ON) W.ticks[w] = (unsigned int)(SO101_CLOCK() - t0);
+      }
+    }
+  }
+}
+
+// Longest-processing-time-first launch order for k_pipe_solve.  A launch ends with its slowest env (Newton iteration
+// counts: mean 2.7, max ~19) and workgroups are dispatched in index order, so envs that were expensive in the
+// previous control step go first: counting sort of the group's envs by log2(cost), descending.  The order only
+// changes WHEN an env is processed, never its result.  One workgroup for the whole batch.
+__global__ void __launch_bounds__(1024) k_order(const unsigned int* cost, int* order, int e0, int ng) {   // e0 = 0, ng = N
+  __shared__ int hist[32], start[32];
+  int t = threadIdx.x;
+  if (t < 32) hist[t] = 0;
+  __syncthreads();
+  for (int i = t; i < ng; i += 1024) {
+    unsigned int c = cost[e0 + i];
+    int b = c ? __clz((int)c) : 31;                      // large cost -> small bucket index (factor-of-two buckets)
+    atomicAdd(&hist[b], 1);
+  }
+  __syncthreads();
+  if (t == 0) { int acc = 0; for (int b = 0; b < 32; b++) { start[b] = acc; acc += hist[b]; } }
+  __syncthreads();
+  for (int i = t; i < ng; i += 1024) {
+    unsigned int c = cost[e0 + i];
+    int b = c ? __clz((int)c) : 31;
+    order[e0 + atomicAdd(&start[b], 1)] = e0 + i;
+  }
+}
+
+__global__ void __launch_bounds__(64, 2) k_pipe_solve(const DevModel* m, StepParams P, DevBuffers B, EventBuffers E, PipeBuffers W, int s, int last,
+                                                   float* obs, float* reward, float* discount, unsigned char* step_type,
+                                                   unsigned char* need_reset, int* diag, int e0) {
+  __shared__ EnvLDS L;
+  int e = wave_uniform_i(W.order[e0 + blockIdx.x]), lane = wave_lane(), N = P.n_envs;
+  int act = W.active[e];
+  if (act == 0) return;
+  int sc = B.step_count[e] + 1;
+  unsigned long long c0 = SO101_CLOCK(), c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0;
+  load_state(L, B, e, N);
+  bool diverged = act == 2;
+  if (!diverged) {
+    forward_smooth(m, L);
+    c1 = SO101_CLOCK();
+    gather_contacts(m, L, W, e);
+    c2 = SO101_CLOCK();
+    unsigned long long t_solve0 = wall_clock64();            // scheduling hint of k_order: always measured
+    make_constraints(m, L, false);
+    c3 = SO101_CLOCK();
+    solve_newton(m, L, P.iterations, P.tolerance);
+    c4 = SO101_CLOCK();
+    forward_accelerations(L);
+    if (lane == 0) { unsigned int dt = (unsigned int)(wall_clock64() - t_solve0); L.t_solve += dt; W.cost[e] = dt; }
+    euler(m, L);
+    diverged = check_divergence(L);
+    if (diverged && lane == 0) W.active[e] = 2;
+    c5 = SO101_CLOCK();
+  } else {
+    if (lane == 0) { L.ncon = 0; L.nrow = 0; L.iters = 0; L.ncand = 0; L.overflow = 8; }
+    wave_sync();
+  }
+  if (!last) {
+    store_state(L, B, e, N);
+    if (!diverged) {
+      kinematics(m, L);
+      broadphase(m, L);
+      publish_candidates(L, W, e, N, s + 1);
+    } else if (lane == 0) W.ncand[e] = 0;
+    if (lane == 0) {
+      if (L.overflow) E.flags[e] |= L.overflow;          // rare; summed into the event counters by finish_step()
+      if (SO101_CLOCKS_ON) {
+        unsigned int* st = W.stage + (size_t)e * 8;
+        st[0] = (unsigned int)(c1 - c0); st[1] = (unsigned int)(c2 - c1); st[2] = (unsigned int)(c3 - c2); st[3] = (unsigned int)(c4 - c3);
+        st[4] = (unsigned int)(c5 - c4); st[5] = (unsigned int)(SO101_CLOCK() - c5); st[6] = (unsigned int)L.ncon; st[7] = (unsigned int)L.iters;
+      }
+    }
+    return;
+  }
+  finish_step(m, L, P, B, e, sc, diverged, obs, reward, discount, step_type, need_reset, diag, E);
+}
+
+namespace so101 {
+void launch_order(hipStream_t st, const unsigned int* cost, int* order, int n_envs) {
+  hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, cost, order, 0, n_envs);
+}
+void launch_narrow(int waves, hipStream_t st, const DevModel* m, int n_envs, const PipeBuffers& W, int substep) {
+  hipLaunchKernelGGL(k_narrow, dim3(waves), dim3(64), 0, st, m, n_envs, W, substep);
+}
+void launch_pipe_solve(int n_group, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B, const EventBuffers& E,
+                       const PipeBuffers& W, int substep, int last, const StepIO& io, unsigned char* need_reset, int* diag, int e0) {
+  hipLaunchKernelGGL(k_pipe_solve, dim3(n_group), dim3(64), 0, st, m, P, B, E, W, substep, last, io.obs, io.reward, io.discount, io.step_type,
+                     need_reset, diag, e0);
+}
+}  // namespace so101

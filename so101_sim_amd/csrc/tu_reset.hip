@@ -1,0 +1,14 @@
+// Translation unit: env.reset() and the reset prefetch (Newton).
+#include "so101_kernels.hpp"
+#include "so101_launch.hpp"
+
+namespace so101 {
+void launch_reset(int solver, int n_envs, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B,
+                  const PrepBuffers& C, const EventBuffers& E, const unsigned char* mask, unsigned char* need_reset, int* diag) {
+  if (solver == 0) { launch_reset_pgs(n_envs, st, m, P, B, C, E, mask, need_reset, diag); return; }
+  hipLaunchKernelGGL(k_reset<1>, dim3(n_envs), dim3(64), 0, st, m, P, B, C, E, mask, need_reset, diag);
+}
+void launch_prepare(int waves, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B, const PrepBuffers& C) {
+  hipLaunchKernelGGL(k_prepare<1>, dim3(waves), dim3(64), 0, st, m, P, B, C);
+}
+}  // namespace so101

@@ -16,6 +16,9 @@ OBS_DIM = 18
 ACT_DIM = 6
 RING_DEPTH = 5
 DIAG_DIM = 8
+NEVENTS = 8
+EVENT_NAMES = ("candidate_overflow", "contact_overflow", "arm_pool_overflow", "diverged", "placement_rejected",
+               "settle_not_converged")
 DEBUG_DIM = 1024
 
 # debug_forward layout (csrc/so101_kernels.hpp DBG_*)
@@ -24,7 +27,7 @@ DBG = dict(M=0, MINV=36, BIAS=72, SMOOTH=78, QACC=96, COUNTS=114, XPOS=120, CON=
 EXPORTS = (
     "so101_version", "so101_max_contacts", "so101_create", "so101_destroy", "so101_default_config",
     "so101_configure", "so101_bind_state", "so101_reset", "so101_begin_episode", "so101_step", "so101_physics", "so101_reward",
-    "so101_get_returns", "so101_get_diag", "so101_debug_forward", "so101_debug_candidates", "so101_debug_stages", "so101_last_error",
+    "so101_get_returns", "so101_get_diag", "so101_get_events", "so101_debug_forward", "so101_debug_candidates", "so101_debug_stages", "so101_last_error",
 )
 
 
@@ -76,6 +79,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.so101_reward.argtypes = [vp, vp, vp]
     L.so101_get_returns.argtypes = [vp, vp, vp]
     L.so101_get_diag.argtypes = [vp, vp, vp]
+    L.so101_get_events.argtypes = [vp, vp, C.c_int, vp]
     L.so101_debug_forward.argtypes = [vp, vp, vp]
     L.so101_debug_candidates.argtypes = [vp, vp, vp, vp, vp, vp]
     L.so101_debug_stages.argtypes = [vp, vp, vp]
@@ -151,6 +155,9 @@ class Sim:
 
     def get_diag(self, out, stream=0):
         self._check(self.L.so101_get_diag(self.h, out, stream), "so101_get_diag")
+
+    def get_events(self, out, clear=False, stream=0):
+        self._check(self.L.so101_get_events(self.h, out, int(bool(clear)), stream), "so101_get_events")
 
     def debug_candidates(self, ncand=None, cand=None, ticks=None, conres=None, stream=0):
         self._check(self.L.so101_debug_candidates(self.h, ncand, cand, ticks, conres, stream), "so101_debug_candidates")

@@ -7,3 +7,10 @@ float emu_xchg_f[64];
 int emu_xchg_i[64];
 unsigned long long emu_xchg_u;
 #include "../../so101_sim_amd/csrc/so101_hip.hip"
+#include "../../so101_sim_amd/csrc/tu_step.hip"
+#include "../../so101_sim_amd/csrc/tu_reset.hip"
+#include "../../so101_sim_amd/csrc/tu_misc.hip"
+#include "../../so101_sim_amd/csrc/tu_pipe_begin.hip"
+#include "../../so101_sim_amd/csrc/tu_pipe_solve.hip"
+#include "../../so101_sim_amd/csrc/tu_pgs_a.hip"
+#include "../../so101_sim_amd/csrc/tu_pgs_b.hip"

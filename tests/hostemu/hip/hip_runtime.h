@@ -46,6 +46,7 @@ inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStrea
 inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return 0; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
 inline hipError_t hipSetDevice(int) { return 0; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
 // streams and events: launches are synchronous here, so these only have to exist
 typedef void* hipEvent_t;
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
@@ -64,6 +65,7 @@ inline unsigned long long wall_clock64() { return 0ull; }
 inline int __builtin_amdgcn_readlane(int v, int l) { emu_xchg_i[threadIdx.x] = v; __syncthreads(); int r = emu_xchg_i[l]; __syncthreads(); return r; }
 inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline hipError_t hipGetLastError() { return 0; }
 

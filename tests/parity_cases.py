@@ -200,15 +200,22 @@ def check_env_semantics(make_sim, blobs, n=2, settle=30, steps=8, last_step=7, s
         oracles.append(o)
     rng = np.random.RandomState(seed)
     undelayed_hist = []
+    touched = [False] * n          # the arm has been in contact during this episode
     for t in range(1, steps + 1):
         act = rng.uniform(-0.4, 0.4, size=(n, 6)).astype(np.float32)
         obs, rew, disc, st = sim.step(act)
         for e, o in enumerate(oracles):
             oo, orew, odisc, ost = o.env_step(act[e].astype(np.float64))
             assert (rew[e], disc[e], st[e]) == (orew, odisc, ost), (t, e)
-            if ost != 0:
-                np.testing.assert_allclose(obs[e, 6:12], oo[6:12], atol=5e-5)
-                np.testing.assert_allclose(obs[e, 0:6], oo[0:6], atol=5e-5)
+            if ost == 0:
+                touched[e] = False
+            else:
+                touched[e] = touched[e] or any(_arm_geom(c["geom1"]) or _arm_geom(c["geom2"]) for c in o.contacts())
+                # free-space arm: fp32 vs fp64 round-off only.  Once the arm pushes against the table or a prop, the
+                # joint trajectory depends on the contact phase (same bound as check_control_step)
+                tol = 5e-3 if touched[e] else 5e-5
+                np.testing.assert_allclose(obs[e, 6:12], oo[6:12], atol=tol)
+                np.testing.assert_allclose(obs[e, 0:6], oo[0:6], atol=tol)
                 np.testing.assert_array_equal(obs[e, 12:18], act[e])          # commanded = raw action (offsets 0)
         undelayed_hist.append(obs[:, 6:12].copy())
         if t <= last_step:

@@ -20,7 +20,7 @@ def test_native_library_is_the_hip_build():
     import os
     from so101_sim_amd import native
     assert os.path.exists(native.LIB_PATH)
-    assert native.load_library().so101_version() == 2
+    assert native.load_library().so101_version() == 3
 
 
 def test_forward_stages(make_sim, blobs):
@@ -146,8 +146,9 @@ def test_properties_at_benchmark_size(make_sim, blobs):
     assert np.all(np.isfinite(q)) and np.all(np.isfinite(v))
     rlo = np.array([-2.2, -3.14158, 0, -2, -3.14158, -0.2])[:, None]
     rhi = np.array([2.2, 0.2, 3.14158, 1.8, 3.14158, 2])[:, None]
-    # joint limits are soft rows (solref 0.02) against 35 N.m motors at up to ~90 rad/s: bounded overshoot only
-    assert np.all(q[:6] > rlo - 1.0) and np.all(q[:6] < rhi + 1.0)
+    # joint limits are soft rows (solref 0.02: stiffness ~2.8e3 s^-2) against 35 N.m motors on ~0.1 kg m^2 links
+    # arriving at up to ~90 rad/s: the overshoot is v / sqrt(k) ~ 1.7 rad at worst, bounded but not small
+    assert np.all(q[:6] > rlo - 2.5) and np.all(q[:6] < rhi + 2.5)
     d = sim.get_diag()
     assert np.all(d[:, 4] == 0), "contact/candidate overflow at benchmark size"
     ep = sim._get(sim.ep_return)
