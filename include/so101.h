@@ -156,12 +156,12 @@ int so101_get_events(so101_sim* sim, uint64_t* out, int clear, void* hip_stream)
 
 /* Stage dump of one forward pass (no integration) for parity tests against the oracle:
  * out is [N][SO101_DEBUG_DIM] float32; layout documented in csrc/so101_device.hpp (DBG_*). */
-#define SO101_DEBUG_DIM 1024
+#define SO101_DEBUG_DIM 2048
 int so101_debug_forward(so101_sim* sim, float* out, void* hip_stream);
 
 /* Diagnostics of the pipelined step's last narrowphase launch (device buffers, any may be NULL):
  * ncand[N] (count | overflow << 16), cand[N][256] (geom1 | geom2 << 16), ticks[N][256] (10 ns per candidate),
- * conres[N][256][8] (dist, normal, position, valid). */
+ * conres[N][256][24] (contact count, normal, 5 x (dist, position)). */
 /* (profiling builds, -DSO101_DEBUG_CLOCKS; zeros otherwise) Stage clocks of k_pipe_solve's second-to-last substep: stage[N][8] = smooth dynamics, contact gather, constraint
  * rows, solver, integrate, next broadphase (10 ns ticks), ncon, solver iterations. */
 int so101_debug_stages(so101_sim* sim, uint32_t* stage, void* hip_stream);

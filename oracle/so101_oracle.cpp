@@ -624,6 +624,69 @@ void set_contact_params(const Model& m, Contact& c, int g1, int g2) {
   for (int k = 0; k < 5; k++) c.solimp[k] = mix * m.geom_solimp[5 * g1 + k] + (1 - mix) * m.geom_solimp[5 * g2 + k];
 }
 
+// ---------------------------------------------------------------- multi-contact for flat faces ("multiccd")
+// The reference enables mjENBL_MULTICCD (so101_sim/tasks/base/so100_task.py:151).  MuJoCo's convex-pair multi-contact
+// re-runs the penetration query on configurations tilted by +-1e-3 rad about the two tangent axes and keeps results
+// farther apart than 1e-3 of the smaller bounding radius (libccd path); the native-ccd path of >= 3.3 clips the
+// aligned faces of box / mesh pairs.  Both amount to sampling the extreme points of the flat contact patch.  Restated
+// here for the configurations in which the tilted query has a closed form: one geom presents a flat REFERENCE FACE
+// (the plane, or the face of a box whose outward normal is within acos(FACE_COS) of the contact normal) and the other
+// geom (any convex type, the INCIDENT geom) is sampled with its support function:
+//   a_0 = support(-f)                       deepest point below the face (f = outward face normal)
+//   a_k = support(-f + eps * s_k), k=1..4   s_k = (+-u +- v)/sqrt(2), u/v the face axes, eps = 1e-3 (the tilt angle)
+// A sample is a contact if it lies below the face plane, inside the face rectangle, and farther than
+// 1e-3 * min(rbound) from the contacts (positions) already accepted.  All contacts of the pair share the normal +-f.  When a_0
+// does not qualify the single MPR contact is kept.  Other convex pairs (hull-hull, cylinder, capsule) keep one contact.
+constexpr real FACE_COS = 0.9999, PATCH_EPS = 1e-3, PATCH_DUP = 1e-3;
+constexpr int NCPP = 5;
+
+struct Patch { int n; real nrm[3], dist[NCPP], pos[NCPP][3]; };
+
+// reference face: outward normal f (towards the incident geom), point c on it, axes u, v with half extents hu, hv
+// (hu < 0: unbounded plane); dup_tol: minimal distance between two contacts of the pair
+bool face_patch(const orc_sim* s, int gI, const real* f, const real* c, const real* u, const real* v, real hu, real hv,
+                real dup_tol, Patch* out) {
+  out->n = 0;
+  static const real su[4] = {1, -1, -1, 1}, sv[4] = {1, 1, -1, -1};
+  for (int k = 0; k < NCPP; k++) {
+    real d[3];
+    for (int i = 0; i < 3; i++) d[i] = -f[i] + (k == 0 ? 0.0 : PATCH_EPS * (su[k - 1] * u[i] + sv[k - 1] * v[i]) * 0.70710678118654752440);
+    normalize3(d);
+    real p[3]; support(s, gI, d, p);
+    real rel[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]};
+    real dist = dot3(rel, f);
+    bool ok = dist < 0;
+    if (hu >= 0) ok = ok && std::fabs(dot3(rel, u)) <= hu && std::fabs(dot3(rel, v)) <= hv;
+    if (k == 0 && !ok) return false;
+    real cp[3] = {p[0] - 0.5 * dist * f[0], p[1] - 0.5 * dist * f[1], p[2] - 0.5 * dist * f[2]};   // contact position
+    for (int j = 0; j < out->n && ok; j++) {
+      real dd[3] = {cp[0] - out->pos[j][0], cp[1] - out->pos[j][1], cp[2] - out->pos[j][2]};
+      if (norm3(dd) < dup_tol) ok = false;
+    }
+    if (!ok) continue;
+    int n = out->n++;
+    for (int i = 0; i < 3; i++) out->pos[n][i] = cp[i];
+    out->dist[n] = dist;
+  }
+  return true;
+}
+
+// reference face of box g facing direction `toward` (unit, world): returns the face area, or -1 when no face normal is
+// within FACE_COS of it
+real box_face(const orc_sim* s, int g, const real* toward, real* f, real* c, real* u, real* v, real* hu, real* hv) {
+  const real* R = &s->gmat[9 * g]; const real* P = &s->gpos[3 * g]; const real* sz = &s->m.geom_size[3 * g];
+  real loc[3]; mulmatTvec3(loc, R, toward);
+  int i = 0;
+  if (std::fabs(loc[1]) > std::fabs(loc[i])) i = 1;
+  if (std::fabs(loc[2]) > std::fabs(loc[i])) i = 2;
+  if (std::fabs(loc[i]) < FACE_COS) return -1;
+  real sg = loc[i] >= 0 ? 1.0 : -1.0;
+  int iu = (i + 1) % 3, iv = (i + 2) % 3;
+  for (int k = 0; k < 3; k++) { f[k] = sg * R[3 * k + i]; u[k] = R[3 * k + iu]; v[k] = R[3 * k + iv]; c[k] = P[k] + f[k] * sz[i]; }
+  *hu = sz[iu]; *hv = sz[iv];
+  return 4 * sz[iu] * sz[iv];
+}
+
 void collision(orc_sim* s) {
   const Model& m = s->m;
   s->con.clear();
@@ -633,21 +696,19 @@ void collision(orc_sim* s) {
   for (int p = 0; p < m.npair; p++) {
     int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
     if (m.geom_type[g1] > m.geom_type[g2]) std::swap(g1, g2);   // collision table is upper-triangular in type
-    Contact c;
+    Patch pt; pt.n = 0;
     if (m.geom_type[g1] == G_PLANE) {
-      // plane : convex  — deepest support point against the plane normal (one contact)
+      // plane : convex  — reference face = the plane, incident = the other geom
       const real* R = &s->gmat[9 * g1];
-      real nrm[3] = {R[2], R[5], R[8]}, nn[3] = {-R[2], -R[5], -R[8]}, sp[3];
+      real nrm[3] = {R[2], R[5], R[8]};
       // cheap reject on the world box
       real lowest = 0;
       for (int k = 0; k < 3; k++) lowest += nrm[k] * ((nrm[k] >= 0 ? lo[3 * g2 + k] : hi[3 * g2 + k]) - s->gpos[3 * g1 + k]);
       if (lowest > 0) continue;
-      support(s, g2, nn, sp);
-      real t[3] = {sp[0] - s->gpos[3 * g1], sp[1] - s->gpos[3 * g1 + 1], sp[2] - s->gpos[3 * g1 + 2]};
-      real dist = dot3(t, nrm);
-      if (dist >= 0) continue;
-      c.dist = dist;
-      for (int k = 0; k < 3; k++) { c.frame[k] = nrm[k]; c.pos[k] = sp[k] - 0.5 * dist * nrm[k]; }
+      real fr[9] = {nrm[0], nrm[1], nrm[2], 0, 0, 0, 0, 0, 0};
+      make_frame(fr);
+      if (!face_patch(s, g2, nrm, &s->gpos[3 * g1], fr + 3, fr + 6, -1, -1, PATCH_DUP * m.geom_rbound[g2], &pt)) continue;
+      for (int k = 0; k < 3; k++) pt.nrm[k] = nrm[k];
     } else {
       bool sep = false;
       for (int k = 0; k < 3; k++) if (lo[3 * g1 + k] > hi[3 * g2 + k] || lo[3 * g2 + k] > hi[3 * g1 + k]) sep = true;
@@ -655,13 +716,40 @@ void collision(orc_sim* s) {
       real depth, dir[3], pos[3];
       if (!mpr_penetration(s, g1, g2, &depth, dir, pos)) continue;
       if (depth <= 0) continue;               // margin 0: only penetrating contacts are kept
-      c.dist = -depth;
-      for (int k = 0; k < 3; k++) { c.frame[k] = dir[k]; c.pos[k] = pos[k]; }
+      // reference face: a box face aligned with the contact normal (the larger one if both geoms offer one)
+      real f[3], c[3], u[3], v[3], hu = 0, hv = 0, area = -1;
+      int ref = -1;
+      for (int side = 0; side < 2; side++) {
+        int g = side == 0 ? g1 : g2;
+        if (m.geom_type[g] != G_BOX) continue;
+        real toward[3] = {side == 0 ? dir[0] : -dir[0], side == 0 ? dir[1] : -dir[1], side == 0 ? dir[2] : -dir[2]};
+        real f2[3], c2[3], u2[3], v2[3], hu2, hv2;
+        real a2 = box_face(s, g, toward, f2, c2, u2, v2, &hu2, &hv2);
+        if (a2 > area) {
+          area = a2; ref = side; hu = hu2; hv = hv2;
+          for (int k = 0; k < 3; k++) { f[k] = f2[k]; c[k] = c2[k]; u[k] = u2[k]; v[k] = v2[k]; }
+        }
+      }
+      bool patched = false;
+      if (ref >= 0) {
+        int gI = ref == 0 ? g2 : g1;
+        patched = face_patch(s, gI, f, c, u, v, hu, hv, PATCH_DUP * std::min(m.geom_rbound[g1], m.geom_rbound[g2]), &pt);
+        for (int k = 0; k < 3; k++) pt.nrm[k] = ref == 0 ? f[k] : -f[k];
+      }
+      if (!patched) {
+        pt.n = 1; pt.dist[0] = -depth;
+        for (int k = 0; k < 3; k++) { pt.nrm[k] = dir[k]; pt.pos[0][k] = pos[k]; }
+      }
     }
-    c.g1 = g1; c.g2 = g2;
-    make_frame(c.frame);
-    set_contact_params(m, c, g1, g2);
-    s->con.push_back(c);
+    for (int j = 0; j < pt.n; j++) {
+      Contact c;
+      c.dist = pt.dist[j];
+      for (int k = 0; k < 3; k++) { c.frame[k] = pt.nrm[k]; c.pos[k] = pt.pos[j][k]; }
+      c.g1 = g1; c.g2 = g2;
+      make_frame(c.frame);
+      set_contact_params(m, c, g1, g2);
+      s->con.push_back(c);
+    }
   }
 }
 

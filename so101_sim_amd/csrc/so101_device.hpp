@@ -751,25 +751,127 @@ DEV void broadphase(const DevModel* m, EnvLDS& L) {
   wave_sync();
 }
 
-// Narrowphase of one candidate pair (geom types ordered): penetration distance (<0), normal geom1 -> geom2, position.
+// ---- multi-contact for flat faces ("multiccd", so101_sim/tasks/base/so100_task.py:151) --------------------------
+// MuJoCo's convex-pair multi-contact re-runs the penetration query on configurations tilted by +-1e-3 rad about the
+// two tangent axes and keeps results farther apart than 1e-3 of the smaller bounding radius; its native-ccd path
+// clips the aligned faces of box / mesh pairs.  Both sample the extreme points of a flat contact patch.  Here that is
+// done in closed form whenever one geom presents a flat REFERENCE FACE - the plane, or a box face whose outward normal
+// is within acos(FACE_COS) of the MPR normal - and the other (INCIDENT) geom is sampled through its support function:
+//   a_0 = support(-f), a_k = support(-f + eps s_k), s_k = (+-u +- v)/sqrt(2) along the face axes, eps = 1e-3.
+// A sample becomes a contact when it is below the face plane, inside the face rectangle and farther than
+// 1e-3 min(rbound) from the contacts already accepted; all contacts of the pair share the normal +-f.  When a_0 does
+// not qualify, the single MPR contact stays.  Other convex pairs keep one contact.  The supports are wave-parallel,
+// the control flow is wave-uniform.  oracle/so101_oracle.cpp restates the same rule in fp64.
+#define FACE_COS 0.9999f
+#define PATCH_EPS 1e-3f
+#define PATCH_DUP 1e-3f
+
+struct PairContacts { int n; float nrm[3], dist[NCPP], pos[NCPP][3]; };
+
 template <class Cache>
-DEV bool narrow_pair(const DevModel* m, const GeomW& G1, const GeomW& G2, float* dist, float* nrm, float* pos) {
+DEV bool face_patch(const DevModel* m, const GeomW& GI, const Cache& HI, const float* f, const float* c, const float* u,
+                    const float* v, float hu, float hv, float dup_tol, PairContacts& out) {
+  out.n = 0;
+#pragma unroll 1
+  for (int k = 0; k < NCPP; k++) {
+    float su = (k == 1 || k == 4) ? 1.f : -1.f, sv = (k == 1 || k == 2) ? 1.f : -1.f;
+    float e = k == 0 ? 0.f : PATCH_EPS * 0.70710678f;
+    float d[3], p[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) d[i] = -f[i] + e * (su * u[i] + sv * v[i]);
+    normalize3(d);
+    support(m, GI, d, p, HI);
+    float rel[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]};
+    float dist = dot3(rel, f);
+    bool ok = dist < 0.f;
+    if (hu >= 0.f) ok = ok && fabsf(dot3(rel, u)) <= hu && fabsf(dot3(rel, v)) <= hv;
+    if (k == 0 && !ok) return false;
+    float cp[3] = {p[0] - 0.5f * dist * f[0], p[1] - 0.5f * dist * f[1], p[2] - 0.5f * dist * f[2]};
+#pragma unroll
+    for (int j = 0; j < NCPP - 1; j++) {
+      float dd[3] = {cp[0] - out.pos[j][0], cp[1] - out.pos[j][1], cp[2] - out.pos[j][2]};
+      if (j < out.n && sqrtf(dot3(dd, dd)) < dup_tol) ok = false;
+    }
+    if (ok) {
+#pragma unroll
+      for (int j = 0; j < NCPP; j++) if (j == out.n) { out.dist[j] = dist; out.pos[j][0] = cp[0]; out.pos[j][1] = cp[1]; out.pos[j][2] = cp[2]; }
+      out.n++;
+    }
+  }
+  return true;
+}
+
+// face of box G whose outward normal is closest to `toward`: area of the face, or -1 when it is not within FACE_COS
+DEV float box_face(const GeomW& G, const float* toward, float* f, float* c, float* u, float* v, float* hu, float* hv) {
+  float loc[3]; matTvec3(loc, G.R, toward);
+  float a0 = fabsf(loc[0]), a1 = fabsf(loc[1]), a2 = fabsf(loc[2]);
+  int i = 0;
+  if (a1 > a0) i = 1;
+  if (a2 > (i == 1 ? a1 : a0)) i = 2;
+  float li = i == 0 ? loc[0] : (i == 1 ? loc[1] : loc[2]);
+  if (fabsf(li) < FACE_COS) return -1.f;
+  float sg = li >= 0.f ? 1.f : -1.f;
+  int iu = (i + 1) % 3, iv = (i + 2) % 3;
+  float si = i == 0 ? G.size[0] : (i == 1 ? G.size[1] : G.size[2]);
+  float su = iu == 0 ? G.size[0] : (iu == 1 ? G.size[1] : G.size[2]);
+  float sv = iv == 0 ? G.size[0] : (iv == 1 ? G.size[1] : G.size[2]);
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    float ri = i == 0 ? G.R[3 * k] : (i == 1 ? G.R[3 * k + 1] : G.R[3 * k + 2]);
+    f[k] = sg * ri;
+    u[k] = iu == 0 ? G.R[3 * k] : (iu == 1 ? G.R[3 * k + 1] : G.R[3 * k + 2]);
+    v[k] = iv == 0 ? G.R[3 * k] : (iv == 1 ? G.R[3 * k + 1] : G.R[3 * k + 2]);
+    c[k] = G.p[k] + f[k] * si;
+  }
+  *hu = su; *hv = sv;
+  return 4.f * su * sv;
+}
+
+// Narrowphase of one candidate pair (geom types ordered): up to NCPP contacts sharing one normal (geom1 -> geom2),
+// each with its penetration distance (< 0) and position.
+template <class Cache>
+DEV void narrow_pair(const DevModel* m, const GeomW& G1, const GeomW& G2, int g1, int g2, PairContacts& out) {
   Cache H1, H2;
   hull_load(m, G1, H1); hull_load(m, G2, H2);
-  if (G1.type == G_PLANE) {
-    nrm[0] = G1.R[2]; nrm[1] = G1.R[5]; nrm[2] = G1.R[8];
-    float nn[3] = {-nrm[0], -nrm[1], -nrm[2]}, sp[3];
-    support(m, G2, nn, sp, H2);
-    float t[3] = {sp[0] - G1.p[0], sp[1] - G1.p[1], sp[2] - G1.p[2]};
-    *dist = dot3(t, nrm);
+  out.n = 0; out.nrm[0] = out.nrm[1] = out.nrm[2] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 3; i++) pos[i] = sp[i] - 0.5f * *dist * nrm[i];
-    return *dist < 0.f;
+  for (int j = 0; j < NCPP; j++) { out.dist[j] = 0.f; out.pos[j][0] = out.pos[j][1] = out.pos[j][2] = 0.f; }
+  float rb1 = ldc(ldc(&m->geom_rbound) + g1), rb2 = ldc(ldc(&m->geom_rbound) + g2);
+  if (G1.type == G_PLANE) {
+    float fr[9] = {G1.R[2], G1.R[5], G1.R[8], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    make_frame(fr);
+    face_patch(m, G2, H2, fr, G1.p, fr + 3, fr + 6, -1.f, -1.f, PATCH_DUP * rb2, out);
+    out.nrm[0] = fr[0]; out.nrm[1] = fr[1]; out.nrm[2] = fr[2];
+    return;
   }
-  float depth;
+  float depth, nrm[3], pos[3];
   bool ok = mpr_penetration(m, G1, G2, &depth, nrm, pos, H1, H2);
-  *dist = -depth;
-  return ok && depth > 0.f;
+  if (!ok || !(depth > 0.f)) return;
+  // reference face: a box face aligned with the contact normal (the larger one when both geoms offer one)
+  float f[3], c[3], u[3], v[3], hu = 0.f, hv = 0.f, area = -1.f;
+  int ref = -1;
+  if (G1.type == G_BOX) { area = box_face(G1, nrm, f, c, u, v, &hu, &hv); if (area >= 0.f) ref = 0; }
+  if (G2.type == G_BOX) {
+    float tw[3] = {-nrm[0], -nrm[1], -nrm[2]}, f2[3], c2[3], u2[3], v2[3], hu2, hv2;
+    float a2 = box_face(G2, tw, f2, c2, u2, v2, &hu2, &hv2);
+    if (a2 > area) {
+      area = a2; ref = 1; hu = hu2; hv = hv2;
+#pragma unroll
+      for (int k = 0; k < 3; k++) { f[k] = f2[k]; c[k] = c2[k]; u[k] = u2[k]; v[k] = v2[k]; }
+    }
+  }
+  bool patched = false;
+  float tol = PATCH_DUP * fminf(rb1, rb2);
+  if (ref == 0) patched = face_patch(m, G2, H2, f, c, u, v, hu, hv, tol, out);
+  else if (ref == 1) patched = face_patch(m, G1, H1, f, c, u, v, hu, hv, tol, out);
+  if (patched) {
+    float sg = ref == 0 ? 1.f : -1.f;
+    out.nrm[0] = sg * f[0]; out.nrm[1] = sg * f[1]; out.nrm[2] = sg * f[2];
+  } else {
+    out.n = 1; out.dist[0] = -depth;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { out.nrm[k] = nrm[k]; out.pos[0][k] = pos[k]; }
+  }
 }
 
 // Contact record of an accepted pair (one lane): frame, body indices, mixed friction / solref / solimp
@@ -800,15 +902,20 @@ DEV void collision(const DevModel* m, EnvLDS& L) {
   int lane = wave_lane();
   broadphase(m, L);
   int ncand = L.ncand, ncon = 0;
-  for (int k = 0; k < ncand; k++) {
+  bool full = false;
+  for (int k = 0; k < ncand && !full; k++) {
     int g1 = L.cand[k][0], g2 = L.cand[k][1];
     GeomW G1, G2;
     load_geom(m, L, g1, G1); load_geom(m, L, g2, G2);
-    float dist, nrm[3], pos[3];
-    if (!narrow_pair<NoCache>(m, G1, G2, &dist, nrm, pos)) continue;
-    if (ncon >= MAXCON) { if (lane == 0) L.overflow |= 2; break; }
-    if (lane == 0) contact_init(m, L.con[ncon], g1, g2, dist, nrm, pos);
-    ncon++;
+    PairContacts pc;
+    narrow_pair<NoCache>(m, G1, G2, g1, g2, pc);
+#pragma unroll
+    for (int j = 0; j < NCPP; j++) {
+      if (j < pc.n && !full) {
+        if (ncon >= MAXCON) { if (lane == 0) L.overflow |= 2; full = true; }
+        else { if (lane == 0) contact_init(m, L.con[ncon], g1, g2, pc.dist[j], pc.nrm, pc.pos[j]); ncon++; }
+      }
+    }
   }
   if (lane == 0) L.ncon = ncon;
   wave_sync();
@@ -865,8 +972,10 @@ DEV void arm_jac_row(const EnvLDS& L, int link, const float* p, const float* u, 
   }
 }
 
-// pgs_data: also build what only PGS needs (diagonal block of A, spectral form of its friction block)
-DEV void make_constraints(const DevModel* m, EnvLDS& L, bool pgs_data = true) {
+// Constraint rows of the current contacts: scalar rows (dof frictionloss, joint limits), and per contact the
+// regularisers R, the cone parameter mu, the reference accelerations and - for contacts that touch an arm link - the
+// joint-space Jacobian rows in the LDS pool.  What only PGS needs (the diagonal blocks of A) is built by solve_pgs().
+DEV void make_constraints(const DevModel* m, EnvLDS& L) {
   int lane = wave_lane();
   // ---- scalar rows: frictionloss (dof order) then active joint limits (joint order) — lane 0 builds the list
   if (lane == 0) {
@@ -912,13 +1021,12 @@ DEV void make_constraints(const DevModel* m, EnvLDS& L, bool pgs_data = true) {
   int ncon = L.ncon;
   if (lane < ncon) {
     Contact& c = L.con[lane];
-    int dim = c.dim;
     float solref[2] = {c.aref[0], c.aref[1]}, solimp[5] = {c.f[0], c.f[1], c.f[2], c.f[3], c.f[4]};
     float imp = impedance(solimp, c.dist), K, B;
     kb_from_solref(m, solref, solimp, &K, &B);
-    float tran = 0.f, rotw = 0.f;
-    if (c.d1 >= 0) { tran += m->dyn_invweight0[c.d1][0]; rotw += m->dyn_invweight0[c.d1][1]; }
-    if (c.d2 >= 0) { tran += m->dyn_invweight0[c.d2][0]; rotw += m->dyn_invweight0[c.d2][1]; }
+    float tran = 0.f;
+    if (c.d1 >= 0) tran += m->dyn_invweight0[c.d1][0];
+    if (c.d2 >= 0) tran += m->dyn_invweight0[c.d2][0];
     float R0 = fmaxf(MINVAL_F, (1.f - imp) * tran / imp);
     float R1 = R0 / fmaxf(MINVAL_F, m->impratio);
     float mu0 = c.fric[0];
@@ -926,13 +1034,8 @@ DEV void make_constraints(const DevModel* m, EnvLDS& L, bool pgs_data = true) {
     c.R[2] = fmaxf(MINVAL_F, R1 * mu0 * mu0 / (c.fric[1] * c.fric[1]));
     c.R[3] = fmaxf(MINVAL_F, R1 * mu0 * mu0 / (c.fric[2] * c.fric[2]));
     c.mu = mu0 * sqrtf(R1 / R0);
-    if (c.armslot == -2) { c.dim = 0; dim = 0; }
-    // per-row world "wrench directions": translational rows j<3 use frame[j]; rotational rows frame[j-3]
-    float A[6][6];
-#pragma unroll
-    for (int j = 0; j < 6; j++)
-#pragma unroll
-      for (int k = 0; k < 6; k++) A[j][k] = 0.f;
+    if (c.armslot == -2) c.dim = 0;
+    // row velocities J qvel: translational rows j<3 use frame[j] at the contact point, rotational rows frame[j-3]
     float vel[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int side = 0; side < 2; side++) {
@@ -941,28 +1044,16 @@ DEV void make_constraints(const DevModel* m, EnvLDS& L, bool pgs_data = true) {
       if (d >= NARM) {
         int f = d - NARM;
         float r[3] = {c.pos[0] - L.xipos[d][0], c.pos[1] - L.xipos[d][1], c.pos[2] - L.xipos[d][2]};
-        float ul[6][3], ua[6][3], Iua[6][3];
+        float wr[3]; cross3(wr, &L.fvel[f][3], r);
+        float pv[3] = {L.fvel[f][0] + wr[0], L.fvel[f][1] + wr[1], L.fvel[f][2] + wr[2]};      // velocity of the contact point
 #pragma unroll
-        for (int j = 0; j < 6; j++) {
-          const float* u = &c.frame[3 * (j % 3)];
-          if (j < 3) { ul[j][0] = u[0]; ul[j][1] = u[1]; ul[j][2] = u[2]; cross3(ua[j], r, u); }
-          else { ul[j][0] = ul[j][1] = ul[j][2] = 0.f; ua[j][0] = u[0]; ua[j][1] = u[1]; ua[j][2] = u[2]; }
-          symvec3(Iua[j], L.fIinv[f], ua[j]);
-          vel[j] += sgn * (dot3(ul[j], &L.fvel[f][0]) + dot3(ua[j], &L.fvel[f][3]));
-        }
-        float mi = L.fminv[f];
-        if (pgs_data) {
-#pragma unroll
-          for (int j = 0; j < 6; j++)
-#pragma unroll
-            for (int k = 0; k <= j; k++) A[j][k] += mi * dot3(ul[j], ul[k]) + dot3(ua[j], Iua[k]);
-        }
+        for (int j = 0; j < 3; j++) { vel[j] += sgn * dot3(&c.frame[3 * j], pv); vel[3 + j] += sgn * dot3(&c.frame[3 * j], &L.fvel[f][3]); }
       }
     }
     if (c.armslot >= 0) {
       // Arm part, ONCE per contact: J = J(link of geom2) - J(link of geom1) in the 6 arm dofs (either side may
-      // be static or a free body; for arm-arm self-collision both contribute).  Rows are streamed through this
-      // contact's slot of the LDS pool (private to the lane) to keep the register footprint small.
+      // be static or a free body; for arm-arm self-collision both contribute), kept dof-major in this contact's
+      // slot of the LDS pool.
       ArmCon& ac = L.armcon[c.armslot];
       int l1 = (c.d1 >= 0 && c.d1 < NARM) ? c.d1 : -1, l2 = (c.d2 >= 0 && c.d2 < NARM) ? c.d2 : -1;
 #pragma unroll
@@ -970,91 +1061,16 @@ DEV void make_constraints(const DevModel* m, EnvLDS& L, bool pgs_data = true) {
         float Jr[NARM], J1[NARM];
         arm_jac_row(L, l2, c.pos, &c.frame[3 * (j % 3)], j >= 3, Jr);      // link -1 gives a zero row
         arm_jac_row(L, l1, c.pos, &c.frame[3 * (j % 3)], j >= 3, J1);
-#pragma unroll
-        for (int q = 0; q < NARM; q++) Jr[q] -= J1[q];
         float vj = 0.f;
 #pragma unroll
-        for (int q = 0; q < NARM; q++) { ac.J[j][q] = Jr[q]; vj += Jr[q] * L.qvel[q]; }
+        for (int q = 0; q < NARM; q++) { float e = Jr[q] - J1[q]; ac.Jt[q][j] = e; vj += e * L.qvel[q]; }
         vel[j] += vj;
       }
-#pragma unroll
-      for (int k = 0; k < (pgs_data ? 6 : 0); k++) {
-        float Bk[NARM];                    // column k of Minv J^T
-#pragma unroll
-        for (int q = 0; q < NARM; q++) {
-          float v = 0.f;
-#pragma unroll
-          for (int s = 0; s < NARM; s++) v += L.Minv[q][s] * ac.J[k][s];
-          Bk[q] = v;
-        }
-#pragma unroll
-        for (int j = k; j < 6; j++) {
-          float v = 0.f;
-#pragma unroll
-          for (int q = 0; q < NARM; q++) v += ac.J[j][q] * Bk[q];
-          A[j][k] += v;
-        }
-      }
     }
-    const float Rj[6] = {c.R[0], c.R[1], c.R[1], c.R[2], c.R[3], c.R[3]};
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-      A[j][j] += Rj[j];
       c.aref[j] = -B * vel[j] - (j == 0 ? K * imp * c.dist : 0.f);
       c.f[j] = 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < 6; j++)
-#pragma unroll
-      for (int k = 0; k <= j; k++) c.A[j * (j + 1) / 2 + k] = A[j][k];
-    if (pgs_data)
-    // Spectral form of the friction block for the cone QCQP (mju_QCQP): with D = diag(mu_j) the scaled block
-    // D Ac D = Q diag(lam) Q^T is decomposed ONCE per substep (cyclic Jacobi, lane = contact); every Newton step
-    // on the cone multiplier inside the PGS sweep is then O(5) instead of a 5x5 Cholesky factorisation.  Rows
-    // >= dim are decoupled (identity).
-    {
-      const float fr5[5] = {c.fric[0], c.fric[0], c.fric[1], c.fric[2], c.fric[2]};
-      int nf = dim - 1;
-      float S[5][5], Qm[5][5];
-#pragma unroll
-      for (int i = 0; i < 5; i++)
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-          float aik = i >= k ? A[i + 1][k + 1] : A[k + 1][i + 1];        // only the lower triangle of A is filled
-          S[i][k] = (i < nf && k < nf) ? aik * fr5[i] * fr5[k] : (i == k ? 1.f : 0.f);
-          Qm[i][k] = i == k ? 1.f : 0.f;
-        }
-      for (int sweep = 0; sweep < 6; sweep++) {
-#pragma unroll
-        for (int p = 0; p < 4; p++)
-#pragma unroll
-          for (int q = p + 1; q < 5; q++) {
-            float apq = S[p][q];
-            if (fabsf(apq) > 1e-30f) {
-              float app = S[p][p], aqq = S[q][q];
-              float tau = (aqq - app) / (2.f * apq);
-              float t = (tau >= 0.f ? 1.f : -1.f) / (fabsf(tau) + sqrtf(1.f + tau * tau));
-              float cs = 1.f / sqrtf(1.f + t * t), sn = t * cs;
-#pragma unroll
-              for (int k = 0; k < 5; k++) {
-                if (k != p && k != q) {
-                  float skp = S[k][p], skq = S[k][q];
-                  float np_ = cs * skp - sn * skq, nq_ = sn * skp + cs * skq;
-                  S[k][p] = np_; S[p][k] = np_; S[k][q] = nq_; S[q][k] = nq_;
-                }
-                float qkp = Qm[k][p], qkq = Qm[k][q];
-                Qm[k][p] = cs * qkp - sn * qkq; Qm[k][q] = sn * qkp + cs * qkq;
-              }
-              S[p][p] = app - t * apq; S[q][q] = aqq + t * apq; S[p][q] = 0.f; S[q][p] = 0.f;
-            }
-          }
-      }
-#pragma unroll
-      for (int i = 0; i < 5; i++) {
-        c.lam[i] = fmaxf(S[i][i], 1e-30f);
-#pragma unroll
-        for (int k = 0; k < 5; k++) c.Q[5 * i + k] = Qm[i][k];
-      }
     }
   }
   wave_sync();
@@ -1096,7 +1112,7 @@ DEV void forward_accelerations(EnvLDS& L) {
 template <int SOLVER>
 DEV void forward_constrained(const DevModel* m, EnvLDS& L, int max_iter, float tolerance, int phases) {
   if (phases & 2) {
-    make_constraints(m, L, SOLVER == 0);
+    make_constraints(m, L);
     if constexpr (SOLVER == 1) solve_newton(m, L, (phases & 4) ? max_iter : 0, tolerance);
     else solve_pgs(m, L, (phases & 4) ? max_iter : 0, tolerance);
   }

@@ -175,7 +175,7 @@ int build_model(so101_sim* s, const BlobView& b) {
       {"task_con_pos_lo", 3}, {"task_con_pos_hi", 3}, {"task_home_ctrl", NU}, {"geom_type", ngeom}, {"geom_body", ngeom}, {"geom_condim", ngeom},
       {"geom_vertadr", ngeom}, {"geom_vertnum", ngeom}, {"geom_pos", 3 * ngeom}, {"geom_quat", 4 * ngeom}, {"geom_size", 3 * ngeom},
       {"geom_friction", 3 * ngeom}, {"geom_solref", 2 * ngeom}, {"geom_solimp", 5 * ngeom}, {"geom_center", 3 * ngeom}, {"geom_aabb", 6 * ngeom},
-      {"geom_solmix", ngeom}, {"geom_margin", ngeom}, {"geom_gap", ngeom}, {"geom_priority", ngeom}, {"mesh_vert", 3 * nvert}, {"pair_geom", 2 * npair}};
+      {"geom_solmix", ngeom}, {"geom_margin", ngeom}, {"geom_gap", ngeom}, {"geom_priority", ngeom}, {"geom_rbound", ngeom}, {"mesh_vert", 3 * nvert}, {"pair_geom", 2 * npair}};
     for (const Need& a : arrays) if (b.count(a.name) < a.count) return fail(std::string("blob entry missing or too short: ") + a.name);
     auto in_range = [&](const char* name, size_t limit, bool allow_negative) {
       for (int v : b.I(name)) if ((v < 0 && !allow_negative) || (v >= 0 && (size_t)v >= limit)) return false;
@@ -273,6 +273,7 @@ int build_model(so101_sim* s, const BlobView& b) {
   auto gpos = b.F("geom_pos"), gquat = b.F("geom_quat"), gsize = b.F("geom_size"), gfr = b.F("geom_friction"), gsr = b.F("geom_solref");
   auto gsi = b.F("geom_solimp"), gctr = b.F("geom_center"), gaabb = b.F("geom_aabb"), gmix = b.F("geom_solmix"), gmargin = b.F("geom_margin"), ggap = b.F("geom_gap");
   auto gprio = b.I("geom_priority");
+  auto grb = b.F("geom_rbound");
   std::vector<int> gdyn(ngeom);
   std::vector<float> gp(3 * ngeom), gm(9 * ngeom);
   for (int i = 0; i < ngeom; i++) {
@@ -306,7 +307,7 @@ int build_model(so101_sim* s, const BlobView& b) {
             upload(s, gva, &M.geom_vertadr) && upload(s, gvn, &M.geom_vertnum) && upload(s, gp, &M.geom_pos) &&
             upload(s, gm, &M.geom_mat) && upload(s, gsize, &M.geom_size) && upload(s, gfr, &M.geom_friction) &&
             upload(s, gsr, &M.geom_solref) && upload(s, gsi, &M.geom_solimp) && upload(s, gctr, &M.geom_center) &&
-            upload(s, gaabb, &M.geom_aabb) && upload(s, vx, &M.vx) && upload(s, vy, &M.vy) && upload(s, vz, &M.vz) &&
+            upload(s, gaabb, &M.geom_aabb) && upload(s, grb, &M.geom_rbound) && upload(s, vx, &M.vx) && upload(s, vy, &M.vy) && upload(s, vz, &M.vz) &&
             upload(s, pairs, &M.pair) && upload(s, packed, &M.pair_packed);
   if (!ok) return SO101_ERR_HIP;
   void* dm = nullptr;
@@ -410,7 +411,7 @@ int so101_create(const void* blob, size_t bytes, int n_envs, int device, uint64_
     bool ok = dev_alloc(s, &W.pose, NDYN * 12 * n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.cand, MAXCAND * n, 0, "hipMalloc(pipe)") &&
               dev_alloc(s, &W.ncand, n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.work, 2 * MAXCAND * n, 0, "hipMalloc(pipe)") &&
               dev_alloc(s, &W.counters, (size_t)2 * MAXSUB * so101_sim::MAXGROUPS, 0, "hipMalloc(pipe)") &&
-              dev_alloc(s, &W.conres, 8 * MAXCAND * n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.active, n, 0, "hipMalloc(pipe)") &&
+              dev_alloc(s, &W.conres, CONRES_DIM * MAXCAND * n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.active, n, 0, "hipMalloc(pipe)") &&
               dev_alloc(s, &W.ticks, MAXCAND * n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.stage, 8 * n, 0, "hipMalloc(pipe)") &&
               dev_alloc(s, &W.cost, n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.order, n, 0, "hipMalloc(pipe)");
     W.work_cap = 0u;
@@ -622,7 +623,7 @@ int so101_debug_candidates(so101_sim* s, int32_t* ncand, uint32_t* cand, uint32_
   if (ncand) ok = ok && hip_ok(s, hipMemcpyAsync(ncand, s->pipe.ncand, sizeof(int) * n, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync(debug)");
   if (cand) ok = ok && hip_ok(s, hipMemcpyAsync(cand, s->pipe.cand, sizeof(int) * MAXCAND * n, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync(debug)");
   if (ticks) ok = ok && hip_ok(s, hipMemcpyAsync(ticks, s->pipe.ticks, sizeof(int) * MAXCAND * n, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync(debug)");
-  if (conres) ok = ok && hip_ok(s, hipMemcpyAsync(conres, s->pipe.conres, sizeof(float) * 8 * MAXCAND * n, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync(debug)");
+  if (conres) ok = ok && hip_ok(s, hipMemcpyAsync(conres, s->pipe.conres, sizeof(float) * CONRES_DIM * MAXCAND * n, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync(debug)");
   return ok ? SO101_OK : SO101_ERR_HIP;
 }
 

@@ -88,8 +88,8 @@ template <int SOLVER>
 __global__ void __launch_bounds__(64) k_debug_forward(const DevModel* m, StepParams P, DevBuffers B, float* out) {
   __shared__ EnvLDS L;
   int e = blockIdx.x, lane = wave_lane();
-  float* o = out + (size_t)e * 1024;
-  for (int i = lane; i < 1024; i += WAVE) o[i] = 0.f;
+  float* o = out + (size_t)e * DBG_DIM;
+  for (int i = lane; i < DBG_DIM; i += WAVE) o[i] = 0.f;
   load_state(L, B, e, P.n_envs);
   kinematics(m, L);
   crba_arm(m, L);
@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(64) k_debug_forward(const DevModel* m, StepPar
   if (lane < 24) o[DBG_XPOS + lane] = L.xpos[lane / 3][lane % 3];
   wave_sync();
   collision(m, L);
-  make_constraints(m, L, SOLVER == 0);
+  make_constraints(m, L);
   if constexpr (SOLVER == 1) solve_newton(m, L, P.iterations, P.tolerance); else solve_pgs(m, L, P.iterations, P.tolerance);
   twist_to_qacc(L);
   if (lane < NV) o[DBG_QACC + lane] = L.qacc[lane];

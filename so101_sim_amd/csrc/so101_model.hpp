@@ -15,8 +15,10 @@
 #define NU 6
 #define MAXGEOM 96
 #define MAXCAND 256
-#define MAXCON 32
-#define MAXARMCON MAXCON
+#define MAXCON 64                 // contacts per env (one lane each in the Newton solver)
+#define MAXCON_PGS 32             // the PGS kernels keep the lane layout contacts 0..31 | scalar rows 32..43
+#define MAXARMCON 40              // contacts that touch an arm link (their joint-space Jacobian rows live in an LDS pool)
+#define NCPP 5                    // contacts per candidate pair: deepest point + up to 4 samples of a flat patch
 #define MAXROW1 (2 * NARM)
 #define NVS NV                    // solver coordinates: arm qacc | object twist | container twist
 
@@ -56,6 +58,7 @@ struct DevModel {
   const float* geom_solimp;   // [g][5]
   const float* geom_center;   // [g][3]  MPR interior point, geom frame
   const float* geom_aabb;     // [g][6]  centre, half in the geom frame
+  const float* geom_rbound;   // [g]     bounding-sphere radius (0 for the plane)
   const float* vx;            // hull vertices, struct-of-arrays, geom frame
   const float* vy;
   const float* vz;
@@ -71,33 +74,27 @@ struct StepParams {
   unsigned long long seed, env_id_base;
 };
 
-struct Contact {
+struct Contact {               // 40 words
   float pos[3], frame[9], dist;
   int d1, d2, dim, armslot;   // dyn index of geom1/geom2 body (-1 static); slot in the arm pool or -1
   int g1, g2;
   float fric[3];              // tangential, torsional, rolling
   float R[4];                 // normal, tangential, torsional, rolling
-  float aref[6], f[6];
-  float A[21];                // diagonal block of AR = J Minv J^T + R, packed lower triangle
-  float Q[25], lam[5];        // eigen-decomposition D Ac D = Q diag(lam) Q^T of the mu-scaled friction block
+  float aref[6], f[6];        // (contact_init() parks the mixed solref in aref[0..1] and solimp in f[0..4])
   float mu, pad;
 };
 
-struct ArmCon {                // rows of an arm-link contact in joint space: J(link of geom2) - J(link of geom1)
-  float J[6][NARM];
+struct ArmCon {                // arm-link contact in joint space, dof-major: Jt[q][j] = (J(link of geom2) - J(link of geom1))[row j][dof q]
+  float Jt[NARM][6];
 };
 
 struct Row1 {                  // scalar rows: dof frictionloss and joint limits
   int dof; float sign, R, aref, f, floss, Ainv, pad;
 };
 
-struct NewtonScratch {          // working set of solve_newton()
+struct NewtonScratch {          // LDS working set of solve_newton(): the vectors every lane reads, and the transposed factor
   float H[NVS][NVS + 1];
-  float x[NVS], xs[NVS], xw[NVS], tmp[NVS], mxd[NVS], grad[NVS], search[NVS], mxs[NVS];
-  float Jst[6][12], Wst[6][12], Hst[6][6];
-  float jtf[MAXCON][12];
-  float rowf[MAXROW1], rowh[MAXROW1];
-  int zone[MAXCON];
+  float x[NVS], xs[NVS], xw[NVS], tmp[NVS], search[NVS];
 };
 
 struct EnvLDS {
@@ -151,6 +148,7 @@ struct EventBuffers {
 #define SO101_NEVENTS 8
 
 #define MAXSUB 32
+#define CONRES_DIM (4 + 4 * NCPP)
 
 // Scratch of the pipelined step (so101_pipeline.hpp)
 struct PipeBuffers {
@@ -159,7 +157,7 @@ struct PipeBuffers {
   int* ncand;             // [N]           count | broadphase overflow flag << 16
   unsigned int* work;     // [2][work_cap] env * MAXCAND + k, double buffered over substeps (per env group)
   int* counters;          // [MAXSUB][2]   work items, cursor
-  float* conres;          // [N][MAXCAND][8] dist, normal, position, valid
+  float* conres;          // [N][MAXCAND][CONRES_DIM] narrowphase result: count, normal, NCPP x (dist, position)
   unsigned char* active;  // [N] 0 not stepping in this call (auto-reset), 1 stepping, 2 diverged
   unsigned int* stage;    // [N][8] k_pipe_solve stage clocks of the last substep (10 ns ticks; SO101_DEBUG_CLOCKS builds)
   unsigned int* cost;     // [N] solver time of the env in its last substep (ticks): scheduling hint only
@@ -177,6 +175,7 @@ struct PipeBuffers {
 #define DBG_COUNTS 114   // ncon, nrow, iters, ncand, overflow
 #define DBG_XPOS 120     // 8*3 dynamic body positions
 #define DBG_CON 144      // MAXCON * 10: pos3 normal3 dist g1 g2 dim
-#define DBG_FORCE 464    // MAXCON * 6
-#define DBG_ROWF 656     // MAXROW1
-#define DBG_REWARD 672
+#define DBG_FORCE (DBG_CON + 10 * MAXCON)    // MAXCON * 6
+#define DBG_ROWF (DBG_FORCE + 6 * MAXCON)    // MAXROW1
+#define DBG_REWARD (DBG_ROWF + 16)
+#define DBG_DIM 2048

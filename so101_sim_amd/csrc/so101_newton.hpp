@@ -3,19 +3,28 @@
 //   min_x  0.5 (x - x_s)' M (x - x_s) + sum_blocks s_b(J_b x - aref_b)
 //
 // in the solver coordinates x = [arm qacc (6) | object twist (6) | container twist (6)], where M is block diagonal:
-// the 6x6 arm matrix and, per free body, (m I3, I_world).  Unlike PGS (a long sequential chain of tiny block
-// updates) every stage here is dense lane-parallel work:
-//   lanes = constraint blocks : residual r = J x - aref, zone / force / block Hessian, line-search derivatives
-//   lanes = matrix entries    : H = M + sum J_b' Hc_b J_b (12x12 local blocks staged through LDS), Cholesky, solves
+// the 6x6 arm matrix and, per free body, (m I3, I_world).
+//
+// Layout: lane k < ncon owns contact k for the whole solve - its Jacobian (12 local columns: the one or two coordinate
+// groups the contact touches), regularisers and reference accelerations live in that lane's registers (ConReg); lane
+// r < nrow additionally owns scalar row r (dof frictionloss / joint limit).  Everything that couples blocks is a
+// wave-level sum over lanes (DPP adds, no LDS, no barrier):
+//   gradient  g_d      = (M (x - x_s))_d - sum_k (J_k' f_k)_d                      18 sums
+//   Hessian   H_(a,b)  = M_(a,b) + sum_k (J_k' Hc_k J_k)_(a,b)                      <= 171 sums, lane a keeps row a
+// followed by the register-resident Cholesky (lane i owns row i of H, pivot rows broadcast with v_readlane).  The
+// per-contact LDS staging of the previous version (three barrier rounds per contact and iteration) is gone; the only
+// LDS traffic left is the 18-vector x / search direction that every lane reads, and one transposition of the factor.
 // The minimiser is unique, so results agree with the fp64 oracle at solution level (not iterate level).
 #pragma once
 
-#define NBLK (MAXCON + MAXROW1)     // lane k < MAXCON: contact k ; lane 32 + r: scalar row r
+struct ConReg {
+  float J[12][6];            // J[c][j]: row j, local column c (0-5: group g0, 6-11: group g1)
+  float Dj[6], fr[5], aref[6], mu;
+  int dim, g0, g1;           // coordinate groups: 0 arm, 1 object, 2 container, -1 none; g0 < g1 when both are present
+};
 
 // block cost s(r), force = -ds/dr and (optionally) the symmetric block Hessian d2s/dr2 (packed lower triangle)
-DEV float contact_cost(const Contact& c, const float* r, float* force, float* Hc, bool want_h, int* zone) {
-  const float fr[5] = {c.fric[0], c.fric[0], c.fric[1], c.fric[2], c.fric[2]};
-  const float Dj[6] = {1.f / c.R[0], 1.f / c.R[1], 1.f / c.R[1], 1.f / c.R[2], 1.f / c.R[3], 1.f / c.R[3]};
+DEV float contact_cost(const ConReg& c, const float* r, float* force, float* Hc, bool want_h, int* zone) {
   int dim = c.dim;
   if (want_h) {
 #pragma unroll
@@ -24,7 +33,7 @@ DEV float contact_cost(const Contact& c, const float* r, float* force, float* Hc
   float mu = c.mu, U[6], T = 0.f;
   U[0] = r[0] * mu;
 #pragma unroll
-  for (int j = 1; j < 6; j++) { U[j] = (j < dim) ? r[j] * fr[j - 1] : 0.f; T += U[j] * U[j]; }
+  for (int j = 1; j < 6; j++) { U[j] = (j < dim) ? r[j] * c.fr[j - 1] : 0.f; T += U[j] * U[j]; }
   T = sqrtf(T);
   float N = U[0];
   if (dim == 0 || (N >= mu * T) || (T <= 0.f && N >= 0.f)) {           // top zone (or dropped contact): free
@@ -37,34 +46,60 @@ DEV float contact_cost(const Contact& c, const float* r, float* force, float* Hc
     float cost = 0.f;
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-      float D = (j < dim) ? Dj[j] : 0.f;
+      float D = (j < dim) ? c.Dj[j] : 0.f;
       force[j] = -D * r[j]; cost += 0.5f * D * r[j] * r[j];
       if (want_h) Hc[j * (j + 1) / 2 + j] = D;
     }
     *zone = 1;
     return cost;
   }
-  float Dm = Dj[0] / fmaxf(mu * mu * (1.f + mu * mu), MINVAL_F), sN = N - mu * T, iT = 1.f / T;   // middle zone
+  float Dm = c.Dj[0] / fmaxf(mu * mu * (1.f + mu * mu), MINVAL_F), sN = N - mu * T, iT = 1.f / T;   // middle zone
   force[0] = -Dm * sN * mu;
 #pragma unroll
-  for (int j = 1; j < 6; j++) force[j] = (j < dim) ? -force[0] * iT * U[j] * fr[j - 1] : 0.f;
+  for (int j = 1; j < 6; j++) force[j] = (j < dim) ? -force[0] * iT * U[j] * c.fr[j - 1] : 0.f;
   if (want_h) {
     float a = Dm * mu * mu, b = Dm * sN * mu;
     Hc[0] = a;
 #pragma unroll
     for (int k = 1; k < 6; k++) {
-      float wk = (k < dim) ? U[k] * fr[k - 1] * iT : 0.f;          // mu_k u_k / T
+      float wk = (k < dim) ? U[k] * c.fr[k - 1] * iT : 0.f;          // mu_k u_k / T
       Hc[k * (k + 1) / 2] = -a * wk;
 #pragma unroll
       for (int l = 1; l <= k; l++) {
-        float wl = (l < dim) ? U[l] * fr[l - 1] * iT : 0.f;
-        float diag = (k == l && k < dim) ? fr[k - 1] * fr[k - 1] * iT : 0.f;
+        float wl = (l < dim) ? U[l] * c.fr[l - 1] * iT : 0.f;
+        float diag = (k == l && k < dim) ? c.fr[k - 1] * c.fr[k - 1] * iT : 0.f;
         Hc[k * (k + 1) / 2 + l] = a * wk * wl - b * (diag - wk * wl * iT);
       }
     }
   }
   *zone = 2;
   return 0.5f * Dm * sN * sN;
+}
+
+// first and second derivative of the block cost along the line r + alpha dr (closed form per zone; the zone is that
+// of the point itself, as in mj_solNewton's line search)
+DEV void contact_line(const ConReg& c, const float* r, const float* dr, float* d1, float* d2) {
+  int dim = c.dim;
+  float mu = c.mu, N = r[0] * mu, dN = dr[0] * mu, TT = 0.f, UdU = 0.f, dUdU = 0.f;
+#pragma unroll
+  for (int j = 1; j < 6; j++) {
+    float u = (j < dim) ? r[j] * c.fr[j - 1] : 0.f, du = (j < dim) ? dr[j] * c.fr[j - 1] : 0.f;
+    TT += u * u; UdU += u * du; dUdU += du * du;
+  }
+  float T = sqrtf(TT);
+  *d1 = 0.f; *d2 = 0.f;
+  if (dim == 0 || (N >= mu * T) || (T <= 0.f && N >= 0.f)) return;
+  if ((mu * N + T <= 0.f) || (T <= 0.f && N < 0.f)) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; j++) { float D = (j < dim) ? c.Dj[j] : 0.f; a += D * r[j] * dr[j]; b += D * dr[j] * dr[j]; }
+    *d1 = a; *d2 = b;
+    return;
+  }
+  float Dm = c.Dj[0] / fmaxf(mu * mu * (1.f + mu * mu), MINVAL_F), sN = N - mu * T, iT = 1.f / T;
+  float dT = UdU * iT, ddT = (dUdU - dT * dT) * iT, dS = dN - mu * dT;
+  *d1 = Dm * sN * dS;
+  *d2 = Dm * (dS * dS - sN * mu * ddT);
 }
 
 DEV float row_cost(const Row1& r, float jar, float* force, float* h) {
@@ -79,30 +114,47 @@ DEV float row_cost(const Row1& r, float jar, float* force, float* h) {
   *force = 0.f; *h = 0.f; return 0.f;
 }
 
-// solver-coordinate groups a contact touches: slot 0 / slot 1 (-1 = none); 0 arm, 1 object, 2 container
-DEV void contact_groups(const Contact& c, int* g0, int* g1) {
-  int a = c.armslot >= 0 ? 0 : -1;
-  int f1 = c.d1 >= NARM ? c.d1 - NARM + 1 : -1, f2 = c.d2 >= NARM ? c.d2 - NARM + 1 : -1;
-  int first = a >= 0 ? a : (f1 >= 0 ? f1 : f2);
-  int second = a >= 0 ? (f1 >= 0 ? f1 : f2) : (f1 >= 0 ? f2 : -1);
-  *g0 = first; *g1 = second;
-}
-
-// entry (row j, local column q of group g) of the contact Jacobian in solver coordinates
-DEV float contact_jentry(const EnvLDS& L, const Contact& c, int g, int j, int q) {
-  if (g == 0) return L.armcon[c.armslot].J[j][q];
-  int d = NARM + g - 1;
-  float sgn = (c.d2 == d) ? 1.f : -1.f;
-  int jj = j % 3, qq = q % 3;
-  float u0 = c.frame[3 * jj], u1 = c.frame[3 * jj + 1], u2 = c.frame[3 * jj + 2];
-  float uq = qq == 0 ? u0 : (qq == 1 ? u1 : u2);           // selects, never a lane-indexed register array
-  if (j < 3) {
-    if (q < 3) return sgn * uq;
-    float r0 = c.pos[0] - L.xipos[d][0], r1 = c.pos[1] - L.xipos[d][1], r2 = c.pos[2] - L.xipos[d][2];
-    float t0 = r1 * u2 - r2 * u1, t1 = r2 * u0 - r0 * u2, t2 = r0 * u1 - r1 * u0;      // r x u
-    return sgn * (qq == 0 ? t0 : (qq == 1 ? t1 : t2));
+// the contact's Jacobian and parameters, from the LDS record into the lane's registers
+DEV void conreg_load(const EnvLDS& L, const Contact& c, ConReg& r) {
+  r.dim = c.dim; r.mu = c.mu;
+  r.fr[0] = c.fric[0]; r.fr[1] = c.fric[0]; r.fr[2] = c.fric[1]; r.fr[3] = c.fric[2]; r.fr[4] = c.fric[2];
+  r.Dj[0] = 1.f / c.R[0]; r.Dj[1] = 1.f / c.R[1]; r.Dj[2] = r.Dj[1]; r.Dj[3] = 1.f / c.R[2]; r.Dj[4] = 1.f / c.R[3]; r.Dj[5] = r.Dj[4];
+#pragma unroll
+  for (int j = 0; j < 6; j++) r.aref[j] = c.aref[j];
+  int a = c.armslot >= 0 ? 0 : 3, f1 = c.d1 >= NARM ? c.d1 - NARM + 1 : 3, f2 = c.d2 >= NARM ? c.d2 - NARM + 1 : 3;   // 3 = none
+  int lo = min(a, min(f1, f2)), hi = max(a == 3 ? -1 : a, max(f1 == 3 ? -1 : f1, f2 == 3 ? -1 : f2));
+  r.g0 = lo == 3 ? -1 : lo;
+  r.g1 = hi > lo ? hi : -1;
+#pragma unroll
+  for (int s = 0; s < 2; s++) {
+    int g = s == 0 ? r.g0 : r.g1;
+    if (g == 0) {
+      const ArmCon& ac = L.armcon[c.armslot];
+#pragma unroll
+      for (int q = 0; q < 6; q++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) r.J[6 * s + q][j] = ac.Jt[q][j];
+    } else if (g > 0) {
+      int d = NARM + g - 1;
+      float sgn = (c.d2 == d) ? 1.f : -1.f;
+      float rr[3] = {c.pos[0] - L.xipos[d][0], c.pos[1] - L.xipos[d][1], c.pos[2] - L.xipos[d][2]};
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        float u[3] = {sgn * c.frame[3 * j], sgn * c.frame[3 * j + 1], sgn * c.frame[3 * j + 2]}, t[3];
+        cross3(t, rr, u);
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          r.J[6 * s + q][j] = u[q]; r.J[6 * s + 3 + q][j] = t[q];
+          r.J[6 * s + q][3 + j] = 0.f; r.J[6 * s + 3 + q][3 + j] = u[q];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 6; q++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) r.J[6 * s + q][j] = 0.f;
+    }
   }
-  return q < 3 ? 0.f : sgn * uq;
 }
 
 // M * v in solver coordinates, element `lane` (lane < NVS)
@@ -121,18 +173,47 @@ DEV float mass_times(const DevModel* m, const EnvLDS& L, const float* v /*LDS*/,
   return k == 3 ? o[0] : (k == 4 ? o[1] : o[2]);
 }
 
+// entry (a, b) of the block-diagonal M
+DEV float mass_entry(const DevModel* m, const EnvLDS& L, int a, int b) {
+  if (a < NARM) return b < NARM ? L.Marm[a][b] : 0.f;
+  if (b < NARM || (a - NARM) / 6 != (b - NARM) / 6) return 0.f;
+  int f = (a - NARM) / 6, i = (a - NARM) % 6, j = (b - NARM) % 6;
+  if (i < 3 && j < 3) return i == j ? m->free_mass[f] : 0.f;
+  if (i >= 3 && j >= 3) {
+    int p = i - 3, q = j - 3;
+    return L.Iw[NARM + f][p == q ? p : p + q + 2];        // packed xx yy zz xy xz yz: (0,1)->3, (0,2)->4, (1,2)->5
+  }
+  return 0.f;
+}
+
 DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float tolerance) {
   int lane = wave_lane();
   int nrow = L.nrow, ncon = L.ncon;
   NewtonScratch& W = L.nw;
   if (lane == 0) L.iters = 0;
   if (nrow + ncon == 0) { wave_sync(); return; }
-  bool has_con = lane < ncon, has_row = lane >= 32 && lane - 32 < nrow;
-  Contact creg; Row1 rreg;
-  if (has_con) creg = L.con[lane];
-  if (has_row) rreg = L.row[lane - 32];
-  int g0 = -1, g1 = -1;
-  if (has_con) contact_groups(creg, &g0, &g1);
+  bool has_con = lane < ncon, has_row = lane < nrow;
+  ConReg C;
+  // lanes without a contact carry an all-zero block (every field is read by the wave-wide arithmetic below)
+  C.dim = 0; C.g0 = -1; C.g1 = -1; C.mu = 0.f;
+#pragma unroll
+  for (int c = 0; c < 12; c++)
+#pragma unroll
+    for (int j = 0; j < 6; j++) C.J[c][j] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 6; j++) { C.Dj[j] = 0.f; C.aref[j] = 0.f; }
+#pragma unroll
+  for (int j = 0; j < 5; j++) C.fr[j] = 0.f;
+  if (has_con) conreg_load(L, L.con[lane], C);
+  Row1 rreg; rreg.dof = 0; rreg.sign = 0.f; rreg.R = 1.f; rreg.aref = 0.f; rreg.floss = 0.f; rreg.f = 0.f; rreg.Ainv = 0.f; rreg.pad = 0.f;
+  if (has_row) rreg = L.row[lane];
+  // which coordinate groups / group pairs any contact touches (wave-uniform): sums over absent blocks are skipped
+  bool anyG[3], anyX[3];
+#pragma unroll
+  for (int G = 0; G < 3; G++) anyG[G] = wave_ballot(has_con && (C.g0 == G || C.g1 == G)) != 0ull;
+  anyX[0] = wave_ballot(has_con && C.g0 == 0 && C.g1 == 1) != 0ull;
+  anyX[1] = wave_ballot(has_con && C.g0 == 0 && C.g1 == 2) != 0ull;
+  anyX[2] = wave_ballot(has_con && C.g0 == 1 && C.g1 == 2) != 0ull;
   // x_s (smooth) and the warm start in solver coordinates; x lives in W.x
   if (lane < NARM) { W.xs[lane] = L.qacc_arm[lane]; W.xw[lane] = L.warm[lane]; }
   if (lane >= 32 && lane < 32 + NFREE) {
@@ -149,39 +230,37 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
     }
   }
   wave_sync();
-  // residual of this lane's block at the point `x` (LDS vector of NVS), and J*v for a direction
+  // J * v of this lane's contact for an LDS vector v in solver coordinates
   auto block_jx = [&](const float* x, float* out6) {
-    if (has_con) {
-      Acc a;
+    int o0 = C.g0 < 0 ? 0 : 6 * C.g0, o1 = C.g1 < 0 ? 0 : 6 * C.g1;
 #pragma unroll
-      for (int q = 0; q < NARM; q++) a.arm[q] = x[q];
+    for (int j = 0; j < 6; j++) out6[j] = 0.f;
 #pragma unroll
-      for (int f = 0; f < NFREE; f++)
+    for (int q = 0; q < 6; q++) {
+      float x0 = x[o0 + q], x1 = x[o1 + q];
 #pragma unroll
-        for (int i = 0; i < 6; i++) a.fr[f][i] = x[NARM + 6 * f + i];
-      jacc_reg(L, creg, a, out6);
-    } else if (has_row) out6[0] = rreg.sign * x[rreg.dof];
+      for (int j = 0; j < 6; j++) out6[j] += C.J[q][j] * x0 + C.J[6 + q][j] * x1;
+    }
   };
-  // total cost at x (also leaves this lane's residual in jar); gauss part via W.mxd = M (x - x_s)
-  float jar[6] = {0, 0, 0, 0, 0, 0}, force[6] = {0, 0, 0, 0, 0, 0}, Hc[21];
+  // total cost at x; leaves this lane's residuals (jar, rjar), forces and block Hessians in registers
+  float jar[6] = {0, 0, 0, 0, 0, 0}, force[6] = {0, 0, 0, 0, 0, 0}, Hc[21], rjar = 0.f, rforce = 0.f, rh = 0.f, mxd = 0.f;
+  int zone = 0;
+#pragma unroll
+  for (int k = 0; k < 21; k++) Hc[k] = 0.f;
   auto eval_cost = [&](const float* x, bool want_h) -> float {
     if (lane < NVS) W.tmp[lane] = x[lane] - W.xs[lane];
     wave_sync();
     float part = 0.f;
-    if (lane < NVS) { float mv = mass_times(m, L, W.tmp, lane); W.mxd[lane] = mv; part = 0.5f * mv * W.tmp[lane]; }
-    block_jx(x, jar);
+    if (lane < NVS) { mxd = mass_times(m, L, W.tmp, lane); part = 0.5f * mxd * W.tmp[lane]; }
     if (has_con) {
+      block_jx(x, jar);
 #pragma unroll
-      for (int j = 0; j < 6; j++) jar[j] -= creg.aref[j];
-      int zn;
-      part += contact_cost(creg, jar, force, Hc, want_h, &zn);
-      if (want_h) W.zone[lane] = zn;
-    } else if (has_row) {
-      jar[0] -= rreg.aref;
-      float h;
-      part += row_cost(rreg, jar[0], &force[0], &h);
-      Hc[0] = h;
-      if (want_h) { W.rowf[lane - 32] = force[0]; W.rowh[lane - 32] = h; }
+      for (int j = 0; j < 6; j++) jar[j] -= C.aref[j];
+      part += contact_cost(C, jar, force, Hc, want_h, &zone);
+    }
+    if (has_row) {
+      rjar = rreg.sign * x[rreg.dof] - rreg.aref;
+      part += row_cost(rreg, rjar, &rforce, &rh);
     }
     float tot = wave_sum_f(part);
     wave_sync();
@@ -195,100 +274,102 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
   float cost = eval_cost(W.x, true);
   int it = 0;
   for (; it < max_iter; it++) {
-    // ---- gradient g = M (x - x_s) - J' f : per-block contributions in local columns, summed in block order
-    if (has_con) {
+    // ---- gradient g = M (x - x_s) - J' f, lane d keeps g_d
+    float jl[12];
 #pragma unroll
-      for (int col = 0; col < 12; col++) {
-        int g = col < 6 ? g0 : g1;
-        float s = 0.f;
-        if (g >= 0) {
+    for (int c = 0; c < 12; c++) {
+      float s = 0.f;
 #pragma unroll
-          for (int j = 0; j < 6; j++) s += contact_jentry(L, creg, g, j, col % 6) * force[j];
+      for (int j = 0; j < 6; j++) s += C.J[c][j] * force[j];
+      jl[c] = s;
+    }
+    float grad = mxd;
+#pragma unroll
+    for (int d = 0; d < NVS; d++) {
+      const int G = d / 6, q = d % 6;
+      if (anyG[G] || G == 0) {
+        float v = (C.g0 == G) ? jl[q] : ((C.g1 == G) ? jl[6 + q] : 0.f);
+        if (G == 0) v += (has_row && rreg.dof == q) ? rreg.sign * rforce : 0.f;
+        float tot = wave_sum_f(v);
+        if (lane == d) grad -= tot;
+      }
+    }
+    // ---- Hessian H = M + sum_blocks J' Hc J: lane a < NVS keeps row a in registers
+    float h[NVS];
+#pragma unroll
+    for (int b = 0; b < NVS; b++) h[b] = lane < NVS ? mass_entry(m, L, lane, b) : 0.f;
+#pragma unroll
+    for (int q = 0; q < NARM; q++) {                       // scalar rows: J = +-e_dof, Hc = D when quadratic
+      float tot = wave_sum_f((has_row && rreg.dof == q) ? rh : 0.f);
+      if (lane == q) h[q] += tot;
+    }
+    bool actG[3], actX[3];
+    {
+      bool on = has_con && zone != 0;
+#pragma unroll
+      for (int G = 0; G < 3; G++) actG[G] = wave_ballot(on && (C.g0 == G || C.g1 == G)) != 0ull;
+      actX[0] = wave_ballot(on && C.g0 == 0 && C.g1 == 1) != 0ull;
+      actX[1] = wave_ballot(on && C.g0 == 0 && C.g1 == 2) != 0ull;
+      actX[2] = wave_ballot(on && C.g0 == 1 && C.g1 == 2) != 0ull;
+    }
+    if (actG[0] || actG[1] || actG[2]) {
+#pragma unroll
+      for (int b = 0; b < 6; b++) {
+        // W0 = Hc J[:, b of slot 0], W1 = Hc J[:, b of slot 1]
+        float W0[6], W1[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+          float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+          for (int j = 0; j < 6; j++) { float hc = Hc[i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i]; s0 += hc * C.J[b][j]; s1 += hc * C.J[6 + b][j]; }
+          W0[i] = s0; W1[i] = s1;
         }
-        W.jtf[lane][col] = s;
-      }
-    }
-    wave_sync();
-    if (lane < NVS) {
-      float gsum = W.mxd[lane];
-      int grp = lane / 6, q = lane % 6;
-      for (int k = 0; k < ncon; k++) {
-        int a0, a1; contact_groups(L.con[k], &a0, &a1);
-        if (a0 == grp) gsum -= W.jtf[k][q];
-        else if (a1 == grp) gsum -= W.jtf[k][6 + q];
-      }
-      if (lane < NARM) for (int k = 0; k < nrow; k++) if (L.row[k].dof == lane) gsum -= L.row[k].sign * W.rowf[k];
-      W.grad[lane] = gsum;
-    }
-    // ---- Hessian H = M + sum_blocks J' Hc J   (lower triangle kept full for simplicity)
-    for (int e = lane; e < NVS * NVS; e += WAVE) {
-      int a = e / NVS, b = e % NVS;
-      float v = 0.f;
-      if (a < NARM && b < NARM) v = L.Marm[a][b];
-      else if (a >= NARM && b >= NARM && (a - NARM) / 6 == (b - NARM) / 6) {
-        int f = (a - NARM) / 6, i = (a - NARM) % 6, j = (b - NARM) % 6;
-        if (i < 3 && j < 3) v = (i == j) ? m->free_mass[f] : 0.f;
-        else if (i >= 3 && j >= 3) {
-          const float* I = L.Iw[NARM + f];
-          int p = i - 3, q = j - 3;
-          v = I[p == q ? p : p + q + 2];        // packed xx yy zz xy xz yz: (0,1)->3, (0,2)->4, (1,2)->5
+        // diagonal blocks: entries (a, b), a <= b, of slot 0 and slot 1
+#pragma unroll
+        for (int a = 0; a <= b; a++) {
+          float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+          for (int j = 0; j < 6; j++) { s0 += C.J[a][j] * W0[j]; s1 += C.J[6 + a][j] * W1[j]; }
+#pragma unroll
+          for (int G = 0; G < 3; G++) {
+            if (actG[G]) {
+              float tot = wave_sum_f((C.g0 == G) ? s0 : ((C.g1 == G) ? s1 : 0.f));
+              if (lane == 6 * G + a) h[6 * G + b] += tot;
+              if (a != b && lane == 6 * G + b) h[6 * G + a] += tot;
+            }
+          }
+        }
+        // cross blocks: entry (a of slot 0, b of slot 1)
+        if (actX[0] || actX[1] || actX[2]) {
+#pragma unroll
+          for (int a = 0; a < 6; a++) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; j++) s += C.J[a][j] * W1[j];
+#pragma unroll
+            for (int p = 0; p < 3; p++) {
+              const int G = p == 2 ? 1 : 0, G2 = p == 0 ? 1 : 2;
+              if (actX[p]) {
+                float tot = wave_sum_f((C.g0 == G && C.g1 == G2) ? s : 0.f);
+                if (lane == 6 * G + a) h[6 * G2 + b] += tot;
+                if (lane == 6 * G2 + b) h[6 * G + a] += tot;
+              }
+            }
+          }
         }
       }
-      W.H[a][b] = v;
-    }
-    wave_sync();
-    if (lane < NARM) {                       // scalar rows: J = +-e_dof, Hc = D when quadratic
-      float add = 0.f;
-      for (int k = 0; k < nrow; k++) if (L.row[k].dof == lane) add += W.rowh[k];
-      W.H[lane][lane] += add;
-    }
-    for (int k = 0; k < ncon; k++) {         // contacts with a non-zero block Hessian
-      if (W.zone[k] == 0) continue;
-      const Contact& c = L.con[k];
-      int a0, a1; contact_groups(c, &a0, &a1);
-      if (lane == k) {
-#pragma unroll
-        for (int i = 0; i < 6; i++)
-#pragma unroll
-          for (int j = 0; j <= i; j++) { W.Hst[i][j] = Hc[i * (i + 1) / 2 + j]; W.Hst[j][i] = Hc[i * (i + 1) / 2 + j]; }
-      }
-      for (int t = lane; t < 72; t += WAVE) {
-        int j = t / 12, col = t % 12, g = col < 6 ? a0 : a1;
-        W.Jst[j][col] = g >= 0 ? contact_jentry(L, c, g, j, col % 6) : 0.f;
-      }
-      wave_sync();
-      for (int t = lane; t < 72; t += WAVE) {
-        int kk = t / 12, col = t % 12;
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < 6; j++) s += W.Hst[kk][j] * W.Jst[j][col];
-        W.Wst[kk][col] = s;
-      }
-      wave_sync();
-      int ncol = a1 >= 0 ? 12 : 6;
-      for (int t = lane; t < ncol * ncol; t += WAVE) {
-        int la = t / ncol, lb = t % ncol;
-        float s = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < 6; kk++) s += W.Jst[kk][la] * W.Wst[kk][lb];
-        int ga = (la < 6 ? a0 : a1) * 6 + la % 6, gb = (lb < 6 ? a0 : a1) * 6 + lb % 6;
-        W.H[ga][gb] += s;
-      }
-      wave_sync();
     }
     // ---- symmetric diagonal scaling  H~ = S H S, S = diag(H)^-1/2 : translational (mass ~ 4e-2) and rotational
     // (inertia ~ 1e-5) coordinates differ by ~1e3 in scale, which puts cond(H) near 1/eps_fp32; after scaling the
     // fp32 Cholesky is safe.  Solve H~ y = -S g, search = S y.
-    if (lane < NVS) W.mxs[lane] = 1.f / sqrtf(fmaxf(W.H[lane][lane], 1e-30f));
-    wave_sync();
-    for (int e = lane; e < NVS * NVS; e += WAVE) { int a = e / NVS, b = e % NVS; W.H[a][b] *= W.mxs[a] * W.mxs[b]; }
-    wave_sync();
-    // ---- Cholesky H~ = L L' and the two triangular solves, register resident: lane i < NVS owns row i of H~ (and
-    // of L), the pivot row is broadcast with v_readlane.  No LDS traffic and no barriers inside the factorisation
-    // (the LDS version spent ~130 barrier rounds per Newton iteration here).
-    float h[NVS];
+    float dg = 1.f;
 #pragma unroll
-    for (int b = 0; b < NVS; b++) h[b] = lane < NVS ? W.H[lane][b] : 0.f;
+    for (int b = 0; b < NVS; b++) dg = (lane == b) ? h[b] : dg;
+    float mxs = 1.f / sqrtf(fmaxf(dg, 1e-30f));
+#pragma unroll
+    for (int b = 0; b < NVS; b++) h[b] *= mxs * wave_get_f(mxs, b);
+    // ---- Cholesky H~ = L L' and the two triangular solves, register resident: lane i < NVS owns row i of H~ (and
+    // of L), the pivot row is broadcast with v_readlane
 #pragma unroll
     for (int j = 0; j < NVS; j++) {
       float d = sqrtf(fmaxf(wave_get_f(h[j], j), 1e-7f));       // pivot floor: H~ has unit diagonal
@@ -297,7 +378,7 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
 #pragma unroll
       for (int k = j + 1; k < NVS; k++) h[k] -= l * wave_get_f(l, k);     // rows i < k hold unused upper entries
     }
-    float y = lane < NVS ? -W.grad[lane] * W.mxs[lane] : 0.f;
+    float y = lane < NVS ? -grad * mxs : 0.f;
 #pragma unroll
     for (int i = 0; i < NVS; i++) {          // forward substitution L y = b
       float yi = wave_get_f(y, i) / wave_get_f(h[i], i);
@@ -305,7 +386,6 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
       else if (lane > i) y -= h[i] * yi;
     }
     // backward substitution needs column `lane` of L: one transposed round trip through LDS
-    wave_sync();
     if (lane < NVS) {
 #pragma unroll
       for (int b = 0; b < NVS; b++) W.H[lane][b] = h[b];
@@ -320,34 +400,29 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
       if (lane == i) y = xi;
       else if (lane < i) y -= t[i] * xi;
     }
-    if (lane < NVS) { float sv = y * W.mxs[lane]; W.tmp[lane] = sv; W.search[lane] = sv; }
+    float sv = y * mxs;
+    if (lane < NVS) W.search[lane] = sv;
     wave_sync();
     // ---- exact line search: phi'(alpha) = 0 by safeguarded Newton
-    float jv[6] = {0, 0, 0, 0, 0, 0}, jar0[6];
-    block_jx(W.search, jv);
-#pragma unroll
-    for (int j = 0; j < 6; j++) jar0[j] = jar[j];
+    float jv[6] = {0, 0, 0, 0, 0, 0}, rjv = 0.f;
+    if (has_con) block_jx(W.search, jv);
+    if (has_row) rjv = rreg.sign * W.search[rreg.dof];
     float q1p = 0.f, q2p = 0.f;
-    if (lane < NVS) { float ms = mass_times(m, L, W.search, lane); q1p = W.search[lane] * W.mxd[lane]; q2p = W.search[lane] * ms; }
+    if (lane < NVS) { float ms = mass_times(m, L, W.search, lane); q1p = sv * mxd; q2p = sv * ms; }
     float q1 = wave_sum_f(q1p), q2 = wave_sum_f(q2p);
     float alpha = 0.f, lo = 0.f, hi = -1.f, d10 = 0.f;
     for (int ls = 0; ls < 12; ls++) {
       float d1p = 0.f, d2p = 0.f;
       if (has_con) {
-        float r6[6], f6[6], h21[21];
+        float r6[6];
 #pragma unroll
-        for (int j = 0; j < 6; j++) r6[j] = jar0[j] + alpha * jv[j];
-        int zn; contact_cost(creg, r6, f6, h21, true, &zn);
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-          d1p -= f6[j] * jv[j];
-#pragma unroll
-          for (int k = 0; k < 6; k++) d2p += jv[j] * h21[tri(j, k)] * jv[k];
-        }
-      } else if (has_row) {
+        for (int j = 0; j < 6; j++) r6[j] = jar[j] + alpha * jv[j];
+        contact_line(C, r6, jv, &d1p, &d2p);
+      }
+      if (has_row) {
         float f1, h1;
-        row_cost(rreg, jar0[0] + alpha * jv[0], &f1, &h1);
-        d1p = -f1 * jv[0]; d2p = h1 * jv[0] * jv[0];
+        row_cost(rreg, rjar + alpha * rjv, &f1, &h1);
+        d1p -= f1 * rjv; d2p += h1 * rjv * rjv;
       }
       float d1 = q1 + q2 * alpha + wave_sum_f(d1p), d2 = q2 + wave_sum_f(d2p);
       if (ls == 0) { d10 = fabsf(d1); if (!(d1 < 0.f)) break; }
@@ -359,12 +434,11 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
       if (hi > 0.f && (cand <= lo || cand >= hi)) cand = 0.5f * (lo + hi);
       alpha = cand;
     }
-    if (lane < NVS) W.x[lane] += alpha * W.search[lane];
+    if (lane < NVS) W.x[lane] += alpha * sv;
     wave_sync();
     float newcost = eval_cost(W.x, true);
 
-    float gp = lane < NVS ? W.grad[lane] * W.grad[lane] : 0.f;       // gradient of the previous point (cheap proxy)
-    float gnorm = scale * sqrtf(wave_sum_f(gp));
+    float gnorm = scale * sqrtf(wave_sum_f(lane < NVS ? grad * grad : 0.f));   // gradient of the previous point (cheap proxy)
     float improvement = scale * (cost - newcost);
     float floor32 = 4e-7f * scale * fabsf(cost);                      // cost differences below fp32 resolution
     cost = newcost;
@@ -377,7 +451,7 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
 #pragma unroll
     for (int j = 0; j < 6; j++) L.con[lane].f[j] = force[j];
   }
-  if (has_row) L.row[lane - 32].f = force[0];
+  if (has_row) L.row[lane].f = rforce;
   if (lane == 0) L.iters = it;
   wave_sync();
 }

@@ -44,23 +44,35 @@ DEV void publish_candidates(const EnvLDS& L, const PipeBuffers& W, int e, int N,
   }
 }
 
-// contacts of this env for the current substep, in candidate order, truncated at MAXCON like the fused loop
+// contacts of this env for the current substep, in candidate order (a pair's contacts stay together, in the order the
+// narrowphase produced them), truncated at MAXCON like the fused loop.  lane = candidate.
 DEV void gather_contacts(const DevModel* m, EnvLDS& L, const PipeBuffers& W, int e) {
   int lane = wave_lane();
   int info = W.ncand[e], ncand = info & 0xffff, ncon = 0;
   for (int k0 = 0; k0 < ncand; k0 += WAVE) {
     int k = k0 + lane;
     size_t w = (size_t)e * MAXCAND + k;
-    bool valid = k < ncand && W.conres[w * 8 + 7] != 0.f;
-    unsigned long long mask = wave_ballot(valid);
-    int idx = ncon + wave_prefix(mask);
-    if (valid && idx < MAXCON) {
-      const float* r = W.conres + w * 8;
-      unsigned int c = W.cand[w];
-      float nrm[3] = {r[1], r[2], r[3]}, pos[3] = {r[4], r[5], r[6]};
-      contact_init(m, L.con[idx], (int)(c & 0xffffu), (int)(c >> 16), r[0], nrm, pos);
+    const float* r = W.conres + w * CONRES_DIM;
+    int cnt = k < ncand ? (int)r[0] : 0;
+    // exclusive prefix of the per-candidate contact counts (at most NCPP each): one ballot per possible count bit
+    int idx = ncon, total = 0;
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+      unsigned long long mask = wave_ballot((cnt >> b) & 1);
+      idx += wave_prefix(mask) << b;
+      total += __popcll(mask) << b;
     }
-    ncon += __popcll(mask);
+    if (cnt > 0) {
+      unsigned int c = W.cand[w];
+      float nrm[3] = {r[1], r[2], r[3]};
+      for (int j = 0; j < cnt; j++) {
+        if (idx + j < MAXCON) {
+          float pos[3] = {r[5 + 4 * j], r[6 + 4 * j], r[7 + 4 * j]};
+          contact_init(m, L.con[idx + j], (int)(c & 0xffffu), (int)(c >> 16), r[4 + 4 * j], nrm, pos);
+        }
+      }
+    }
+    ncon += total;
   }
   if (lane == 0) {
     L.ncand = ncand; L.narmcon = 0;
@@ -70,4 +82,3 @@ DEV void gather_contacts(const DevModel* m, EnvLDS& L, const PipeBuffers& W, int
   }
   wave_sync();
 }
-

@@ -51,7 +51,7 @@ DEV void jacc_reg(const EnvLDS& L, const Contact& c, const Acc& a, float* jv) {
     for (int j = 0; j < 6; j++) {
       float v = 0.f;
 #pragma unroll
-      for (int q = 0; q < NARM; q++) v += ac.J[j][q] * a.arm[q];
+      for (int q = 0; q < NARM; q++) v += ac.Jt[q][j] * a.arm[q];
       jv[j] += v;
     }
   }
@@ -91,7 +91,7 @@ DEV void apply_reg(const EnvLDS& L, const Contact& c, const float* df, Acc& a) {
     for (int q = 0; q < NARM; q++) {
       float v = 0.f;
 #pragma unroll
-      for (int j = 0; j < 6; j++) v += ac.J[j][q] * df[j];
+      for (int j = 0; j < 6; j++) v += ac.Jt[q][j] * df[j];
       g[q] = v;
     }
 #pragma unroll
@@ -127,8 +127,117 @@ DEV float row_update(const EnvLDS& L, Row1& r, Acc& a) {
   return -change;
 }
 
+// What only PGS needs per contact, kept in the registers of the contact's lane for the whole solve: the diagonal
+// block A = J Minv J' + R of the dual problem (packed lower triangle) and the spectral form D Ac D = Q diag(lam) Q'
+// of its mu-scaled friction block.
+struct PgsReg { float A[21], Q[25], lam[5]; };
+
+DEV void pgs_block(const EnvLDS& L, const Contact& c, PgsReg& P) {
+  int dim = c.dim;
+  float A[6][6];
+#pragma unroll
+  for (int j = 0; j < 6; j++)
+#pragma unroll
+    for (int k = 0; k < 6; k++) A[j][k] = 0.f;
+#pragma unroll
+  for (int side = 0; side < 2; side++) {
+    int d = side == 0 ? c.d1 : c.d2;
+    if (d >= NARM) {
+      int f = d - NARM;
+      float r[3] = {c.pos[0] - L.xipos[d][0], c.pos[1] - L.xipos[d][1], c.pos[2] - L.xipos[d][2]};
+      float ul[6][3], ua[6][3], Iua[6][3];
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        const float* u = &c.frame[3 * (j % 3)];
+        if (j < 3) { ul[j][0] = u[0]; ul[j][1] = u[1]; ul[j][2] = u[2]; cross3(ua[j], r, u); }
+        else { ul[j][0] = ul[j][1] = ul[j][2] = 0.f; ua[j][0] = u[0]; ua[j][1] = u[1]; ua[j][2] = u[2]; }
+        symvec3(Iua[j], L.fIinv[f], ua[j]);
+      }
+      float mi = L.fminv[f];
+#pragma unroll
+      for (int j = 0; j < 6; j++)
+#pragma unroll
+        for (int k = 0; k <= j; k++) A[j][k] += mi * dot3(ul[j], ul[k]) + dot3(ua[j], Iua[k]);
+    }
+  }
+  if (c.armslot >= 0) {
+    const ArmCon& ac = L.armcon[c.armslot];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      float Bk[NARM];                    // column k of Minv J^T
+#pragma unroll
+      for (int q = 0; q < NARM; q++) {
+        float v = 0.f;
+#pragma unroll
+        for (int s = 0; s < NARM; s++) v += L.Minv[q][s] * ac.Jt[s][k];
+        Bk[q] = v;
+      }
+#pragma unroll
+      for (int j = k; j < 6; j++) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < NARM; q++) v += ac.Jt[q][j] * Bk[q];
+        A[j][k] += v;
+      }
+    }
+  }
+  const float Rj[6] = {c.R[0], c.R[1], c.R[1], c.R[2], c.R[3], c.R[3]};
+#pragma unroll
+  for (int j = 0; j < 6; j++) A[j][j] += Rj[j];
+#pragma unroll
+  for (int j = 0; j < 6; j++)
+#pragma unroll
+    for (int k = 0; k <= j; k++) P.A[j * (j + 1) / 2 + k] = A[j][k];
+  // Spectral form of the friction block for the cone QCQP (mju_QCQP): with D = diag(mu_j) the scaled block
+  // D Ac D = Q diag(lam) Q^T is decomposed ONCE per substep (cyclic Jacobi, lane = contact); every Newton step
+  // on the cone multiplier inside the PGS sweep is then O(5) instead of a 5x5 Cholesky factorisation.  Rows
+  // >= dim are decoupled (identity).
+  const float fr5[5] = {c.fric[0], c.fric[0], c.fric[1], c.fric[2], c.fric[2]};
+  int nf = dim - 1;
+  float S[5][5], Qm[5][5];
+#pragma unroll
+  for (int i = 0; i < 5; i++)
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      float aik = i >= k ? A[i + 1][k + 1] : A[k + 1][i + 1];        // only the lower triangle of A is filled
+      S[i][k] = (i < nf && k < nf) ? aik * fr5[i] * fr5[k] : (i == k ? 1.f : 0.f);
+      Qm[i][k] = i == k ? 1.f : 0.f;
+    }
+  for (int sweep = 0; sweep < 6; sweep++) {
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+#pragma unroll
+      for (int q = p + 1; q < 5; q++) {
+        float apq = S[p][q];
+        if (fabsf(apq) > 1e-30f) {
+          float app = S[p][p], aqq = S[q][q];
+          float tau = (aqq - app) / (2.f * apq);
+          float t = (tau >= 0.f ? 1.f : -1.f) / (fabsf(tau) + sqrtf(1.f + tau * tau));
+          float cs = 1.f / sqrtf(1.f + t * t), sn = t * cs;
+#pragma unroll
+          for (int k = 0; k < 5; k++) {
+            if (k != p && k != q) {
+              float skp = S[k][p], skq = S[k][q];
+              float np_ = cs * skp - sn * skq, nq_ = sn * skp + cs * skq;
+              S[k][p] = np_; S[p][k] = np_; S[k][q] = nq_; S[q][k] = nq_;
+            }
+            float qkp = Qm[k][p], qkq = Qm[k][q];
+            Qm[k][p] = cs * qkp - sn * qkq; Qm[k][q] = sn * qkp + cs * qkq;
+          }
+          S[p][p] = app - t * apq; S[q][q] = aqq + t * apq; S[p][q] = 0.f; S[q][p] = 0.f;
+        }
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    P.lam[i] = fmaxf(S[i][i], 1e-30f);
+#pragma unroll
+    for (int k = 0; k < 5; k++) P.Q[5 * i + k] = Qm[i][k];
+  }
+}
+
 // one PGS update of an elliptic contact block; returns the cost decrease
-DEV float contact_update(const EnvLDS& L, Contact& c, Acc& a) {
+DEV float contact_update(const EnvLDS& L, Contact& c, const PgsReg& P, Acc& a) {
   int dim = c.dim;
   if (dim == 0) return 0.f;
   float res[6], old[6], f[6];
@@ -139,7 +248,7 @@ DEV float contact_update(const EnvLDS& L, Contact& c, Acc& a) {
 #pragma unroll
   for (int j = 0; j < 6; j++)
 #pragma unroll
-    for (int q = 0; q <= j; q++) { float v = c.A[j * (j + 1) / 2 + q]; A[j][q] = v; A[q][j] = v; }
+    for (int q = 0; q <= j; q++) { float v = P.A[j * (j + 1) / 2 + q]; A[j][q] = v; A[q][j] = v; }
 #pragma unroll
   for (int j = 0; j < 6; j++) { old[j] = c.f[j]; f[j] = old[j]; res[j] = (j < dim) ? res[j] - c.aref[j] + Rj[j] * old[j] : 0.f; }
   // normal / ray update
@@ -184,14 +293,14 @@ DEV float contact_update(const EnvLDS& L, Contact& c, Acc& a) {
     for (int i = 0; i < 5; i++) {
       float s = 0.f;
 #pragma unroll
-      for (int j = 0; j < 5; j++) s += c.Q[5 * j + i] * (bc[j] * fr[j]);
+      for (int j = 0; j < 5; j++) s += P.Q[5 * j + i] * (bc[j] * fr[j]);
       g[i] = s;
     }
     for (int iter = 0; iter < 20; iter++) {
       float val = -r2, deriv = 0.f;
 #pragma unroll
       for (int i = 0; i < 5; i++) {
-        float inv = 1.f / (c.lam[i] + la);
+        float inv = 1.f / (P.lam[i] + la);
         z[i] = -g[i] * inv;
         val += z[i] * z[i];
         deriv -= 2.f * z[i] * z[i] * inv;
@@ -206,7 +315,7 @@ DEV float contact_update(const EnvLDS& L, Contact& c, Acc& a) {
     for (int j = 0; j < 5; j++) {
       float s = 0.f;
 #pragma unroll
-      for (int i = 0; i < 5; i++) s += c.Q[5 * j + i] * z[i];
+      for (int i = 0; i < 5; i++) s += P.Q[5 * j + i] * z[i];
       v[j] = (j + 1 < dim) ? s * fr[j] : 0.f;
     }
     if (la != 0.f) {          // constraint active: put v exactly on the cone (no drift)
@@ -242,6 +351,8 @@ DEV void solve_pgs(const DevModel* m, EnvLDS& L, int max_iter, float tolerance) 
   int nrow = L.nrow, ncon = L.ncon;
   if (lane == 0) L.iters = 0;
   if (nrow + ncon == 0) { wave_sync(); return; }
+  // this solver's lane layout holds MAXCON_PGS contacts; further ones are dropped and flagged
+  if (ncon > MAXCON_PGS) { ncon = MAXCON_PGS; if (lane == 0) L.overflow |= 2; }
   // ---- islands (uniform): union the dynamic bodies each contact couples
   int root[3] = {0, 1, 2};
   for (int k = 0; k < ncon; k++) {
@@ -389,15 +500,16 @@ DEV void solve_pgs(const DevModel* m, EnvLDS& L, int max_iter, float tolerance) 
     }
   }
   wave_sync();
-  // ---- main iteration, lane = constraint block.  Lane k < MAXCON keeps contact k (A block, friction-block
+  // ---- main iteration, lane = constraint block.  Lane k < MAXCON_PGS keeps contact k (A block, friction-block
   // inverse, frame, aref, R, forces) in REGISTERS for the whole solve; lane 32+r keeps scalar row r.  A sweep
   // runs in turns: at turn t every lane whose block is the t-th of its island (MuJoCo order: scalar rows, then
   // contacts) updates at once — islands advance in parallel, blocks of one island stay sequential, so the
   // iterates are those of the plain Gauss-Seidel sweep.  Only the island accelerations travel through LDS.
   bool has_con = lane < ncon, has_row = lane >= 32 && lane - 32 < nrow;
   Contact creg;
+  PgsReg preg;
   Row1 rreg;
-  if (has_con) creg = L.con[lane];
+  if (has_con) { creg = L.con[lane]; pgs_block(L, creg, preg); }
   if (has_row) rreg = L.row[lane - 32];
   int myroot = has_con ? island_of(creg) : (has_row ? root[0] : -1);
   unsigned long long below = (1ull << lane) - 1ull;
@@ -429,7 +541,7 @@ DEV void solve_pgs(const DevModel* m, EnvLDS& L, int max_iter, float tolerance) 
       if (has_con && mypos == t) {
         Acc b;
         acc_load(L, b);
-        improvement += contact_update(L, creg, b);
+        improvement += contact_update(L, creg, preg, b);
         if (creg.armslot >= 0) {
 #pragma unroll
           for (int q = 0; q < NARM; q++) L.qacc_arm[q] = b.arm[q];

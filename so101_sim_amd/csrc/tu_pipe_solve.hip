@@ -29,11 +29,13 @@ __global__ void __launch_bounds__(64, 2) k_narrow(const DevModel* m, int N, Pipe
       const float* p1 = pose + 12 * (d1 < 0 ? 0 : d1); const float* p2 = pose + 12 * (d2 < 0 ? 0 : d2);
       GeomW G1, G2;
       load_geom_at(m, g1, p1, p1 + 3, G1); load_geom_at(m, g2, p2, p2 + 3, G2);
-      float dist, nrm[3], pos[3];
-      bool ok = narrow_pair<HullCache>(m, G1, G2, &dist, nrm, pos);
+      PairContacts pc;
+      narrow_pair<HullCache>(m, G1, G2, g1, g2, pc);
       if (lane == 0) {
-        float* r = W.conres + (size_t)w * 8;
-        r[0] = dist; r[1] = nrm[0]; r[2] = nrm[1]; r[3] = nrm[2]; r[4] = pos[0]; r[5] = pos[1]; r[6] = pos[2]; r[7] = ok ? 1.f : 0.f;
+        float* r = W.conres + (size_t)w * CONRES_DIM;
+        r[0] = (float)pc.n; r[1] = pc.nrm[0]; r[2] = pc.nrm[1]; r[3] = pc.nrm[2];
+#pragma unroll
+        for (int q = 0; q < NCPP; q++) if (q < pc.n) { r[4 + 4 * q] = pc.dist[q]; r[5 + 4 * q] = pc.pos[q][0]; r[6 + 4 * q] = pc.pos[q][1]; r[7 + 4 * q] = pc.pos[q][2]; }
         if (SO101_CLOCKS_ON) W.ticks[w] = (unsigned int)(SO101_CLOCK() - t0);
       }
     }
@@ -81,7 +83,7 @@ __global__ void __launch_bounds__(64, 2) k_pipe_solve(const DevModel* m, StepPar
     gather_contacts(m, L, W, e);
     c2 = SO101_CLOCK();
     unsigned long long t_solve0 = wall_clock64();            // scheduling hint of k_order: always measured
-    make_constraints(m, L, false);
+    make_constraints(m, L);
     c3 = SO101_CLOCK();
     solve_newton(m, L, P.iterations, P.tolerance);
     c4 = SO101_CLOCK();

@@ -51,15 +51,20 @@ __device__ __forceinline__ int wave_min_i(int v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 
-// all-lanes sum with a fixed xor-butterfly order (the emulation harness reproduces the same order)
+// all-lanes sum, every lane gets the result: butterflies inside each row of 16 with DPP (xor 1, xor 2, half-row
+// mirror, row mirror: both partners of every step add the same two values, so all 16 lanes of a row end with
+// identical bits), then the four row sums are combined as (r0 + r1) + (r2 + r3) through v_readlane.  No LDS crossbar
+// (ds_bpermute) round trips; the emulation harness reproduces the same order.  Must be called with all lanes active.
 __device__ __forceinline__ float wave_sum_f(float v) {
-  v += __shfl_xor(v, 32);
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 8);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 1);
-  return v;
+  v += dpp_f<DPP_QUAD_XOR1>(v);
+  v += dpp_f<DPP_QUAD_XOR2>(v);
+  v += dpp_f<DPP_ROW_HALF_MIRROR>(v);
+  v += dpp_f<DPP_ROW_MIRROR>(v);
+  float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (r0 + r1) + (r2 + r3);
 }
 
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __ballot(p); }

@@ -19,10 +19,12 @@ DIAG_DIM = 8
 NEVENTS = 8
 EVENT_NAMES = ("candidate_overflow", "contact_overflow", "arm_pool_overflow", "diverged", "placement_rejected",
                "settle_not_converged")
-DEBUG_DIM = 1024
+DEBUG_DIM = 2048
+MAXCON = 64
 
 # debug_forward layout (csrc/so101_kernels.hpp DBG_*)
-DBG = dict(M=0, MINV=36, BIAS=72, SMOOTH=78, QACC=96, COUNTS=114, XPOS=120, CON=144, FORCE=464, ROWF=656, REWARD=672)
+DBG = dict(M=0, MINV=36, BIAS=72, SMOOTH=78, QACC=96, COUNTS=114, XPOS=120, CON=144, FORCE=144 + 10 * MAXCON,
+           ROWF=144 + 16 * MAXCON, REWARD=144 + 16 * MAXCON + 16)
 
 EXPORTS = (
     "so101_version", "so101_max_contacts", "so101_create", "so101_destroy", "so101_default_config",

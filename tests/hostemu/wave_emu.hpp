@@ -13,10 +13,16 @@ inline float wave_max_f(float v) {
 }
 inline float wave_sum_f(float v) {
   emu_xchg_f[threadIdx.x] = v; __syncthreads();
-  // same butterfly order as the device version so that rounding matches
-  float t[64]; for (int i = 0; i < 64; i++) t[i] = emu_xchg_f[i];
-  for (int s = 32; s >= 1; s >>= 1) { float u[64]; for (int i = 0; i < 64; i++) u[i] = t[i] + t[i ^ s]; for (int i = 0; i < 64; i++) t[i] = u[i]; }
-  __syncthreads(); return t[threadIdx.x];
+  // same order as the device version so that rounding matches: xor 1, xor 2, half-row mirror, row mirror inside each
+  // row of 16, then (r0 + r1) + (r2 + r3)
+  float t[64], u[64];
+  for (int i = 0; i < 64; i++) t[i] = emu_xchg_f[i];
+  for (int i = 0; i < 64; i++) u[i] = t[i] + t[i ^ 1];
+  for (int i = 0; i < 64; i++) t[i] = u[i] + u[i ^ 2];
+  for (int i = 0; i < 64; i++) u[i] = t[i] + t[(i & ~7) | (7 - (i & 7))];
+  for (int i = 0; i < 64; i++) t[i] = u[i] + u[(i & ~15) | (15 - (i & 15))];
+  float r = (t[0] + t[16]) + (t[32] + t[48]);
+  __syncthreads(); return r;
 }
 inline unsigned long long wave_ballot(bool p) {
   emu_xchg_i[threadIdx.x] = p; __syncthreads();
