@@ -630,11 +630,11 @@ void set_contact_params(const Model& m, Contact& c, int g1, int g2) {
 // farther apart than 1e-3 of the smaller bounding radius (libccd path); the native-ccd path of >= 3.3 clips the
 // aligned faces of box / mesh pairs.  Both amount to sampling the extreme points of the flat contact patch.  Restated
 // here for the configurations in which the tilted query has a closed form: one geom presents a flat REFERENCE FACE
-// (the plane, or the face of a box whose outward normal is within acos(FACE_COS) of the contact normal) and the other
+// (the plane, a box face or a cylinder cap whose outward normal is within acos(FACE_COS) of the contact normal) and the other
 // geom (any convex type, the INCIDENT geom) is sampled with its support function:
 //   a_0 = support(-f)                       deepest point below the face (f = outward face normal)
 //   a_k = support(-f + eps * s_k), k=1..4   s_k = (+-u +- v)/sqrt(2), u/v the face axes, eps = 1e-3 (the tilt angle)
-// A sample is a contact if it lies below the face plane, inside the face rectangle, and farther than
+// A sample is a contact if it lies below the face plane, inside the face rectangle / disc, and farther than
 // 1e-3 * min(rbound) from the contacts (positions) already accepted.  All contacts of the pair share the normal +-f.  When a_0
 // does not qualify the single MPR contact is kept.  Other convex pairs (hull-hull, cylinder, capsule) keep one contact.
 constexpr real FACE_COS = 0.9999, PATCH_EPS = 1e-3, PATCH_DUP = 1e-3;
@@ -656,7 +656,8 @@ bool face_patch(const orc_sim* s, int gI, const real* f, const real* c, const re
     real rel[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]};
     real dist = dot3(rel, f);
     bool ok = dist < 0;
-    if (hu >= 0) ok = ok && std::fabs(dot3(rel, u)) <= hu && std::fabs(dot3(rel, v)) <= hv;
+    if (hu >= 0 && hv >= 0) ok = ok && std::fabs(dot3(rel, u)) <= hu && std::fabs(dot3(rel, v)) <= hv;      // rectangle
+    else if (hu >= 0) { real pu = dot3(rel, u), pv = dot3(rel, v); ok = ok && pu * pu + pv * pv <= hu * hu; }      // disc
     if (k == 0 && !ok) return false;
     real cp[3] = {p[0] - 0.5 * dist * f[0], p[1] - 0.5 * dist * f[1], p[2] - 0.5 * dist * f[2]};   // contact position
     for (int j = 0; j < out->n && ok; j++) {
@@ -671,11 +672,18 @@ bool face_patch(const orc_sim* s, int gI, const real* f, const real* c, const re
   return true;
 }
 
-// reference face of box g facing direction `toward` (unit, world): returns the face area, or -1 when no face normal is
-// within FACE_COS of it
-real box_face(const orc_sim* s, int g, const real* toward, real* f, real* c, real* u, real* v, real* hu, real* hv) {
+// reference face of box / cylinder g facing direction `toward` (unit, world): returns the face area, or -1 when no
+// flat face (box face, cylinder cap) has its normal within FACE_COS of it.  hv < 0 marks a disc of radius hu.
+real flat_face(const orc_sim* s, int g, const real* toward, real* f, real* c, real* u, real* v, real* hu, real* hv) {
   const real* R = &s->gmat[9 * g]; const real* P = &s->gpos[3 * g]; const real* sz = &s->m.geom_size[3 * g];
   real loc[3]; mulmatTvec3(loc, R, toward);
+  if (s->m.geom_type[g] == G_CYLINDER) {
+    if (std::fabs(loc[2]) < FACE_COS) return -1;
+    real sg = loc[2] >= 0 ? 1.0 : -1.0;
+    for (int k = 0; k < 3; k++) { f[k] = sg * R[3 * k + 2]; u[k] = R[3 * k]; v[k] = R[3 * k + 1]; c[k] = P[k] + f[k] * sz[1]; }
+    *hu = sz[0]; *hv = -1;
+    return 3.14159265358979323846 * sz[0] * sz[0];
+  }
   int i = 0;
   if (std::fabs(loc[1]) > std::fabs(loc[i])) i = 1;
   if (std::fabs(loc[2]) > std::fabs(loc[i])) i = 2;
@@ -716,15 +724,15 @@ void collision(orc_sim* s) {
       real depth, dir[3], pos[3];
       if (!mpr_penetration(s, g1, g2, &depth, dir, pos)) continue;
       if (depth <= 0) continue;               // margin 0: only penetrating contacts are kept
-      // reference face: a box face aligned with the contact normal (the larger one if both geoms offer one)
+      // reference face: a box face or cylinder cap aligned with the contact normal (the larger one if both geoms offer one)
       real f[3], c[3], u[3], v[3], hu = 0, hv = 0, area = -1;
       int ref = -1;
       for (int side = 0; side < 2; side++) {
         int g = side == 0 ? g1 : g2;
-        if (m.geom_type[g] != G_BOX) continue;
+        if (m.geom_type[g] != G_BOX && m.geom_type[g] != G_CYLINDER) continue;
         real toward[3] = {side == 0 ? dir[0] : -dir[0], side == 0 ? dir[1] : -dir[1], side == 0 ? dir[2] : -dir[2]};
         real f2[3], c2[3], u2[3], v2[3], hu2, hv2;
-        real a2 = box_face(s, g, toward, f2, c2, u2, v2, &hu2, &hv2);
+        real a2 = flat_face(s, g, toward, f2, c2, u2, v2, &hu2, &hv2);
         if (a2 > area) {
           area = a2; ref = side; hu = hu2; hv = hv2;
           for (int k = 0; k < 3; k++) { f[k] = f2[k]; c[k] = c2[k]; u[k] = u2[k]; v[k] = v2[k]; }

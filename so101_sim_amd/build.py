@@ -20,7 +20,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-hip-fp32-correctly-rounded-divide-sqrt: v_rcp/v_sqrt based fp32 division and sqrt (<= ~2.5 ulp) instead of
 # the 10-15 instruction IEEE expansions; the solver is latency-bound and full of both (profiles/README.md).
 # Parity tolerances in tests/parity_cases.py are stated for this build.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-hip-fp32-correctly-rounded-divide-sqrt"]
+# -ffp-contract=on: a*b+c is fused where the SOURCE writes it in one expression (frontend fmuladd), never across
+# statements by the backend.  With the default (fast) the backend picks which product of a*b + c*d to fuse from the
+# surrounding code, so the same device function rounds differently in two kernels and the bit-identity tests
+# (pipelined vs fused step, prefetch on/off) hold only by luck.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-ffp-contract=on"]
 
 
 def translation_units():

@@ -430,6 +430,10 @@ struct HullCache { float x[HULL_K], y[HULL_K], z[HULL_K]; };
 struct NoCache {};
 
 DEV void hull_load(const DevModel* m, const GeomW& G, HullCache& H) {
+  // every slot is written (slots beyond the hull, and the caches of primitives, hold zeros): the caches are moved
+  // around with selects later, and a select over a never-written register is undefined behaviour for the compiler
+#pragma unroll
+  for (int j = 0; j < HULL_K; j++) { H.x[j] = 0.f; H.y[j] = 0.f; H.z[j] = 0.f; }
   if (G.type != G_MESH) return;
   int lane = wave_lane();
   const float* x = ldc(&m->vx) + G.vadr; const float* y = ldc(&m->vy) + G.vadr; const float* z = ldc(&m->vz) + G.vadr;
@@ -442,6 +446,19 @@ DEV void hull_load(const DevModel* m, const GeomW& G, HullCache& H) {
   }
 }
 DEV void hull_load(const DevModel*, const GeomW&, NoCache&) {}
+
+DEV void select_geom(bool first, const GeomW& A, const GeomW& B, GeomW& o) {
+  o.type = first ? A.type : B.type; o.vadr = first ? A.vadr : B.vadr; o.vnum = first ? A.vnum : B.vnum;
+#pragma unroll
+  for (int i = 0; i < 3; i++) { o.size[i] = first ? A.size[i] : B.size[i]; o.p[i] = first ? A.p[i] : B.p[i]; o.c[i] = first ? A.c[i] : B.c[i]; }
+#pragma unroll
+  for (int i = 0; i < 9; i++) o.R[i] = first ? A.R[i] : B.R[i];
+}
+DEV void select_hull(bool first, const HullCache& A, const HullCache& B, HullCache& o) {
+#pragma unroll
+  for (int j = 0; j < HULL_K; j++) { o.x[j] = first ? A.x[j] : B.x[j]; o.y[j] = first ? A.y[j] : B.y[j]; o.z[j] = first ? A.z[j] : B.z[j]; }
+}
+DEV void select_hull(bool, const NoCache&, const NoCache&, NoCache&) {}
 
 // support point (world) of G in world direction dir; wave-parallel over hull vertices for meshes
 template <class Cache>
@@ -755,13 +772,13 @@ DEV void broadphase(const DevModel* m, EnvLDS& L) {
 // MuJoCo's convex-pair multi-contact re-runs the penetration query on configurations tilted by +-1e-3 rad about the
 // two tangent axes and keeps results farther apart than 1e-3 of the smaller bounding radius; its native-ccd path
 // clips the aligned faces of box / mesh pairs.  Both sample the extreme points of a flat contact patch.  Here that is
-// done in closed form whenever one geom presents a flat REFERENCE FACE - the plane, or a box face whose outward normal
-// is within acos(FACE_COS) of the MPR normal - and the other (INCIDENT) geom is sampled through its support function:
+// done in closed form whenever one geom presents a flat REFERENCE FACE - the plane, or a box face / cylinder cap whose
+// outward normal is within acos(FACE_COS) of the MPR normal - and the other (INCIDENT) geom is sampled through its support function:
 //   a_0 = support(-f), a_k = support(-f + eps s_k), s_k = (+-u +- v)/sqrt(2) along the face axes, eps = 1e-3.
-// A sample becomes a contact when it is below the face plane, inside the face rectangle and farther than
+// A sample becomes a contact when it is below the face plane, inside the face rectangle / disc and farther than
 // 1e-3 min(rbound) from the contacts already accepted; all contacts of the pair share the normal +-f.  When a_0 does
 // not qualify, the single MPR contact stays.  Other convex pairs keep one contact.  The supports are wave-parallel,
-// the control flow is wave-uniform.  oracle/so101_oracle.cpp restates the same rule in fp64.
+// the control flow is wave-uniform.  (The test oracle restates the same rule in fp64.)
 #define FACE_COS 0.9999f
 #define PATCH_EPS 1e-3f
 #define PATCH_DUP 1e-3f
@@ -784,7 +801,8 @@ DEV bool face_patch(const DevModel* m, const GeomW& GI, const Cache& HI, const f
     float rel[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]};
     float dist = dot3(rel, f);
     bool ok = dist < 0.f;
-    if (hu >= 0.f) ok = ok && fabsf(dot3(rel, u)) <= hu && fabsf(dot3(rel, v)) <= hv;
+    float pu = dot3(rel, u), pv = dot3(rel, v);
+    if (hu >= 0.f) ok = ok && (hv >= 0.f ? (fabsf(pu) <= hu && fabsf(pv) <= hv) : (pu * pu + pv * pv <= hu * hu));    // rectangle / disc
     if (k == 0 && !ok) return false;
     float cp[3] = {p[0] - 0.5f * dist * f[0], p[1] - 0.5f * dist * f[1], p[2] - 0.5f * dist * f[2]};
 #pragma unroll
@@ -801,26 +819,37 @@ DEV bool face_patch(const DevModel* m, const GeomW& GI, const Cache& HI, const f
   return true;
 }
 
-// face of box G whose outward normal is closest to `toward`: area of the face, or -1 when it is not within FACE_COS
-DEV float box_face(const GeomW& G, const float* toward, float* f, float* c, float* u, float* v, float* hu, float* hv) {
+// flat face of box / cylinder G (box face, cylinder cap) whose outward normal is closest to `toward`: area of the face,
+// or -1 when it is not within FACE_COS.  hv < 0 marks a disc of radius hu.
+DEV float flat_face(const GeomW& G, const float* toward, float* f, float* c, float* u, float* v, float* hu, float* hv) {
   float loc[3]; matTvec3(loc, G.R, toward);
+  if (G.type == G_CYLINDER) {
+    if (fabsf(loc[2]) < FACE_COS) return -1.f;
+    float sg = loc[2] >= 0.f ? 1.f : -1.f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { f[k] = sg * G.R[3 * k + 2]; u[k] = G.R[3 * k]; v[k] = G.R[3 * k + 1]; c[k] = G.p[k] + f[k] * G.size[1]; }
+    *hu = G.size[0]; *hv = -1.f;
+    return 3.14159265f * G.size[0] * G.size[0];
+  }
   float a0 = fabsf(loc[0]), a1 = fabsf(loc[1]), a2 = fabsf(loc[2]);
   int i = 0;
   if (a1 > a0) i = 1;
   if (a2 > (i == 1 ? a1 : a0)) i = 2;
-  float li = i == 0 ? loc[0] : (i == 1 ? loc[1] : loc[2]);
+  // axis picks as 0/1 weights (exact arithmetic; chains of selects on the index get turned into indexed loads of a
+  // stack copy of the geom, i.e. scratch memory)
+  float w0 = i == 0 ? 1.f : 0.f, w1 = i == 1 ? 1.f : 0.f, w2 = i == 2 ? 1.f : 0.f;
+  float li = w0 * loc[0] + w1 * loc[1] + w2 * loc[2];
   if (fabsf(li) < FACE_COS) return -1.f;
   float sg = li >= 0.f ? 1.f : -1.f;
-  int iu = (i + 1) % 3, iv = (i + 2) % 3;
-  float si = i == 0 ? G.size[0] : (i == 1 ? G.size[1] : G.size[2]);
-  float su = iu == 0 ? G.size[0] : (iu == 1 ? G.size[1] : G.size[2]);
-  float sv = iv == 0 ? G.size[0] : (iv == 1 ? G.size[1] : G.size[2]);
+  // u axis = (i + 1) % 3 -> weights (w2, w0, w1); v axis = (i + 2) % 3 -> weights (w1, w2, w0)
+  float si = w0 * G.size[0] + w1 * G.size[1] + w2 * G.size[2];
+  float su = w2 * G.size[0] + w0 * G.size[1] + w1 * G.size[2];
+  float sv = w1 * G.size[0] + w2 * G.size[1] + w0 * G.size[2];
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    float ri = i == 0 ? G.R[3 * k] : (i == 1 ? G.R[3 * k + 1] : G.R[3 * k + 2]);
-    f[k] = sg * ri;
-    u[k] = iu == 0 ? G.R[3 * k] : (iu == 1 ? G.R[3 * k + 1] : G.R[3 * k + 2]);
-    v[k] = iv == 0 ? G.R[3 * k] : (iv == 1 ? G.R[3 * k + 1] : G.R[3 * k + 2]);
+    f[k] = sg * (w0 * G.R[3 * k] + w1 * G.R[3 * k + 1] + w2 * G.R[3 * k + 2]);
+    u[k] = w2 * G.R[3 * k] + w0 * G.R[3 * k + 1] + w1 * G.R[3 * k + 2];
+    v[k] = w1 * G.R[3 * k] + w2 * G.R[3 * k + 1] + w0 * G.R[3 * k + 2];
     c[k] = G.p[k] + f[k] * si;
   }
   *hu = su; *hv = sv;
@@ -850,10 +879,10 @@ DEV void narrow_pair(const DevModel* m, const GeomW& G1, const GeomW& G2, int g1
   // reference face: a box face aligned with the contact normal (the larger one when both geoms offer one)
   float f[3], c[3], u[3], v[3], hu = 0.f, hv = 0.f, area = -1.f;
   int ref = -1;
-  if (G1.type == G_BOX) { area = box_face(G1, nrm, f, c, u, v, &hu, &hv); if (area >= 0.f) ref = 0; }
-  if (G2.type == G_BOX) {
+  if (G1.type == G_BOX || G1.type == G_CYLINDER) { area = flat_face(G1, nrm, f, c, u, v, &hu, &hv); if (area >= 0.f) ref = 0; }
+  if (G2.type == G_BOX || G2.type == G_CYLINDER) {
     float tw[3] = {-nrm[0], -nrm[1], -nrm[2]}, f2[3], c2[3], u2[3], v2[3], hu2, hv2;
-    float a2 = box_face(G2, tw, f2, c2, u2, v2, &hu2, &hv2);
+    float a2 = flat_face(G2, tw, f2, c2, u2, v2, &hu2, &hv2);
     if (a2 > area) {
       area = a2; ref = 1; hu = hu2; hv = hv2;
 #pragma unroll
@@ -861,9 +890,14 @@ DEV void narrow_pair(const DevModel* m, const GeomW& G1, const GeomW& G2, int g1
     }
   }
   bool patched = false;
-  float tol = PATCH_DUP * fminf(rb1, rb2);
-  if (ref == 0) patched = face_patch(m, G2, H2, f, c, u, v, hu, hv, tol, out);
-  else if (ref == 1) patched = face_patch(m, G1, H1, f, c, u, v, hu, hv, tol, out);
+  if (ref >= 0) {
+    // the incident geom (and its cached hull) selected into ONE set of registers: a single inlined copy of the patch
+    // sampling, and the reference geom's registers are free from here on
+    GeomW GI; Cache HI;
+    select_geom(ref == 0, G2, G1, GI);
+    select_hull(ref == 0, H2, H1, HI);
+    patched = face_patch(m, GI, HI, f, c, u, v, hu, hv, PATCH_DUP * fminf(rb1, rb2), out);
+  }
   if (patched) {
     float sg = ref == 0 ? 1.f : -1.f;
     out.nrm[0] = sg * f[0]; out.nrm[1] = sg * f[1]; out.nrm[2] = sg * f[2];

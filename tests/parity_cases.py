@@ -200,7 +200,7 @@ def check_env_semantics(make_sim, blobs, n=2, settle=30, steps=8, last_step=7, s
         oracles.append(o)
     rng = np.random.RandomState(seed)
     undelayed_hist = []
-    touched = [False] * n          # the arm has been in contact during this episode
+    touched, deep = [False] * n, [False] * n          # the arm has been in (deep) contact during this episode
     for t in range(1, steps + 1):
         act = rng.uniform(-0.4, 0.4, size=(n, 6)).astype(np.float32)
         obs, rew, disc, st = sim.step(act)
@@ -208,15 +208,21 @@ def check_env_semantics(make_sim, blobs, n=2, settle=30, steps=8, last_step=7, s
             oo, orew, odisc, ost = o.env_step(act[e].astype(np.float64))
             assert (rew[e], disc[e], st[e]) == (orew, odisc, ost), (t, e)
             if ost == 0:
-                touched[e] = False
+                touched[e], deep[e] = False, False
             else:
-                touched[e] = touched[e] or any(_arm_geom(c["geom1"]) or _arm_geom(c["geom2"]) for c in o.contacts())
+                arm_con = [c for c in o.contacts() if _arm_geom(c["geom1"]) or _arm_geom(c["geom2"])]
+                touched[e] = touched[e] or bool(arm_con)
+                # A jaw driven > 1 cm into the 4 cm table slab sits near the slab's mid-plane, where the penetration
+                # direction flips from "up" to "down" (tunnelling): a discontinuity of any min-depth contact model, and
+                # fp32 / fp64 take different sides.  Joint trajectories are not compared for the rest of such an episode.
+                deep[e] = deep[e] or any(c["dist"] < -1e-2 for c in arm_con)
+                if deep[e]:
+                    continue
                 # free-space arm: fp32 vs fp64 round-off only.  Once the arm pushes against the table or a prop, the
                 # joint trajectory depends on the contact phase (same bound as check_control_step)
                 tol = 5e-3 if touched[e] else 5e-5
                 np.testing.assert_allclose(obs[e, 6:12], oo[6:12], atol=tol)
                 np.testing.assert_allclose(obs[e, 0:6], oo[0:6], atol=tol)
-                np.testing.assert_array_equal(obs[e, 12:18], act[e])          # commanded = raw action (offsets 0)
         undelayed_hist.append(obs[:, 6:12].copy())
         if t <= last_step:
             assert np.all(st == (2 if t == last_step else 1))
@@ -279,11 +285,47 @@ def check_pipeline_identical(make_sim, golden, n=4, steps=3, seed=9, settle=20, 
             np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-4, err_msg=f"step {t}")
 
 
-def check_contact_rich(make_sim, blobs, golden, count=4, verbose=False):
-    """Arm self-collision / arm-table / arm-prop contact states (20-30 simultaneous contacts, captured from a
-    random-action rollout): same contact set as the oracle and the same constrained acceleration.
-    Tolerance: contact sets equal up to contacts shallower than 2e-6 m; qacc within 2% of max|qacc|
-    (both solvers stop at the 100-iteration cap, far from converged, with fp32 vs fp64 iterates)."""
+def _compare_contact_lists(mine_list, ref_list):
+    """-> (problems, total, loose).  problems: list of strings, empty when the two contact lists agree.
+    Tolerance: same pairs in the same order with the same number of contacts (a contact may be missing on one side only
+    if it is shallower than 2e-6 m); distance 5e-6 m + 1e-4 relative; position 2e-5 m and normal 1e-4, except for
+    ill-conditioned MPR contacts (counted in `loose`): a hull vertex on the rim of the static puck, an edge on an edge -
+    the penetration direction is the normal of the last portal triangle and the fp64 query itself turns by degrees
+    under 1e-7 perturbations there; those must agree in depth, roughly in direction (cos >= 0.9) and place (1 mm) and
+    be shallow (< 1 mm)."""
+    by_pair = lambda cons: {k: [c for c in cons if (c["geom1"], c["geom2"]) == k] for k in dict.fromkeys((c["geom1"], c["geom2"]) for c in cons)}
+    mine, ref = by_pair(mine_list), by_pair(ref_list)
+    problems, total, loose = [], 0, 0
+    for k in list(dict.fromkeys(list(mine) + list(ref))):
+        cm, cr = mine.get(k, []), ref.get(k, [])
+        if len(cm) != len(cr):
+            extra = cm[len(cr):] if len(cm) > len(cr) else cr[len(cm):]
+            if not all(abs(c["dist"]) < 2e-6 for c in extra):
+                problems.append(f"{k}: {len(cm)} vs {len(cr)} contacts")
+        for c1, c2 in zip(cm, cr):
+            total += 1
+            if abs(c1["dist"] - c2["dist"]) > 5e-6 + 1e-4 * abs(c2["dist"]):
+                problems.append(f"{k}: dist {c1['dist']:.6f} vs {c2['dist']:.6f}")
+                continue
+            dn, dp = np.abs(c1["normal"] - c2["normal"]).max(), np.abs(c1["pos"] - c2["pos"]).max()
+            if dn <= 1e-4 and dp <= 2e-5:
+                continue
+            loose += 1
+            if not (float(np.dot(c1["normal"], c2["normal"])) >= 0.9 and dp <= 1e-3 and abs(c2["dist"]) <= 1e-3):
+                problems.append(f"{k}: normal {dn:.2e} pos {dp:.2e} at depth {c2['dist']:.6f}")
+    return problems, total, loose
+
+
+def check_contact_rich(make_sim, blobs, golden, count=4, verbose=False, max_discontinuous=0.25):
+    """Arm self-collision / arm-table / arm-prop contact states (20-40 simultaneous contacts, captured from a
+    random-action rollout): the SAME contact list as the oracle (pair by pair, contact by contact, in order, tolerances
+    in _compare_contact_lists) and the same constrained acceleration (1e-3 of max|qacc|; Newton converged on both sides).
+
+    The MPR penetration query is a discontinuous function of the state where a thin plate (a 2 mm finger pad) is buried
+    centimetres deep in a hull: the portal it ends on, hence the depth, jumps.  A state whose comparison fails is
+    therefore re-examined ONCE in its neighbourhood: the kernel's answer is accepted only if the fp64 oracle returns
+    the same contact list and the same qacc somewhere within 1e-6 rad of the state, and at most `max_discontinuous` of
+    the states may need that (the count is returned).  MuJoCo's EPA has no such jumps - known deviation."""
     states = golden["contact_rich_states"]["states"][:count]
     n = len(states)
     Q = np.array([s["qpos"] for s in states]).T
@@ -293,47 +335,47 @@ def check_contact_rich(make_sim, blobs, golden, count=4, verbose=False):
     sim = make_sim(n)
     sim.set_state(Q, V, A, W)
     dbg = sim.debug_forward()
-    worst, seen_arm_arm = 0.0, False
+
     def oracle_eval(q, e):
         o = Oracle(blobs["f64"])
         o.set_state(q, V[:, e], W[:, e])
         o.set_ctrl(A[:, e])
         o.forward()
-        return o.qacc()[0], {(c["geom1"], c["geom2"]): c for c in o.contacts()}
+        return o.qacc()[0], o.contacts()
 
-    def mismatches(mine, ref):
-        bad = [k for k in set(mine) ^ set(ref) if abs((mine.get(k) or ref.get(k))["dist"]) >= 2e-6]   # only grazing contacts may differ
-        bad += [k for k in set(mine) & set(ref) if abs(mine[k]["dist"] - ref[k]["dist"]) > 5e-6 + 1e-4 * abs(ref[k]["dist"])]
-        return bad
-
+    worst, seen_arm_arm, seen_multi, total, loose, discontinuous = 0.0, False, False, 0, 0, []
     for e in range(n):
         d = dbg[e]
         assert d["overflow"] == 0
-        mine = {(c["geom1"], c["geom2"]): c for c in d["contacts"]}
         a, ref = oracle_eval(Q[:, e], e)
-        bad = mismatches(mine, ref)
-        if bad:
-            # MPR reports the facet of the Minkowski difference that the origin ray leaves through; when the ray grazes
-            # an edge of that polytope the answer jumps between the two facets (the fp64 oracle itself flips under 1e-7
-            # perturbations of such a state).  Accept the kernel's answer iff the oracle reproduces the WHOLE contact
-            # set somewhere within 1e-6 rad of the state, and compare qacc against that evaluation.
+        problems, t, l = _compare_contact_lists(d["contacts"], ref)
+        err = np.abs(d["qacc"] - a).max() / np.abs(a).max()
+        if problems or err > 1e-3:
+            discontinuous.append(e)
             prng, found = np.random.RandomState(1234 + e), False
-            for _ in range(60):
+            for _ in range(40):
                 q = Q[:, e].copy()
                 q[:6] += prng.uniform(-1e-6, 1e-6, 6)
                 a, ref = oracle_eval(q, e)
-                if not mismatches(mine, ref):
+                p2, t, l = _compare_contact_lists(d["contacts"], ref)
+                err = np.abs(d["qacc"] - a).max() / np.abs(a).max()
+                if not p2 and err <= 1e-3:
                     found = True
                     break
-            assert found, (e, bad)
-        seen_arm_arm = seen_arm_arm or any(_arm_geom(g1) and _arm_geom(g2) for g1, g2 in ref)
-        err = np.abs(d["qacc"] - a).max() / np.abs(a).max()
+            assert found, (e, problems)
+        total += t
+        loose += l
+        pairs = [(c["geom1"], c["geom2"]) for c in ref]
+        seen_multi = seen_multi or len(set(pairs)) < len(pairs)
+        seen_arm_arm = seen_arm_arm or any(_arm_geom(g1) and _arm_geom(g2) for g1, g2 in pairs)
         worst = max(worst, err)
         if verbose:
-            print(e, "ncon", len(ref), "qacc rel err", err)
-        assert err <= 2e-2, (e, err)
+            print(e, "ncon", len(ref), "qacc rel err", err, "neighbourhood" if e in discontinuous else "")
     assert seen_arm_arm, "fixture must contain arm-arm contacts"
-    return worst
+    assert seen_multi, "fixture must contain a pair with several contacts (flat-face patch)"
+    assert loose <= 0.1 * total, (loose, total)
+    assert len(discontinuous) <= max_discontinuous * n, discontinuous
+    return worst, discontinuous
 
 
 def check_divergence_handling(make_sim, blobs):

@@ -53,7 +53,7 @@ def test_kat2_reset_state(blobs, golden):
     ob = golden["kat2"]["observation"]
     np.testing.assert_allclose(ob["commanded_joints_pos"], scenes.SO100_HOME_CTRL, atol=1e-12)   # no calibration file
     o = Oracle(blobs["f64"])
-    o.env_config(seed=3, env_id=0)
+    o.env_config(seed=5, env_id=0)          # a placement on the flat table (seed 3 drops the bowl onto the static puck)
     obs = o.env_reset()
     q, v, _ = o.get_state()
     assert np.all(q[:6] == 0) and np.all(v[:6] == 0)                  # arm untouched by placement and settle
@@ -64,8 +64,37 @@ def test_kat2_reset_state(blobs, golden):
     yaw = 2 * np.arctan2(q[12], q[9])
     assert abs(yaw) <= 0.1 * np.pi + 1e-2
     # rest heights: notebook banana z = 0.42171 (both KATs); bowl on the flat table z = 0.422622 (KAT-1)
-    assert abs(q[8] - ob["physics_state"][8]) < 1e-4
-    assert abs(q[15] - golden["kat1"]["observation"]["physics_state"][15]) < 5e-5 or q[15] > 0.4227   # or on the puck
+    # (the banana's resting roll angle depends on its proxy centre of mass: 2.4e-5 m; the bowl is symmetric: 7e-7 m)
+    assert abs(q[8] - ob["physics_state"][8]) < 5e-5
+    assert abs(q[15] - golden["kat1"]["observation"]["physics_state"][15]) < 1e-5
+
+
+def test_notebook_rest_pose_is_an_equilibrium_of_the_contact_model(blobs, golden):
+    """KAT-1's reset state is a resting pose produced by the reference's MuJoCo (multiccd on, so100_task.py:151): banana
+    0.10 mm and bowl 0.15 mm into the table top.  Rest penetration of the soft-contact model does not depend on the
+    props' (proxy) mass, only on the contact set and solref/solimp, so the pose pins the contact generation: at the
+    notebook's pose the props' net vertical acceleration must vanish, and one control step must leave their height
+    where the notebook has it.  (With one contact per hull pair the same pose accelerates upwards at ~2 m/s^2 and
+    settles 25 um higher.)"""
+    ob = golden["kat1"]["observation"]
+    start, after = np.array(ob["delayed_physics_state"]), np.array(ob["physics_state"])
+    o = Oracle(blobs["f64"])
+    o.set_state(start[:20], np.zeros(18), None)
+    o.set_ctrl(np.zeros(6))
+    o.forward()
+    a, _ = o.qacc()
+    assert abs(a[8]) < 0.05 and abs(a[14]) < 0.05, (a[8], a[14])          # |z accelerations| < 0.5 % of g
+    assert len(o.contacts()) >= 8
+    o.set_state(start[:20], start[20:], None)
+    o.substeps(10, True)
+    q, _, _ = o.get_state()
+    assert abs(q[8] - after[8]) < 1e-5 and abs(q[15] - after[15]) < 1e-5, (q[8] - after[8], q[15] - after[15])
+    # KAT-2 (another seed): the banana rests at the same depth; the bowl there was still rocking on the static puck
+    k2 = np.array(golden["kat2"]["observation"]["physics_state"])
+    o.set_state(k2[:20], k2[20:], None)
+    o.substeps(10, True)
+    q, _, _ = o.get_state()
+    assert abs(q[8] - k2[8]) < 1e-5, q[8] - k2[8]
 
 
 def test_kat3_api_facts(blobs, golden):
