@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SO101_ABI_VERSION 3
+#define SO101_ABI_VERSION 4
 #define SO101_OBS_DIM 18      /* joints_pos(6, delayed) | undelayed_joints_pos(6) | commanded_joints_pos(6) */
 #define SO101_ACT_DIM 6
 #define SO101_SOLVER_PGS 0
@@ -60,6 +60,10 @@ typedef struct {
   float* ep_return;    /* [N] running sum of rewards of the current episode */
   int32_t* step_count; /* [N] control steps since reset */
   int32_t* episode;    /* [N] episode counter (keys the reset RNG) */
+  const float* mass_scale; /* [2][N] per-env scale of the free props' mass and inertia (object, container): domain
+                          randomisation beyond the reference, which randomises poses only (so100_hand_over.py:37-55);
+                          NULL = 1.0 everywhere.  Read at every step and reset; after changing values call
+                          so101_configure (cached initial states were settled with the old masses). */
 } so101_buffers;
 
 /* Tunables that the reference fixes through its MJCF / dm_control arguments. */
@@ -107,6 +111,14 @@ int so101_bind_state(so101_sim* sim, const so101_buffers* buffers);
  * (seed, env_id, episode), container rejection-sampled against collisions, props settled with the arm
  * held, delay line filled with the reset value.  mask: [N] bytes, nonzero = reset that env; NULL = all. */
 int so101_reset(so101_sim* sim, const uint8_t* mask, void* hip_stream);
+
+/* Reset pool: with pool_size > 0 every reset (so101_reset and the auto-reset inside so101_step) starts the episode
+ * from entry floor(u * pool_size) of the caller's pool, u = the counter RNG at (seed, global env id, episode, draw
+ * 1000), instead of placement + settle: scripted pre-grasp states for contact-heavy workloads
+ * (examples/automated_lerobot_dataset_generator.py:180-205 scripts such states on the reference), checkpoints.
+ * qpos[20][K], qvel[18][K], ctrl[6][K] are device pointers that must outlive their use; pool_size = 0 restores the
+ * reference's reset. */
+int so101_set_reset_pool(so101_sim* sim, const float* qpos, const float* qvel, const float* ctrl, int pool_size);
 
 /* Starts an episode from whatever state the caller wrote into the bound buffers (checkpoint restore,
  * known-answer tests): ctrl = home + offsets, delay line filled with the current joints_pos,

@@ -45,6 +45,8 @@ def lib():
             getattr(L, n).argtypes = [C.c_void_p]
         L.orc_set_solver.argtypes = [C.c_void_p, C.c_int, C.c_double]
         L.orc_set_collision.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_mass_scale.argtypes = [C.c_void_p, dp]
+        L.orc_inject_contacts.argtypes = [C.c_void_p, C.c_int, dp]
         L.orc_set_solver_type.argtypes = [C.c_void_p, C.c_int]
         L.orc_ls_evals.restype = C.c_int
         L.orc_ls_evals.argtypes = [C.c_void_p]
@@ -118,6 +120,15 @@ class Oracle:
 
     def set_solver_type(self, newton: bool):
         self.L.orc_set_solver_type(self.h, int(bool(newton)))
+
+    def set_mass_scale(self, scale):
+        sc = np.ascontiguousarray(scale, dtype=np.float64)
+        self.L.orc_set_mass_scale(self.h, _p(sc))
+
+    def inject_contacts(self, contacts):
+        """contacts: list of dicts (pos, normal, dist, geom1, geom2) used by forward() instead of the narrowphase; [] clears"""
+        rows = np.array([[*c["pos"], *c["normal"], c["dist"], c["geom1"], c["geom2"]] for c in contacts], dtype=np.float64).reshape(-1, 9)
+        self.L.orc_inject_contacts(self.h, len(contacts), _p(np.ascontiguousarray(rows)) if len(contacts) else None)
 
     def set_collision(self, enable: bool):
         self.L.orc_set_collision(self.h, int(enable))

@@ -160,6 +160,8 @@ struct orc_sim {
   std::vector<real> J, efc_pos, efc_D, efc_R, efc_aref, efc_force, efc_floss, efc_b, AR;
   std::vector<int> efc_type, efc_id, efc_dim;
   int iterations; real tolerance; bool collide = true;
+  std::vector<real> mass0, inertia0, invweight0;     // unscaled prop masses (orc_set_mass_scale)
+  std::vector<Contact> injected;                      // orc_inject_contacts
   int solver = 1;              // 1 = Newton (mujoco default; the reference scene sets no solver), 0 = PGS (north_star)
   int ls_evals = 0;
   // env layer
@@ -630,17 +632,25 @@ void set_contact_params(const Model& m, Contact& c, int g1, int g2) {
 // farther apart than 1e-3 of the smaller bounding radius (libccd path); the native-ccd path of >= 3.3 clips the
 // aligned faces of box / mesh pairs.  Both amount to sampling the extreme points of the flat contact patch.  Restated
 // here for the configurations in which the tilted query has a closed form: one geom presents a flat REFERENCE FACE
-// (the plane, a box face or a cylinder cap whose outward normal is within acos(FACE_COS) of the contact normal) and the other
+// (the plane, or the box face / cylinder cap along which the pair is shallowest, see collision()) and the other
 // geom (any convex type, the INCIDENT geom) is sampled with its support function:
 //   a_0 = support(-f)                       deepest point below the face (f = outward face normal)
 //   a_k = support(-f + eps * s_k), k=1..4   s_k = (+-u +- v)/sqrt(2), u/v the face axes, eps = 1e-3 (the tilt angle)
 // A sample is a contact if it lies below the face plane, inside the face rectangle / disc, and farther than
 // 1e-3 * min(rbound) from the contacts (positions) already accepted.  All contacts of the pair share the normal +-f.  When a_0
 // does not qualify the single MPR contact is kept.  Other convex pairs (hull-hull, cylinder, capsule) keep one contact.
-constexpr real FACE_COS = 0.9999, PATCH_EPS = 1e-3, PATCH_DUP = 1e-3;
+constexpr real FACE_DEPTH_REL = 1e-2, FACE_DEPTH_ABS = 1e-6, PATCH_EPS = 1e-3, PATCH_DUP = 1e-3;
 constexpr int NCPP = 5;
 
 struct Patch { int n; real nrm[3], dist[NCPP], pos[NCPP][3]; };
+
+bool inside_face(const real* rel, const real* u, const real* v, real hu, real hv) {
+  if (hu < 0) return true;                                            // unbounded plane
+  real pu = dot3(rel, u), pv = dot3(rel, v);
+  return hv >= 0 ? (std::fabs(pu) <= hu && std::fabs(pv) <= hv) : (pu * pu + pv * pv <= hu * hu);
+}
+
+
 
 // reference face: outward normal f (towards the incident geom), point c on it, axes u, v with half extents hu, hv
 // (hu < 0: unbounded plane); dup_tol: minimal distance between two contacts of the pair
@@ -656,8 +666,7 @@ bool face_patch(const orc_sim* s, int gI, const real* f, const real* c, const re
     real rel[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]};
     real dist = dot3(rel, f);
     bool ok = dist < 0;
-    if (hu >= 0 && hv >= 0) ok = ok && std::fabs(dot3(rel, u)) <= hu && std::fabs(dot3(rel, v)) <= hv;      // rectangle
-    else if (hu >= 0) { real pu = dot3(rel, u), pv = dot3(rel, v); ok = ok && pu * pu + pv * pv <= hu * hu; }      // disc
+    ok = ok && inside_face(rel, u, v, hu, hv);
     if (k == 0 && !ok) return false;
     real cp[3] = {p[0] - 0.5 * dist * f[0], p[1] - 0.5 * dist * f[1], p[2] - 0.5 * dist * f[2]};   // contact position
     for (int j = 0; j < out->n && ok; j++) {
@@ -672,27 +681,24 @@ bool face_patch(const orc_sim* s, int gI, const real* f, const real* c, const re
   return true;
 }
 
-// reference face of box / cylinder g facing direction `toward` (unit, world): returns the face area, or -1 when no
-// flat face (box face, cylinder cap) has its normal within FACE_COS of it.  hv < 0 marks a disc of radius hu.
-real flat_face(const orc_sim* s, int g, const real* toward, real* f, real* c, real* u, real* v, real* hu, real* hv) {
+// flat face number `axis` (box: 0..2 = local x/y/z on the side facing `toward`; cylinder: only axis 2 = the cap) of
+// geom g: outward normal f, centre c, in-plane axes u/v with half extents (hv < 0: disc of radius hu).  Returns the
+// cosine between f and `toward` (unit, world); the face is a candidate when that exceeds FACE_MIN_COS.
+real flat_face(const orc_sim* s, int g, int axis, const real* toward, real* f, real* c, real* u, real* v, real* hu, real* hv) {
   const real* R = &s->gmat[9 * g]; const real* P = &s->gpos[3 * g]; const real* sz = &s->m.geom_size[3 * g];
   real loc[3]; mulmatTvec3(loc, R, toward);
   if (s->m.geom_type[g] == G_CYLINDER) {
-    if (std::fabs(loc[2]) < FACE_COS) return -1;
+    if (axis != 2) return -1;
     real sg = loc[2] >= 0 ? 1.0 : -1.0;
     for (int k = 0; k < 3; k++) { f[k] = sg * R[3 * k + 2]; u[k] = R[3 * k]; v[k] = R[3 * k + 1]; c[k] = P[k] + f[k] * sz[1]; }
     *hu = sz[0]; *hv = -1;
-    return 3.14159265358979323846 * sz[0] * sz[0];
+    return 1;
   }
-  int i = 0;
-  if (std::fabs(loc[1]) > std::fabs(loc[i])) i = 1;
-  if (std::fabs(loc[2]) > std::fabs(loc[i])) i = 2;
-  if (std::fabs(loc[i]) < FACE_COS) return -1;
+  int i = axis, iu = (i + 1) % 3, iv = (i + 2) % 3;
   real sg = loc[i] >= 0 ? 1.0 : -1.0;
-  int iu = (i + 1) % 3, iv = (i + 2) % 3;
   for (int k = 0; k < 3; k++) { f[k] = sg * R[3 * k + i]; u[k] = R[3 * k + iu]; v[k] = R[3 * k + iv]; c[k] = P[k] + f[k] * sz[i]; }
   *hu = sz[iu]; *hv = sz[iv];
-  return 4 * sz[iu] * sz[iv];
+  return 1;
 }
 
 void collision(orc_sim* s) {
@@ -724,17 +730,34 @@ void collision(orc_sim* s) {
       real depth, dir[3], pos[3];
       if (!mpr_penetration(s, g1, g2, &depth, dir, pos)) continue;
       if (depth <= 0) continue;               // margin 0: only penetrating contacts are kept
-      // reference face: a box face or cylinder cap aligned with the contact normal (the larger one if both geoms offer one)
-      real f[3], c[3], u[3], v[3], hu = 0, hv = 0, area = -1;
+      // Reference face: every flat face (box face, cylinder cap) of either geom on the side that looks towards the other
+      // geom is a candidate direction of separation: its depth is how far the other
+      // geom's deepest point a0 = support(-f) lies below the face plane, valid when a0 is inside the face outline.
+      // The shallowest candidate wins if it is not deeper than MPR's own answer (1 % + 1e-6 m slack: for a face contact
+      // both are the same number).  MPR's depth is the depth along ITS final portal normal, which for a thin plate
+      // (finger pad) against a hull can be an oblique direction ten times deeper than the plate's face normal; the
+      // minimum over both repairs that, in fp64 as in fp32.
+      real f[3], c[3], u[3], v[3], hu = 0, hv = 0, best = depth * (1 + FACE_DEPTH_REL) + FACE_DEPTH_ABS;
       int ref = -1;
       for (int side = 0; side < 2; side++) {
-        int g = side == 0 ? g1 : g2;
+        int g = side == 0 ? g1 : g2, gI = side == 0 ? g2 : g1;
         if (m.geom_type[g] != G_BOX && m.geom_type[g] != G_CYLINDER) continue;
-        real toward[3] = {side == 0 ? dir[0] : -dir[0], side == 0 ? dir[1] : -dir[1], side == 0 ? dir[2] : -dir[2]};
-        real f2[3], c2[3], u2[3], v2[3], hu2, hv2;
-        real a2 = flat_face(s, g, toward, f2, c2, u2, v2, &hu2, &hv2);
-        if (a2 > area) {
-          area = a2; ref = side; hu = hu2; hv = hv2;
+        // of the two faces of an axis, the one on the side of the incident geom's centre
+        real ci[3], cg[3]; geom_center(s, gI, ci); geom_center(s, g, cg);
+        real toward[3] = {ci[0] - cg[0], ci[1] - cg[1], ci[2] - cg[2]};
+        for (int axis = 0; axis < 3; axis++) {
+          real f2[3], c2[3], u2[3], v2[3], hu2, hv2;
+          if (flat_face(s, g, axis, toward, f2, c2, u2, v2, &hu2, &hv2) < 0) continue;
+          // a0 is at least as deep as any interior point of the incident geom: skip the support when even its centre
+          // is not shallower than the best answer so far (the side faces of the table top, a metre away)
+          real cr[3] = {c2[0] - ci[0], c2[1] - ci[1], c2[2] - ci[2]};
+          if (dot3(cr, f2) >= best) continue;
+          real nf[3] = {-f2[0], -f2[1], -f2[2]}, a0[3];
+          support(s, gI, nf, a0);
+          real rel[3] = {a0[0] - c2[0], a0[1] - c2[1], a0[2] - c2[2]};
+          real d0 = -dot3(rel, f2);
+          if (!(d0 > 0) || !(d0 < best) || !inside_face(rel, u2, v2, hu2, hv2)) continue;
+          best = d0; ref = side; hu = hu2; hv = hv2;
           for (int k = 0; k < 3; k++) { f[k] = f2[k]; c[k] = c2[k]; u[k] = u2[k]; v[k] = v2[k]; }
         }
       }
@@ -1224,7 +1247,16 @@ void forward(orc_sim* s, bool freeze_arm) {
     for (int c = 0; c < nv; c++) v += s->Minv[r * nv + c] * (s->qfrc_act[c] - s->bias[c]);   // damping = 0 in this model
     s->qacc_smooth[r] = v;
   }
-  collision(s);
+  if (s->injected.empty()) collision(s);
+  else {                                   // solver-parity tests: the caller's contact list instead of the narrowphase
+    s->con.clear();
+    for (const Contact& c0 : s->injected) {
+      Contact c = c0;
+      make_frame(c.frame);
+      set_contact_params(m, c, c.g1, c.g2);
+      s->con.push_back(c);
+    }
+  }
   make_constraints(s, freeze_arm);
   if (s->solver == 1) solve_newton(s); else solve_pgs(s);
 }
@@ -1447,6 +1479,27 @@ int orc_nv(const orc_sim* s) { return s->m.nv; }
 int orc_nu(const orc_sim* s) { return s->m.nu; }
 void orc_set_solver(orc_sim* s, int it, double tol) { if (it > 0) s->iterations = it; if (tol >= 0) s->tolerance = tol; }
 void orc_set_collision(orc_sim* s, int e) { s->collide = e != 0; }
+void orc_inject_contacts(orc_sim* s, int n, const double* rows) {     // rows [n][9]: pos3 normal3 dist geom1 geom2; n = 0 clears
+  s->injected.clear();
+  for (int k = 0; k < n; k++) {
+    const double* r = rows + 9 * k;
+    Contact c{};
+    for (int i = 0; i < 3; i++) { c.pos[i] = r[i]; c.frame[i] = r[3 + i]; }
+    normalize3(c.frame);
+    c.dist = r[6]; c.g1 = (int)r[7]; c.g2 = (int)r[8];
+    s->injected.push_back(c);
+  }
+}
+void orc_set_mass_scale(orc_sim* s, const double* scale) {
+  Model& m = s->m;
+  if (s->mass0.empty()) { s->mass0 = m.body_mass; s->inertia0 = m.body_inertia; s->invweight0 = m.body_invweight0; }
+  for (int f = 0; f < m.nfree; f++) {
+    int b = m.free_body[f];
+    m.body_mass[b] = s->mass0[b] * scale[f];
+    for (int k = 0; k < 3; k++) m.body_inertia[3 * b + k] = s->inertia0[3 * b + k] * scale[f];
+    for (int k = 0; k < 2; k++) m.body_invweight0[2 * b + k] = s->invweight0[2 * b + k] / scale[f];
+  }
+}
 void orc_set_solver_type(orc_sim* s, int t) { s->solver = t; }
 int orc_ls_evals(const orc_sim* s) { return s->ls_evals; }
 void orc_set_state(orc_sim* s, const double* q, const double* v, const double* w) {
@@ -1478,6 +1531,12 @@ void orc_get_contact(const orc_sim* s, int k, double* o) {
   o[6] = c.dist; o[7] = c.g1; o[8] = c.g2; o[9] = c.dim;
 }
 void orc_get_efc_force(const orc_sim* s, double* f) { std::copy(s->efc_force.begin(), s->efc_force.end(), f); }
+void orc_get_efc_array(const orc_sim* s, int which, double* out) {
+  if (which == 0) std::copy(s->efc_R.begin(), s->efc_R.end(), out);
+  else if (which == 1) std::copy(s->efc_aref.begin(), s->efc_aref.end(), out);
+  else if (which == 2) for (size_t i = 0; i < s->efc_type.size(); i++) out[i] = s->efc_type[i];
+  else if (which == 3) std::copy(s->J.begin(), s->J.end(), out);
+}
 void orc_get_body_pose(const orc_sim* s, int b, double* p, double* q) {
   for (int k = 0; k < 3; k++) p[k] = s->xpos[3 * b + k];
   for (int k = 0; k < 4; k++) q[k] = s->xquat[4 * b + k];

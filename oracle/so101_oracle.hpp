@@ -42,6 +42,11 @@ int orc_nu(const orc_sim*);
 // solver knobs: iterations<=0 keeps the model's (100), tolerance<0 keeps the model's (1e-8)
 void orc_set_solver(orc_sim*, int iterations, double tolerance);
 void orc_set_collision(orc_sim*, int enable);
+/* per-env domain randomisation of the free props' mass (object, container): mass, inertia scale by s, body_invweight0 by 1/s */
+void orc_set_mass_scale(orc_sim*, const double* scale /*[nfree]*/);
+/* solver-parity tests: forward() uses this contact list instead of its own narrowphase; rows [n][9] = pos3 normal3
+ * dist geom1 geom2, n = 0 restores the narrowphase */
+void orc_inject_contacts(orc_sim*, int n, const double* rows);
 // 0 = PGS (default; BASELINE north_star), 1 = Newton (mujoco's default solver, mj_solNewton restated)
 void orc_set_solver_type(orc_sim*, int type);
 int orc_ls_evals(const orc_sim*);

@@ -1,28 +1,25 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
+import numpy as np, torch
+from so101_sim_amd import task_suite, pregrasp
 from so101_sim_amd.model import scenes
 from oracle.oracle import Oracle
 from tests.simharness import ArraySim
 raw32, _ = scenes.load_blob("banana", "f32"); raw64, _ = scenes.load_blob("banana", "f64")
-n, seed, settle, last_step, iterations = 4, 11, 200, 7, 50
-sim = ArraySim(raw32, n, backend="gpu", seed=seed, settle_max_substeps=settle, last_step=last_step, solver_iterations=iterations, env_id_base=100)
-sim.reset()
-q0, v0, _ = sim.get_state()
-oracles = []
-for e in range(n):
-    o = Oracle(raw64); o.set_solver(iterations, -1.0)
-    o.env_config(seed=seed, env_id=100 + e, last_step=last_step, settle_max_substeps=settle)
-    o.env_reset(); oracles.append(o)
-    qo, vo, _ = o.get_state()
-    print("reset env", e, "dq", np.abs(q0[:, e] - qo).max(), "dv", np.abs(v0[:, e] - vo).max())
-rng = np.random.RandomState(seed)
-for t in range(1, 8):
-    act = rng.uniform(-0.4, 0.4, size=(n, 6)).astype(np.float32)
-    obs, rew, disc, st = sim.step(act)
-    q1, v1, _ = sim.get_state()
-    for e, o in enumerate(oracles):
-        oo, orew, odisc, ost = o.env_step(act[e].astype(np.float64))
-        qo, vo, _ = o.get_state()
-        arm = [(c["geom1"], c["geom2"], round(c["dist"], 6)) for c in o.contacts() if 1 <= c["geom1"] <= 18 or 1 <= c["geom2"] <= 18]
-        print(" t", t, "env", e, "dq arm %.2e" % np.abs(q1[:6, e] - qo[:6]).max(), "dq props %.2e" % np.abs(q1[6:, e] - qo[6:]).max(), "diag", sim.get_diag()[e][:5], "arm contacts", arm[:6])
+cwd = os.getcwd(); os.chdir("/tmp")
+n = 64
+env = task_suite.create_task_env("SO100HandOverBanana", time_limit=10.0, random_state=0, n_envs=n)
+PQ, PV, PC = (t.cpu().numpy().astype(np.float64) for t in pregrasp.build_pickplace_pool(env, pool_size=n, seed=3))
+env.close(); os.chdir(cwd)
+np.savez("gpurun_out/pool_debug.npz", PQ=PQ, PV=PV, PC=PC)
+idx = list(range(8))
+for iters in (100, 300):
+    sim = ArraySim(raw32, len(idx), backend="gpu", last_step=500, solver_iterations=iters)
+    sim.set_state(PQ[:, idx], PV[:, idx], PC[:, idx], np.zeros((18, len(idx))))
+    dbg = sim.debug_forward()
+    for j, k in enumerate(idx):
+        o = Oracle(raw64); o.set_solver(iters, -1.0); o.set_state(PQ[:, k], PV[:, k], np.zeros(18)); o.set_ctrl(PC[:, k]); o.forward()
+        a, asm = o.qacc()
+        err = np.abs(dbg[j]["qacc"] - a)
+        print("iters cap", iters, "entry", k, "gpu iters", dbg[j]["iters"], "oracle iters", o.solver_iter if hasattr(o, "solver_iter") else "?", "ncon", dbg[j]["ncon"],
+              "max|a| %.1f" % np.abs(a).max(), "rel err %.2e" % (err.max() / np.abs(a).max()), "worst dof", int(err.argmax()), "a_o %.3f a_g %.3f" % (a[err.argmax()], dbg[j]["qacc"][err.argmax()]))

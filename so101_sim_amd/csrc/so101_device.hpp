@@ -187,15 +187,18 @@ DEV void kinematics(const DevModel* m, EnvLDS& L) {
   // world inertia of every dynamic body (lane-parallel)
   if (lane < NDYN) {
     const float* Ib = lane < NARM ? m->arm_Ib[lane] : m->free_Ib[lane - NARM];
+    float sc = lane < NARM ? 1.f : L.fscale[lane - NARM];      // per-env prop mass scale: mass and inertia scale together
     float o[6]; rotsym(o, L.xmat[lane], Ib);
 #pragma unroll
-    for (int i = 0; i < 6; i++) L.Iw[lane][i] = o[i];
+    for (int i = 0; i < 6; i++) L.Iw[lane][i] = sc * o[i];
     if (lane >= NARM) {
       int f = lane - NARM;
       float oi[6]; rotsym(oi, L.xmat[lane], m->free_Ibinv[f]);
+      float isc = 1.f / sc;
 #pragma unroll
-      for (int i = 0; i < 6; i++) L.fIinv[f][i] = oi[i];
-      L.fminv[f] = 1.f / m->free_mass[f];
+      for (int i = 0; i < 6; i++) L.fIinv[f][i] = isc * oi[i];
+      L.fmass[f] = sc * m->free_mass[f];
+      L.fminv[f] = 1.f / L.fmass[f];
     }
   }
   wave_sync();
@@ -772,18 +775,27 @@ DEV void broadphase(const DevModel* m, EnvLDS& L) {
 // MuJoCo's convex-pair multi-contact re-runs the penetration query on configurations tilted by +-1e-3 rad about the
 // two tangent axes and keeps results farther apart than 1e-3 of the smaller bounding radius; its native-ccd path
 // clips the aligned faces of box / mesh pairs.  Both sample the extreme points of a flat contact patch.  Here that is
-// done in closed form whenever one geom presents a flat REFERENCE FACE - the plane, or a box face / cylinder cap whose
-// outward normal is within acos(FACE_COS) of the MPR normal - and the other (INCIDENT) geom is sampled through its support function:
+// done in closed form whenever one geom presents a flat REFERENCE FACE - the plane, or the box face / cylinder cap along
+// which the pair is shallowest (narrow_pair) - and the other (INCIDENT) geom is sampled through its support function:
 //   a_0 = support(-f), a_k = support(-f + eps s_k), s_k = (+-u +- v)/sqrt(2) along the face axes, eps = 1e-3.
 // A sample becomes a contact when it is below the face plane, inside the face rectangle / disc and farther than
 // 1e-3 min(rbound) from the contacts already accepted; all contacts of the pair share the normal +-f.  When a_0 does
 // not qualify, the single MPR contact stays.  Other convex pairs keep one contact.  The supports are wave-parallel,
 // the control flow is wave-uniform.  (The test oracle restates the same rule in fp64.)
-#define FACE_COS 0.9999f
+#define FACE_DEPTH_REL 1e-2f
+#define FACE_DEPTH_ABS 1e-6f
 #define PATCH_EPS 1e-3f
 #define PATCH_DUP 1e-3f
 
 struct PairContacts { int n; float nrm[3], dist[NCPP], pos[NCPP][3]; };
+
+DEV bool inside_face(const float* rel, const float* u, const float* v, float hu, float hv) {
+  if (hu < 0.f) return true;                                          // unbounded plane
+  float pu = dot3(rel, u), pv = dot3(rel, v);
+  return hv >= 0.f ? (fabsf(pu) <= hu && fabsf(pv) <= hv) : (pu * pu + pv * pv <= hu * hu);      // rectangle / disc
+}
+
+
 
 template <class Cache>
 DEV bool face_patch(const DevModel* m, const GeomW& GI, const Cache& HI, const float* f, const float* c, const float* u,
@@ -801,8 +813,7 @@ DEV bool face_patch(const DevModel* m, const GeomW& GI, const Cache& HI, const f
     float rel[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]};
     float dist = dot3(rel, f);
     bool ok = dist < 0.f;
-    float pu = dot3(rel, u), pv = dot3(rel, v);
-    if (hu >= 0.f) ok = ok && (hv >= 0.f ? (fabsf(pu) <= hu && fabsf(pv) <= hv) : (pu * pu + pv * pv <= hu * hu));    // rectangle / disc
+    ok = ok && inside_face(rel, u, v, hu, hv);
     if (k == 0 && !ok) return false;
     float cp[3] = {p[0] - 0.5f * dist * f[0], p[1] - 0.5f * dist * f[1], p[2] - 0.5f * dist * f[2]};
 #pragma unroll
@@ -819,32 +830,28 @@ DEV bool face_patch(const DevModel* m, const GeomW& GI, const Cache& HI, const f
   return true;
 }
 
-// flat face of box / cylinder G (box face, cylinder cap) whose outward normal is closest to `toward`: area of the face,
-// or -1 when it is not within FACE_COS.  hv < 0 marks a disc of radius hu.
-DEV float flat_face(const GeomW& G, const float* toward, float* f, float* c, float* u, float* v, float* hu, float* hv) {
+// flat face number `axis` of box / cylinder G on the side that `toward` (world, any length) points to (box: local
+// x/y/z; cylinder: only axis 2, the cap): outward normal f, centre c, in-plane axes u/v with half extents (hv < 0: disc
+// of radius hu).  Returns false when the geom has no such face.
+DEV bool flat_face(const GeomW& G, int axis, const float* toward, float* f, float* c, float* u, float* v, float* hu, float* hv) {
   float loc[3]; matTvec3(loc, G.R, toward);
   if (G.type == G_CYLINDER) {
-    if (fabsf(loc[2]) < FACE_COS) return -1.f;
+    if (axis != 2) return false;
     float sg = loc[2] >= 0.f ? 1.f : -1.f;
 #pragma unroll
     for (int k = 0; k < 3; k++) { f[k] = sg * G.R[3 * k + 2]; u[k] = G.R[3 * k]; v[k] = G.R[3 * k + 1]; c[k] = G.p[k] + f[k] * G.size[1]; }
     *hu = G.size[0]; *hv = -1.f;
-    return 3.14159265f * G.size[0] * G.size[0];
+    return true;
   }
-  float a0 = fabsf(loc[0]), a1 = fabsf(loc[1]), a2 = fabsf(loc[2]);
-  int i = 0;
-  if (a1 > a0) i = 1;
-  if (a2 > (i == 1 ? a1 : a0)) i = 2;
   // axis picks as 0/1 weights (exact arithmetic; chains of selects on the index get turned into indexed loads of a
   // stack copy of the geom, i.e. scratch memory)
-  float w0 = i == 0 ? 1.f : 0.f, w1 = i == 1 ? 1.f : 0.f, w2 = i == 2 ? 1.f : 0.f;
+  float w0 = axis == 0 ? 1.f : 0.f, w1 = axis == 1 ? 1.f : 0.f, w2 = axis == 2 ? 1.f : 0.f;
   float li = w0 * loc[0] + w1 * loc[1] + w2 * loc[2];
-  if (fabsf(li) < FACE_COS) return -1.f;
   float sg = li >= 0.f ? 1.f : -1.f;
-  // u axis = (i + 1) % 3 -> weights (w2, w0, w1); v axis = (i + 2) % 3 -> weights (w1, w2, w0)
+  // u axis = (axis + 1) % 3 -> weights (w2, w0, w1); v axis = (axis + 2) % 3 -> weights (w1, w2, w0)
   float si = w0 * G.size[0] + w1 * G.size[1] + w2 * G.size[2];
-  float su = w2 * G.size[0] + w0 * G.size[1] + w1 * G.size[2];
-  float sv = w1 * G.size[0] + w2 * G.size[1] + w0 * G.size[2];
+  *hu = w2 * G.size[0] + w0 * G.size[1] + w1 * G.size[2];
+  *hv = w1 * G.size[0] + w2 * G.size[1] + w0 * G.size[2];
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     f[k] = sg * (w0 * G.R[3 * k] + w1 * G.R[3 * k + 1] + w2 * G.R[3 * k + 2]);
@@ -852,8 +859,35 @@ DEV float flat_face(const GeomW& G, const float* toward, float* f, float* c, flo
     v[k] = w1 * G.R[3 * k] + w2 * G.R[3 * k + 1] + w0 * G.R[3 * k + 2];
     c[k] = G.p[k] + f[k] * si;
   }
-  *hu = su; *hv = sv;
-  return 4.f * su * sv;
+  return true;
+}
+
+struct FaceRef { float f[3], c[3], u[3], v[3], hu, hv, depth; int side; };
+
+// Candidate reference faces of GR (box / cylinder) against the incident geom GI: every flat face on the side of GI's
+// centre is a candidate direction of separation; its depth is how far GI's deepest point a0 = support(-f) lies below
+// the face plane, valid when a0 is inside the face outline.  Keeps the shallowest candidate below best.depth.
+template <class Cache>
+DEV void face_candidates(const DevModel* m, const GeomW& GR, const GeomW& GI, const Cache& HI, int side, FaceRef& best) {
+  if (GR.type != G_BOX && GR.type != G_CYLINDER) return;
+  float toward[3] = {GI.c[0] - GR.c[0], GI.c[1] - GR.c[1], GI.c[2] - GR.c[2]};
+#pragma unroll 1
+  for (int axis = 0; axis < 3; axis++) {
+    float f[3], c[3], u[3], v[3], hu, hv;
+    if (!flat_face(GR, axis, toward, f, c, u, v, &hu, &hv)) continue;
+    // a0 is at least as deep as any interior point of the incident geom: skip the support when even its centre is not
+    // shallower than the best answer so far (the side faces of the table top, a metre away)
+    float cr[3] = {c[0] - GI.c[0], c[1] - GI.c[1], c[2] - GI.c[2]};
+    if (dot3(cr, f) >= best.depth) continue;
+    float nf[3] = {-f[0], -f[1], -f[2]}, a0[3];
+    support(m, GI, nf, a0, HI);
+    float rel[3] = {a0[0] - c[0], a0[1] - c[1], a0[2] - c[2]};
+    float d0 = -dot3(rel, f);
+    if (!(d0 > 0.f) || !(d0 < best.depth) || !inside_face(rel, u, v, hu, hv)) continue;
+    best.depth = d0; best.side = side; best.hu = hu; best.hv = hv;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { best.f[k] = f[k]; best.c[k] = c[k]; best.u[k] = u[k]; best.v[k] = v[k]; }
+  }
 }
 
 // Narrowphase of one candidate pair (geom types ordered): up to NCPP contacts sharing one normal (geom1 -> geom2),
@@ -876,19 +910,17 @@ DEV void narrow_pair(const DevModel* m, const GeomW& G1, const GeomW& G2, int g1
   float depth, nrm[3], pos[3];
   bool ok = mpr_penetration(m, G1, G2, &depth, nrm, pos, H1, H2);
   if (!ok || !(depth > 0.f)) return;
-  // reference face: a box face aligned with the contact normal (the larger one when both geoms offer one)
-  float f[3], c[3], u[3], v[3], hu = 0.f, hv = 0.f, area = -1.f;
-  int ref = -1;
-  if (G1.type == G_BOX || G1.type == G_CYLINDER) { area = flat_face(G1, nrm, f, c, u, v, &hu, &hv); if (area >= 0.f) ref = 0; }
-  if (G2.type == G_BOX || G2.type == G_CYLINDER) {
-    float tw[3] = {-nrm[0], -nrm[1], -nrm[2]}, f2[3], c2[3], u2[3], v2[3], hu2, hv2;
-    float a2 = flat_face(G2, tw, f2, c2, u2, v2, &hu2, &hv2);
-    if (a2 > area) {
-      area = a2; ref = 1; hu = hu2; hv = hv2;
+  // Reference face: the shallowest flat-face candidate of either geom, if it is not deeper than MPR's own answer (1 % +
+  // 1e-6 m slack: for a face contact both are the same number).  MPR's depth is the depth along ITS final portal
+  // normal, which for a thin plate (finger pad) against a hull can be an oblique direction ten times deeper than the
+  // plate's face normal; the minimum over both repairs that.
+  FaceRef best;
+  best.depth = depth * (1.f + FACE_DEPTH_REL) + FACE_DEPTH_ABS; best.side = -1; best.hu = 0.f; best.hv = 0.f;
 #pragma unroll
-      for (int k = 0; k < 3; k++) { f[k] = f2[k]; c[k] = c2[k]; u[k] = u2[k]; v[k] = v2[k]; }
-    }
-  }
+  for (int k = 0; k < 3; k++) { best.f[k] = 0.f; best.c[k] = 0.f; best.u[k] = 0.f; best.v[k] = 0.f; }
+  face_candidates(m, G1, G2, H2, 0, best);
+  face_candidates(m, G2, G1, H1, 1, best);
+  int ref = best.side;
   bool patched = false;
   if (ref >= 0) {
     // the incident geom (and its cached hull) selected into ONE set of registers: a single inlined copy of the patch
@@ -896,8 +928,9 @@ DEV void narrow_pair(const DevModel* m, const GeomW& G1, const GeomW& G2, int g1
     GeomW GI; Cache HI;
     select_geom(ref == 0, G2, G1, GI);
     select_hull(ref == 0, H2, H1, HI);
-    patched = face_patch(m, GI, HI, f, c, u, v, hu, hv, PATCH_DUP * fminf(rb1, rb2), out);
+    patched = face_patch(m, GI, HI, best.f, best.c, best.u, best.v, best.hu, best.hv, PATCH_DUP * fminf(rb1, rb2), out);
   }
+  const float* f = best.f;
   if (patched) {
     float sg = ref == 0 ? 1.f : -1.f;
     out.nrm[0] = sg * f[0]; out.nrm[1] = sg * f[1]; out.nrm[2] = sg * f[2];
@@ -1058,9 +1091,9 @@ DEV void make_constraints(const DevModel* m, EnvLDS& L) {
     float solref[2] = {c.aref[0], c.aref[1]}, solimp[5] = {c.f[0], c.f[1], c.f[2], c.f[3], c.f[4]};
     float imp = impedance(solimp, c.dist), K, B;
     kb_from_solref(m, solref, solimp, &K, &B);
-    float tran = 0.f;
-    if (c.d1 >= 0) tran += m->dyn_invweight0[c.d1][0];
-    if (c.d2 >= 0) tran += m->dyn_invweight0[c.d2][0];
+    float tran = 0.f;      // body_invweight0 of a free prop scales with 1 / mass scale
+    if (c.d1 >= 0) tran += m->dyn_invweight0[c.d1][0] / (c.d1 >= NARM ? L.fscale[c.d1 - NARM] : 1.f);
+    if (c.d2 >= 0) tran += m->dyn_invweight0[c.d2][0] / (c.d2 >= NARM ? L.fscale[c.d2 - NARM] : 1.f);
     float R0 = fmaxf(MINVAL_F, (1.f - imp) * tran / imp);
     float R1 = R0 / fmaxf(MINVAL_F, m->impratio);
     float mu0 = c.fric[0];

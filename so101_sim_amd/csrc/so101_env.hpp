@@ -3,8 +3,15 @@
 #pragma once
 #include "so101_device.hpp"
 
+// per-env constants that are not part of the integrated state
+DEV void load_env_constants(EnvLDS& L, const DevBuffers& B, int e, int N) {
+  int lane = wave_lane();
+  if (lane < NFREE) L.fscale[lane] = B.mass_scale ? B.mass_scale[(size_t)lane * N + e] : 1.f;
+}
+
 DEV void load_state(EnvLDS& L, const DevBuffers& B, int e, int N) {
   int lane = wave_lane();
+  load_env_constants(L, B, e, N);
   if (lane < NQ) L.qpos[lane] = B.qpos[(size_t)lane * N + e];
   if (lane < NV) { L.qvel[lane] = B.qvel[(size_t)lane * N + e]; L.warm[lane] = B.warm[(size_t)lane * N + e]; }
   if (lane < NU) L.ctrl[lane] = B.ctrl[(size_t)lane * N + e];
@@ -98,8 +105,21 @@ template <int SOLVER>
 DEV void env_reset(const DevModel* m, EnvLDS& L, const StepParams& P, const DevBuffers& B, const PrepBuffers& C, int e) {
   int lane = wave_lane(), N = P.n_envs;
   unsigned int episode = (unsigned int)B.episode[e];
+  load_env_constants(L, B, e, N);
   bool cached = C.tag && __atomic_load_n(&C.tag[e], __ATOMIC_ACQUIRE) == (int)episode;
-  if (cached) {
+  if (C.pool_size > 0) {
+    // reset pool: the episode starts from a caller-provided state (pre-grasp pools, checkpoints) instead of
+    // placement + settle; the entry is a pure function of (seed, global env id, episode)
+    float u = rng_uniform(P.seed, P.env_id_base + (unsigned long long)e, episode, 1000u);
+    int k = (int)(u * (float)C.pool_size);
+    k = k < C.pool_size - 1 ? k : C.pool_size - 1;
+    size_t K = (size_t)C.pool_size;
+    if (lane < NQ) L.qpos[lane] = C.pool_qpos[(size_t)lane * K + k];
+    if (lane < NV) { L.qvel[lane] = C.pool_qvel[(size_t)lane * K + k]; L.warm[lane] = 0.f; }
+    if (lane < NU) L.ctrl[lane] = C.pool_ctrl[(size_t)lane * K + k];
+    if (lane == 0) { L.ncon = 0; L.nrow = 0; L.iters = 0; L.ncand = 0; }
+    wave_sync();
+  } else if (cached) {
     if (lane < NQ) L.qpos[lane] = C.qpos[(size_t)lane * N + e];
     if (lane < NV) { L.qvel[lane] = C.qvel[(size_t)lane * N + e]; L.warm[lane] = C.warm[(size_t)lane * N + e]; }
     if (lane < NU) L.ctrl[lane] = m->home_ctrl[lane] + P.action_offset[lane];

@@ -320,7 +320,8 @@ int build_model(so101_sim* s, const BlobView& b) {
 
 // Launches k_prepare behind whatever `stream` holds now, unless the previous one is still running (it picks up
 // every env whose next episode is missing, so skipping a launch only delays the refill).
-bool prefetch_on(const so101_sim* s) { return s->cfg.prefetch_resets && s->prep_stream && s->cfg.solver == SO101_SOLVER_NEWTON; }
+// (pool resets are plain copies: nothing to prefetch)
+bool prefetch_on(const so101_sim* s) { return s->cfg.prefetch_resets && s->prep_stream && s->cfg.solver == SO101_SOLVER_NEWTON && s->prep.pool_size == 0; }
 
 void launch_prepare(so101_sim* s, hipStream_t stream) {
   if (!prefetch_on(s)) return;
@@ -467,6 +468,7 @@ int so101_bind_state(so101_sim* s, const so101_buffers* b) {
   if (s->bound && s->prep.tag && !hip_ok(s, hipMemset(s->prep.tag, 0xFF, sizeof(int) * (size_t)s->n_envs), "hipMemset(prep)")) return SO101_ERR_HIP;
   s->buf.qpos = b->qpos; s->buf.qvel = b->qvel; s->buf.ctrl = b->ctrl; s->buf.warm = b->warmstart; s->buf.ring = b->obs_ring;
   s->buf.ep_return = b->ep_return; s->buf.step_count = b->step_count; s->buf.episode = b->episode;
+  s->buf.mass_scale = b->mass_scale;
   s->bound = true;
   return SO101_OK;
 }
@@ -480,6 +482,16 @@ int so101_reset(so101_sim* s, const uint8_t* mask, void* stream) {
   so101::launch_reset(s->cfg.solver, s->n_envs, (hipStream_t)stream, s->dm, make_params(s), s->buf, prep_view(s), s->ev, mask, s->need_reset, s->diag);
   LAUNCH_CHECK(s, "k_reset");
   launch_prepare(s, (hipStream_t)stream);
+  return SO101_OK;
+}
+
+int so101_set_reset_pool(so101_sim* s, const float* qpos, const float* qvel, const float* ctrl, int pool_size) {
+  if (!s || pool_size < 0) return SO101_ERR_ARG;
+  if (pool_size > 0 && (!qpos || !qvel || !ctrl)) { s->err = "so101_set_reset_pool: NULL pool array"; return SO101_ERR_ARG; }
+  GUARD_DEVICE(s);
+  if (!drain_prepare(s)) return SO101_ERR_HIP;
+  s->prep.pool_qpos = pool_size ? qpos : nullptr; s->prep.pool_qvel = pool_size ? qvel : nullptr;
+  s->prep.pool_ctrl = pool_size ? ctrl : nullptr; s->prep.pool_size = pool_size;
   return SO101_OK;
 }
 

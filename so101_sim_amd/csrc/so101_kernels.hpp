@@ -18,6 +18,7 @@ __global__ void __launch_bounds__(64, 2) k_prepare(const DevModel* m, StepParams
     int target = __atomic_load_n(&B.episode[e], __ATOMIC_ACQUIRE);
     if (__atomic_load_n(&C.tag[e], __ATOMIC_ACQUIRE) == target) continue;
     if (lane == 0) { L.overflow = 0; L.t_collision = 0; L.t_solve = 0; }
+    load_env_constants(L, B, e, N);
     env_settle<SOLVER>(m, L, P, e, (unsigned int)target);
     wave_sync();
     if (lane < NQ) C.qpos[(size_t)lane * N + e] = L.qpos[lane];

@@ -102,6 +102,7 @@ struct EnvLDS {
   float xpos[NDYN][3], xmat[NDYN][9], xipos[NDYN][3], axis[NARM][3], Iw[NDYN][6];
   float Marm[NARM][NARM], Minv[NARM][NARM];
   float fminv[NFREE], fIinv[NFREE][6], fvel[NFREE][6], facc[NFREE][6];   // COM-twist coordinates
+  float fscale[NFREE], fmass[NFREE];      // per-env mass / inertia scale of the free props (domain randomisation), scaled mass
   float tau[NARM], bias[NARM], qacc[NV], qacc_arm[NARM];
   float arm0_q[NARM], arm0_v[NARM];
   // collision-phase scratch (geom boxes, broadphase candidates) shares storage with the arm-contact Jacobian
@@ -122,6 +123,7 @@ struct EnvLDS {
 struct DevBuffers {
   float *qpos, *qvel, *ctrl, *warm, *ring, *ep_return;
   int *step_count, *episode;
+  const float* mass_scale;     // [NFREE][n_envs] or NULL (= 1)
 };
 
 // Library-owned cache of settled initial states.  The settled state of an episode is a pure function of
@@ -134,6 +136,10 @@ struct PrepBuffers {
   int *tag;                    // episode index the entry belongs to, -1 = empty
   int *cursor;                 // work-queue head of k_prepare
   int *flags;                  // [n_envs] flag word of the settle that produced the entry (placement / settle failures)
+  // Reset pool (so101_set_reset_pool): when pool_size > 0 an episode starts from pool entry
+  // floor(u * pool_size), u = rng_uniform(seed, env id, episode, draw 1000), instead of placement + settle
+  const float *pool_qpos, *pool_qvel, *pool_ctrl;   // [NQ|NV|NU][pool_size]
+  int pool_size;
 };
 
 // Event accounting (so101_get_events): flags[e] ORs the per-substep flag words of env e within one control step;

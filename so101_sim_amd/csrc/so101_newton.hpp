@@ -166,7 +166,7 @@ DEV float mass_times(const DevModel* m, const EnvLDS& L, const float* v /*LDS*/,
     return s;
   }
   int f = (lane - NARM) / 6, k = (lane - NARM) % 6;
-  if (k < 3) return m->free_mass[f] * v[lane];
+  if (k < 3) return L.fmass[f] * v[lane];
   const float* I = L.Iw[NARM + f];
   const float* w = &v[NARM + 6 * f + 3];
   float o[3]; symvec3(o, I, w);
@@ -178,7 +178,7 @@ DEV float mass_entry(const DevModel* m, const EnvLDS& L, int a, int b) {
   if (a < NARM) return b < NARM ? L.Marm[a][b] : 0.f;
   if (b < NARM || (a - NARM) / 6 != (b - NARM) / 6) return 0.f;
   int f = (a - NARM) / 6, i = (a - NARM) % 6, j = (b - NARM) % 6;
-  if (i < 3 && j < 3) return i == j ? m->free_mass[f] : 0.f;
+  if (i < 3 && j < 3) return i == j ? L.fmass[f] : 0.f;
   if (i >= 3 && j >= 3) {
     int p = i - 3, q = j - 3;
     return L.Iw[NARM + f][p == q ? p : p + q + 2];        // packed xx yy zz xy xz yz: (0,1)->3, (0,2)->4, (1,2)->5
@@ -205,6 +205,10 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
 #pragma unroll
   for (int j = 0; j < 5; j++) C.fr[j] = 0.f;
   if (has_con) conreg_load(L, L.con[lane], C);
+#ifdef SO101_EMU_TRACE
+  if (has_con) fprintf(stderr, "  con %d dim %d g %d %d R %.6g %.6g %.6g %.6g aref %.6g %.6g %.6g %.6g %.6g %.6g mu %.6g\n", lane, C.dim, C.g0, C.g1,
+                       L.con[lane].R[0], L.con[lane].R[1], L.con[lane].R[2], L.con[lane].R[3], C.aref[0], C.aref[1], C.aref[2], C.aref[3], C.aref[4], C.aref[5], C.mu);
+#endif
   Row1 rreg; rreg.dof = 0; rreg.sign = 0.f; rreg.R = 1.f; rreg.aref = 0.f; rreg.floss = 0.f; rreg.f = 0.f; rreg.Ainv = 0.f; rreg.pad = 0.f;
   if (has_row) rreg = L.row[lane];
   // which coordinate groups / group pairs any contact touches (wave-uniform): sums over absent blocks are skipped
@@ -271,7 +275,7 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
   if (lane < NVS) W.x[lane] = (cw < cs) ? W.xw[lane] : W.xs[lane];
   wave_sync();
   float scale = 1.f / (m->meaninertia * (float)NV);
-  float cost = eval_cost(W.x, true);
+  float cost = eval_cost(W.x, true), dec_prev = 0.f;
   int it = 0;
   for (; it < max_iter; it++) {
     // ---- gradient g = M (x - x_s) - J' f, lane d keeps g_d
@@ -403,6 +407,15 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
     float sv = y * mxs;
     if (lane < NVS) W.search[lane] = sv;
     wave_sync();
+    // ---- termination test on the Newton decrement  dec = -g' search  (twice the cost the quadratic model still
+    // expects to gain; in exact arithmetic MuJoCo's test "cost improvement < tolerance" is 0.5 dec < tolerance).
+    // The cost itself cannot be used in fp32: with stiff contacts (finger pads squeezing a prop: cost ~1e8) a wrong
+    // angular acceleration of a 1e-5 kg m^2 body changes it by less than one ulp, while the decrement, built from the
+    // per-coordinate gradient, still resolves it.  Once 0.5 dec is below the cost's fp32 resolution the iteration goes
+    // on only while the decrement keeps collapsing (quadratic convergence) and stops when it stalls (rounding floor).
+    float dec = wave_sum_f(lane < NVS ? -grad * sv : 0.f);
+    bool done = scale * 0.5f * dec < tolerance || (it > 0 && 0.5f * dec < 4e-7f * fabsf(cost) && dec > 0.5f * dec_prev);
+    dec_prev = dec;
     // ---- exact line search: phi'(alpha) = 0 by safeguarded Newton
     float jv[6] = {0, 0, 0, 0, 0, 0}, rjv = 0.f;
     if (has_con) block_jx(W.search, jv);
@@ -436,13 +449,12 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
     }
     if (lane < NVS) W.x[lane] += alpha * sv;
     wave_sync();
-    float newcost = eval_cost(W.x, true);
-
+#ifdef SO101_EMU_TRACE
+    { float oldc = cost; float nc = eval_cost(W.x, true); if (lane == 0) fprintf(stderr, "  newton it %d cost %.9g -> %.9g dec %.4g alpha %.4g done %d\n", it, oldc, nc, dec, alpha, (int)done); }
+#endif
+    cost = eval_cost(W.x, true);
     float gnorm = scale * sqrtf(wave_sum_f(lane < NVS ? grad * grad : 0.f));   // gradient of the previous point (cheap proxy)
-    float improvement = scale * (cost - newcost);
-    float floor32 = 4e-7f * scale * fabsf(cost);                      // cost differences below fp32 resolution
-    cost = newcost;
-    if (improvement < fmaxf(tolerance, floor32) || gnorm < tolerance) { it++; break; }
+    if (done || gnorm < tolerance) { it++; break; }
   }
   // constrained accelerations back to the shared island state; forces for diagnostics
   if (lane < NARM) L.qacc_arm[lane] = W.x[lane];

@@ -1,11 +1,58 @@
 """Multi-GPU sharding of independent environments: contiguous global env-id ranges per rank, no
 data-path collective; one all-gather of episode returns (RCCL over xGMI on GPUs, gloo in CPU tests)
-for logging only."""
+for logging only.  bench.py drives its N > 1 runs through exactly these functions, and
+tests/test_distributed_gloo.py runs the same functions with world size 2 on CPU."""
 from __future__ import annotations
+
+import os
+import time
+
+
+def rank_info() -> tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torchrun environment; (0, 0, 1) when launched plainly."""
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init(device=None, backend: str | None = None):
+    """Initialise the process group when WORLD_SIZE > 1 (nccl = RCCL on ROCm for a GPU device, gloo otherwise)."""
+    import torch.distributed as dist
+    _, _, world = rank_info()
+    if world == 1 or dist.is_initialized():
+        return
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend is None:
+        backend = "nccl" if device is not None and getattr(device, "type", "cpu") == "cuda" else "gloo"
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=device)
+    else:
+        dist.init_process_group(backend)
+
+
+def finalize():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def _active():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def barrier():
+    if _active():
+        import torch.distributed as dist
+        dist.barrier()
+
+
+def shard_base(rank: int, envs_per_rank: int) -> int:
+    """Weak scaling: every rank owns `envs_per_rank` envs; global id of its env 0 (keys the per-env RNG, so a shard
+    reproduces the same envs of the unsharded run)."""
+    return int(rank) * int(envs_per_rank)
 
 
 def shard_range(n_global: int, world_size: int, rank: int) -> tuple[int, int]:
-    """[start, stop) of the global env ids owned by `rank`; remainders go to the lowest ranks."""
+    """[start, stop) of the global env ids owned by `rank` (strong scaling); remainders go to the lowest ranks."""
     if not (0 <= rank < world_size):
         raise ValueError("rank out of range")
     base, rem = divmod(int(n_global), int(world_size))
@@ -13,11 +60,22 @@ def shard_range(n_global: int, world_size: int, rank: int) -> tuple[int, int]:
     return start, start + base + (1 if rank < rem else 0)
 
 
+def max_over_ranks(value: float, device=None) -> float:
+    """Slowest rank's time: what the whole-job throughput is computed from."""
+    if not _active():
+        return float(value)
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def all_gather_returns(local_returns):
     """Concatenate per-rank episode-return vectors in rank order (ranks may own different counts)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active():
         return local_returns.clone()
     world = dist.get_world_size()
     n = torch.tensor([local_returns.numel()], device=local_returns.device, dtype=torch.int64)
@@ -29,3 +87,24 @@ def all_gather_returns(local_returns):
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad)
     return torch.cat([o[: int(s.item())] for o, s in zip(out, sizes)])
+
+
+def run_sharded(make_env, step_fn, envs_per_rank: int, steps: int, device=None, sync=None):
+    """The timed region of a weak-scaling run, as bench.py does it: every rank builds its shard with
+    `make_env(env_id_base)`, a barrier brackets `steps` calls of `step_fn(env, i)`, the time is the MAX over ranks and
+    the value is world * envs_per_rank * steps / time.  Returns (value, elapsed, all episode returns in rank order).
+    `sync()` drains the device before the clocks are read (torch.cuda.synchronize on a GPU)."""
+    rank, _, world = rank_info()
+    env = make_env(shard_base(rank, envs_per_rank))
+    if sync:
+        sync()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step_fn(env, i)
+    if sync:
+        sync()
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0, device)
+    returns = all_gather_returns(env.episode_returns())
+    return world * envs_per_rank * steps / elapsed, elapsed, returns

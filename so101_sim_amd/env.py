@@ -128,8 +128,12 @@ class BatchedEnvironment:
         self.obs, self.reward, self.discount = z(N, native.OBS_DIM), z(N), z(N)
         self.step_type = z(N, dt=torch.uint8)
         self._action = z(N, native.ACT_DIM)
+        # per-env mass / inertia scale of (object, container): domain randomisation, 1.0 = the model's props
+        self.mass_scale = torch.ones(2, N, dtype=torch.float32, device=self.device)
+        self._events = torch.zeros(native.NEVENTS, dtype=torch.int64, device=self.device)
+        self._pool = None
         self.sim.bind(*(t.data_ptr() for t in (self.qpos, self.qvel, self.ctrl, self.warm, self.ring,
-                                                 self.ep_return, self.step_count, self.episode)))
+                                                 self.ep_return, self.step_count, self.episode, self.mass_scale)))
         nsub = int(round(task.control_timestep / PHYSICS_TIMESTEP))
         last = scenes.time_limit_last_step(time_limit, task.control_timestep, PHYSICS_TIMESTEP) if np.isfinite(time_limit) else 1 << 30
         self.last_step = last
@@ -204,6 +208,42 @@ class BatchedEnvironment:
             a = a.unsqueeze(0)
         self.step_tensor(a)
         return TimeStep(self.step_type, self.reward, self.discount, self._obs_dict())
+
+    def begin_episode(self):
+        """Start an episode from the state currently in `qpos` / `qvel` (no placement, no settle)."""
+        self.sim.begin_episode(self._stream())
+        self.obs[:, 0:6] = self.qpos[0:6].t()
+        self.obs[:, 6:12] = self.qpos[0:6].t()
+        self.obs[:, 12:18] = self.ctrl.t()
+        self.step_type.zero_()
+
+    def set_mass_scale(self, scale):
+        """scale: [2, N] (object, container) multipliers of the props' mass and inertia.  Flushes the reset prefetch
+        (cached initial states were settled with the old masses)."""
+        self.mass_scale.copy_(self.torch.as_tensor(scale, dtype=self.torch.float32, device=self.device).reshape(2, self.n_envs))
+        self.sim.configure()
+
+    def set_reset_pool(self, qpos=None, qvel=None, ctrl=None):
+        """Resets draw the initial state from this pool ([20, K], [18, K], [6, K] device tensors) instead of the
+        reference's placement + settle; None restores the reference behaviour."""
+        if qpos is None:
+            self._pool = None
+            self.sim.set_reset_pool(None, None, None, 0)
+            return
+        t = self.torch
+        pool = tuple(t.as_tensor(a, dtype=t.float32, device=self.device).contiguous() for a in (qpos, qvel, ctrl))
+        K = pool[0].shape[1]
+        assert pool[0].shape == (20, K) and pool[1].shape == (18, K) and pool[2].shape == (6, K)
+        self._pool = pool                      # keeps the tensors alive while the library reads them
+        self.sim.set_reset_pool(pool[0].data_ptr(), pool[1].data_ptr(), pool[2].data_ptr(), K)
+
+    def events(self, clear: bool = False) -> dict:
+        """Counts since creation (or the last clear) of env-steps / env-resets that raised a flag: contact or candidate
+        overflow, physics divergence (episode ended like a dm_control PhysicsError), rejected placement, unsettled
+        reset.  See so101_get_events in include/so101.h."""
+        self.sim.get_events(self._events.data_ptr(), clear, self._stream())
+        v = self._events.cpu().tolist()
+        return dict(zip(native.EVENT_NAMES, v))
 
     def episode_returns(self):
         out = self.torch.empty_like(self.ep_return)

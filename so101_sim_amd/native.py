@@ -28,7 +28,7 @@ DBG = dict(M=0, MINV=36, BIAS=72, SMOOTH=78, QACC=96, COUNTS=114, XPOS=120, CON=
 
 EXPORTS = (
     "so101_version", "so101_max_contacts", "so101_create", "so101_destroy", "so101_default_config",
-    "so101_configure", "so101_bind_state", "so101_reset", "so101_begin_episode", "so101_step", "so101_physics", "so101_reward",
+    "so101_configure", "so101_bind_state", "so101_set_reset_pool", "so101_reset", "so101_begin_episode", "so101_step", "so101_physics", "so101_reward",
     "so101_get_returns", "so101_get_diag", "so101_get_events", "so101_debug_forward", "so101_debug_candidates", "so101_debug_stages", "so101_last_error",
 )
 
@@ -36,7 +36,7 @@ EXPORTS = (
 class Buffers(C.Structure):
     _fields_ = [("qpos", C.c_void_p), ("qvel", C.c_void_p), ("ctrl", C.c_void_p), ("warmstart", C.c_void_p),
                 ("obs_ring", C.c_void_p), ("ep_return", C.c_void_p), ("step_count", C.c_void_p),
-                ("episode", C.c_void_p)]
+                ("episode", C.c_void_p), ("mass_scale", C.c_void_p)]
 
 
 class Config(C.Structure):
@@ -74,6 +74,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.so101_default_config.argtypes = [C.POINTER(Config)]
     L.so101_configure.argtypes = [vp, C.POINTER(Config)]
     L.so101_bind_state.argtypes = [vp, C.POINTER(Buffers)]
+    L.so101_set_reset_pool.argtypes = [vp, vp, vp, vp, C.c_int]
     L.so101_reset.argtypes = [vp, vp, vp]
     L.so101_begin_episode.argtypes = [vp, vp]
     L.so101_step.argtypes = [vp, vp, vp, vp, vp, vp, vp]
@@ -133,9 +134,12 @@ class Sim:
                 setattr(self.cfg, k, v)
         self._check(self.L.so101_configure(self.h, C.byref(self.cfg)), "so101_configure")
 
-    def bind(self, qpos, qvel, ctrl, warmstart, obs_ring, ep_return, step_count, episode):
-        b = Buffers(qpos, qvel, ctrl, warmstart, obs_ring, ep_return, step_count, episode)
+    def bind(self, qpos, qvel, ctrl, warmstart, obs_ring, ep_return, step_count, episode, mass_scale=None):
+        b = Buffers(qpos, qvel, ctrl, warmstart, obs_ring, ep_return, step_count, episode, mass_scale)
         self._check(self.L.so101_bind_state(self.h, C.byref(b)), "so101_bind_state")
+
+    def set_reset_pool(self, qpos, qvel, ctrl, pool_size: int):
+        self._check(self.L.so101_set_reset_pool(self.h, qpos, qvel, ctrl, int(pool_size)), "so101_set_reset_pool")
 
     def reset(self, mask=None, stream=0):
         self._check(self.L.so101_reset(self.h, mask, stream), "so101_reset")

@@ -46,12 +46,15 @@ class ArraySim:
         self.action, self.obs = z(N, 6), z(N, 18)
         self.reward_, self.discount, self.step_type = z(N), z(N), z(N, dt=u8)
         self.diag = z(N, native.DIAG_DIM, dt=i32)
+        self.mass_scale = z(2, N)
+        self._put(self.mass_scale, np.ones((2, N)))
+        self._pool = None
         self.dbg = z(N, native.DEBUG_DIM)
         # free-body quaternions default to identity
         self.set_state(np.tile(np.concatenate([np.zeros(6), [0, 0, 0, 1, 0, 0, 0] * 2])[:, None], (1, N)))
         p = self.ptr
         self.sim.bind(p(self.qpos), p(self.qvel), p(self.ctrl), p(self.warm), p(self.ring), p(self.ep_return),
-                      p(self.step_count), p(self.episode))
+                      p(self.step_count), p(self.episode), p(self.mass_scale))
         if backend == "emu":
             # launches are synchronous in the emulator: a prefetch would settle every env after every call
             cfg.setdefault("prefetch_resets", 0)
@@ -92,6 +95,33 @@ class ArraySim:
 
     def configure(self, **kw):
         self.sim.configure(**kw)
+
+    def set_mass_scale(self, scale):
+        """scale [2, N]: per-env multiplier of the (object, container) mass and inertia"""
+        self._put(self.mass_scale, np.asarray(scale, dtype=np.float32))
+        self.sim.configure()
+
+    def set_reset_pool(self, qpos, qvel, ctrl):
+        """pool arrays [20, K], [18, K], [6, K]; None disables"""
+        if qpos is None:
+            self._pool = None
+            self.sim.set_reset_pool(None, None, None, 0)
+            return
+        K = np.asarray(qpos).shape[1]
+        if self.backend == "gpu":
+            t = self.torch
+            self._pool = tuple(t.as_tensor(np.ascontiguousarray(a, dtype=np.float32)).to(self.dev) for a in (qpos, qvel, ctrl))
+        else:
+            self._pool = tuple(np.ascontiguousarray(a, dtype=np.float32) for a in (qpos, qvel, ctrl))
+        self.sim.set_reset_pool(self.ptr(self._pool[0]), self.ptr(self._pool[1]), self.ptr(self._pool[2]), K)
+
+    def get_events(self, clear=False):
+        if self.backend == "gpu":
+            ev = self.torch.zeros(native.NEVENTS, dtype=self.torch.int64, device=self.dev)
+        else:
+            ev = np.zeros(native.NEVENTS, dtype=np.int64)
+        self.sim.get_events(self.ptr(ev), clear, self.stream())
+        return dict(zip(native.EVENT_NAMES, [int(x) for x in self._get(ev)]))
 
     def physics(self, nsub=10, freeze_arm=False):
         self.sim.physics(nsub, freeze_arm, self.stream())

@@ -1,10 +1,13 @@
-"""N>1 path on CPU: two gloo ranks shard the env ids and all-gather episode returns in rank order."""
+"""N>1 path on CPU: two gloo ranks run the functions bench.py uses for its multi-GPU runs
+(so101_sim_amd.distributed: rank_info / init / shard_base / barrier / max_over_ranks / all_gather_returns /
+run_sharded) with the env step stubbed - sharding by global env id, MAX-over-ranks timing, whole-job value, and the
+all-gather of episode returns in rank order."""
 import os
 import socket
+import time
 
 import numpy as np
 import torch
-import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
@@ -16,20 +19,40 @@ def _free_port():
     return p
 
 
+class _StubEnv:
+    """Stands in for BatchedEnvironment: returns are a function of the GLOBAL env id, like the kernels' RNG keying."""
+
+    def __init__(self, env_id_base, n):
+        self.ids = torch.arange(env_id_base, env_id_base + n, dtype=torch.float32)
+        self.ret = torch.zeros(n)
+
+    def step(self, i, delay):
+        time.sleep(delay)
+        self.ret += 0.5 * self.ids
+
+    def episode_returns(self):
+        return self.ret.clone()
+
+
 def _worker(rank, world, port, n_global, out):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from so101_sim_amd.distributed import all_gather_returns, shard_range
-    lo, hi = shard_range(n_global, world, rank)
-    local = torch.arange(lo, hi, dtype=torch.float32) * 0.5          # stand-in for per-env episode returns
-    g = all_gather_returns(local)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    from so101_sim_amd import distributed as sd
+    assert sd.rank_info() == (rank, rank, world)
+    sd.init(torch.device("cpu"))
+    # uneven strong-scaling split + gather in rank order
+    lo, hi = sd.shard_range(n_global, world, rank)
+    g = sd.all_gather_returns(torch.arange(lo, hi, dtype=torch.float32) * 0.5)
+    # the weak-scaling timed region of bench.py with a stub step: rank 1 is 3x slower, the job time is ITS time
+    per_rank, steps = 4, 3
+    delay = 0.02 * (1 + 2 * rank)
+    value, elapsed, rets = sd.run_sharded(lambda base: _StubEnv(base, per_rank), lambda env, i: env.step(i, delay), per_rank, steps)
+    tmax = sd.max_over_ranks(float(rank + 1))
     if rank == 0:
-        out.put(g.numpy())
-    dist.destroy_process_group()
+        out.put((g.numpy(), value, elapsed, rets.numpy(), tmax))
+    sd.finalize()
 
 
-def test_all_gather_returns_world2():
+def test_bench_sharding_path_world2():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -37,8 +60,26 @@ def test_all_gather_returns_world2():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n_global, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = q.get(timeout=120)
+    g, value, elapsed, rets, tmax = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    np.testing.assert_array_equal(got, np.arange(n_global, dtype=np.float32) * 0.5)
+    np.testing.assert_array_equal(g, np.arange(n_global, dtype=np.float32) * 0.5)
+    # global env ids 0..7 over two ranks of 4, three steps of 0.5 * id each, gathered in rank order
+    np.testing.assert_allclose(rets, 1.5 * np.arange(8, dtype=np.float32))
+    assert elapsed >= 3 * 0.06 * 0.9                                  # the slow rank's time, not rank 0's
+    np.testing.assert_allclose(value, 2 * 4 * 3 / elapsed)            # whole-job aggregate
+    assert tmax == 2.0
+
+
+def test_single_process_is_a_no_op():
+    from so101_sim_amd import distributed as sd
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        os.environ.pop(k, None)
+    assert sd.rank_info() == (0, 0, 1)
+    sd.init(None)
+    sd.barrier()
+    assert sd.max_over_ranks(1.25) == 1.25
+    r = torch.arange(4, dtype=torch.float32)
+    assert torch.equal(sd.all_gather_returns(r), r)
+    assert sd.shard_base(3, 4096) == 12288
