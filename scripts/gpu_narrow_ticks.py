@@ -16,7 +16,7 @@ for t in range(30):
     s.step(rng.uniform(lo, hi, size=(N, 6)).astype(np.float32))
 dev = s.dev
 nc = torch.zeros(N, dtype=torch.int32, device=dev); cand = torch.zeros(N, 256, dtype=torch.int32, device=dev)
-tk = torch.zeros(N, 256, dtype=torch.int32, device=dev); cr = torch.zeros(N, 256, 8, device=dev)
+tk = torch.zeros(N, 256, dtype=torch.int32, device=dev); cr = torch.zeros(N, 256, 24, device=dev)
 s.sim.debug_candidates(nc.data_ptr(), cand.data_ptr(), tk.data_ptr(), cr.data_ptr())
 torch.cuda.synchronize()
 nc = (nc.cpu().numpy() & 0xffff); cand = cand.cpu().numpy(); tk = tk.cpu().numpy(); cr = cr.cpu().numpy()
@@ -24,7 +24,7 @@ mask = np.arange(256)[None, :] < nc[:, None]
 t = tk[mask] * 1e-2          # us
 print("candidates", mask.sum(), "sum %.1f ms, mean %.2f us, p50 %.2f p90 %.2f p99 %.2f max %.1f" % (t.sum() * 1e-3, t.mean(), *np.percentile(t, [50, 90, 99]), t.max()))
 print("sum/2048 waves = %.3f ms" % (t.sum() * 1e-3 / 2048))
-hit = cr[..., 7][mask] != 0
+hit = cr[..., 0][mask] != 0
 print("hit fraction %.2f; mean us hit %.2f miss %.2f" % (hit.mean(), t[hit].mean(), t[~hit].mean()))
 c = cand[mask]; g1 = c & 0xffff; g2 = (c >> 16) & 0xffff
 agg = collections.defaultdict(lambda: [0, 0.0])

@@ -411,10 +411,13 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
     // expects to gain; in exact arithmetic MuJoCo's test "cost improvement < tolerance" is 0.5 dec < tolerance).
     // The cost itself cannot be used in fp32: with stiff contacts (finger pads squeezing a prop: cost ~1e8) a wrong
     // angular acceleration of a 1e-5 kg m^2 body changes it by less than one ulp, while the decrement, built from the
-    // per-coordinate gradient, still resolves it.  Once 0.5 dec is below the cost's fp32 resolution the iteration goes
-    // on only while the decrement keeps collapsing (quadratic convergence) and stops when it stalls (rounding floor).
+    // per-coordinate gradient, still resolves it.  Once 0.5 dec is below the cost's fp32 resolution, this step is the
+    // last one if the decrement has stalled (rounding floor) or has just collapsed by more than 100x (quadratic
+    // convergence: the step about to be taken leaves an error far below the tolerance); the iteration only goes on while
+    // the decrement shrinks slowly, i.e. while cone zones are still switching.
     float dec = wave_sum_f(lane < NVS ? -grad * sv : 0.f);
-    bool done = scale * 0.5f * dec < tolerance || (it > 0 && 0.5f * dec < 4e-7f * fabsf(cost) && dec > 0.5f * dec_prev);
+    bool done = scale * 0.5f * dec < tolerance ||
+                (it > 0 && 0.5f * dec < 4e-7f * fabsf(cost) && (dec > 0.5f * dec_prev || dec < 1e-2f * dec_prev));
     dec_prev = dec;
     // ---- exact line search: phi'(alpha) = 0 by safeguarded Newton
     float jv[6] = {0, 0, 0, 0, 0, 0}, rjv = 0.f;
