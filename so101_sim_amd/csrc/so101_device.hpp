@@ -707,7 +707,10 @@ DEV void make_frame(float* fr) {
 
 // ------------------------------------------------------------------ collision driver
 // Broadphase: world boxes of all geoms, then the statically filtered pair list is tested lane-parallel; survivors
-// are appended to L.cand in pair order.
+// are appended to L.cand in pair order.  The pair words of a chunk (PAIR_CHUNK x 64 pairs) are fetched into registers
+// with one burst of loads before any of them is used (the loop used to pay one L2 round trip per 64 pairs), and a
+// geom's box is two 16-byte LDS reads.
+#define PAIR_CHUNK 32
 DEV void broadphase(const DevModel* m, EnvLDS& L) {
   int lane = wave_lane();
   for (int g = lane; g < m->ngeom; g += WAVE) {
@@ -734,7 +737,7 @@ DEV void broadphase(const DevModel* m, EnvLDS& L) {
 #pragma unroll
     for (int i = 0; i < 3; i++) {
       float e = fabsf(R[3 * i]) * h[0] + fabsf(R[3 * i + 1]) * h[1] + fabsf(R[3 * i + 2]) * h[2];
-      L.aabb[g][i] = p[i] + cw[i] - e; L.aabb[g][3 + i] = p[i] + cw[i] + e;
+      L.aabb[g][i] = p[i] + cw[i] - e; L.aabb[g][4 + i] = p[i] + cw[i] + e;
     }
   }
   if (lane == 0) { L.ncand = 0; L.ncon = 0; L.narmcon = 0; }
@@ -742,30 +745,40 @@ DEV void broadphase(const DevModel* m, EnvLDS& L) {
   int base = 0;
   const unsigned int* pairs = ldc(&m->pair_packed);
   const int npair = ldc(&m->npair);
-#pragma unroll 4
-  for (int p0 = 0; p0 < npair; p0 += WAVE) {
-    int p = p0 + lane;
-    bool hit = false; int g1 = 0, g2 = 0;
-    if (p < npair) {
-      unsigned int w = pairs[p];
-      g1 = (int)(w & 0xffu); g2 = (int)((w >> 8) & 0xffu);
-      if (w >> 16) {
-        // plane: test the lowest corner of the other box against the plane
-        const float* gm = m->geom_mat + 9 * g1; const float* gp = m->geom_pos + 3 * g1;
-        float n[3] = {gm[2], gm[5], gm[8]}, low = 0.f;
+  for (int c0 = 0; c0 < npair; c0 += PAIR_CHUNK * WAVE) {
+    unsigned int w[PAIR_CHUNK];
 #pragma unroll
-        for (int i = 0; i < 3; i++) low += n[i] * ((n[i] >= 0.f ? L.aabb[g2][i] : L.aabb[g2][3 + i]) - gp[i]);
-        hit = low <= 0.f;
-      } else {
-        hit = true;
-#pragma unroll
-        for (int i = 0; i < 3; i++) if (L.aabb[g1][i] > L.aabb[g2][3 + i] || L.aabb[g2][i] > L.aabb[g1][3 + i]) hit = false;
-      }
+    for (int i = 0; i < PAIR_CHUNK; i++) {
+      int p = c0 + i * WAVE + lane;
+      w[i] = p < npair ? pairs[p] : 0xffffffffu;
     }
-    unsigned long long mask = wave_ballot(hit);
-    int idx = base + wave_prefix(mask);
-    if (hit && idx < MAXCAND) { L.cand[idx][0] = (unsigned short)g1; L.cand[idx][1] = (unsigned short)g2; }
-    base += __popcll(mask);
+#pragma unroll
+    for (int i = 0; i < PAIR_CHUNK; i++) {
+      if (c0 + i * WAVE >= npair) break;
+      bool hit = false; int g1 = 0, g2 = 0;
+      if (w[i] != 0xffffffffu) {
+        g1 = (int)(w[i] & 0xffu); g2 = (int)((w[i] >> 8) & 0xffu);
+        const float* b2 = L.aabb[g2];
+        float lo2[3] = {b2[0], b2[1], b2[2]}, hi2[3] = {b2[4], b2[5], b2[6]};
+        if (w[i] >> 16) {
+          // plane: test the lowest corner of the other box against the plane
+          const float* gm = m->geom_mat + 9 * g1; const float* gp = m->geom_pos + 3 * g1;
+          float n[3] = {gm[2], gm[5], gm[8]}, low = 0.f;
+#pragma unroll
+          for (int k = 0; k < 3; k++) low += n[k] * ((n[k] >= 0.f ? lo2[k] : hi2[k]) - gp[k]);
+          hit = low <= 0.f;
+        } else {
+          const float* b1 = L.aabb[g1];
+          hit = true;
+#pragma unroll
+          for (int k = 0; k < 3; k++) if (b1[k] > hi2[k] || lo2[k] > b1[4 + k]) hit = false;
+        }
+      }
+      unsigned long long mask = wave_ballot(hit);
+      int idx = base + wave_prefix(mask);
+      if (hit && idx < MAXCAND) { L.cand[idx][0] = (unsigned short)g1; L.cand[idx][1] = (unsigned short)g2; }
+      base += __popcll(mask);
+    }
   }
   if (lane == 0) { L.ncand = base < MAXCAND ? base : MAXCAND; if (base > MAXCAND) L.overflow |= 1; }
   wave_sync();

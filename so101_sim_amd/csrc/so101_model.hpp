@@ -108,7 +108,7 @@ struct EnvLDS {
   // collision-phase scratch (geom boxes, broadphase candidates) shares storage with the arm-contact Jacobian
   // pool: the pool is first written by make_constraints(), after collision() has consumed boxes and candidates
   union {
-    struct { float aabb[MAXGEOM][6]; unsigned short cand[MAXCAND][2]; };
+    struct { float aabb[MAXGEOM][8]; unsigned short cand[MAXCAND][2]; };     // lo xyz, pad, hi xyz, pad: two 16-byte reads per geom
     ArmCon armcon[MAXARMCON];
   };
   Contact con[MAXCON];
