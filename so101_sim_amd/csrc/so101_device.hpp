@@ -386,20 +386,42 @@ DEV void smooth_dynamics(const DevModel* m, EnvLDS& L) {
 }
 
 // ------------------------------------------------------------------ geometry
+// Lane-group policies of the narrowphase.  The query of one geom pair is "uniform" code (every lane of the group
+// computes the same portal) around a lane-parallel hull scan.  G64: the whole wavefront works on one pair (fused
+// kernels: the env's wave walks its candidates).  G16: one pair per DPP row of 16 lanes, four pairs per wavefront
+// (k_narrow): the uniform part is issued once for four pairs, the hull scan takes four times as many steps per pair;
+// rows diverge freely (each row's reductions are row-local DPP butterflies, loads become vector loads with a
+// row-uniform address).  Both pick the same support vertex (max dot, smallest index), hence bit-identical contacts.
+struct G64 {
+  static constexpr int N = 64;
+  DEV static int sub() { return wave_lane(); }
+  DEV static void argmax3(float& val, int& idx, float& x, float& y, float& z) { wave_argmax3(val, idx, x, y, z); }
+  template <class T> DEV static T ld(const T* p) { return ldc(p); }
+  DEV static int uni(int v) { return wave_uniform_i(v); }
+};
+struct G16 {
+  static constexpr int N = 16;
+  DEV static int sub() { return wave_lane() & 15; }
+  DEV static void argmax3(float& val, int& idx, float& x, float& y, float& z) { row_argmax3(val, idx, x, y, z); }
+  template <class T> DEV static T ld(const T* p) { return *p; }
+  DEV static int uni(int v) { return v; }
+};
+
 struct GeomW { int type, vadr, vnum; float size[3], R[9], p[3], c[3]; };
 
 // xp/xm: world position and orientation of the geom's dynamic body (ignored for static geoms)
+template <class GP = G64>
 DEV void load_geom_at(const DevModel* m, int g, const float* xp, const float* xm, GeomW& G) {
-  g = wave_uniform_i(g);
-  G.type = ldc(ldc(&m->geom_type) + g); G.vadr = ldc(ldc(&m->geom_vertadr) + g); G.vnum = ldc(ldc(&m->geom_vertnum) + g);
+  g = GP::uni(g);
+  G.type = GP::ld(ldc(&m->geom_type) + g); G.vadr = GP::ld(ldc(&m->geom_vertadr) + g); G.vnum = GP::ld(ldc(&m->geom_vertnum) + g);
   const float* gp = ldc(&m->geom_pos) + 3 * g; const float* gm = ldc(&m->geom_mat) + 9 * g;
   const float* gc = ldc(&m->geom_center) + 3 * g; const float* gs = ldc(&m->geom_size) + 3 * g;
 #pragma unroll
-  for (int i = 0; i < 3; i++) G.size[i] = ldc(gs + i);
-  int d = ldc(ldc(&m->geom_dyn) + g);
-  float lp[3] = {ldc(gp), ldc(gp + 1), ldc(gp + 2)}, lm[9], lc[3] = {ldc(gc), ldc(gc + 1), ldc(gc + 2)};
+  for (int i = 0; i < 3; i++) G.size[i] = GP::ld(gs + i);
+  int d = GP::ld(ldc(&m->geom_dyn) + g);
+  float lp[3] = {GP::ld(gp), GP::ld(gp + 1), GP::ld(gp + 2)}, lm[9], lc[3] = {GP::ld(gc), GP::ld(gc + 1), GP::ld(gc + 2)};
 #pragma unroll
-  for (int i = 0; i < 9; i++) lm[i] = ldc(gm + i);
+  for (int i = 0; i < 9; i++) lm[i] = GP::ld(gm + i);
   // static geoms go through the same arithmetic with an identity pose (exact: 1*a + 0*b + 0*c == a), so that the
   // geom stays in registers instead of becoming a stack object selected by the branch
   float X[9], P0[3];
@@ -432,22 +454,24 @@ DEV void load_geom(const DevModel* m, const EnvLDS& L, int g, GeomW& G) {
 struct HullCache { float x[HULL_K], y[HULL_K], z[HULL_K]; };
 struct NoCache {};
 
+template <class GP = G64>
 DEV void hull_load(const DevModel* m, const GeomW& G, HullCache& H) {
   // every slot is written (slots beyond the hull, and the caches of primitives, hold zeros): the caches are moved
   // around with selects later, and a select over a never-written register is undefined behaviour for the compiler
 #pragma unroll
   for (int j = 0; j < HULL_K; j++) { H.x[j] = 0.f; H.y[j] = 0.f; H.z[j] = 0.f; }
   if (G.type != G_MESH) return;
-  int lane = wave_lane();
+  int lane = GP::sub();
   const float* x = ldc(&m->vx) + G.vadr; const float* y = ldc(&m->vy) + G.vadr; const float* z = ldc(&m->vz) + G.vadr;
 #pragma unroll
   for (int j = 0; j < HULL_K; j++) {
-    if (WAVE * j >= G.vnum) break;
-    int i = lane + WAVE * j;
+    if (GP::N * j >= G.vnum) break;
+    int i = lane + GP::N * j;
     bool v = i < G.vnum;
     H.x[j] = v ? x[i] : 0.f; H.y[j] = v ? y[i] : 0.f; H.z[j] = v ? z[i] : 0.f;
   }
 }
+template <class GP = G64>
 DEV void hull_load(const DevModel*, const GeomW&, NoCache&) {}
 
 DEV void select_geom(bool first, const GeomW& A, const GeomW& B, GeomW& o) {
@@ -464,12 +488,12 @@ DEV void select_hull(bool first, const HullCache& A, const HullCache& B, HullCac
 DEV void select_hull(bool, const NoCache&, const NoCache&, NoCache&) {}
 
 // support point (world) of G in world direction dir; wave-parallel over hull vertices for meshes
-template <class Cache>
+template <class Cache, class GP = G64>
 DEV void support(const DevModel* m, const GeomW& G, const float* dir, float* out, const Cache& H) {
   float dl[3]; matTvec3(dl, G.R, dir);
   float loc[3] = {0.f, 0.f, 0.f};
   if (G.type == G_MESH) {
-    int lane = wave_lane();
+    int lane = GP::sub();
     // each lane scans vertices lane, lane+64, ... (coalesced SoA loads) and keeps its best vertex in registers;
     // the wave-level argmax then broadcasts the winner with v_readlane (no second memory access, and a
     // non-finite direction of a diverged state can never index out of range)
@@ -479,21 +503,21 @@ DEV void support(const DevModel* m, const GeomW& G, const float* dir, float* out
     if constexpr (sizeof(Cache) >= sizeof(HullCache)) {
 #pragma unroll
       for (int j = 0; j < HULL_K; j++) {
-        if (WAVE * j >= G.vnum) break;
-        int i = lane + WAVE * j;
+        if (GP::N * j >= G.vnum) break;
+        int i = lane + GP::N * j;
         float X = H.x[j], Y = H.y[j], Z = H.z[j];
         float d = X * dl[0] + Y * dl[1] + Z * dl[2];
         if (i < G.vnum && d > best) { best = d; bi = i; bx = X; by = Y; bz = Z; }
       }
-      first = lane + WAVE * HULL_K;
+      first = lane + GP::N * HULL_K;
     }
 #pragma unroll 4
-    for (int i = first; i < G.vnum; i += WAVE) {
+    for (int i = first; i < G.vnum; i += GP::N) {
       float X = x[i], Y = y[i], Z = z[i];
       float d = X * dl[0] + Y * dl[1] + Z * dl[2];
       if (d > best) { best = d; bi = i; bx = X; by = Y; bz = Z; }
     }
-    wave_argmax3(best, bi, bx, by, bz);
+    GP::argmax3(best, bi, bx, by, bz);
     loc[0] = bx; loc[1] = by; loc[2] = bz;
   } else if (G.type == G_BOX) {
 #pragma unroll
@@ -516,12 +540,12 @@ DEV void support(const DevModel* m, const GeomW& G, const float* dir, float* out
 
 struct MV { float v[3], a[3], b[3]; };
 
-template <class Cache>
+template <class Cache, class GP = G64>
 DEV void mdsupport(const DevModel* m, const GeomW& G1, const GeomW& G2, const float* dir, const float* org, MV& o,
                    const Cache& H1, const Cache& H2) {
   float nd[3] = {-dir[0], -dir[1], -dir[2]};
-  support(m, G1, dir, o.a, H1);
-  support(m, G2, nd, o.b, H2);
+  support<Cache, GP>(m, G1, dir, o.a, H1);
+  support<Cache, GP>(m, G2, nd, o.b, H2);
 #pragma unroll
   for (int i = 0; i < 3; i++) { o.a[i] -= org[i]; o.b[i] -= org[i]; o.v[i] = o.a[i] - o.b[i]; }
 }
@@ -585,7 +609,7 @@ DEV void interior_point(const GeomW& G, const float* target, float* out) {
 }
 
 // MPR penetration query (XenoCollide / libccd ccdMPRPenetration).  Entirely wave-uniform control flow.
-template <class Cache>
+template <class Cache, class GP = G64>
 DEV bool mpr_penetration(const DevModel* m, const GeomW& G1, const GeomW& G2, float* depth, float* dir, float* pos,
                          const Cache& H1, const Cache& H2) {
   const float mpr_tol = ldc(&m->mpr_tol); const int mpr_iter = ldc(&m->mpr_iter);
@@ -598,7 +622,7 @@ DEV bool mpr_penetration(const DevModel* m, const GeomW& G1, const GeomW& G2, fl
   if (isz(v0.v[0]) && isz(v0.v[1]) && isz(v0.v[2])) v0.v[0] += 1e-5f;
   float d[3] = {-v0.v[0], -v0.v[1], -v0.v[2]};
   normalize3(d);
-  mdsupport(m, G1, G2, d, org, v1, H1, H2);
+  mdsupport<Cache, GP>(m, G1, G2, d, org, v1, H1, H2);
   float dt = dot3(v1.v, d);
   if (isz(dt) || dt < 0.f) return false;
   cross3(d, v0.v, v1.v);
@@ -616,7 +640,7 @@ DEV bool mpr_penetration(const DevModel* m, const GeomW& G1, const GeomW& G2, fl
     return true;
   }
   normalize3(d);
-  mdsupport(m, G1, G2, d, org, v2, H1, H2);
+  mdsupport<Cache, GP>(m, G1, G2, d, org, v2, H1, H2);
   dt = dot3(v2.v, d);
   if (isz(dt) || dt < 0.f) return false;
   float va[3], vb[3];
@@ -629,7 +653,7 @@ DEV bool mpr_penetration(const DevModel* m, const GeomW& G1, const GeomW& G2, fl
   }
   bool have3 = false;
   for (int guard = 0; guard < 100 && !have3; guard++) {
-    mdsupport(m, G1, G2, d, org, v3, H1, H2);
+    mdsupport<Cache, GP>(m, G1, G2, d, org, v3, H1, H2);
     dt = dot3(v3.v, d);
     if (isz(dt) || dt < 0.f) return false;
     bool cont = false;
@@ -658,7 +682,7 @@ DEV bool mpr_penetration(const DevModel* m, const GeomW& G1, const GeomW& G2, fl
       dt = dot3(d, v1.v);
       if (isz(dt) || dt > 0.f) { inside = true; it = -1; continue; }   // portal encapsules origin: start penetration phase
     }
-    mdsupport(m, G1, G2, d, org, v4, H1, H2);
+    mdsupport<Cache, GP>(m, G1, G2, d, org, v4, H1, H2);
     float dv1 = dot3(v1.v, d), dv2 = dot3(v2.v, d), dv3 = dot3(v3.v, d), dv4 = dot3(v4.v, d);
     float dm = fminf(fminf(dv4 - dv1, dv4 - dv2), dv4 - dv3);
     bool reached = isz(dm - mpr_tol) || dm < mpr_tol;
@@ -706,6 +730,89 @@ DEV void make_frame(float* fr) {
 }
 
 // ------------------------------------------------------------------ collision driver
+// oriented box of geom g in the world: axes R (columns), centre c, half extents h (the geom-frame box that the model
+// compiler put around the hull / primitive)
+DEV void geom_obb(const DevModel* m, const EnvLDS& L, int g, float* R, float* c, float* h) {
+  const float* ab = m->geom_aabb + 6 * g;
+  const float* gp = m->geom_pos + 3 * g; const float* gm = m->geom_mat + 9 * g;
+  int d = m->geom_dyn[g];
+  float lm[9], lp[3] = {gp[0], gp[1], gp[2]}, p[3];
+#pragma unroll
+  for (int i = 0; i < 9; i++) lm[i] = gm[i];
+  if (d < 0) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) R[i] = lm[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) p[i] = lp[i];
+  } else {
+    matmul3(R, L.xmat[d], lm);
+    float t[3]; matvec3(t, L.xmat[d], lp);
+#pragma unroll
+    for (int i = 0; i < 3; i++) p[i] = L.xpos[d][i] + t[i];
+  }
+  float lc[3] = {ab[0], ab[1], ab[2]}, cw[3];
+  matvec3(cw, R, lc);
+#pragma unroll
+  for (int i = 0; i < 3; i++) { c[i] = p[i] + cw[i]; h[i] = ab[3 + i]; }
+}
+
+// Second broadphase pass, lane = candidate: separating-axis test of the two geoms' ORIENTED boxes (15 axes).  The world
+// axis-aligned box of a long tilted link overlaps many hulls it is nowhere near; the oriented box is tight.  A pair whose
+// oriented boxes are more than 1e-6 m apart cannot touch, so dropping it here changes no contact - it only spares the
+// narrowphase a query that would end in "no intersection" (a wavefront's work for a few microseconds; here it costs one
+// lane a few hundred instructions).  Plane pairs pass untouched.  The candidate list is compacted in place, order kept.
+DEV void obb_filter(const DevModel* m, EnvLDS& L) {
+  int lane = wave_lane();
+  int ncand = L.ncand, nout = 0;
+  for (int k0 = 0; k0 < ncand; k0 += WAVE) {
+    int k = k0 + lane;
+    bool keep = false; int g1 = 0, g2 = 0;
+    if (k < ncand) {
+      g1 = L.cand[k][0]; g2 = L.cand[k][1];
+      keep = true;
+      if (m->geom_type[g1] != G_PLANE) {
+        float A[9], ca[3], a[3], B[9], cb[3], b[3];
+        geom_obb(m, L, g1, A, ca, a); geom_obb(m, L, g2, B, cb, b);
+        // B in A's frame: Rm = A' B, t = A' (cb - ca)
+        float Rm[3][3], Ab[3][3], dv[3] = {cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2]}, t[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          t[i] = A[i] * dv[0] + A[3 + i] * dv[1] + A[6 + i] * dv[2];
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            Rm[i][j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
+            Ab[i][j] = fabsf(Rm[i][j]) + 1e-6f;
+          }
+        }
+        const float gap = 1e-6f;
+        bool sep = false;
+#pragma unroll
+        for (int i = 0; i < 3; i++) sep = sep || fabsf(t[i]) > a[i] + b[0] * Ab[i][0] + b[1] * Ab[i][1] + b[2] * Ab[i][2] + gap;
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+          sep = sep || fabsf(t[0] * Rm[0][j] + t[1] * Rm[1][j] + t[2] * Rm[2][j]) > a[0] * Ab[0][j] + a[1] * Ab[1][j] + a[2] * Ab[2][j] + b[j] + gap;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+            float ra = a[i1] * Ab[i2][j] + a[i2] * Ab[i1][j], rb = b[j1] * Ab[i][j2] + b[j2] * Ab[i][j1];
+            sep = sep || fabsf(t[i2] * Rm[i1][j] - t[i1] * Rm[i2][j]) > ra + rb + gap;
+          }
+        keep = !sep;
+      }
+    }
+    unsigned long long mask = wave_ballot(keep);
+    int idx = nout + wave_prefix(mask);
+    wave_sync();                                   // every lane has read its candidate before the slots are rewritten
+    if (keep) { L.cand[idx][0] = (unsigned short)g1; L.cand[idx][1] = (unsigned short)g2; }
+    nout += __popcll(mask);
+  }
+  wave_sync();
+  if (lane == 0) L.ncand = nout;
+  wave_sync();
+}
+
 // Broadphase: world boxes of all geoms, then the statically filtered pair list is tested lane-parallel; survivors
 // are appended to L.cand in pair order.  The pair words of a chunk (PAIR_CHUNK x 64 pairs) are fetched into registers
 // with one burst of loads before any of them is used (the loop used to pay one L2 round trip per 64 pairs), and a
@@ -782,6 +889,7 @@ DEV void broadphase(const DevModel* m, EnvLDS& L) {
   }
   if (lane == 0) { L.ncand = base < MAXCAND ? base : MAXCAND; if (base > MAXCAND) L.overflow |= 1; }
   wave_sync();
+  obb_filter(m, L);
 }
 
 // ---- multi-contact for flat faces ("multiccd", so101_sim/tasks/base/so100_task.py:151) --------------------------
@@ -817,7 +925,7 @@ DEV bool inside_face(const float* rel, const float* u, const float* v, float hu,
 
 
 
-template <class Cache>
+template <class Cache, class GP = G64>
 DEV bool face_patch(const DevModel* m, const GeomW& GI, const Cache& HI, const float* f, const float* c, const float* u,
                     const float* v, float hu, float hv, float dup_tol, PairContacts& out) {
   out.n = 0;
@@ -829,7 +937,7 @@ DEV bool face_patch(const DevModel* m, const GeomW& GI, const Cache& HI, const f
 #pragma unroll
     for (int i = 0; i < 3; i++) d[i] = -f[i] + e * (su * u[i] + sv * v[i]);
     normalize3(d);
-    support(m, GI, d, p, HI);
+    support<Cache, GP>(m, GI, d, p, HI);
     float rel[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]};
     float dist = dot3(rel, f);
     bool ok = dist < 0.f;
@@ -894,7 +1002,7 @@ struct FaceRef { float f[3], c[3], u[3], v[3], hu, hv, depth; int side; bool exa
 //    iterative query is needed (R.exact: props resting on the table top, finger pads, the static puck);
 //  * a0 merely inside the outline (d0 <= half thickness): a CANDIDATE; the shallowest one is kept in R and later wins
 //    over MPR's answer when it is not deeper (narrow_pair).
-template <class Cache>
+template <class Cache, class GP = G64>
 DEV void scan_faces(const DevModel* m, const GeomW& GR, const GeomW& GI, const Cache& HI, int side, FaceRef& R) {
   if (GR.type != G_BOX && GR.type != G_CYLINDER) return;
   float toward[3] = {GI.c[0] - GR.c[0], GI.c[1] - GR.c[1], GI.c[2] - GR.c[2]};
@@ -906,7 +1014,7 @@ DEV void scan_faces(const DevModel* m, const GeomW& GR, const GeomW& GI, const C
     float cr[3] = {c[0] - GI.c[0], c[1] - GI.c[1], c[2] - GI.c[2]};
     if (dot3(cr, f) > half) continue;                  // d0 >= depth of the incident's centre > half thickness
     float nf[3] = {-f[0], -f[1], -f[2]}, a0[3];
-    support(m, GI, nf, a0, HI);
+    support<Cache, GP>(m, GI, nf, a0, HI);
     float rel[3] = {a0[0] - c[0], a0[1] - c[1], a0[2] - c[2]};
     float d0 = -dot3(rel, f);
     if (!(d0 > 0.f)) { R.separated = true; continue; }
@@ -921,18 +1029,18 @@ DEV void scan_faces(const DevModel* m, const GeomW& GR, const GeomW& GI, const C
 
 // Narrowphase of one candidate pair (geom types ordered): up to NCPP contacts sharing one normal (geom1 -> geom2),
 // each with its penetration distance (< 0) and position.
-template <class Cache>
+template <class Cache, class GP = G64>
 DEV void narrow_pair(const DevModel* m, const GeomW& G1, const GeomW& G2, int g1, int g2, PairContacts& out) {
   Cache H1, H2;
-  hull_load(m, G1, H1); hull_load(m, G2, H2);
+  hull_load<GP>(m, G1, H1); hull_load<GP>(m, G2, H2);
   out.n = 0; out.nrm[0] = out.nrm[1] = out.nrm[2] = 0.f;
 #pragma unroll
   for (int j = 0; j < NCPP; j++) { out.dist[j] = 0.f; out.pos[j][0] = out.pos[j][1] = out.pos[j][2] = 0.f; }
-  float rb1 = ldc(ldc(&m->geom_rbound) + g1), rb2 = ldc(ldc(&m->geom_rbound) + g2);
+  float rb1 = GP::ld(ldc(&m->geom_rbound) + g1), rb2 = GP::ld(ldc(&m->geom_rbound) + g2);
   if (G1.type == G_PLANE) {
     float fr[9] = {G1.R[2], G1.R[5], G1.R[8], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     make_frame(fr);
-    face_patch(m, G2, H2, fr, G1.p, fr + 3, fr + 6, -1.f, -1.f, PATCH_DUP * rb2, out);
+    face_patch<Cache, GP>(m, G2, H2, fr, G1.p, fr + 3, fr + 6, -1.f, -1.f, PATCH_DUP * rb2, out);
     out.nrm[0] = fr[0]; out.nrm[1] = fr[1]; out.nrm[2] = fr[2];
     return;
   }
@@ -940,15 +1048,15 @@ DEV void narrow_pair(const DevModel* m, const GeomW& G1, const GeomW& G2, int g1
   best.depth = 3.0e38f; best.side = -1; best.hu = 0.f; best.hv = 0.f; best.exact = false; best.separated = false;
 #pragma unroll
   for (int k = 0; k < 3; k++) { best.f[k] = 0.f; best.c[k] = 0.f; best.u[k] = 0.f; best.v[k] = 0.f; }
-  scan_faces(m, G1, G2, H2, 0, best);
-  if (!best.separated) scan_faces(m, G2, G1, H1, 1, best);
+  scan_faces<Cache, GP>(m, G1, G2, H2, 0, best);
+  if (!best.separated) scan_faces<Cache, GP>(m, G2, G1, H1, 1, best);
   if (best.separated) return;
   float depth = 0.f, nrm[3] = {0.f, 0.f, 0.f}, pos[3] = {0.f, 0.f, 0.f};
   if (!best.exact) {
     // MPR's depth is the depth along ITS final portal normal, which for a thin plate (finger pad) against a hull can be
     // an oblique direction ten times deeper than the plate's face normal: the shallowest face candidate wins when it
     // is not deeper (1 % + 1e-6 m slack: for a face contact both are the same number)
-    bool ok = mpr_penetration(m, G1, G2, &depth, nrm, pos, H1, H2);
+    bool ok = mpr_penetration<Cache, GP>(m, G1, G2, &depth, nrm, pos, H1, H2);
     if (!ok || !(depth > 0.f)) return;
     if (best.side >= 0 && !(best.depth <= depth * (1.f + FACE_DEPTH_REL) + FACE_DEPTH_ABS)) best.side = -1;
   }
@@ -960,7 +1068,7 @@ DEV void narrow_pair(const DevModel* m, const GeomW& G1, const GeomW& G2, int g1
     GeomW GI; Cache HI;
     select_geom(ref == 0, G2, G1, GI);
     select_hull(ref == 0, H2, H1, HI);
-    patched = face_patch(m, GI, HI, best.f, best.c, best.u, best.v, best.hu, best.hv, PATCH_DUP * fminf(rb1, rb2), out);
+    patched = face_patch<Cache, GP>(m, GI, HI, best.f, best.c, best.u, best.v, best.hu, best.hv, PATCH_DUP * fminf(rb1, rb2), out);
   }
   const float* f = best.f;
   if (patched) {

@@ -544,8 +544,7 @@ int so101_step(so101_sim* s, const float* action, float* obs, float* reward, flo
       W.work = s->pipe.work + (size_t)2 * MAXCAND * e0;
       W.work_cap = (unsigned int)ng * MAXCAND;
       // persistent narrowphase waves (they pull work items until the list is empty): two per env of the slice, at
-      // most what fills 256 CUs.  Measured with three slices: 2/env 466 k env-steps/s, 1/env 463 k, >= 4/env 451 k -
-      // a smaller narrowphase grid leaves slots to the other chains' solve kernels.
+      // most what fills 256 CUs - a smaller narrowphase grid leaves slots to the other chains' solve kernels
       int nw = ng * 2 < 4096 ? ng * 2 : 4096;
       if (G > 1 && !hip_ok(s, hipStreamWaitEvent(gs, s->step_begin, 0), "hipStreamWaitEvent")) return SO101_ERR_HIP;
       if (!hip_ok(s, hipMemsetAsync(W.counters, 0, sizeof(int) * 2 * MAXSUB, gs), "hipMemsetAsync(pipe)")) return SO101_ERR_HIP;

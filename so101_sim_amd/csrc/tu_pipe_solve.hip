@@ -2,9 +2,14 @@
 #include "so101_pipeline.hpp"
 #include "so101_launch.hpp"
 
-// One wavefront per candidate pair.  No LDS; the two geoms (and the first 512 vertices of their hulls) live in
-// registers.  Work items are taken NARROW_CHUNK at a time: one atomic and one dependent pair of loads per chunk
-// instead of per item (that chain costs ~3 us, an MPR query on two boxes ~7 us).
+// One wavefront per candidate pair (policy G64 of so101_device.hpp).  No LDS; the two geoms (and the first 512 vertices
+// of their hulls) live in registers.  Work items are taken NARROW_CHUNK at a time: one atomic and one dependent pair
+// of loads per chunk instead of per item (that chain costs ~3 us, an MPR query on two boxes ~7 us).
+//
+// Measured alternative (kept as policy G16, bit-identical results): one pair per DPP row of 16 lanes, four pairs per
+// wavefront.  It is SLOWER (4096-env bench 490-509 k against 635 k env-steps/s): ~70 % of a query's instructions are
+// the lane-parallel hull scans, not the uniform portal math, and a row caches only 128 vertices of a hull in registers
+// (the arm links have 400-525), so every support call of a big hull goes back to L2.
 #define NARROW_CHUNK 4
 __global__ void __launch_bounds__(64, 2) k_narrow(const DevModel* m, int N, PipeBuffers W, int s) {
   int lane = wave_lane();

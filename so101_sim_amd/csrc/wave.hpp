@@ -111,4 +111,21 @@ __device__ __forceinline__ void wave_argmax3(float& val, int& idx, float& x, flo
   val = mx;
   idx = best;
 }
+// argmax with a 3-vector payload inside each DPP row of 16 lanes (four independent groups per wavefront): four
+// butterfly steps (xor 1, xor 2, half-row mirror, row mirror) carry (value, index, payload) and keep the better of the
+// two partners - larger value, smaller index on ties - so all 16 lanes of a row end with the row's winner.  Rows may be
+// individually inactive (EXEC), the exchanges never leave the row.
+template <int CTRL>
+__device__ __forceinline__ void row_argmax3_step(float& val, int& idx, float& x, float& y, float& z) {
+  float pv = dpp_f<CTRL>(val), px = dpp_f<CTRL>(x), py = dpp_f<CTRL>(y), pz = dpp_f<CTRL>(z);
+  int pi = dpp_i<CTRL>(idx);
+  bool take = pv > val || (pv == val && pi < idx);
+  val = take ? pv : val; idx = take ? pi : idx; x = take ? px : x; y = take ? py : y; z = take ? pz : z;
+}
+__device__ __forceinline__ void row_argmax3(float& val, int& idx, float& x, float& y, float& z) {
+  row_argmax3_step<DPP_QUAD_XOR1>(val, idx, x, y, z);
+  row_argmax3_step<DPP_QUAD_XOR2>(val, idx, x, y, z);
+  row_argmax3_step<DPP_ROW_HALF_MIRROR>(val, idx, x, y, z);
+  row_argmax3_step<DPP_ROW_MIRROR>(val, idx, x, y, z);
+}
 #endif  // SO101_WAVE_HPP_

@@ -3,6 +3,7 @@
 thread_local emu_idx threadIdx;
 thread_local emu_idx blockIdx;
 pthread_barrier_t emu_barrier;
+pthread_barrier_t emu_row_barrier[4];
 float emu_xchg_f[64];
 int emu_xchg_i[64];
 unsigned long long emu_xchg_u;

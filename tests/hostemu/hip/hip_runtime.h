@@ -25,6 +25,7 @@ struct emu_idx { unsigned x, y, z; };
 extern thread_local emu_idx threadIdx;
 extern thread_local emu_idx blockIdx;
 extern pthread_barrier_t emu_barrier;
+extern pthread_barrier_t emu_row_barrier[4];      // one per DPP row of 16 lanes: rows of a wave may diverge (k_narrow)
 extern float emu_xchg_f[64];
 extern int emu_xchg_i[64];
 extern unsigned long long emu_xchg_u;
@@ -73,11 +74,13 @@ template <typename K, typename... A>
 void emu_launch(K kernel, dim3 grid, dim3 block, A... args) {
   for (unsigned b = 0; b < grid.x; b++) {
     pthread_barrier_init(&emu_barrier, nullptr, block.x);
+    if (block.x == 64) for (int r = 0; r < 4; r++) pthread_barrier_init(&emu_row_barrier[r], nullptr, 16);
     std::vector<std::thread> th;
     for (unsigned t = 0; t < block.x; t++)
       th.emplace_back([=]() { threadIdx = {t, 0, 0}; blockIdx = {b, 0, 0}; kernel(args...); });
     for (auto& x : th) x.join();
     pthread_barrier_destroy(&emu_barrier);
+    if (block.x == 64) for (int r = 0; r < 4; r++) pthread_barrier_destroy(&emu_row_barrier[r]);
   }
 }
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emu_launch(kernel, grid, block, __VA_ARGS__)

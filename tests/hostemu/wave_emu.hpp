@@ -60,4 +60,18 @@ inline void wave_argmax3(float& val, int& idx, float& x, float& y, float& z) {
   __syncthreads();
   val = m; idx = b; x = ox; y = oy; z = oz;
 }
+// row-local argmax with payload: the 16 lanes of a DPP row agree on (max value, smallest index, winner's payload).
+// Rows of a wave may diverge (k_narrow runs one geom pair per row), so the exchange synchronises the row only.
+inline void row_argmax3(float& val, int& idx, float& x, float& y, float& z) {
+  static float pv[64], px[64], py[64], pz[64];
+  static int pi[64];
+  int t = threadIdx.x, row = t >> 4, r0 = t & ~15, src = r0;
+  pv[t] = val; pi[t] = idx; px[t] = x; py[t] = y; pz[t] = z;
+  pthread_barrier_wait(&emu_row_barrier[row]);
+  for (int i = r0 + 1; i < r0 + 16; i++)
+    if (pv[i] > pv[src] || (pv[i] == pv[src] && pi[i] < pi[src])) src = i;
+  float ov = pv[src], ox = px[src], oy = py[src], oz = pz[src]; int oi = pi[src];
+  pthread_barrier_wait(&emu_row_barrier[row]);
+  val = ov; idx = oi; x = ox; y = oy; z = oz;
+}
 #endif
