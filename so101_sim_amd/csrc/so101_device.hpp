@@ -396,6 +396,7 @@ struct G64 {
   static constexpr int N = 64;
   DEV static int sub() { return wave_lane(); }
   DEV static void argmax3(float& val, int& idx, float& x, float& y, float& z) { wave_argmax3(val, idx, x, y, z); }
+  DEV static void argmax(float& val, int& idx) { wave_argmax(val, idx); }
   template <class T> DEV static T ld(const T* p) { return ldc(p); }
   DEV static int uni(int v) { return wave_uniform_i(v); }
 };
@@ -403,6 +404,7 @@ struct G16 {
   static constexpr int N = 16;
   DEV static int sub() { return wave_lane() & 15; }
   DEV static void argmax3(float& val, int& idx, float& x, float& y, float& z) { row_argmax3(val, idx, x, y, z); }
+  DEV static void argmax(float& val, int& idx) { float x = 0.f, y = 0.f, z = 0.f; row_argmax3(val, idx, x, y, z); }
   template <class T> DEV static T ld(const T* p) { return *p; }
   DEV static int uni(int v) { return v; }
 };
@@ -908,7 +910,72 @@ DEV void broadphase(const DevModel* m, EnvLDS& L) {
 #define PATCH_EPS 1e-3f
 #define PATCH_DUP 1e-3f
 
-struct PairContacts { int n; float nrm[3], dist[NCPP], pos[NCPP][3]; };
+// The five sample points of a flat contact patch in ONE pass over the hull: a_0 = support(-f) and
+// a_k = support(-f + eps s_k), s_k = (+-u +- v)/sqrt(2) (see face_patch).  Five separate support calls scan a hull five
+// times; the banana's hulls have a thousand vertices, more than the register cache holds, so each scan went back to L2
+// twice.  Here every vertex is read once and scored against the five directions; the five winners (max dot, smallest
+// index - the same vertex support() would return) are fetched afterwards.
+struct Patch5 { float p[NCPP][3]; };
+
+template <class Cache, class GP = G64>
+DEV void support_patch(const DevModel* m, const GeomW& G, const float* f, const float* u, const float* v, Patch5& P, const Cache& H) {
+  float d[NCPP][3];
+#pragma unroll
+  for (int k = 0; k < NCPP; k++) {
+    float su = (k == 1 || k == 4) ? 1.f : -1.f, sv = (k == 1 || k == 2) ? 1.f : -1.f;
+    float e = k == 0 ? 0.f : PATCH_EPS * 0.70710678f;
+#pragma unroll
+    for (int i = 0; i < 3; i++) d[k][i] = -f[i] + e * (su * u[i] + sv * v[i]);
+    normalize3(d[k]);
+  }
+  if (G.type != G_MESH) {
+#pragma unroll
+    for (int k = 0; k < NCPP; k++) support<Cache, GP>(m, G, d[k], P.p[k], H);
+    return;
+  }
+  float dl[NCPP][3], best[NCPP];
+  int bi[NCPP];
+#pragma unroll
+  for (int k = 0; k < NCPP; k++) { matTvec3(dl[k], G.R, d[k]); best[k] = -3.0e38f; bi[k] = 0x7fffffff; }
+  int lane = GP::sub();
+  const float* x = ldc(&m->vx) + G.vadr; const float* y = ldc(&m->vy) + G.vadr; const float* z = ldc(&m->vz) + G.vadr;
+  int first = lane;
+  if constexpr (sizeof(Cache) >= sizeof(HullCache)) {
+#pragma unroll
+    for (int j = 0; j < HULL_K; j++) {
+      if (GP::N * j >= G.vnum) break;
+      int i = lane + GP::N * j;
+      float X = H.x[j], Y = H.y[j], Z = H.z[j];
+#pragma unroll
+      for (int k = 0; k < NCPP; k++) {
+        float s = X * dl[k][0] + Y * dl[k][1] + Z * dl[k][2];
+        if (i < G.vnum && s > best[k]) { best[k] = s; bi[k] = i; }
+      }
+    }
+    first = lane + GP::N * HULL_K;
+  }
+#pragma unroll 4
+  for (int i = first; i < G.vnum; i += GP::N) {
+    float X = x[i], Y = y[i], Z = z[i];
+#pragma unroll
+    for (int k = 0; k < NCPP; k++) {
+      float s = X * dl[k][0] + Y * dl[k][1] + Z * dl[k][2];
+      if (s > best[k]) { best[k] = s; bi[k] = i; }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NCPP; k++) {
+    GP::argmax(best[k], bi[k]);
+    int w = (unsigned int)bi[k] < (unsigned int)G.vnum ? bi[k] : 0;       // (a non-finite direction selects nothing)
+    float loc[3] = {x[w], y[w], z[w]}, wv[3];
+    matvec3(wv, G.R, loc);
+    P.p[k][0] = G.p[0] + wv[0]; P.p[k][1] = G.p[1] + wv[1]; P.p[k][2] = G.p[2] + wv[2];
+  }
+}
+
+// contacts of one geom pair: slot k holds patch sample k (or the single MPR contact in slot 0) when bit k of `valid` is
+// set - fixed slots instead of a compacted list: "store at the running count" is register indexing, i.e. scratch memory
+struct PairContacts { unsigned int valid; float nrm[3], dist[NCPP], pos[NCPP][3]; };
 
 // inside the face outline (rectangle hu x hv, or disc of radius hu when hv < 0) by at least `margin`
 DEV bool inside_margin(const float* rel, const float* u, const float* v, float hu, float hv, float margin) {
@@ -925,19 +992,12 @@ DEV bool inside_face(const float* rel, const float* u, const float* v, float hu,
 
 
 
-template <class Cache, class GP = G64>
-DEV bool face_patch(const DevModel* m, const GeomW& GI, const Cache& HI, const float* f, const float* c, const float* u,
-                    const float* v, float hu, float hv, float dup_tol, PairContacts& out) {
-  out.n = 0;
-#pragma unroll 1
-  for (int k = 0; k < NCPP; k++) {
-    float su = (k == 1 || k == 4) ? 1.f : -1.f, sv = (k == 1 || k == 2) ? 1.f : -1.f;
-    float e = k == 0 ? 0.f : PATCH_EPS * 0.70710678f;
-    float d[3], p[3];
+DEV bool face_patch(const Patch5& P, const float* f, const float* c, const float* u, const float* v, float hu, float hv,
+                    float dup_tol, PairContacts& out) {
+  out.valid = 0u;
 #pragma unroll
-    for (int i = 0; i < 3; i++) d[i] = -f[i] + e * (su * u[i] + sv * v[i]);
-    normalize3(d);
-    support<Cache, GP>(m, GI, d, p, HI);
+  for (int k = 0; k < NCPP; k++) {
+    const float* p = P.p[k];
     float rel[3] = {p[0] - c[0], p[1] - c[1], p[2] - c[2]};
     float dist = dot3(rel, f);
     bool ok = dist < 0.f;
@@ -945,15 +1005,12 @@ DEV bool face_patch(const DevModel* m, const GeomW& GI, const Cache& HI, const f
     if (k == 0 && !ok) return false;
     float cp[3] = {p[0] - 0.5f * dist * f[0], p[1] - 0.5f * dist * f[1], p[2] - 0.5f * dist * f[2]};
 #pragma unroll
-    for (int j = 0; j < NCPP - 1; j++) {
+    for (int j = 0; j < k; j++) {
       float dd[3] = {cp[0] - out.pos[j][0], cp[1] - out.pos[j][1], cp[2] - out.pos[j][2]};
-      if (j < out.n && sqrtf(dot3(dd, dd)) < dup_tol) ok = false;
+      if (((out.valid >> j) & 1u) && sqrtf(dot3(dd, dd)) < dup_tol) ok = false;
     }
-    if (ok) {
-#pragma unroll
-      for (int j = 0; j < NCPP; j++) if (j == out.n) { out.dist[j] = dist; out.pos[j][0] = cp[0]; out.pos[j][1] = cp[1]; out.pos[j][2] = cp[2]; }
-      out.n++;
-    }
+    out.dist[k] = dist; out.pos[k][0] = cp[0]; out.pos[k][1] = cp[1]; out.pos[k][2] = cp[2];
+    if (ok) out.valid |= 1u << k;
   }
   return true;
 }
@@ -991,7 +1048,7 @@ DEV bool flat_face(const GeomW& G, int axis, const float* toward, float* f, floa
   return true;
 }
 
-struct FaceRef { float f[3], c[3], u[3], v[3], hu, hv, depth; int side; bool exact, separated; };
+struct FaceRef { float f[3], c[3], u[3], v[3], hu, hv, depth; int side; bool exact, separated; Patch5 P; };
 
 // Flat-face scan of GR (box / cylinder) against the incident geom GI, before any iterative query.  For every flat face
 // on the side of GI's centre, a0 = GI's deepest point below the face plane, d0 its depth:
@@ -1024,6 +1081,11 @@ DEV void scan_faces(const DevModel* m, const GeomW& GR, const GeomW& GI, const C
     R.exact = ex; R.depth = d0; R.side = side; R.hu = hu; R.hv = hv;
 #pragma unroll
     for (int k = 0; k < 3; k++) { R.f[k] = f[k]; R.c[k] = c[k]; R.u[k] = u[k]; R.v[k] = v[k]; }
+    // the face is (so far) the reference face: its five patch samples in one more pass over the incident hull
+    Patch5 P;
+    support_patch<Cache, GP>(m, GI, f, u, v, P, HI);
+#pragma unroll
+    for (int k = 0; k < NCPP; k++) { R.P.p[k][0] = P.p[k][0]; R.P.p[k][1] = P.p[k][1]; R.P.p[k][2] = P.p[k][2]; }
   }
 }
 
@@ -1033,14 +1095,16 @@ template <class Cache, class GP = G64>
 DEV void narrow_pair(const DevModel* m, const GeomW& G1, const GeomW& G2, int g1, int g2, PairContacts& out) {
   Cache H1, H2;
   hull_load<GP>(m, G1, H1); hull_load<GP>(m, G2, H2);
-  out.n = 0; out.nrm[0] = out.nrm[1] = out.nrm[2] = 0.f;
+  out.valid = 0u; out.nrm[0] = out.nrm[1] = out.nrm[2] = 0.f;
 #pragma unroll
   for (int j = 0; j < NCPP; j++) { out.dist[j] = 0.f; out.pos[j][0] = out.pos[j][1] = out.pos[j][2] = 0.f; }
   float rb1 = GP::ld(ldc(&m->geom_rbound) + g1), rb2 = GP::ld(ldc(&m->geom_rbound) + g2);
   if (G1.type == G_PLANE) {
     float fr[9] = {G1.R[2], G1.R[5], G1.R[8], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     make_frame(fr);
-    face_patch<Cache, GP>(m, G2, H2, fr, G1.p, fr + 3, fr + 6, -1.f, -1.f, PATCH_DUP * rb2, out);
+    Patch5 P;
+    support_patch<Cache, GP>(m, G2, fr, fr + 3, fr + 6, P, H2);
+    face_patch(P, fr, G1.p, fr + 3, fr + 6, -1.f, -1.f, PATCH_DUP * rb2, out);
     out.nrm[0] = fr[0]; out.nrm[1] = fr[1]; out.nrm[2] = fr[2];
     return;
   }
@@ -1048,6 +1112,8 @@ DEV void narrow_pair(const DevModel* m, const GeomW& G1, const GeomW& G2, int g1
   best.depth = 3.0e38f; best.side = -1; best.hu = 0.f; best.hv = 0.f; best.exact = false; best.separated = false;
 #pragma unroll
   for (int k = 0; k < 3; k++) { best.f[k] = 0.f; best.c[k] = 0.f; best.u[k] = 0.f; best.v[k] = 0.f; }
+#pragma unroll
+  for (int k = 0; k < NCPP; k++) { best.P.p[k][0] = 0.f; best.P.p[k][1] = 0.f; best.P.p[k][2] = 0.f; }
   scan_faces<Cache, GP>(m, G1, G2, H2, 0, best);
   if (!best.separated) scan_faces<Cache, GP>(m, G2, G1, H1, 1, best);
   if (best.separated) return;
@@ -1062,22 +1128,15 @@ DEV void narrow_pair(const DevModel* m, const GeomW& G1, const GeomW& G2, int g1
   }
   int ref = best.side;
   bool patched = false;
-  if (ref >= 0) {
-    // the incident geom (and its cached hull) selected into ONE set of registers: a single inlined copy of the patch
-    // sampling, and the reference geom's registers are free from here on
-    GeomW GI; Cache HI;
-    select_geom(ref == 0, G2, G1, GI);
-    select_hull(ref == 0, H2, H1, HI);
-    patched = face_patch<Cache, GP>(m, GI, HI, best.f, best.c, best.u, best.v, best.hu, best.hv, PATCH_DUP * fminf(rb1, rb2), out);
-  }
+  if (ref >= 0) patched = face_patch(best.P, best.f, best.c, best.u, best.v, best.hu, best.hv, PATCH_DUP * fminf(rb1, rb2), out);
   const float* f = best.f;
   if (patched) {
     float sg = ref == 0 ? 1.f : -1.f;
     out.nrm[0] = sg * f[0]; out.nrm[1] = sg * f[1]; out.nrm[2] = sg * f[2];
   } else if (best.exact) {
-    out.n = 0;
+    out.valid = 0u;
   } else {
-    out.n = 1; out.dist[0] = -depth;
+    out.valid = 1u; out.dist[0] = -depth;
 #pragma unroll
     for (int k = 0; k < 3; k++) { out.nrm[k] = nrm[k]; out.pos[0][k] = pos[k]; }
   }
@@ -1120,7 +1179,7 @@ DEV void collision(const DevModel* m, EnvLDS& L) {
     narrow_pair<NoCache>(m, G1, G2, g1, g2, pc);
 #pragma unroll
     for (int j = 0; j < NCPP; j++) {
-      if (j < pc.n && !full) {
+      if (((pc.valid >> j) & 1u) && !full) {
         if (ncon >= MAXCON) { if (lane == 0) L.overflow |= 2; full = true; }
         else { if (lane == 0) contact_init(m, L.con[ncon], g1, g2, pc.dist[j], pc.nrm, pc.pos[j]); ncon++; }
       }

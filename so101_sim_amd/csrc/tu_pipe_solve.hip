@@ -38,9 +38,11 @@ __global__ void __launch_bounds__(64, 2) k_narrow(const DevModel* m, int N, Pipe
       narrow_pair<HullCache>(m, G1, G2, g1, g2, pc);
       if (lane == 0) {
         float* r = W.conres + (size_t)w * CONRES_DIM;
-        r[0] = (float)pc.n; r[1] = pc.nrm[0]; r[2] = pc.nrm[1]; r[3] = pc.nrm[2];
+        r[0] = (float)__popc(pc.valid); r[1] = pc.nrm[0]; r[2] = pc.nrm[1]; r[3] = pc.nrm[2];
+        int o = 4;                                     // valid slots are written compactly, in slot order
 #pragma unroll
-        for (int q = 0; q < NCPP; q++) if (q < pc.n) { r[4 + 4 * q] = pc.dist[q]; r[5 + 4 * q] = pc.pos[q][0]; r[6 + 4 * q] = pc.pos[q][1]; r[7 + 4 * q] = pc.pos[q][2]; }
+        for (int q = 0; q < NCPP; q++)
+          if ((pc.valid >> q) & 1u) { r[o] = pc.dist[q]; r[o + 1] = pc.pos[q][0]; r[o + 2] = pc.pos[q][1]; r[o + 3] = pc.pos[q][2]; o += 4; }
         if (SO101_CLOCKS_ON) W.ticks[w] = (unsigned int)(SO101_CLOCK() - t0);
       }
     }

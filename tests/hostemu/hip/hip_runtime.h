@@ -32,6 +32,7 @@ extern unsigned long long emu_xchg_u;
 
 inline void __syncthreads() { pthread_barrier_wait(&emu_barrier); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __popc(unsigned int v) { return __builtin_popcount(v); }
 using std::max;
 using std::min;
 
