@@ -120,6 +120,13 @@ int so101_reset(so101_sim* sim, const uint8_t* mask, void* hip_stream);
  * reference's reset. */
 int so101_set_reset_pool(so101_sim* sim, const float* qpos, const float* qvel, const float* ctrl, int pool_size);
 
+/* PropPlacer settle only (so100_hand_over.py:222-229, settle_physics=True): from the state in the bound buffers, arm
+ * held, props integrated until |qvel| < 1e-3 and |qacc| < 1e-2 or settle_max_substeps are used.  For callers that draw
+ * the placements themselves - the single-env Python facade draws them from numpy.random.RandomState in the reference's
+ * order (object xyz, object yaw, container xyz per attempt), so that a seed reproduces the reference's episode; follow
+ * with so101_begin_episode. */
+int so101_settle(so101_sim* sim, void* hip_stream);
+
 /* Starts an episode from whatever state the caller wrote into the bound buffers (checkpoint restore,
  * known-answer tests): ctrl = home + offsets, delay line filled with the current joints_pos,
  * step_count/ep_return cleared, no placement, no settle.  The reference's equivalent is

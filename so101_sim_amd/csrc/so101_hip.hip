@@ -495,6 +495,14 @@ int so101_set_reset_pool(so101_sim* s, const float* qpos, const float* qvel, con
   return SO101_OK;
 }
 
+int so101_settle(so101_sim* s, void* stream) {
+  REQUIRE_BOUND(s);
+  GUARD_DEVICE(s);
+  so101::launch_settle(s->cfg.solver, s->n_envs, (hipStream_t)stream, s->dm, make_params(s), s->buf, s->ev, s->diag);
+  LAUNCH_CHECK(s, "k_settle");
+  return SO101_OK;
+}
+
 int so101_begin_episode(so101_sim* s, void* stream) {
   REQUIRE_BOUND(s);
   GUARD_DEVICE(s);

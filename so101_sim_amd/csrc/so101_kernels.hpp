@@ -46,6 +46,32 @@ __global__ void __launch_bounds__(64, 2) k_reset(const DevModel* m, StepParams P
   if (wave_lane() == 0) need_reset[e] = 0;
 }
 
+// PropPlacer settle only (dm_control initializers.PropPlacer(settle_physics=True), so100_hand_over.py:222-229) from the
+// bound state: the placements were drawn by the caller (the single-env facade draws them from numpy's RandomState in
+// the reference's order, so that a seed reproduces the reference's episode).  Arm held, props integrated until
+// |qvel| < 1e-3 and |qacc| < 1e-2 or the budget is used; flags as in env_settle().
+template <int SOLVER>
+__global__ void __launch_bounds__(64, 2) k_settle(const DevModel* m, StepParams P, DevBuffers B, EventBuffers E, int* diag) {
+  __shared__ EnvLDS L;
+  int e = blockIdx.x, lane = wave_lane();
+  load_state(L, B, e, P.n_envs);
+  if (lane < NARM) { L.arm0_q[lane] = L.qpos[lane]; L.arm0_v[lane] = L.qvel[lane]; }
+  wave_sync();
+  bool settled = P.settle_max == 0;
+  for (int k = 0; k < P.settle_max && !settled; k++) {
+    if (substep<SOLVER>(m, L, P.iterations, P.tolerance, true, 7)) break;
+    float mv = 0.f, ma = 0.f;
+    if (lane >= NARM && lane < NV) { mv = fabsf(L.qvel[lane]); ma = fabsf(L.qacc[lane]); }
+    mv = wave_max_f(mv); ma = wave_max_f(ma);
+    settled = mv < 1e-3f && ma < 1e-2f;
+  }
+  if (!settled && lane == 0) L.overflow |= 32;
+  wave_sync();
+  store_state(L, B, e, P.n_envs);
+  store_diag(L, diag, e);
+  count_events(L, E, e);
+}
+
 template <int SOLVER>
 __global__ void __launch_bounds__(64, 2) k_step(const DevModel* m, StepParams P, DevBuffers B, PrepBuffers C, EventBuffers E,
                                              const float* action, float* obs, float* reward, float* discount,

@@ -9,6 +9,9 @@ void launch_step_pgs(int n_envs, hipStream_t st, const DevModel* m, const StepPa
   hipLaunchKernelGGL(k_step<0>, dim3(n_envs), dim3(64), 0, st, m, P, B, C, E, io.action, io.obs, io.reward, io.discount, io.step_type,
                      need_reset, diag);
 }
+void launch_settle_pgs(int n_envs, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B, const EventBuffers& E, int* diag) {
+  hipLaunchKernelGGL(k_settle<0>, dim3(n_envs), dim3(64), 0, st, m, P, B, E, diag);
+}
 void launch_reset_pgs(int n_envs, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B, const PrepBuffers& C,
                       const EventBuffers& E, const unsigned char* mask, unsigned char* need_reset, int* diag) {
   hipLaunchKernelGGL(k_reset<0>, dim3(n_envs), dim3(64), 0, st, m, P, B, C, E, mask, need_reset, diag);

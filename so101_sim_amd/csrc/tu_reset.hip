@@ -8,6 +8,10 @@ void launch_reset(int solver, int n_envs, hipStream_t st, const DevModel* m, con
   if (solver == 0) { launch_reset_pgs(n_envs, st, m, P, B, C, E, mask, need_reset, diag); return; }
   hipLaunchKernelGGL(k_reset<1>, dim3(n_envs), dim3(64), 0, st, m, P, B, C, E, mask, need_reset, diag);
 }
+void launch_settle(int solver, int n_envs, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B, const EventBuffers& E, int* diag) {
+  if (solver == 0) { launch_settle_pgs(n_envs, st, m, P, B, E, diag); return; }
+  hipLaunchKernelGGL(k_settle<1>, dim3(n_envs), dim3(64), 0, st, m, P, B, E, diag);
+}
 void launch_prepare(int waves, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B, const PrepBuffers& C) {
   hipLaunchKernelGGL(k_prepare<1>, dim3(waves), dim3(64), 0, st, m, P, B, C);
 }

@@ -261,11 +261,73 @@ class BatchedEnvironment:
 
 class SingleEnvironment(BatchedEnvironment):
     """N = 1 facade with the reference's numpy observation dict (keys/order:
-    examples/so101_rl_breakdown.ipynb:65; shapes :115-122)."""
+    examples/so101_rl_breakdown.ipynb:65; shapes :115-122).
 
-    def __init__(self, task, **kw):
-        super().__init__(task, n_envs=1, **kw)
+    Seed compatibility: the reference's placements come from `np.random.RandomState(seed)` inside dm_control's
+    PropPlacer.  With `seed_compatible=True` (default) this facade draws them from the same generator in the same
+    order - object position `uniform(low, high)` (3 draws, so100_hand_over.py:37-41), object yaw (1, :42-49),
+    container position (3 per attempt, at most 20 attempts against collisions, :51-55 / :216-221) - writes them into
+    the state and lets the kernels settle (so101_settle) and start the episode.  An int seed or a RandomState therefore
+    reproduces the reference's initial placements; the batched environments key a counter RNG by (seed, env id,
+    episode) instead."""
+
+    def __init__(self, task, seed_compatible: bool = True, random_state=None, **kw):
+        self._seed_compatible = bool(seed_compatible)
+        if isinstance(random_state, np.random.RandomState):
+            self._np_random = random_state
+        elif random_state is None:
+            self._np_random = np.random.RandomState()
+        else:
+            self._np_random = np.random.RandomState(int(random_state))
+        super().__init__(task, n_envs=1, random_state=(random_state if not isinstance(random_state, np.random.RandomState) else 0), **kw)
         self._state_ring = collections.deque(maxlen=_PHYSICS_DELAY_STEPS)
+        self._pending_first = False
+        from .model import blob as blobfmt
+        m = blobfmt.unpack(scenes.load_blob(task.object_name, "f64")[0])
+        self._placer = dict(obj_lo=np.asarray(m["task_obj_pos_lo"], dtype=np.float64), obj_hi=np.asarray(m["task_obj_pos_hi"], dtype=np.float64),
+                            yaw=np.asarray(m["task_obj_yaw"], dtype=np.float64), con_lo=np.asarray(m["task_con_pos_lo"], dtype=np.float64),
+                            con_hi=np.asarray(m["task_con_pos_hi"], dtype=np.float64),
+                            con_geoms=set(np.nonzero(np.asarray(m["geom_body"]) == int(np.asarray(m["task_container_body"]).ravel()[0]))[0].tolist()))
+        self._dbg = self.torch.zeros(1, native.DEBUG_DIM, device=self.device)
+
+    # ---- reference-order placement + settle
+    def _container_collides(self) -> bool:
+        self.sim.debug_forward(self._dbg.data_ptr(), self._stream())
+        r = self._dbg[0].cpu().numpy()
+        D = native.DBG
+        ncon = int(r[D["COUNTS"]])
+        for k in range(ncon):
+            g1, g2 = int(r[D["CON"] + 10 * k + 7]), int(r[D["CON"] + 10 * k + 8])
+            if g1 in self._placer["con_geoms"] or g2 in self._placer["con_geoms"]:
+                return True
+        return False
+
+    def _reset_seed_compatible(self):
+        torch, P, rs = self.torch, self._placer, self._np_random
+        opos = rs.uniform(P["obj_lo"], P["obj_hi"])                       # distributions.Uniform(low, high, single_sample=True)
+        yaw = rs.uniform(P["yaw"][0], P["yaw"][1])                        # QuaternionFromAxisAngle(axis=z, angle=Uniform)
+        q = np.zeros(20)
+        q[6:9] = opos
+        q[9:13] = [np.cos(0.5 * yaw), 0.0, 0.0, np.sin(0.5 * yaw)]
+        q[16] = 1.0
+        placed = False
+        for _ in range(20):                                               # PropPlacer max_attempts_per_prop
+            q[13:16] = rs.uniform(P["con_lo"], P["con_hi"])
+            self.qpos.copy_(torch.as_tensor(q, dtype=torch.float32, device=self.device).unsqueeze(1))
+            self.qvel.zero_()
+            self.warm.zero_()
+            if not self._container_collides():
+                placed = True
+                break
+        if not placed:
+            raise RuntimeError("Failed to place the container without collisions in 20 attempts (dm_control PropPlacer raises here too)")
+        self.placements = dict(object_position=opos.copy(), object_yaw=float(yaw), container_position=q[13:16].copy())
+        self.events(clear=True)
+        self.sim.settle(self._stream())
+        self.begin_episode()
+        if self.events()["settle_not_converged"]:
+            import warnings
+            warnings.warn("Failed to settle physics within the settle budget (dm_control warns likewise)")
 
     def _physics_state(self):
         return np.concatenate([self.qpos[:, 0].detach().cpu().numpy(), self.qvel[:, 0].detach().cpu().numpy()]).astype(np.float64)
@@ -291,7 +353,11 @@ class SingleEnvironment(BatchedEnvironment):
         return o
 
     def reset(self) -> TimeStep:
-        self.reset_all()
+        if self._seed_compatible and self._pool is None:
+            self._reset_seed_compatible()
+        else:
+            self.reset_all()
+        self._pending_first = False
         self.torch.cuda.synchronize(self.device)
         return TimeStep(StepType.FIRST, None, None, self._np_obs(first=True))
 
@@ -299,8 +365,12 @@ class SingleEnvironment(BatchedEnvironment):
         a = np.asarray(action, dtype=np.float64).reshape(-1)
         if len(a) != 6:
             raise ValueError(f"Expected 6 joint positions, got {len(a)}")
+        if self._pending_first:            # the step after LAST restarts the episode and reports FIRST (dm_control)
+            return self.reset()
         self.step_tensor(self.torch.as_tensor(a, dtype=self.torch.float32, device=self.device).unsqueeze(0))
         st = StepType(int(self.step_type[0].item()))
+        if st == StepType.LAST and self._seed_compatible and self._pool is None:
+            self._pending_first = True     # the host draws the next placements; the kernels' own auto-reset is not used
         if st == StepType.FIRST:
             return TimeStep(st, None, None, self._np_obs(first=True))
         return TimeStep(st, float(self.reward[0].item()), float(self.discount[0].item()), self._np_obs(first=False))

@@ -28,7 +28,7 @@ DBG = dict(M=0, MINV=36, BIAS=72, SMOOTH=78, QACC=96, COUNTS=114, XPOS=120, CON=
 
 EXPORTS = (
     "so101_version", "so101_max_contacts", "so101_create", "so101_destroy", "so101_default_config",
-    "so101_configure", "so101_bind_state", "so101_set_reset_pool", "so101_reset", "so101_begin_episode", "so101_step", "so101_physics", "so101_reward",
+    "so101_configure", "so101_bind_state", "so101_set_reset_pool", "so101_reset", "so101_settle", "so101_begin_episode", "so101_step", "so101_physics", "so101_reward",
     "so101_get_returns", "so101_get_diag", "so101_get_events", "so101_debug_forward", "so101_debug_candidates", "so101_debug_stages", "so101_last_error",
 )
 
@@ -77,6 +77,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.so101_set_reset_pool.argtypes = [vp, vp, vp, vp, C.c_int]
     L.so101_reset.argtypes = [vp, vp, vp]
     L.so101_begin_episode.argtypes = [vp, vp]
+    L.so101_settle.argtypes = [vp, vp]
     L.so101_step.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.so101_physics.argtypes = [vp, C.c_int, C.c_int, vp]
     L.so101_reward.argtypes = [vp, vp, vp]
@@ -143,6 +144,9 @@ class Sim:
 
     def reset(self, mask=None, stream=0):
         self._check(self.L.so101_reset(self.h, mask, stream), "so101_reset")
+
+    def settle(self, stream=0):
+        self._check(self.L.so101_settle(self.h, stream), "so101_settle")
 
     def begin_episode(self, stream=0):
         self._check(self.L.so101_begin_episode(self.h, stream), "so101_begin_episode")

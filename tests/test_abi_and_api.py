@@ -116,3 +116,26 @@ def test_lerobot_packaging_format():
     b = lerobot.to_lerobot_format(np.zeros((5, 6)), None, 2, 1, n_envs=5)
     assert b["observation.state"].shape == (5, 6) and b["action"].shape == (5, 6) and b["frame_index"].shape == (5,)
     assert torch.all(b["frame_index"] == 2) and torch.allclose(b["timestamp"], torch.full((5,), 0.2))
+
+
+def test_lerobot_packaging_matches_the_reference_wrapper():
+    """tests/golden/lerobot_cases.json holds outputs of the reference's own SO101LeRobotWrapper._convert_to_lerobot_format
+    (scripts/make_golden_lerobot.py executes it on synthetic time steps): same keys, dtypes, shapes and bit-identical
+    values from so101_sim_amd.lerobot.to_lerobot_format."""
+    import json
+    import numpy as np
+    import torch
+    from so101_sim_amd.lerobot import to_lerobot_format
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "lerobot_cases.json")))
+    assert len(g["cases"]) >= 10
+    for c in g["cases"]:
+        act = None if c["action"] is None else np.asarray(c["action"], dtype=c["action_dtype"])
+        out = to_lerobot_format(np.asarray(c["joints_pos"]), act, c["frame_index"], c["episode_index"], device="cpu", n_envs=1)
+        assert set(out) == set(c["expected"]), (set(out) ^ set(c["expected"]))
+        for k, want in c["expected"].items():
+            if isinstance(want, str):
+                assert out[k] == want
+                continue
+            got = out[k]
+            assert str(got.dtype) == want["dtype"] and list(got.shape) == want["shape"], (k, got.dtype, got.shape, want)
+            assert got.double().flatten().tolist() == want["value"], k

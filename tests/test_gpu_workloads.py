@@ -334,3 +334,56 @@ def test_env_on_a_non_current_device_guard():
     ev = env.events()
     assert set(ev) == {"candidate_overflow", "contact_overflow", "arm_pool_overflow", "diverged", "placement_rejected", "settle_not_converged"}
     env.close()
+
+
+def test_single_env_reset_is_seed_compatible_with_the_reference(blobs):
+    """create_task_env(..., random_state=123) (the seed of the reference's own test, hand_over_test.py:34-39): the
+    placements are numpy RandomState(123) draws in dm_control's PropPlacer order - object xyz (3), object yaw (1),
+    container xyz (3 per attempt) - and the settled state matches the oracle settling the same placements; the next
+    episode continues the same stream."""
+    import os
+    from so101_sim_amd import task_suite
+    cwd = os.getcwd()
+    os.chdir("/tmp")
+    try:
+        env = task_suite.create_task_env("SO100HandOverBanana", time_limit=0.06, random_state=123)
+    finally:
+        os.chdir(cwd)
+    ts = env.reset()
+    rs = np.random.RandomState(123)
+    opos = rs.uniform([0.2, -0.1, 0.45], [0.3, 0.1, 0.45])
+    yaw = rs.uniform(-np.pi * 0.1, np.pi * 0.1)
+    cpos = rs.uniform([-0.3, -0.1, 0.45], [-0.2, 0.1, 0.45])
+    np.testing.assert_array_equal(env.placements["object_position"], opos)
+    assert env.placements["object_yaw"] == yaw
+    np.testing.assert_array_equal(env.placements["container_position"], cpos)      # first attempt accepted for this seed
+    assert ts.first() and np.all(ts.observation["joints_pos"] == 0)
+    state = ts.observation["physics_state"]
+    q = state[:20]
+    assert abs(q[6] - opos[0]) < 5e-3 and abs(q[7] - opos[1]) < 5e-3 and abs(q[13] - cpos[0]) < 5e-3 and abs(q[14] - cpos[1]) < 5e-3
+    assert 0.4210 < q[8] < 0.4225 and abs(2 * np.arctan2(q[12], q[9]) - yaw) < 2e-2          # banana came to rest, yaw kept
+    # the oracle, same placements, same settle rule
+    o = Oracle(blobs["f64"])
+    q0 = np.zeros(20)
+    q0[6:9] = opos
+    q0[9:13] = [np.cos(0.5 * yaw), 0, 0, np.sin(0.5 * yaw)]
+    q0[13:16] = cpos
+    q0[16] = 1.0
+    o.set_state(q0, np.zeros(18), np.zeros(18))
+    o.set_ctrl(np.array([0.0, -1.57079, 1.57079, 1.57079, -1.57079, 0.0]))
+    for k in range(1000):
+        o.substeps(1, True)
+        _, v, _ = o.get_state()
+        if np.abs(v[6:]).max() < 1e-3 and o.L.orc_max_prop_qacc(o.h) < 1e-2:
+            break
+    qo, _, _ = o.get_state()
+    assert np.abs(q - qo).max() < 5e-3, np.abs(q - qo).max()
+    # three steps to the time limit, then the next reset draws the following numbers of the SAME stream
+    for _ in range(3):
+        ts = env.step(np.zeros(6))
+    assert ts.last()
+    ts = env.step(np.zeros(6))
+    assert ts.first()
+    opos2 = rs.uniform([0.2, -0.1, 0.45], [0.3, 0.1, 0.45])
+    np.testing.assert_array_equal(env.placements["object_position"], opos2)
+    env.close()
