@@ -177,7 +177,8 @@ def main():
     if args.workload == "pickplace":
         hold[0].copy_(envs[0].obs[:, 12:18])
 
-    stats = {"reward_sum": torch.zeros((), device=dev), "ncon": torch.zeros((), device=dev), "nefc": torch.zeros((), device=dev), "samples": 0}
+    stats = {k: torch.zeros((), device=dev) for k in ("reward_sum", "ncon", "nefc", "iters", "ncand")}
+    stats["samples"] = 0
 
     def one_step(i, timed):
         for k, env in enumerate(envs):
@@ -199,6 +200,8 @@ def main():
                     d = env.diagnostics().float()
                     stats["ncon"] += d[:, 0].sum()
                     stats["nefc"] += d[:, 1].sum()
+                    stats["iters"] += d[:, 2].sum()
+                    stats["ncand"] += d[:, 3].sum()
             stats["samples"] += sum(e.n_envs for e in envs)
 
     for i in range(args.warmup):
@@ -273,7 +276,7 @@ def main():
                                  "chain / MEASURED device-to-device copy bandwidth of this GPU; the path is bound by dependent-issue latency of "
                                  "wave-level geometry / solver code, not by HBM (DESIGN.md section 6); `compute` = VALU wave-instructions x 64 lanes "
                                  "x 2 flop over the same time against the fp32 vector peak, from the PMC pass of this exact build when one is committed"},
-            "diag_mean": {"ncon": float(stats["ncon"]) / max(stats["samples"], 1), "nefc": float(stats["nefc"]) / max(stats["samples"], 1)},
+            "diag_mean": {k2: float(stats[k]) / max(stats["samples"], 1) for k, k2 in (("ncon", "contacts"), ("nefc", "constraint_rows"), ("iters", "solver_iterations"), ("ncand", "narrowphase_candidates"))},
             "events_per_env_step": {k: v / env_steps for k, v in events.items()},
             "events": events,
             "mean_reward_per_env_step": float(stats["reward_sum"]) / env_steps,
