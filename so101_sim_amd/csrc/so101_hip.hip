@@ -414,7 +414,8 @@ int so101_create(const void* blob, size_t bytes, int n_envs, int device, uint64_
               dev_alloc(s, &W.counters, (size_t)2 * MAXSUB * so101_sim::MAXGROUPS, 0, "hipMalloc(pipe)") &&
               dev_alloc(s, &W.conres, CONRES_DIM * MAXCAND * n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.active, n, 0, "hipMalloc(pipe)") &&
               dev_alloc(s, &W.ticks, MAXCAND * n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.stage, 8 * n, 0, "hipMalloc(pipe)") &&
-              dev_alloc(s, &W.cost, n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.order, n, 0, "hipMalloc(pipe)");
+              dev_alloc(s, &W.cost, n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.order, n, 0, "hipMalloc(pipe)") &&
+              dev_alloc(s, &W.state, STATE_AOS * n, 0, "hipMalloc(pipe)");
     W.work_cap = 0u;
     for (int g = 0; g < so101_sim::MAXGROUPS && ok; g++)
       ok = hip_ok(s, hipStreamCreateWithFlags(&s->group_stream[g], hipStreamNonBlocking), "hipStreamCreate") &&
@@ -521,7 +522,7 @@ int so101_step(so101_sim* s, const float* action, float* obs, float* reward, flo
   PrepBuffers C = prep_view(s);
   // the pipelined step is a Newton path; PGS (107 ms per control step at 4096 envs) runs the fused kernel
   if (s->cfg.pipeline && s->cfg.n_substeps <= MAXSUB && s->cfg.solver == SO101_SOLVER_NEWTON) {
-    int G = s->cfg.groups < 1 ? 1 : (s->cfg.groups > 3 ? 3 : s->cfg.groups);
+    int G = s->cfg.groups < 1 ? 1 : (s->cfg.groups > so101_sim::MAXGROUPS ? so101_sim::MAXGROUPS : s->cfg.groups);
     int n = s->n_envs;
     if (n < 64) G = 1;
     // Slices of the cost-sorted env order (most expensive first), one launch chain each.  Measured at 4096 envs
@@ -531,6 +532,7 @@ int so101_step(so101_sim* s, const float* action, float* obs, float* reward, flo
     bounds[0] = 0;
     if (G == 2) bounds[1] = n / 2;
     if (G == 3) { bounds[1] = n / 4; bounds[2] = (5 * n) / 8; }
+    if (G > 3) for (int g = 1; g < G; g++) bounds[g] = (int)((long long)n * g / G);
     bounds[G] = n;
 #ifdef SO101_DEBUG_CLOCKS
     static const char* dbg_bounds = getenv("SO101_DEBUG_BOUNDS");     // profiling builds: "128,1024" = slice ends

@@ -170,7 +170,11 @@ struct PipeBuffers {
   int* order;             // [N] per group: env indices sorted by decreasing cost, see k_order
   unsigned int work_cap;  // capacity of one work list = envs of the group * MAXCAND
   unsigned int* ticks;    // [N][MAXCAND] narrowphase time of each candidate (10 ns ticks; SO101_DEBUG_CLOCKS builds)
+  float* state;           // [N][STATE_AOS] qpos | qvel | warm | ctrl of an env, contiguous: the substep round trips of the
+                          // pipelined step (the caller's buffers are env-fastest struct-of-arrays: with one env per
+                          // wavefront every scalar is its own 64-byte line; they are read once and written once per call)
 };
+#define STATE_AOS 64
 
 // debug dump layout (floats) of so101_debug_forward
 #define DBG_M 0          // 36  arm mass matrix

@@ -276,6 +276,15 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
   wave_sync();
   float scale = 1.f / (m->meaninertia * (float)NV);
   float cost = eval_cost(W.x, true), dec_prev = 0.f;
+  // The factor of the scaled Hessian (lane a: row a of L) and the scaling survive from one iteration to the next: while
+  // no block changes its zone and no contact sits in the middle zone of its cone (the only zone whose Hessian depends on
+  // x), H is the same matrix and is neither assembled nor factorised again - resting props take their two or three
+  // iterations on one factorisation.
+  float h[NVS], mxs = 1.f;
+#pragma unroll
+  for (int b = 0; b < NVS; b++) h[b] = 0.f;
+  int zone_prev = -1;
+  bool rquad_prev = false;
   int it = 0;
   for (; it < max_iter; it++) {
     // ---- gradient g = M (x - x_s) - J' f, lane d keeps g_d
@@ -299,7 +308,10 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
       }
     }
     // ---- Hessian H = M + sum_blocks J' Hc J: lane a < NVS keeps row a in registers
-    float h[NVS];
+    bool rquad = rh != 0.f;
+    bool same = wave_ballot((has_con && (zone != zone_prev || zone == 2)) || (has_row && rquad != rquad_prev)) == 0ull;
+    zone_prev = zone; rquad_prev = rquad;
+    if (!(it > 0 && same)) {
 #pragma unroll
     for (int b = 0; b < NVS; b++) h[b] = lane < NVS ? mass_entry(m, L, lane, b) : 0.f;
 #pragma unroll
@@ -369,7 +381,7 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
     float dg = 1.f;
 #pragma unroll
     for (int b = 0; b < NVS; b++) dg = (lane == b) ? h[b] : dg;
-    float mxs = 1.f / sqrtf(fmaxf(dg, 1e-30f));
+    mxs = 1.f / sqrtf(fmaxf(dg, 1e-30f));
 #pragma unroll
     for (int b = 0; b < NVS; b++) h[b] *= mxs * wave_get_f(mxs, b);
     // ---- Cholesky H~ = L L' and the two triangular solves, register resident: lane i < NVS owns row i of H~ (and
@@ -382,6 +394,13 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
 #pragma unroll
       for (int k = j + 1; k < NVS; k++) h[k] -= l * wave_get_f(l, k);     // rows i < k hold unused upper entries
     }
+    // backward substitution needs column `lane` of L: one transposed round trip through LDS
+    if (lane < NVS) {
+#pragma unroll
+      for (int b = 0; b < NVS; b++) W.H[lane][b] = h[b];
+    }
+    wave_sync();
+    }   // (assembly + factorisation)
     float y = lane < NVS ? -grad * mxs : 0.f;
 #pragma unroll
     for (int i = 0; i < NVS; i++) {          // forward substitution L y = b
@@ -389,12 +408,6 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
       if (lane == i) y = yi;
       else if (lane > i) y -= h[i] * yi;
     }
-    // backward substitution needs column `lane` of L: one transposed round trip through LDS
-    if (lane < NVS) {
-#pragma unroll
-      for (int b = 0; b < NVS; b++) W.H[lane][b] = h[b];
-    }
-    wave_sync();
     float t[NVS];
 #pragma unroll
     for (int i = 0; i < NVS; i++) t[i] = lane < NVS ? W.H[i][lane] : 0.f;

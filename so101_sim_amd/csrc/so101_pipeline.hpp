@@ -23,6 +23,28 @@
 
 #include "so101_env.hpp"
 
+// the env's integrated state as one contiguous 256-byte record (substep round trips of the pipelined step)
+DEV void store_state_aos(const EnvLDS& L, const PipeBuffers& W, int e) {
+  int lane = wave_lane();
+  float v = 0.f;
+  if (lane < NQ) v = L.qpos[lane];
+  else if (lane < NQ + NV) v = L.qvel[lane - NQ];
+  else if (lane < NQ + 2 * NV) v = L.warm[lane - NQ - NV];
+  else if (lane < NQ + 2 * NV + NU) v = L.ctrl[lane - NQ - 2 * NV];
+  W.state[(size_t)e * STATE_AOS + lane] = v;
+}
+DEV void load_state_aos(EnvLDS& L, const DevBuffers& B, const PipeBuffers& W, int e, int N) {
+  int lane = wave_lane();
+  load_env_constants(L, B, e, N);
+  float v = W.state[(size_t)e * STATE_AOS + lane];
+  if (lane < NQ) L.qpos[lane] = v;
+  else if (lane < NQ + NV) L.qvel[lane - NQ] = v;
+  else if (lane < NQ + 2 * NV) L.warm[lane - NQ - NV] = v;
+  else if (lane < NQ + 2 * NV + NU) L.ctrl[lane - NQ - 2 * NV] = v;
+  if (lane == 0) { L.overflow = 0; L.t_collision = 0; L.t_solve = 0; L.t_begin = (unsigned int)SO101_CLOCK(); }
+  wave_sync();
+}
+
 // hands the candidates in L.cand (and the poses the narrowphase needs) to substep s
 DEV void publish_candidates(const EnvLDS& L, const PipeBuffers& W, int e, int N, int s) {
   int lane = wave_lane(), ncand = L.ncand;

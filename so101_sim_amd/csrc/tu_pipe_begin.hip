@@ -19,8 +19,9 @@ __global__ void __launch_bounds__(64, 2) k_pipe_begin(const DevModel* m, StepPar
   }
   load_state(L, B, e, N);
   // before_step: ctrl = action + homing offsets, unclamped (so100_task.py:266-287)
-  if (lane < NU) { float c = action[(size_t)e * NU + lane] + P.action_offset[lane]; L.ctrl[lane] = c; B.ctrl[(size_t)lane * N + e] = c; }
+  if (lane < NU) L.ctrl[lane] = action[(size_t)e * NU + lane] + P.action_offset[lane];
   wave_sync();
+  store_state_aos(L, W, e);
   kinematics(m, L);
   broadphase(m, L);
   publish_candidates(L, W, e, N, 0);

@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(64, 2) k_pipe_solve(const DevModel* m, StepPar
   if (act == 0) return;
   int sc = B.step_count[e] + 1;
   unsigned long long c0 = SO101_CLOCK(), c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0;
-  load_state(L, B, e, N);
+  load_state_aos(L, B, W, e, N);
   bool diverged = act == 2;
   if (!diverged) {
     forward_smooth(m, L);
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(64, 2) k_pipe_solve(const DevModel* m, StepPar
     wave_sync();
   }
   if (!last) {
-    store_state(L, B, e, N);
+    store_state_aos(L, W, e);
     if (!diverged) {
       kinematics(m, L);
       broadphase(m, L);
