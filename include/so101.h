@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SO101_ABI_VERSION 4
+#define SO101_ABI_VERSION 5
 #define SO101_OBS_DIM 18      /* joints_pos(6, delayed) | undelayed_joints_pos(6) | commanded_joints_pos(6) */
 #define SO101_ACT_DIM 6
 #define SO101_SOLVER_PGS 0
@@ -85,9 +85,14 @@ typedef struct {
                               0: always settle inside the call.  Results are identical either way. */
   int32_t pipeline;        /* 1 (default): so101_step runs every substep as narrowphase (one wavefront per candidate pair)
                               + solve (one wavefront per env) launches; 0: one fused launch, one wavefront per env. */
-  int32_t groups;          /* pipelined step: the envs, sorted by the solver time of their previous step, are cut into 1, 2
-                              (split at n/2) or 3 (default; n/4 and 5n/8) slices whose launch chains run on separate
-                              internal streams and fill each other's tails; results do not depend on it */
+  int32_t groups;          /* pipelined step: the envs, sorted by the solver time of their previous step, are cut into 1..8
+                              slices whose launch chains run on separate internal streams and fill each other's tails;
+                              0 (default) = 4 when GPU_MAX_HW_QUEUES >= 6 was set before HIP initialised, else 3 (the
+                              runtime maps streams onto that many hardware queues; chains that share one serialise);
+                              results do not depend on it */
+  int32_t use_graph;       /* 1 (default): the launch sequence of the pipelined step is captured once into a HIP graph and
+                              replayed with one hipGraphLaunch per step (re-captured when configuration, bound buffers,
+                              pool or the step's I/O pointers change); 0: plain launches.  Same kernels either way. */
 } so101_config;
 
 int so101_version(void);

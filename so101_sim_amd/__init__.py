@@ -8,9 +8,15 @@ Public surface mirrors the reference package `so101_sim`:
 `install_as_so101_sim()` registers this package under the reference's import path so notebooks and
 harnesses that say `from so101_sim import task_suite` run unchanged.
 """
+import os as _os
 import sys as _sys
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"
+
+# The pipelined step runs four launch chains + two service streams.  The HIP runtime maps streams onto
+# GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise, so ask for 8 - effective
+# when this package is imported before HIP initialises (the library falls back to three chains otherwise).
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def install_as_so101_sim():

@@ -101,6 +101,11 @@ struct so101_sim {
   hipEvent_t group_done[MAXGROUPS] = {};
   hipEvent_t step_begin = nullptr;
   EventBuffers ev{};           // per-env flag accumulator + global event counters (so101_get_events)
+  // captured launch sequence of the pipelined step (see so101_step)
+  hipGraphExec_t graph_exec = nullptr;
+  so101::StepIO graph_io{};
+  unsigned long long generation = 1, graph_gen = 0;     // bumped by configure / bind_state / set_reset_pool
+  bool graph_failed = false;
   std::string err;
 };
 
@@ -364,6 +369,8 @@ bool dev_alloc(so101_sim* s, T** out, size_t count, int fill, const char* what) 
 
 extern "C" {
 
+static void drop_graph(so101_sim* s);
+
 int so101_version(void) { return SO101_ABI_VERSION; }
 int so101_max_contacts(void) { return MAXCON; }
 
@@ -372,7 +379,7 @@ int so101_default_config(so101_config* cfg) {
   memset(cfg, 0, sizeof *cfg);
   cfg->last_step = 1 << 30; cfg->n_substeps = 10; cfg->solver_iterations = 0; cfg->solver_tolerance = -1.f;
   cfg->settle_max_substeps = 1000; cfg->terminate_on_success = 1; cfg->env_id_base = 0; cfg->solver = SO101_SOLVER_NEWTON;
-  cfg->prefetch_resets = 1; cfg->pipeline = 1; cfg->groups = 3;
+  cfg->prefetch_resets = 1; cfg->pipeline = 1; cfg->groups = 0; cfg->use_graph = 1;
   return SO101_OK;
 }
 
@@ -432,6 +439,7 @@ void so101_destroy(so101_sim* s) {
   if (!s) return;
   {
     DeviceGuard guard(s);
+    drop_graph(s);
     if (s->prep_stream) { (void)hipStreamSynchronize(s->prep_stream); (void)hipStreamDestroy(s->prep_stream); }
     for (int g = 0; g < so101_sim::MAXGROUPS; g++) {
       if (s->group_stream[g]) { (void)hipStreamSynchronize(s->group_stream[g]); (void)hipStreamDestroy(s->group_stream[g]); }
@@ -454,6 +462,7 @@ int so101_configure(so101_sim* s, const so101_config* cfg) {
   if (!drain_prepare(s)) return SO101_ERR_HIP;
   if (s->prep.tag && !hip_ok(s, hipMemset(s->prep.tag, 0xFF, sizeof(int) * (size_t)s->n_envs), "hipMemset(prep)")) return SO101_ERR_HIP;
   s->cfg = *cfg;
+  s->generation++;
   return SO101_OK;
 }
 
@@ -471,6 +480,7 @@ int so101_bind_state(so101_sim* s, const so101_buffers* b) {
   s->buf.ep_return = b->ep_return; s->buf.step_count = b->step_count; s->buf.episode = b->episode;
   s->buf.mass_scale = b->mass_scale;
   s->bound = true;
+  s->generation++;
   return SO101_OK;
 }
 
@@ -493,6 +503,7 @@ int so101_set_reset_pool(so101_sim* s, const float* qpos, const float* qvel, con
   if (!drain_prepare(s)) return SO101_ERR_HIP;
   s->prep.pool_qpos = pool_size ? qpos : nullptr; s->prep.pool_qvel = pool_size ? qvel : nullptr;
   s->prep.pool_ctrl = pool_size ? ctrl : nullptr; s->prep.pool_size = pool_size;
+  s->generation++;
   return SO101_OK;
 }
 
@@ -512,65 +523,108 @@ int so101_begin_episode(so101_sim* s, void* stream) {
   return SO101_OK;
 }
 
+// Enqueues the launch sequence of one pipelined control step on `st` (and the handle's chain streams, forked from and
+// joined to `st` with events).  Also the body of the captured HIP graph.
+static int enqueue_pipelined(so101_sim* s, hipStream_t st, const so101::StepIO& io) {
+  StepParams P = make_params(s);
+  PrepBuffers C = prep_view(s);
+  // groups = 0 (default): four chains when the HIP runtime was given enough hardware queues for them, else three.
+  // The runtime maps streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues; this step uses chains + 2 streams,
+  // and streams that share a queue serialise: with the default, 4 chains run at 400 k env-steps/s against 650 k for
+  // 3; with GPU_MAX_HW_QUEUES=8 (so101_sim_amd sets it when imported before HIP initialises) 4 chains reach 672 k.
+  static const int hwq = getenv("GPU_MAX_HW_QUEUES") ? atoi(getenv("GPU_MAX_HW_QUEUES")) : 4;
+  int G = s->cfg.groups > 0 ? s->cfg.groups : (hwq >= 6 ? 4 : 3);
+  if (G > so101_sim::MAXGROUPS) G = so101_sim::MAXGROUPS;
+  int n = s->n_envs;
+  if (n < 64) G = 1;
+  // Slices of the cost-sorted env order (most expensive first), one launch chain each: 2 chains split at n/2, 3 at n/4
+  // and 5n/8, 4 and more in equal parts (re-measured in round 2 at 4096 envs: 1 chain 515 k, 2 618 k, 3 653 k, 4 672 k
+  // with enough hardware queues, 5-6 650 k env-steps/s; unequal 4-way splits are 1-2 % slower)
+  int bounds[so101_sim::MAXGROUPS + 1];
+  bounds[0] = 0;
+  if (G == 2) bounds[1] = n / 2;
+  if (G == 3) { bounds[1] = n / 4; bounds[2] = (5 * n) / 8; }
+  if (G > 3) for (int g = 1; g < G; g++) bounds[g] = (int)((long long)n * g / G);
+  bounds[G] = n;
+#ifdef SO101_DEBUG_CLOCKS
+  static const char* dbg_bounds = getenv("SO101_DEBUG_BOUNDS");     // profiling builds: "128,1024" = slice ends
+  if (dbg_bounds) {
+    G = 0; bounds[0] = 0;
+    for (const char* p = dbg_bounds; *p && G < so101_sim::MAXGROUPS - 1;) { int v = atoi(p); if (v > bounds[G] && v < n) bounds[++G] = v; while (*p && *p != ',') p++; if (*p) p++; }
+    bounds[++G] = n;
+  }
+#endif
+  so101::launch_order(st, s->pipe.cost, s->pipe.order, n);
+  LAUNCH_CHECK(s, "k_order");
+  if (G > 1 && !hip_ok(s, hipEventRecord(s->step_begin, st), "hipEventRecord")) return SO101_ERR_HIP;
+  for (int g = 0; g < G; g++) {
+    int e0 = bounds[g], ng = bounds[g + 1] - bounds[g];
+    if (ng <= 0) continue;
+    hipStream_t gs = G == 1 ? st : s->group_stream[g];
+    PipeBuffers W = s->pipe;
+    W.counters = s->pipe.counters + 2 * MAXSUB * g;
+    W.work = s->pipe.work + (size_t)2 * MAXCAND * e0;
+    W.work_cap = (unsigned int)ng * MAXCAND;
+    // persistent narrowphase waves (they pull work items until the list is empty): two per env of the slice, at
+    // most what fills 256 CUs - a smaller narrowphase grid leaves slots to the other chains' solve kernels
+    int nw = ng * 2 < 4096 ? ng * 2 : 4096;
+    if (G > 1 && !hip_ok(s, hipStreamWaitEvent(gs, s->step_begin, 0), "hipStreamWaitEvent")) return SO101_ERR_HIP;
+    if (!hip_ok(s, hipMemsetAsync(W.counters, 0, sizeof(int) * 2 * MAXSUB, gs), "hipMemsetAsync(pipe)")) return SO101_ERR_HIP;
+    so101::launch_pipe_begin(ng, gs, s->dm, P, s->buf, C, s->ev, W, io, s->need_reset, s->diag, e0);
+    for (int k = 0; k < P.n_substeps; k++) {
+      so101::launch_narrow(nw, gs, s->dm, s->n_envs, W, k);
+      so101::launch_pipe_solve(ng, gs, s->dm, P, s->buf, s->ev, W, k, (int)(k == P.n_substeps - 1), io, s->need_reset, s->diag, e0);
+    }
+    LAUNCH_CHECK(s, "k_pipe_solve");
+    if (G > 1 && !(hip_ok(s, hipEventRecord(s->group_done[g], gs), "hipEventRecord") &&
+                   hip_ok(s, hipStreamWaitEvent(st, s->group_done[g], 0), "hipStreamWaitEvent"))) return SO101_ERR_HIP;
+  }
+  return SO101_OK;
+}
+
+static void drop_graph(so101_sim* s) {
+  if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
+}
+
 int so101_step(so101_sim* s, const float* action, float* obs, float* reward, float* discount, uint8_t* step_type, void* stream) {
   REQUIRE_BOUND(s);
   if (!action || !obs || !reward || !discount || !step_type) { s->err = "so101_step: NULL argument"; return SO101_ERR_ARG; }
   GUARD_DEVICE(s);
   hipStream_t st = (hipStream_t)stream;
-  StepParams P = make_params(s);
   so101::StepIO io{action, obs, reward, discount, step_type};
-  PrepBuffers C = prep_view(s);
   // the pipelined step is a Newton path; PGS (107 ms per control step at 4096 envs) runs the fused kernel
   if (s->cfg.pipeline && s->cfg.n_substeps <= MAXSUB && s->cfg.solver == SO101_SOLVER_NEWTON) {
-    int G = s->cfg.groups < 1 ? 1 : (s->cfg.groups > so101_sim::MAXGROUPS ? so101_sim::MAXGROUPS : s->cfg.groups);
-    int n = s->n_envs;
-    if (n < 64) G = 1;
-    // Slices of the cost-sorted env order (most expensive first), one launch chain each.  Measured at 4096 envs
-    // (env-steps/s): 1 chain 365 k; 2 chains split at n/2 432 k; 3 chains split at n/4 and 5n/8 452 k (best of a
-    // dozen splits, all 3-chain splits with a first slice of 512..1365 envs are within 3 %); 4 chains 264-276 k.
-    int bounds[so101_sim::MAXGROUPS + 1];
-    bounds[0] = 0;
-    if (G == 2) bounds[1] = n / 2;
-    if (G == 3) { bounds[1] = n / 4; bounds[2] = (5 * n) / 8; }
-    if (G > 3) for (int g = 1; g < G; g++) bounds[g] = (int)((long long)n * g / G);
-    bounds[G] = n;
-#ifdef SO101_DEBUG_CLOCKS
-    static const char* dbg_bounds = getenv("SO101_DEBUG_BOUNDS");     // profiling builds: "128,1024" = slice ends
-    if (dbg_bounds) {
-      G = 0; bounds[0] = 0;
-      for (const char* p = dbg_bounds; *p && G < so101_sim::MAXGROUPS - 1;) { int v = atoi(p); if (v > bounds[G] && v < n) bounds[++G] = v; while (*p && *p != ',') p++; if (*p) p++; }
-      bounds[++G] = n;
-    }
-#endif
-    so101::launch_order(st, s->pipe.cost, s->pipe.order, n);
-    LAUNCH_CHECK(s, "k_order");
-    if (G > 1 && !hip_ok(s, hipEventRecord(s->step_begin, st), "hipEventRecord")) return SO101_ERR_HIP;
-    for (int g = 0; g < G; g++) {
-      int e0 = bounds[g], ng = bounds[g + 1] - bounds[g];
-      if (ng <= 0) continue;
-      hipStream_t gs = G == 1 ? st : s->group_stream[g];
-      PipeBuffers W = s->pipe;
-      W.counters = s->pipe.counters + 2 * MAXSUB * g;
-      W.work = s->pipe.work + (size_t)2 * MAXCAND * e0;
-      W.work_cap = (unsigned int)ng * MAXCAND;
-      // persistent narrowphase waves (they pull work items until the list is empty): two per env of the slice, at
-      // most what fills 256 CUs - a smaller narrowphase grid leaves slots to the other chains' solve kernels
-      int nw = ng * 2 < 4096 ? ng * 2 : 4096;
-      if (G > 1 && !hip_ok(s, hipStreamWaitEvent(gs, s->step_begin, 0), "hipStreamWaitEvent")) return SO101_ERR_HIP;
-      if (!hip_ok(s, hipMemsetAsync(W.counters, 0, sizeof(int) * 2 * MAXSUB, gs), "hipMemsetAsync(pipe)")) return SO101_ERR_HIP;
-      so101::launch_pipe_begin(ng, gs, s->dm, P, s->buf, C, s->ev, W, io, s->need_reset, s->diag, e0);
-      for (int k = 0; k < P.n_substeps; k++) {
-        so101::launch_narrow(nw, gs, s->dm, s->n_envs, W, k);
-        so101::launch_pipe_solve(ng, gs, s->dm, P, s->buf, s->ev, W, k, (int)(k == P.n_substeps - 1), io, s->need_reset, s->diag, e0);
+    // The launch sequence of a control step (~90 kernels, memsets and event edges over 5 streams) depends only on the
+    // configuration and the caller's pointers: it is captured ONCE into a HIP graph and replayed with one call per
+    // step - the host thread issues 1 API call instead of ~110 (with 8 ranks on one host, or a cold host, the
+    // launch loop was the bottleneck).  Any change of configuration, bound buffers, pool or I/O pointers re-captures.
+    if (s->cfg.use_graph && !s->graph_failed) {
+      bool same = s->graph_exec && s->graph_gen == s->generation && s->graph_io.action == io.action && s->graph_io.obs == io.obs &&
+                  s->graph_io.reward == io.reward && s->graph_io.discount == io.discount && s->graph_io.step_type == io.step_type;
+      if (!same) {
+        drop_graph(s);
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+          int rc = enqueue_pipelined(s, st, io);
+          hipError_t e = hipStreamEndCapture(st, &g);
+          if (rc == SO101_OK && e == hipSuccess && g && hipGraphInstantiate(&s->graph_exec, g, nullptr, nullptr, 0) == hipSuccess) {
+            s->graph_gen = s->generation; s->graph_io = io;
+          } else { s->graph_exec = nullptr; s->graph_failed = true; (void)hipGetLastError(); }
+          if (g) (void)hipGraphDestroy(g);
+        } else { s->graph_failed = true; (void)hipGetLastError(); }
       }
-      LAUNCH_CHECK(s, "k_pipe_solve");
-      if (G > 1 && !(hip_ok(s, hipEventRecord(s->group_done[g], gs), "hipEventRecord") &&
-                     hip_ok(s, hipStreamWaitEvent(st, s->group_done[g], 0), "hipStreamWaitEvent"))) return SO101_ERR_HIP;
+      if (s->graph_exec) {
+        if (!hip_ok(s, hipGraphLaunch(s->graph_exec, st), "hipGraphLaunch")) return SO101_ERR_HIP;
+        launch_prepare(s, st);
+        return SO101_OK;
+      }
     }
+    int rc = enqueue_pipelined(s, st, io);
+    if (rc != SO101_OK) return rc;
     launch_prepare(s, st);
     return SO101_OK;
   }
-  so101::launch_step(s->cfg.solver, s->n_envs, st, s->dm, P, s->buf, C, s->ev, io, s->need_reset, s->diag);
+  so101::launch_step(s->cfg.solver, s->n_envs, st, s->dm, make_params(s), s->buf, prep_view(s), s->ev, io, s->need_reset, s->diag);
   LAUNCH_CHECK(s, "k_step");
   launch_prepare(s, st);
   return SO101_OK;

@@ -44,7 +44,7 @@ class Config(C.Structure):
                 ("solver_iterations", C.c_int32), ("solver_tolerance", C.c_float),
                 ("settle_max_substeps", C.c_int32), ("terminate_on_success", C.c_int32),
                 ("env_id_base", C.c_uint64), ("solver", C.c_int32), ("prefetch_resets", C.c_int32), ("pipeline", C.c_int32),
-                ("groups", C.c_int32)]
+                ("groups", C.c_int32), ("use_graph", C.c_int32)]
 
 
 _libs: dict[str, C.CDLL] = {}

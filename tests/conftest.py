@@ -1,6 +1,10 @@
 import os
 import sys
 
+import os
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before HIP initialises (see so101_sim_amd/__init__.py)
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

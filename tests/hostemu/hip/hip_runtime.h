@@ -62,6 +62,16 @@ inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (void*
 inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 inline hipError_t hipEventQuery(hipEvent_t) { return 0; }
+// graphs: capture is refused here, so101_step falls back to plain launches
+typedef void* hipGraph_t;
+typedef void* hipGraphExec_t;
+enum { hipStreamCaptureModeThreadLocal = 1 };
+inline hipError_t hipStreamBeginCapture(hipStream_t, int) { return 1; }
+inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t*) { return 1; }
+inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*, size_t) { return 1; }
+inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return 1; }
+inline hipError_t hipGraphDestroy(hipGraph_t) { return 0; }
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return 0; }
 inline unsigned long long wall_clock64() { return 0ull; }
 // v_readlane: value of lane `l`
 inline int __builtin_amdgcn_readlane(int v, int l) { emu_xchg_i[threadIdx.x] = v; __syncthreads(); int r = emu_xchg_i[l]; __syncthreads(); return r; }
