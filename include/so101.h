@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SO101_ABI_VERSION 5
+#define SO101_ABI_VERSION 6
 #define SO101_OBS_DIM 18      /* joints_pos(6, delayed) | undelayed_joints_pos(6) | commanded_joints_pos(6) */
 #define SO101_ACT_DIM 6
 #define SO101_SOLVER_PGS 0
@@ -124,6 +124,19 @@ int so101_reset(so101_sim* sim, const uint8_t* mask, void* hip_stream);
  * qpos[20][K], qvel[18][K], ctrl[6][K] are device pointers that must outlive their use; pool_size = 0 restores the
  * reference's reset. */
 int so101_set_reset_pool(so101_sim* sim, const float* qpos, const float* qvel, const float* ctrl, int pool_size);
+
+/* Settled-state store: the 1000-substep PropPlacer settle of so100_hand_over.py:222-229 dominates short episodes, and its
+ * result is a pure function of (model, seed, global env id, episode, mass scale, solver settings).
+ * so101_compute_settled() runs placement + settle for episodes first_episode .. first_episode + n_episodes - 1 of
+ * every env into caller-owned device tables qpos[n_episodes][20][N], qvel[..][18][N], warmstart[..][18][N],
+ * flags[n_episodes][N] without touching the envs; the caller may keep them on disk across runs (the Python face
+ * does: BatchedEnvironment.save_settled_cache / load_settled_cache).  so101_set_settled_store() hands such tables
+ * back: resets of those episodes copy the entry (bit-identical to settling again) and the background prefetch skips
+ * them.  n_episodes = 0 detaches the store.  The tables must outlive their use. */
+int so101_compute_settled(so101_sim* sim, int first_episode, int n_episodes, float* qpos, float* qvel, float* warmstart,
+                          int32_t* flags, void* hip_stream);
+int so101_set_settled_store(so101_sim* sim, const float* qpos, const float* qvel, const float* warmstart,
+                            const int32_t* flags, int first_episode, int n_episodes);
 
 /* PropPlacer settle only (so100_hand_over.py:222-229, settle_physics=True): from the state in the bound buffers, arm
  * held, props integrated until |qvel| < 1e-3 and |qacc| < 1e-2 or settle_max_substeps are used.  For callers that draw

@@ -119,6 +119,13 @@ DEV void env_reset(const DevModel* m, EnvLDS& L, const StepParams& P, const DevB
     if (lane < NU) L.ctrl[lane] = C.pool_ctrl[(size_t)lane * K + k];
     if (lane == 0) { L.ncon = 0; L.nrow = 0; L.iters = 0; L.ncand = 0; }
     wave_sync();
+  } else if (episode - (unsigned int)C.store_first < (unsigned int)C.store_count) {
+    size_t k = episode - (unsigned int)C.store_first, o = (size_t)e;
+    if (lane < NQ) L.qpos[lane] = C.store_qpos[(k * NQ + lane) * N + o];
+    if (lane < NV) { L.qvel[lane] = C.store_qvel[(k * NV + lane) * N + o]; L.warm[lane] = C.store_warm[(k * NV + lane) * N + o]; }
+    if (lane < NU) L.ctrl[lane] = m->home_ctrl[lane] + P.action_offset[lane];
+    if (lane == 0) { L.ncon = 0; L.nrow = 0; L.iters = 0; L.ncand = 0; L.overflow |= C.store_flags[k * N + o]; }
+    wave_sync();
   } else if (cached) {
     if (lane < NQ) L.qpos[lane] = C.qpos[(size_t)lane * N + e];
     if (lane < NV) { L.qvel[lane] = C.qvel[(size_t)lane * N + e]; L.warm[lane] = C.warm[(size_t)lane * N + e]; }

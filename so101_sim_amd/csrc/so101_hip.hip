@@ -507,6 +507,28 @@ int so101_set_reset_pool(so101_sim* s, const float* qpos, const float* qvel, con
   return SO101_OK;
 }
 
+int so101_compute_settled(so101_sim* s, int first_episode, int n_episodes, float* qpos, float* qvel, float* warm, int32_t* flags, void* stream) {
+  REQUIRE_BOUND(s);      // the bound mass_scale array (if any) takes part in the settle
+  if (first_episode < 0 || n_episodes <= 0 || !qpos || !qvel || !warm || !flags) { s->err = "so101_compute_settled: bad argument"; return SO101_ERR_ARG; }
+  if ((long long)n_episodes * s->n_envs > (1ll << 30)) { s->err = "so101_compute_settled: table too large for one launch"; return SO101_ERR_ARG; }
+  GUARD_DEVICE(s);
+  so101::launch_settle_table(s->cfg.solver, s->n_envs, first_episode, n_episodes, (hipStream_t)stream, s->dm, make_params(s), s->buf, qpos, qvel, warm, flags);
+  LAUNCH_CHECK(s, "k_settle_table");
+  return SO101_OK;
+}
+
+int so101_set_settled_store(so101_sim* s, const float* qpos, const float* qvel, const float* warm, const int32_t* flags, int first_episode, int n_episodes) {
+  if (!s || n_episodes < 0 || first_episode < 0) return SO101_ERR_ARG;
+  if (n_episodes > 0 && (!qpos || !qvel || !warm || !flags)) { s->err = "so101_set_settled_store: NULL table"; return SO101_ERR_ARG; }
+  GUARD_DEVICE(s);
+  if (!drain_prepare(s)) return SO101_ERR_HIP;
+  s->prep.store_qpos = n_episodes ? qpos : nullptr; s->prep.store_qvel = n_episodes ? qvel : nullptr;
+  s->prep.store_warm = n_episodes ? warm : nullptr; s->prep.store_flags = n_episodes ? (const int*)flags : nullptr;
+  s->prep.store_first = first_episode; s->prep.store_count = n_episodes;
+  s->generation++;
+  return SO101_OK;
+}
+
 int so101_settle(so101_sim* s, void* stream) {
   REQUIRE_BOUND(s);
   GUARD_DEVICE(s);

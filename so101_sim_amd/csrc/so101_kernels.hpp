@@ -17,6 +17,7 @@ __global__ void __launch_bounds__(64, 2) k_prepare(const DevModel* m, StepParams
     if (e >= N) break;
     int target = __atomic_load_n(&B.episode[e], __ATOMIC_ACQUIRE);
     if (__atomic_load_n(&C.tag[e], __ATOMIC_ACQUIRE) == target) continue;
+    if ((unsigned int)target - (unsigned int)C.store_first < (unsigned int)C.store_count) continue;     // in the settled-state store
     if (lane == 0) { L.overflow = 0; L.t_collision = 0; L.t_solve = 0; }
     load_env_constants(L, B, e, N);
     env_settle<SOLVER>(m, L, P, e, (unsigned int)target);
@@ -29,6 +30,24 @@ __global__ void __launch_bounds__(64, 2) k_prepare(const DevModel* m, StepParams
     if (lane == 0) __atomic_store_n(&C.tag[e], target, __ATOMIC_RELEASE);
     wave_sync();
   }
+}
+
+// Placement + settle of episodes first .. first + count - 1 of every env into a caller-owned table (the settled-state
+// store of PrepBuffers); does not touch the envs' state.  One wave per (episode, env).
+template <int SOLVER>
+__global__ void __launch_bounds__(64, 2) k_settle_table(const DevModel* m, StepParams P, DevBuffers B, int first, float* qpos, float* qvel,
+                                                     float* warm, int* flags) {
+  __shared__ EnvLDS L;
+  int lane = wave_lane(), N = P.n_envs;
+  int e = (int)(blockIdx.x % (unsigned int)N);
+  size_t k = blockIdx.x / (unsigned int)N;
+  if (lane == 0) { L.overflow = 0; L.t_collision = 0; L.t_solve = 0; }
+  load_env_constants(L, B, e, N);
+  env_settle<SOLVER>(m, L, P, e, (unsigned int)first + (unsigned int)k);
+  wave_sync();
+  if (lane < NQ) qpos[(k * NQ + lane) * N + e] = L.qpos[lane];
+  if (lane < NV) { qvel[(k * NV + lane) * N + e] = L.qvel[lane]; warm[(k * NV + lane) * N + e] = L.warm[lane]; }
+  if (lane == 0) flags[k * N + e] = L.overflow;
 }
 
 // __launch_bounds__(64, 2): two waves per SIMD => at most 256 VGPRs

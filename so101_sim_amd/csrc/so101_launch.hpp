@@ -15,6 +15,8 @@ struct StepIO {            // per-call arrays of so101_step (device pointers)
 void launch_reset(int solver, int n_envs, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B,
                   const PrepBuffers& C, const EventBuffers& E, const unsigned char* mask, unsigned char* need_reset, int* diag);
 void launch_settle(int solver, int n_envs, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B, const EventBuffers& E, int* diag);
+void launch_settle_table(int solver, int n_envs, int first, int count, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B,
+                         float* qpos, float* qvel, float* warm, int* flags);
 void launch_prepare(int waves, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B, const PrepBuffers& C);   // Newton
 void launch_step(int solver, int n_envs, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B,
                  const PrepBuffers& C, const EventBuffers& E, const StepIO& io, unsigned char* need_reset, int* diag);
@@ -36,6 +38,8 @@ void launch_pipe_solve(int n_group, hipStream_t st, const DevModel* m, const Ste
 void launch_reset_pgs(int n_envs, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B, const PrepBuffers& C,
                       const EventBuffers& E, const unsigned char* mask, unsigned char* need_reset, int* diag);
 void launch_settle_pgs(int n_envs, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B, const EventBuffers& E, int* diag);
+void launch_settle_table_pgs(int n_envs, int first, int count, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B,
+                             float* qpos, float* qvel, float* warm, int* flags);
 void launch_step_pgs(int n_envs, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B, const PrepBuffers& C,
                      const EventBuffers& E, const StepIO& io, unsigned char* need_reset, int* diag);
 void launch_physics_pgs(int n_envs, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B, int nsub, int freeze, int* diag);

@@ -140,6 +140,12 @@ struct PrepBuffers {
   // floor(u * pool_size), u = rng_uniform(seed, env id, episode, draw 1000), instead of placement + settle
   const float *pool_qpos, *pool_qvel, *pool_ctrl;   // [NQ|NV|NU][pool_size]
   int pool_size;
+  // Settled-state store (so101_set_settled_store): the results of placement + settle for episodes
+  // store_first .. store_first + store_count - 1 of every env, computed once (so101_compute_settled) and kept across
+  // runs by the caller.  Entries are what env_settle() would produce, so a reset that finds one is bit-identical.
+  const float *store_qpos, *store_qvel, *store_warm;   // [store_count][NQ|NV|NV][n_envs]
+  const int* store_flags;                               // [store_count][n_envs]
+  int store_first, store_count;
 };
 
 // Event accounting (so101_get_events): flags[e] ORs the per-substep flag words of env e within one control step;

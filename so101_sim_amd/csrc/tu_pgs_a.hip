@@ -12,6 +12,10 @@ void launch_step_pgs(int n_envs, hipStream_t st, const DevModel* m, const StepPa
 void launch_settle_pgs(int n_envs, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B, const EventBuffers& E, int* diag) {
   hipLaunchKernelGGL(k_settle<0>, dim3(n_envs), dim3(64), 0, st, m, P, B, E, diag);
 }
+void launch_settle_table_pgs(int n_envs, int first, int count, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B,
+                             float* qpos, float* qvel, float* warm, int* flags) {
+  hipLaunchKernelGGL(k_settle_table<0>, dim3((unsigned int)n_envs * (unsigned int)count), dim3(64), 0, st, m, P, B, first, qpos, qvel, warm, flags);
+}
 void launch_reset_pgs(int n_envs, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B, const PrepBuffers& C,
                       const EventBuffers& E, const unsigned char* mask, unsigned char* need_reset, int* diag) {
   hipLaunchKernelGGL(k_reset<0>, dim3(n_envs), dim3(64), 0, st, m, P, B, C, E, mask, need_reset, diag);

@@ -12,6 +12,11 @@ void launch_settle(int solver, int n_envs, hipStream_t st, const DevModel* m, co
   if (solver == 0) { launch_settle_pgs(n_envs, st, m, P, B, E, diag); return; }
   hipLaunchKernelGGL(k_settle<1>, dim3(n_envs), dim3(64), 0, st, m, P, B, E, diag);
 }
+void launch_settle_table(int solver, int n_envs, int first, int count, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B,
+                         float* qpos, float* qvel, float* warm, int* flags) {
+  if (solver == 0) { launch_settle_table_pgs(n_envs, first, count, st, m, P, B, qpos, qvel, warm, flags); return; }
+  hipLaunchKernelGGL(k_settle_table<1>, dim3((unsigned int)n_envs * (unsigned int)count), dim3(64), 0, st, m, P, B, first, qpos, qvel, warm, flags);
+}
 void launch_prepare(int waves, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B, const PrepBuffers& C) {
   hipLaunchKernelGGL(k_prepare<1>, dim3(waves), dim3(64), 0, st, m, P, B, C);
 }

@@ -15,6 +15,7 @@ by the kernels behind include/so101.h.
 from __future__ import annotations
 
 import collections
+import hashlib
 import os
 
 import numpy as np
@@ -145,6 +146,12 @@ class BatchedEnvironment:
                            prefetch_resets=int(bool(prefetch_resets)))
         self.physics = _PhysicsView(self)
         self._physics = self.physics
+        self._store = None
+        # what a settled reset state depends on besides (env id, episode) and the mass scale: the key of the on-disk store
+        self._settle_key = dict(
+            blob_sha256=hashlib.sha256(blob).hexdigest(), seed=seed, env_id_base=int(env_id_base), n_envs=N,
+            solver=str(solver).lower(), solver_iterations=int(solver_iterations), solver_tolerance=float(solver_tolerance),
+            settle_max_substeps=int(settle_max_substeps), action_offset=[float(x) for x in task.calibration.homing_offsets])
 
     # ------------------------------------------------------------------ specs
     def action_spec(self) -> BoundedArray:
@@ -221,6 +228,8 @@ class BatchedEnvironment:
         """scale: [2, N] (object, container) multipliers of the props' mass and inertia.  Flushes the reset prefetch
         (cached initial states were settled with the old masses)."""
         self.mass_scale.copy_(self.torch.as_tensor(scale, dtype=self.torch.float32, device=self.device).reshape(2, self.n_envs))
+        if self._store is not None:
+            self.set_settled_store(None)       # a settled-state store belongs to the old masses as well
         self.sim.configure()
 
     def set_reset_pool(self, qpos=None, qvel=None, ctrl=None):
@@ -236,6 +245,54 @@ class BatchedEnvironment:
         assert pool[0].shape == (20, K) and pool[1].shape == (18, K) and pool[2].shape == (6, K)
         self._pool = pool                      # keeps the tensors alive while the library reads them
         self.sim.set_reset_pool(pool[0].data_ptr(), pool[1].data_ptr(), pool[2].data_ptr(), K)
+
+    # ------------------------------------------------------------------ settled-state store
+    def settled_cache_key(self) -> dict:
+        from . import build
+        key = dict(self._settle_key)
+        key["mass_scale_sha256"] = hashlib.sha256(self.mass_scale.detach().cpu().numpy().tobytes()).hexdigest()
+        key["build"] = build.source_hash()       # settled states are only bit-identical within one build of the kernels
+        return key
+
+    def compute_settled(self, n_episodes: int, first_episode: int = 0):
+        """Placement + settle of episodes first_episode .. first_episode + n_episodes - 1 of every env, without touching
+        the envs.  Returns device tensors (qpos [E,20,N], qvel [E,18,N], warmstart [E,18,N], flags [E,N])."""
+        t, N, E = self.torch, self.n_envs, int(n_episodes)
+        out = (t.zeros(E, 20, N, device=self.device), t.zeros(E, 18, N, device=self.device), t.zeros(E, 18, N, device=self.device),
+               t.zeros(E, N, dtype=t.int32, device=self.device))
+        self.sim.compute_settled(first_episode, E, *(a.data_ptr() for a in out), self._stream())
+        return out
+
+    def set_settled_store(self, tables=None, first_episode: int = 0):
+        """Resets of the covered episodes copy their entry instead of settling (bit-identical); None detaches."""
+        if tables is None:
+            self._store = None
+            self.sim.set_settled_store(None, None, None, None, 0, 0)
+            return
+        t, N = self.torch, self.n_envs
+        q, v, w, f = tables
+        q, v, w = (t.as_tensor(a, dtype=t.float32, device=self.device).contiguous() for a in (q, v, w))
+        f = t.as_tensor(f, dtype=t.int32, device=self.device).contiguous()
+        E = f.shape[0]
+        assert q.shape == (E, 20, N) and v.shape == (E, 18, N) and w.shape == (E, 18, N) and f.shape == (E, N)
+        self._store = (q, v, w, f)             # keeps the tensors alive while the library reads them
+        self.sim.set_settled_store(q.data_ptr(), v.data_ptr(), w.data_ptr(), f.data_ptr(), int(first_episode), E)
+
+    def save_settled_cache(self, path: str, n_episodes: int, first_episode: int = 0):
+        """Computes the settled states of n_episodes episodes per env, writes them to `path` and attaches them."""
+        from . import settled_cache
+        tables = self.compute_settled(n_episodes, first_episode)
+        names = [a[0] for a in settled_cache.ARRAYS]
+        settled_cache.write(path, self.settled_cache_key(), first_episode, {n: a.cpu().numpy() for n, a in zip(names, tables)})
+        self.set_settled_store(tables, first_episode)
+
+    def load_settled_cache(self, path: str):
+        """Attaches a file written by save_settled_cache(); refuses one computed for a different model, seed, shard,
+        mass scale, solver setting or build (settled_cache.SettledCacheError names the differing fields)."""
+        from . import settled_cache
+        header, arrays = settled_cache.read(path, expect_key=self.settled_cache_key())
+        self.set_settled_store(tuple(arrays[a[0]] for a in settled_cache.ARRAYS), header["first_episode"])
+        return header
 
     def events(self, clear: bool = False) -> dict:
         """Counts since creation (or the last clear) of env-steps / env-resets that raised a flag: contact or candidate

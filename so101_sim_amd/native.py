@@ -28,7 +28,7 @@ DBG = dict(M=0, MINV=36, BIAS=72, SMOOTH=78, QACC=96, COUNTS=114, XPOS=120, CON=
 
 EXPORTS = (
     "so101_version", "so101_max_contacts", "so101_create", "so101_destroy", "so101_default_config",
-    "so101_configure", "so101_bind_state", "so101_set_reset_pool", "so101_reset", "so101_settle", "so101_begin_episode", "so101_step", "so101_physics", "so101_reward",
+    "so101_configure", "so101_bind_state", "so101_set_reset_pool", "so101_compute_settled", "so101_set_settled_store", "so101_reset", "so101_settle", "so101_begin_episode", "so101_step", "so101_physics", "so101_reward",
     "so101_get_returns", "so101_get_diag", "so101_get_events", "so101_debug_forward", "so101_debug_candidates", "so101_debug_stages", "so101_last_error",
 )
 
@@ -75,6 +75,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.so101_configure.argtypes = [vp, C.POINTER(Config)]
     L.so101_bind_state.argtypes = [vp, C.POINTER(Buffers)]
     L.so101_set_reset_pool.argtypes = [vp, vp, vp, vp, C.c_int]
+    L.so101_compute_settled.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+    L.so101_set_settled_store.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int]
     L.so101_reset.argtypes = [vp, vp, vp]
     L.so101_begin_episode.argtypes = [vp, vp]
     L.so101_settle.argtypes = [vp, vp]
@@ -141,6 +143,14 @@ class Sim:
 
     def set_reset_pool(self, qpos, qvel, ctrl, pool_size: int):
         self._check(self.L.so101_set_reset_pool(self.h, qpos, qvel, ctrl, int(pool_size)), "so101_set_reset_pool")
+
+    def compute_settled(self, first_episode: int, n_episodes: int, qpos, qvel, warm, flags, stream=0):
+        self._check(self.L.so101_compute_settled(self.h, int(first_episode), int(n_episodes), qpos, qvel, warm, flags, stream),
+                    "so101_compute_settled")
+
+    def set_settled_store(self, qpos, qvel, warm, flags, first_episode: int, n_episodes: int):
+        self._check(self.L.so101_set_settled_store(self.h, qpos, qvel, warm, flags, int(first_episode), int(n_episodes)),
+                    "so101_set_settled_store")
 
     def reset(self, mask=None, stream=0):
         self._check(self.L.so101_reset(self.h, mask, stream), "so101_reset")

@@ -289,6 +289,32 @@ def check_prefetch_identical(make_sim, n=3, settle=25, steps=9, last_step=3, see
         np.testing.assert_array_equal(a, b)
 
 
+def check_settled_store_identical(make_sim, n=3, settle=25, steps=9, last_step=3, seed=5, first=1, count=2, prefetch=0):
+    """The settled-state store (so101_compute_settled / so101_set_settled_store) replaces placement +
+    settle by a table lookup for the episodes it covers and must not change a single bit: rollouts across auto-resets
+    with the store attached for episodes [first, first+count) - the others still settle - equal rollouts without."""
+    out, events = [], []
+    for use_store in (False, True):
+        sim = make_sim(n, seed=seed, settle_max_substeps=settle, last_step=last_step, prefetch_resets=prefetch)
+        if use_store:
+            tables = sim.compute_settled(count, first)
+            assert np.all(sim.get_state()[0][:6] == 0) and np.all(sim._get(sim.episode) == 0)    # envs untouched
+            sim.set_settled_store(tables, first)
+        sim.reset()
+        rng = np.random.RandomState(seed)
+        trace = [np.concatenate([a.ravel() for a in sim.get_state()])]
+        for t in range(steps):
+            obs, rew, disc, st = sim.step(rng.uniform(-0.4, 0.4, size=(n, 6)).astype(np.float32))
+            trace.append(np.concatenate([obs.ravel(), rew, disc, st.astype(np.float32)] + [a.ravel() for a in sim.get_state()]))
+        out.append(trace)
+        events.append(sim.get_events())
+        episodes = sim._get(sim.episode)
+    assert episodes.min() > first                      # the rollout did reset into covered episodes
+    for a, b in zip(*out):
+        np.testing.assert_array_equal(a, b)
+    assert events[0] == events[1]                      # placement / settle flags travel with the entries
+
+
 def check_pipeline_identical(make_sim, golden, n=4, steps=3, seed=9, settle=20, exact=True, all_reset_last=True):
     """The pipelined step (k_pipe_begin / k_narrow / k_pipe_solve per substep) and the fused k_step run the same device
     functions in the same order: rollouts from contact-rich states, across a time-limit auto-reset, must agree

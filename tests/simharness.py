@@ -115,6 +115,30 @@ class ArraySim:
             self._pool = tuple(np.ascontiguousarray(a, dtype=np.float32) for a in (qpos, qvel, ctrl))
         self.sim.set_reset_pool(self.ptr(self._pool[0]), self.ptr(self._pool[1]), self.ptr(self._pool[2]), K)
 
+    def compute_settled(self, n_episodes, first_episode=0):
+        """-> numpy (qpos [E,20,N], qvel [E,18,N], warm [E,18,N], flags [E,N]) of so101_compute_settled"""
+        E, N = n_episodes, self.N
+        shapes = ((E, NQ, N), (E, NV, N), (E, NV, N), (E, N))
+        if self.backend == "gpu":
+            t = self.torch
+            out = [t.zeros(*sh, dtype=(t.int32 if i == 3 else t.float32), device=self.dev) for i, sh in enumerate(shapes)]
+        else:
+            out = [np.zeros(sh, dtype=(np.int32 if i == 3 else np.float32)) for i, sh in enumerate(shapes)]
+        self.sim.compute_settled(first_episode, E, *(self.ptr(a) for a in out), self.stream())
+        return tuple(self._get(a) for a in out)
+
+    def set_settled_store(self, tables, first_episode=0):
+        if tables is None:
+            self._store = None
+            self.sim.set_settled_store(None, None, None, None, 0, 0)
+            return
+        dts = (np.float32, np.float32, np.float32, np.int32)
+        if self.backend == "gpu":
+            self._store = tuple(self.torch.as_tensor(np.ascontiguousarray(a, dtype=d)).to(self.dev) for a, d in zip(tables, dts))
+        else:
+            self._store = tuple(np.ascontiguousarray(a, dtype=d) for a, d in zip(tables, dts))
+        self.sim.set_settled_store(*(self.ptr(a) for a in self._store), first_episode, self._store[3].shape[0])
+
     def get_events(self, clear=False):
         if self.backend == "gpu":
             ev = self.torch.zeros(native.NEVENTS, dtype=self.torch.int64, device=self.dev)

@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     lib = native.load_library()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.so101_version() == 5 and lib.so101_max_contacts() >= 16
+    assert lib.so101_version() == 6 and lib.so101_max_contacts() >= 16
 
 
 def test_create_rejects_bad_blobs_without_gpu(hip_lib, blobs):
@@ -139,3 +139,34 @@ def test_lerobot_packaging_matches_the_reference_wrapper():
             got = out[k]
             assert str(got.dtype) == want["dtype"] and list(got.shape) == want["shape"], (k, got.dtype, got.shape, want)
             assert got.double().flatten().tolist() == want["value"], k
+
+
+def test_settled_cache_file_format(tmp_path):
+    """Host logic of the on-disk settled-state store: round trip, key check, damage detection."""
+    from so101_sim_amd import settled_cache as sc
+    E, N = 3, 5
+    rng = np.random.RandomState(0)
+    arrays = {"qpos": rng.randn(E, 20, N).astype(np.float32), "qvel": rng.randn(E, 18, N).astype(np.float32),
+              "warmstart": rng.randn(E, 18, N).astype(np.float32), "flags": rng.randint(0, 64, size=(E, N)).astype(np.int32)}
+    key = {"seed": 7, "blob_sha256": "ab", "env_id_base": 4096, "action_offset": [0.0] * 6, "build": "x"}
+    path = str(tmp_path / "s.bin")
+    sc.write(path, key, 2, arrays)
+    header, got = sc.read(path, expect_key=dict(key))
+    assert header["first_episode"] == 2 and header["n_episodes"] == E and header["n_envs"] == N
+    for k in arrays:
+        np.testing.assert_array_equal(got[k], arrays[k])
+        assert got[k].dtype == arrays[k].dtype
+    with pytest.raises(sc.SettledCacheError, match="env_id_base"):          # another shard's file
+        sc.read(path, expect_key=dict(key, env_id_base=0))
+    with pytest.raises(sc.SettledCacheError, match="build"):
+        sc.read(path, expect_key=dict(key, build="y"))
+    data = bytearray(open(path, "rb").read())
+    data[len(data) // 2] ^= 1
+    open(path, "wb").write(bytes(data))
+    with pytest.raises(sc.SettledCacheError, match="checksum"):
+        sc.read(path)
+    open(path, "wb").write(bytes(data[:100]))
+    with pytest.raises(sc.SettledCacheError):
+        sc.read(path)
+    with pytest.raises(sc.SettledCacheError, match="shape"):
+        sc.write(path, key, 0, dict(arrays, qpos=arrays["qpos"][:, :19]))

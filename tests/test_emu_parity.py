@@ -46,6 +46,10 @@ def test_reset_prefetch_is_bit_identical(make_sim):
     pc.check_prefetch_identical(make_sim, n=1, settle=4, steps=4, last_step=1)
 
 
+def test_settled_store_is_bit_identical(make_sim):
+    pc.check_settled_store_identical(make_sim, n=1, settle=4, steps=5, last_step=1, first=1, count=1)
+
+
 def test_pipelined_step_matches_fused(make_sim, golden):
     pc.check_pipeline_identical(make_sim, golden, n=1, steps=1, settle=3)
 

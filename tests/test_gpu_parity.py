@@ -20,7 +20,7 @@ def test_native_library_is_the_hip_build():
     import os
     from so101_sim_amd import native
     assert os.path.exists(native.LIB_PATH)
-    assert native.load_library().so101_version() == 5
+    assert native.load_library().so101_version() == 6
 
 
 def test_forward_stages(make_sim, blobs):
@@ -76,6 +76,11 @@ def test_env_semantics(make_sim, blobs):
 
 def test_reset_prefetch_is_bit_identical(make_sim):
     pc.check_prefetch_identical(make_sim, n=64, settle=300, steps=14, last_step=3)
+
+
+@pytest.mark.parametrize("prefetch", [0, 1])
+def test_settled_store_is_bit_identical(make_sim, prefetch):
+    pc.check_settled_store_identical(make_sim, n=64, settle=300, steps=14, last_step=3, first=1, count=2, prefetch=prefetch)
 
 
 def test_pipelined_step_matches_fused(make_sim, golden):

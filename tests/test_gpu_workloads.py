@@ -387,3 +387,48 @@ def test_single_env_reset_is_seed_compatible_with_the_reference(blobs):
     opos2 = rs.uniform([0.2, -0.1, 0.45], [0.3, 0.1, 0.45])
     np.testing.assert_array_equal(env.placements["object_position"], opos2)
     env.close()
+
+
+def test_settled_cache_file_roundtrip(tmp_path):
+    """the settled states of the first episodes are written to disk by one environment and picked up by a
+    second one built the same way; its resets then copy them (bit-identical to an environment that settles), and a file
+    made for another seed or another mass scale is refused."""
+    import torch
+    from so101_sim_amd import task_suite, settled_cache
+    N, path = 128, str(tmp_path / "settled.bin")
+    mk = lambda seed=3: task_suite.create_task_env("SO100HandOverBanana", time_limit=0.1, n_envs=N, random_state=seed,
+                                                   device="cuda:0", prefetch_resets=False)
+    act = torch.zeros(N, 6, device="cuda:0")
+
+    def rollout(env, steps=13):
+        env.reset()
+        out = [torch.cat([env.qpos, env.qvel]).cpu().numpy().copy()]
+        for _ in range(steps):
+            env.step_tensor(act)
+            out.append(torch.cat([env.qpos, env.qvel, env.obs.T, env.reward[None], env.discount[None]]).cpu().numpy().copy())
+        return out, env.events()
+
+    a = mk()
+    ref, ev_ref = rollout(a)                           # settles every reset
+    a.close()
+    b = mk()
+    b.save_settled_cache(path, n_episodes=3)
+    b.close()
+    c = mk()
+    header = c.load_settled_cache(path)
+    assert header["n_episodes"] == 3 and header["n_envs"] == N and header["first_episode"] == 0
+    got, ev_got = rollout(c)
+    assert int(c.episode.min()) >= 3                   # 13 steps at a 5-step limit: episodes 0, 1, 2 were all started
+    for x, y in zip(ref, got):
+        np.testing.assert_array_equal(x, y)
+    assert ev_ref == ev_got
+    c.close()
+    d = mk(seed=4)
+    with pytest.raises(settled_cache.SettledCacheError, match="seed"):
+        d.load_settled_cache(path)
+    d.close()
+    e = mk()
+    e.set_mass_scale(torch.full((2, N), 1.1))
+    with pytest.raises(settled_cache.SettledCacheError, match="mass_scale_sha256"):
+        e.load_settled_cache(path)
+    e.close()
