@@ -750,12 +750,22 @@ void collision(orc_sim* s) {
       bool separated = false, exact = false;
       real f[3], c[3], u[3], v[3], hu = 0, hv = 0, cand = 1e30;
       int ref = -1;
-      for (int side = 0; side < 2 && !separated; side++) {
+      // Faces of one geom are visited in order of increasing depth of the other geom's centre below the face plane
+      // (half extent along the axis minus |centre offset along it|, a lower bound of d0); the scan ends at the first
+      // exact face: the geoms then share the point a0, so no other face plane separates them, and another exact face
+      // would give the same depth.
+      for (int side = 0; side < 2 && !separated && !exact; side++) {
         int g = side == 0 ? g1 : g2, gI = side == 0 ? g2 : g1;
         if (m.geom_type[g] != G_BOX && m.geom_type[g] != G_CYLINDER) continue;
         real ci[3], cg[3]; geom_center(s, gI, ci); geom_center(s, g, cg);
         real toward[3] = {ci[0] - cg[0], ci[1] - cg[1], ci[2] - cg[2]};
-        for (int axis = 0; axis < 3; axis++) {
+        real loc[3]; mulmatTvec3(loc, &s->gmat[9 * g], toward);
+        real lb[3];
+        for (int k = 0; k < 3; k++) lb[k] = m.geom_size[3 * g + k] - std::fabs(loc[k]);
+        int order[3] = {0, 1, 2};
+        std::stable_sort(order, order + 3, [&](int a, int b) { return lb[a] < lb[b]; });
+        for (int it = 0; it < 3 && !separated && !exact; it++) {
+          int axis = order[it];
           real f2[3], c2[3], u2[3], v2[3], hu2, hv2, half;
           if (flat_face(s, g, axis, toward, f2, c2, u2, v2, &hu2, &hv2, &half) < 0) continue;
           real cr[3] = {c2[0] - ci[0], c2[1] - ci[1], c2[2] - ci[2]};
@@ -765,7 +775,7 @@ void collision(orc_sim* s) {
           real rel[3] = {a0[0] - c2[0], a0[1] - c2[1], a0[2] - c2[2]};
           real d0 = -dot3(rel, f2);
           if (!(d0 > 0)) { separated = true; break; }
-          if (exact || d0 > half || !inside_face(rel, u2, v2, hu2, hv2)) continue;
+          if (d0 > half || !inside_face(rel, u2, v2, hu2, hv2)) continue;
           bool ex = inside_margin(rel, u2, v2, hu2, hv2, d0);
           if (!ex && !(d0 < cand)) continue;
           exact = ex; cand = d0; ref = side; hu = hu2; hv = hv2;

@@ -1063,9 +1063,23 @@ template <class Cache, class GP = G64>
 DEV void scan_faces(const DevModel* m, const GeomW& GR, const GeomW& GI, const Cache& HI, int side, FaceRef& R) {
   if (GR.type != G_BOX && GR.type != G_CYLINDER) return;
   float toward[3] = {GI.c[0] - GR.c[0], GI.c[1] - GR.c[1], GI.c[2] - GR.c[2]};
+  // Visiting order: increasing depth of the incident's centre below the face plane (= half extent along the axis minus
+  // |centre offset along it|, a lower bound of d0), i.e. the face the incident geom sticks out of first - for a prop on
+  // the table the top face.  The scan ends at the first EXACT face: the geoms then share the point a0, so no other face
+  // plane separates them, and another exact face would give the same depth.  (Saves two of three hull scans for every
+  // hull resting on the table; the result does not depend on the order otherwise.)
+  float loc[3]; matTvec3(loc, GR.R, toward);
+  float lb0 = GR.size[0] - fabsf(loc[0]), lb1 = GR.size[1] - fabsf(loc[1]), lb2 = GR.size[2] - fabsf(loc[2]);
+  unsigned int done = 0u;
 #pragma unroll 1
-  for (int axis = 0; axis < 3; axis++) {
-    if (R.separated) break;
+  for (int it = 0; it < 3; it++) {
+    if (R.separated || R.exact) break;
+    int axis = 0; float bl = 3.0e38f;
+    if (!(done & 1u)) { axis = 0; bl = lb0; }
+    if (!(done & 2u) && lb1 < bl) { axis = 1; bl = lb1; }
+    if (!(done & 4u) && lb2 < bl) { axis = 2; bl = lb2; }
+    if (bl == 3.0e38f) axis = (done & 1u) ? ((done & 2u) ? 2 : 1) : 0;          // (non-finite bounds: plain index order)
+    done |= 1u << axis;
     float f[3], c[3], u[3], v[3], hu, hv, half;
     if (!flat_face(GR, axis, toward, f, c, u, v, &hu, &hv, &half)) continue;
     float cr[3] = {c[0] - GI.c[0], c[1] - GI.c[1], c[2] - GI.c[2]};
@@ -1075,7 +1089,7 @@ DEV void scan_faces(const DevModel* m, const GeomW& GR, const GeomW& GI, const C
     float rel[3] = {a0[0] - c[0], a0[1] - c[1], a0[2] - c[2]};
     float d0 = -dot3(rel, f);
     if (!(d0 > 0.f)) { R.separated = true; continue; }
-    if (R.exact || d0 > half || !inside_face(rel, u, v, hu, hv)) continue;
+    if (d0 > half || !inside_face(rel, u, v, hu, hv)) continue;
     bool ex = inside_margin(rel, u, v, hu, hv, d0);
     if (!ex && !(d0 < R.depth)) continue;
     R.exact = ex; R.depth = d0; R.side = side; R.hu = hu; R.hv = hv;
@@ -1115,7 +1129,7 @@ DEV void narrow_pair(const DevModel* m, const GeomW& G1, const GeomW& G2, int g1
 #pragma unroll
   for (int k = 0; k < NCPP; k++) { best.P.p[k][0] = 0.f; best.P.p[k][1] = 0.f; best.P.p[k][2] = 0.f; }
   scan_faces<Cache, GP>(m, G1, G2, H2, 0, best);
-  if (!best.separated) scan_faces<Cache, GP>(m, G2, G1, H1, 1, best);
+  if (!best.separated && !best.exact) scan_faces<Cache, GP>(m, G2, G1, H1, 1, best);
   if (best.separated) return;
   float depth = 0.f, nrm[3] = {0.f, 0.f, 0.f}, pos[3] = {0.f, 0.f, 0.f};
   if (!best.exact) {

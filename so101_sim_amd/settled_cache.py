@@ -84,7 +84,7 @@ def read(path: str, expect_key: dict | None = None):
         n = int(np.prod(shape)) * np.dtype(dt).itemsize
         if off + n > len(body):
             raise SettledCacheError(f"{path}: array {name} runs past the end of the file")
-        arrays[name] = np.frombuffer(body, dtype=np.dtype(dt), count=int(np.prod(shape)), offset=off).reshape(shape)
+        arrays[name] = np.frombuffer(body, dtype=np.dtype(dt), count=int(np.prod(shape)), offset=off).reshape(shape).copy()
         off += n
     if off != len(body):
         raise SettledCacheError(f"{path}: {len(body) - off} trailing bytes")
