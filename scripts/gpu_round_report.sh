@@ -1,32 +1,27 @@
 #!/bin/bash
-# Round report on the GPU box: tests, smoke, bench (faithful + throughput setting), rocprofv3 kernel stats and HBM PMC passes.
-# Outputs land in gpurun_out/ (merged back by gpurun); summaries to keep are copied into profiles/ by hand.
+# Round report on the GPU box (run through gpurun): GPU tests, smoke, the bench lines of every workload, then the profile
+# of scripts/gpu_profile.sh (rocprofv3 kernel stats + separate PMC passes).  Everything lands in gpurun_out/<tag>_*; the
+# files to keep are copied into profiles/ by hand.
+#   usage: bash scripts/gpu_round_report.sh r02
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out; mkdir -p $O
 cd $R
-timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -5 | tee $O/pytest_gpu.txt
-timeout 200 python -c "import __graft_entry__ as g; g.build(); g.smoke()" 2>&1 | tail -1 | tee $O/smoke.txt
-timeout 900 python bench.py 2>&1 | tail -1 | tee $O/bench_default.json
-timeout 400 python bench.py --fused --no-cpu-baseline --steps 100 2>&1 | tail -1 | tee $O/bench_fused.json
-timeout 400 python bench.py --no-prefetch --no-cpu-baseline --steps 100 2>&1 | tail -1 | tee $O/bench_noprefetch.json
-cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/prof_stats; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $R/bench.py --steps 40 --warmup 2 --no-cpu-baseline > $O/rocprof_stats.log 2>&1
-find /tmp/prof_stats -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
-for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/prof_pmc; timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/prof_pmc -- python3 $R/bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-prefetch > $O/rocprof_pmc_$c.log 2>&1
-  python3 - <<PY
-import csv, glob, collections, json
-tot = collections.defaultdict(float); cnt = collections.defaultdict(set)
-for f in glob.glob('/tmp/prof_pmc/**/*counter_collection.csv', recursive=True):
-    for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name'].split('(')[0]
-        if k in ('k_order', 'k_pipe_begin', 'k_narrow', 'k_pipe_solve') and r['Counter_Name'] == '$c':
-            tot[k] += float(r['Counter_Value']); cnt[k].add(r['Dispatch_Id'])
-steps = max(1, len(cnt['k_order']))          # one k_order per control step (k_pipe_begin: one per env slice)
-out = {k: {'dispatches': len(cnt[k]), 'KB_per_dispatch': tot[k] / max(1, len(cnt[k])), 'KB_per_step': tot[k] / steps} for k in tot}
-out['steps'] = steps
-print('$c', json.dumps(out))
-json.dump(out, open('$O/pmc_$c.json', 'w'))
-PY
-done
-head -12 $O/kernel_stats.csv
+rocm-smi --showclocks 2>/dev/null | grep -E "sclk|mclk" | head -4 > $O/${TAG}_clocks_before.txt
+# the driver's command first, on the cold box
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/${TAG}_bench_driver_args.json
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -6 > $O/${TAG}_pytest_gpu.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke OK')" 2>&1 | tail -2 > $O/${TAG}_smoke.txt
+timeout 600 python bench.py --steps 100 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_100.json
+timeout 900 python bench.py --steps 500 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_500.json
+timeout 900 python bench.py --envs-per-gpu 16384 --steps 40 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_16384.json
+timeout 900 python bench.py --envs-per-gpu 32768 --steps 30 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_32768.json
+timeout 900 python bench.py --workload pickplace --steps 40 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_pickplace.json
+timeout 900 python bench.py --workload mixed --steps 30 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_mixed.json
+timeout 600 python bench.py --fused --no-cpu-baseline --steps 40 2>/dev/null | tail -1 > $O/${TAG}_bench_fused.json
+timeout 600 python scripts/gpu_reset_cost.py 2>&1 | tail -6 > $O/${TAG}_reset_cost.txt
+rocm-smi --showclocks 2>/dev/null | grep -E "sclk|mclk" | head -4 > $O/${TAG}_clocks_after.txt
+bash $R/scripts/gpu_profile.sh $TAG > $O/${TAG}_profile.log 2>&1
+for f in $O/${TAG}_pytest_gpu.txt $O/${TAG}_smoke.txt $O/${TAG}_reset_cost.txt; do echo "== $f"; cat $f; done
+for f in $O/${TAG}_bench_*.json; do echo "== $(basename $f): $(cut -c1-110 $f)"; done
+tail -8 $O/${TAG}_profile.log

@@ -29,3 +29,22 @@ for lo_, hi_ in ((0, 1), (1, 5), (5, 9), (9, 13), (13, 20), (20, 33)):
     mk = (ncon >= lo_) & (ncon < hi_)
     if mk.any():
         print("  ncon [%2d,%2d): %4d envs  constraints %.1f  solver %.1f us  iters %.1f" % (lo_, hi_, mk.sum(), us[mk, 2].mean(), us[mk, 3].mean(), it[mk].mean()))
+
+order = np.argsort(-tot)
+print("slowest envs: total us | smooth gather constraints solver integrate next | ncon iters")
+for e in order[:16]:
+    print("  %6.1f | %s | %3d %3d" % (tot[e], " ".join("%6.1f" % x for x in us[e]), ncon[e], it[e]))
+print("iterations histogram:", np.bincount(it.astype(int))[:25])
+print("solver us per iteration by ncon bucket:")
+for lo_, hi_ in ((1, 5), (5, 9), (9, 13), (13, 20), (20, 33), (33, 65)):
+    mk = (ncon >= lo_) & (ncon < hi_) & (it > 0)
+    if mk.any():
+        print("  ncon [%2d,%2d): %.1f us/iter" % (lo_, hi_, (us[mk, 3] / it[mk]).mean()))
+
+nc_ = torch.zeros(N, dtype=torch.int32, device=s.dev); cand_ = torch.zeros(N, 256, dtype=torch.int32, device=s.dev)
+tk_ = torch.zeros(N, 256, dtype=torch.int32, device=s.dev); cr_ = torch.zeros(N, 256, 24, device=s.dev)
+s.sim.debug_candidates(nc_.data_ptr(), cand_.data_ptr(), tk_.data_ptr(), cr_.data_ptr()); torch.cuda.synchronize()
+ph = tk_.cpu().numpy()[:, 248:256].astype(np.int64) * 1e-2
+print("solver phases (us per env-substep, mean; per iteration): setup gradient hessian factor solve linesearch cost")
+print("   mean  ", " ".join("%6.2f" % x for x in ph[:, :7].mean(0)), " total %.1f" % ph[:, :7].sum(1).mean())
+print("   /iter ", " ".join("%6.2f" % x for x in (ph[:, :7] / np.maximum(it, 1)[:, None]).mean(0)))

@@ -95,6 +95,9 @@ struct Row1 {                  // scalar rows: dof frictionloss and joint limits
 struct NewtonScratch {          // LDS working set of solve_newton(): the vectors every lane reads, and the transposed factor
   float H[NVS][NVS + 1];
   float x[NVS], xs[NVS], xw[NVS], tmp[NVS], search[NVS];
+#ifdef SO101_DEBUG_CLOCKS
+  unsigned int prof[8];        // profiling builds: wall-clock ticks per solver phase (setup, gradient, Hessian, factor, solve, line search, cost, -)
+#endif
 };
 
 struct EnvLDS {

@@ -186,13 +186,23 @@ DEV float mass_entry(const DevModel* m, const EnvLDS& L, int a, int b) {
   return 0.f;
 }
 
-DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float tolerance) {
+template <bool ROW0>
+DEV void solve_newton_impl(const DevModel* m, EnvLDS& L, int max_iter, float tolerance) {
   int lane = wave_lane();
   int nrow = L.nrow, ncon = L.ncon;
   NewtonScratch& W = L.nw;
+#ifdef SO101_DEBUG_CLOCKS
+  unsigned long long pc = SO101_CLOCK();
+  if (lane < 8) W.prof[lane] = 0u;
+#define NPROF(k) { unsigned long long pn = SO101_CLOCK(); if (lane == 0) W.prof[k] += (unsigned int)(pn - pc); pc = pn; }
+#else
+#define NPROF(k)
+#endif
   if (lane == 0) L.iters = 0;
   if (nrow + ncon == 0) { wave_sync(); return; }
   bool has_con = lane < ncon, has_row = lane < nrow;
+  // sums over contact / scalar-row lanes only: with at most 16 of each, lanes 16-63 add exact zeros (wave.hpp)
+  auto csum = [&](float v) -> float { return wave_sum_rows_f(v, ROW0); };
   ConReg C;
   // lanes without a contact carry an all-zero block (every field is read by the wave-wide arithmetic below)
   C.dim = 0; C.g0 = -1; C.g1 = -1; C.mu = 0.f;
@@ -286,6 +296,7 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
   int zone_prev = -1;
   bool rquad_prev = false;
   int it = 0;
+  NPROF(0)
   for (; it < max_iter; it++) {
     // ---- gradient g = M (x - x_s) - J' f, lane d keeps g_d
     float jl[12];
@@ -303,10 +314,11 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
       if (anyG[G] || G == 0) {
         float v = (C.g0 == G) ? jl[q] : ((C.g1 == G) ? jl[6 + q] : 0.f);
         if (G == 0) v += (has_row && rreg.dof == q) ? rreg.sign * rforce : 0.f;
-        float tot = wave_sum_f(v);
+        float tot = csum(v);
         if (lane == d) grad -= tot;
       }
     }
+    NPROF(1)
     // ---- Hessian H = M + sum_blocks J' Hc J: lane a < NVS keeps row a in registers
     bool rquad = rh != 0.f;
     bool same = wave_ballot((has_con && (zone != zone_prev || zone == 2)) || (has_row && rquad != rquad_prev)) == 0ull;
@@ -316,7 +328,7 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
     for (int b = 0; b < NVS; b++) h[b] = lane < NVS ? mass_entry(m, L, lane, b) : 0.f;
 #pragma unroll
     for (int q = 0; q < NARM; q++) {                       // scalar rows: J = +-e_dof, Hc = D when quadratic
-      float tot = wave_sum_f((has_row && rreg.dof == q) ? rh : 0.f);
+      float tot = csum((has_row && rreg.dof == q) ? rh : 0.f);
       if (lane == q) h[q] += tot;
     }
     bool actG[3], actX[3];
@@ -349,7 +361,7 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
 #pragma unroll
           for (int G = 0; G < 3; G++) {
             if (actG[G]) {
-              float tot = wave_sum_f((C.g0 == G) ? s0 : ((C.g1 == G) ? s1 : 0.f));
+              float tot = csum((C.g0 == G) ? s0 : ((C.g1 == G) ? s1 : 0.f));
               if (lane == 6 * G + a) h[6 * G + b] += tot;
               if (a != b && lane == 6 * G + b) h[6 * G + a] += tot;
             }
@@ -366,7 +378,7 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
             for (int p = 0; p < 3; p++) {
               const int G = p == 2 ? 1 : 0, G2 = p == 0 ? 1 : 2;
               if (actX[p]) {
-                float tot = wave_sum_f((C.g0 == G && C.g1 == G2) ? s : 0.f);
+                float tot = csum((C.g0 == G && C.g1 == G2) ? s : 0.f);
                 if (lane == 6 * G + a) h[6 * G2 + b] += tot;
                 if (lane == 6 * G2 + b) h[6 * G + a] += tot;
               }
@@ -375,6 +387,7 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
         }
       }
     }
+    NPROF(2)
     // ---- symmetric diagonal scaling  H~ = S H S, S = diag(H)^-1/2 : translational (mass ~ 4e-2) and rotational
     // (inertia ~ 1e-5) coordinates differ by ~1e3 in scale, which puts cond(H) near 1/eps_fp32; after scaling the
     // fp32 Cholesky is safe.  Solve H~ y = -S g, search = S y.
@@ -400,6 +413,7 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
       for (int b = 0; b < NVS; b++) W.H[lane][b] = h[b];
     }
     wave_sync();
+    NPROF(3)
     }   // (assembly + factorisation)
     float y = lane < NVS ? -grad * mxs : 0.f;
 #pragma unroll
@@ -428,6 +442,7 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
     // last one if the decrement has stalled (rounding floor) or has just collapsed by more than 100x (quadratic
     // convergence: the step about to be taken leaves an error far below the tolerance); the iteration only goes on while
     // the decrement shrinks slowly, i.e. while cone zones are still switching.
+    NPROF(4)
     float dec = wave_sum_f(lane < NVS ? -grad * sv : 0.f);
     bool done = scale * 0.5f * dec < tolerance ||
                 (it > 0 && 0.5f * dec < 4e-7f * fabsf(cost) && (dec > 0.5f * dec_prev || dec < 1e-2f * dec_prev));
@@ -453,7 +468,7 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
         row_cost(rreg, rjar + alpha * rjv, &f1, &h1);
         d1p -= f1 * rjv; d2p += h1 * rjv * rjv;
       }
-      float d1 = q1 + q2 * alpha + wave_sum_f(d1p), d2 = q2 + wave_sum_f(d2p);
+      float d1 = q1 + q2 * alpha + csum(d1p), d2 = q2 + csum(d2p);
       if (ls == 0) { d10 = fabsf(d1); if (!(d1 < 0.f)) break; }
       else {
         if (fabsf(d1) <= 1e-4f * d10) break;
@@ -465,11 +480,13 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
     }
     if (lane < NVS) W.x[lane] += alpha * sv;
     wave_sync();
+    NPROF(5)
 #ifdef SO101_EMU_TRACE
     { float oldc = cost; float nc = eval_cost(W.x, true); if (lane == 0) fprintf(stderr, "  newton it %d cost %.9g -> %.9g dec %.4g alpha %.4g done %d\n", it, oldc, nc, dec, alpha, (int)done); }
 #endif
-    cost = eval_cost(W.x, true);
+    cost = eval_cost(W.x, !done);          // (the block Hessians are only needed if another iteration follows)
     float gnorm = scale * sqrtf(wave_sum_f(lane < NVS ? grad * grad : 0.f));   // gradient of the previous point (cheap proxy)
+    NPROF(6)
     if (done || gnorm < tolerance) { it++; break; }
   }
   // constrained accelerations back to the shared island state; forces for diagnostics
@@ -482,4 +499,13 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
   if (has_row) L.row[lane].f = rforce;
   if (lane == 0) L.iters = it;
   wave_sync();
+}
+
+// Two instances: with at most 16 contacts (and 16 scalar rows) every sum over contact lanes is a single-row sum
+// (wave.hpp wave_sum_rows_f) - same bits, ~100-200 fewer v_readlane + adds per iteration.  A run-time flag inside one
+// instance was slower than no shortcut at all (650 k against 680 k env-steps/s: the scalar branch around each sum stops
+// the scheduler from overlapping neighbouring sums).
+DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float tolerance) {
+  if (wave_uniform_i((int)(L.ncon <= 16 && L.nrow <= 16))) solve_newton_impl<true>(m, L, max_iter, tolerance);
+  else solve_newton_impl<false>(m, L, max_iter, tolerance);
 }

@@ -108,6 +108,7 @@ __global__ void __launch_bounds__(64, 2) k_pipe_solve(const DevModel* m, StepPar
     if (lane == 0) { L.ncon = 0; L.nrow = 0; L.iters = 0; L.ncand = 0; L.overflow = 8; }
     wave_sync();
   }
+  int ncon_solved = L.ncon, iters_solved = L.iters;      // (the next broadphase clears the counts)
   if (!last) {
     store_state_aos(L, W, e);
     if (!diverged) {
@@ -117,10 +118,13 @@ __global__ void __launch_bounds__(64, 2) k_pipe_solve(const DevModel* m, StepPar
     } else if (lane == 0) W.ncand[e] = 0;
     if (lane == 0) {
       if (L.overflow) E.flags[e] |= L.overflow;          // rare; summed into the event counters by finish_step()
+#ifdef SO101_DEBUG_CLOCKS
+      for (int k = 0; k < 8; k++) W.ticks[(size_t)e * MAXCAND + 248 + k] = L.nw.prof[k];      // (solver phases; slots of candidates 248+ are idle)
+#endif
       if (SO101_CLOCKS_ON) {
         unsigned int* st = W.stage + (size_t)e * 8;
         st[0] = (unsigned int)(c1 - c0); st[1] = (unsigned int)(c2 - c1); st[2] = (unsigned int)(c3 - c2); st[3] = (unsigned int)(c4 - c3);
-        st[4] = (unsigned int)(c5 - c4); st[5] = (unsigned int)(SO101_CLOCK() - c5); st[6] = (unsigned int)L.ncon; st[7] = (unsigned int)L.iters;
+        st[4] = (unsigned int)(c5 - c4); st[5] = (unsigned int)(SO101_CLOCK() - c5); st[6] = (unsigned int)ncon_solved; st[7] = (unsigned int)iters_solved;
       }
     }
     return;

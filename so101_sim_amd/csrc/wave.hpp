@@ -67,6 +67,22 @@ __device__ __forceinline__ float wave_sum_f(float v) {
   return (r0 + r1) + (r2 + r3);
 }
 
+// The same sum when the caller knows (wave-uniform `row0_only`) that lanes 16-63 contribute +0.0: their row sums are
+// +0.0, so (r0 + 0) + (0 + 0) == r0 + 0 bit for bit and three v_readlane + two adds are skipped.  The Newton solver's
+// sums over contacts qualify whenever an env has at most 16 contacts (most envs, most of the time).
+__device__ __forceinline__ float wave_sum_rows_f(float v, bool row0_only) {
+  v += dpp_f<DPP_QUAD_XOR1>(v);
+  v += dpp_f<DPP_QUAD_XOR2>(v);
+  v += dpp_f<DPP_ROW_HALF_MIRROR>(v);
+  v += dpp_f<DPP_ROW_MIRROR>(v);
+  float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  if (row0_only) return r0 + 0.f;
+  float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (r0 + r1) + (r2 + r3);
+}
+
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __ballot(p); }
 
 // number of set bits of `mask` strictly below this lane

@@ -3,6 +3,9 @@
 #ifndef SO101_WAVE_HPP_
 #define SO101_WAVE_HPP_
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #define WAVE 64
 inline int wave_lane() { return threadIdx.x; }
 inline void wave_sync() { __syncthreads(); }
@@ -22,6 +25,19 @@ inline float wave_sum_f(float v) {
   for (int i = 0; i < 64; i++) u[i] = t[i] + t[(i & ~7) | (7 - (i & 7))];
   for (int i = 0; i < 64; i++) t[i] = u[i] + u[(i & ~15) | (15 - (i & 15))];
   float r = (t[0] + t[16]) + (t[32] + t[48]);
+  __syncthreads(); return r;
+}
+inline float wave_sum_rows_f(float v, bool row0_only) {
+  emu_xchg_f[threadIdx.x] = v; __syncthreads();
+  float t[64], u[64];
+  for (int i = 0; i < 64; i++) t[i] = emu_xchg_f[i];
+  for (int i = 0; i < 64; i++) u[i] = t[i] + t[i ^ 1];
+  for (int i = 0; i < 64; i++) t[i] = u[i] + u[i ^ 2];
+  for (int i = 0; i < 64; i++) u[i] = t[i] + t[(i & ~7) | (7 - (i & 7))];
+  for (int i = 0; i < 64; i++) t[i] = u[i] + u[(i & ~15) | (15 - (i & 15))];
+  float full = (t[0] + t[16]) + (t[32] + t[48]), r = row0_only ? t[0] + 0.f : full;
+  // the shortcut is only legal when it changes nothing: checked on every call under emulation
+  if (row0_only && std::memcmp(&r, &full, sizeof r) != 0) { std::fprintf(stderr, "wave_sum_rows_f: row-0 shortcut differs from the full sum\n"); std::abort(); }
   __syncthreads(); return r;
 }
 inline unsigned long long wave_ballot(bool p) {
