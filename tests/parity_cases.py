@@ -140,7 +140,8 @@ def check_control_step(make_sim, blobs, n=4, seed=3, iterations=100):
         o.substeps(10)
         qo, vo, _ = o.get_state()
         arm_contact = any(_arm_geom(c["geom1"]) or _arm_geom(c["geom2"]) for c in o.contacts())
-        tol_q, tol_v = (2e-4, 5e-2) if arm_contact else (2e-5, 5e-3)
+        # measured on MI355X (16 + 8 states): free arm dq <= 1.6e-7, dv <= 3.1e-5; with arm contact dq 1.1e-6, dv 2.4e-4
+        tol_q, tol_v = (2e-5, 2e-3) if arm_contact else (2e-6, 2e-4)
         assert np.abs(q1[:6, e] - qo[:6]).max() <= max(tol_q, 2e-6 * np.abs(qo[:6]).max()), e
         assert np.abs(v1[:6, e] - vo[:6]).max() <= max(tol_v, 2e-5 * np.abs(vo[:6]).max()), e
         assert np.abs(q1[6:, e] - qo[6:]).max() <= tol_q and np.abs(v1[6:, e] - vo[6:]).max() <= tol_v, e
@@ -231,8 +232,11 @@ def check_env_semantics(make_sim, blobs, n=2, settle=30, steps=8, last_step=7, s
         # identical RNG draws + same settle.  An object spawned inside the static post is ejected (a chaotic
         # transient: SURVEY.md section 9 item 8), so the bound is loose there and tight otherwise.
         ejected = abs(qo[8] - rest_z) > 2e-3 or np.abs(vo[6:]).max() > 5e-3      # still moving when the budget ran out
-        # (the settle is a dynamic transient of drops/impacts: fp32 vs fp64 drift of a few mm over hundreds of substeps)
-        assert np.abs(q0[:, e] - qo).max() < (0.2 if ejected else 5e-3), (e, np.abs(q0[:, e] - qo).max())
+        at_rest = abs(qo[8] - rest_z) < 2e-4 and np.abs(vo[6:]).max() < 2e-3
+        # (the settle is a dynamic transient of drops/impacts: fp32 vs fp64 drift of up to 2 mm over hundreds of substeps
+        # while the props still move; once at rest the poses agree to 1e-4 - measured 5e-7 .. 1.1e-4 on MI355X)
+        tol = 0.2 if ejected else (5e-4 if at_rest else 5e-3)
+        assert np.abs(q0[:, e] - qo).max() < tol, (e, np.abs(q0[:, e] - qo).max())
         assert np.all(q0[:6, e] == 0)
         oracles.append(o)
     rng = np.random.RandomState(seed)
@@ -379,16 +383,17 @@ def _compare_contact_lists(mine_list, ref_list):
     return problems, total, loose
 
 
-def check_contact_rich(make_sim, blobs, golden, count=4, verbose=False, max_discontinuous=0.25):
+def check_contact_rich(make_sim, blobs, golden, count=4, verbose=False, max_discontinuous=0.1):
     """Arm self-collision / arm-table / arm-prop contact states (20-40 simultaneous contacts, captured from a
     random-action rollout): the SAME contact list as the oracle (pair by pair, contact by contact, in order, tolerances
-    in _compare_contact_lists) and the same constrained acceleration (1e-3 of max|qacc|; Newton converged on both sides).
+    in _compare_contact_lists) and the same constrained acceleration (1e-4 of max|qacc|; Newton converged on both sides;
+    measured on MI355X: <= 1.6e-5 on the twelve golden states).
 
     The MPR penetration query is a discontinuous function of the state where a thin plate (a 2 mm finger pad) is buried
     centimetres deep in a hull: the portal it ends on, hence the depth, jumps.  A state whose comparison fails is
     therefore re-examined ONCE in its neighbourhood: the kernel's answer is accepted only if the fp64 oracle returns
     the same contact list and the same qacc somewhere within 1e-6 rad of the state, and at most `max_discontinuous` of
-    the states may need that (the count is returned).  MuJoCo's EPA has no such jumps - known deviation."""
+    the states may need that (the count is returned; on MI355X one of the twelve golden states does).  MuJoCo's EPA has no such jumps - known deviation."""
     states = golden["contact_rich_states"]["states"][:count]
     n = len(states)
     Q = np.array([s["qpos"] for s in states]).T
@@ -413,7 +418,7 @@ def check_contact_rich(make_sim, blobs, golden, count=4, verbose=False, max_disc
         a, ref = oracle_eval(Q[:, e], e)
         problems, t, l = _compare_contact_lists(d["contacts"], ref)
         err = np.abs(d["qacc"] - a).max() / np.abs(a).max()
-        if problems or err > 1e-3:
+        if problems or err > 1e-4:
             discontinuous.append(e)
             prng, found = np.random.RandomState(1234 + e), False
             for _ in range(40):
@@ -422,7 +427,7 @@ def check_contact_rich(make_sim, blobs, golden, count=4, verbose=False, max_disc
                 a, ref = oracle_eval(q, e)
                 p2, t, l = _compare_contact_lists(d["contacts"], ref)
                 err = np.abs(d["qacc"] - a).max() / np.abs(a).max()
-                if not p2 and err <= 1e-3:
+                if not p2 and err <= 1e-4:
                     found = True
                     break
             assert found, (e, problems)
