@@ -2,6 +2,8 @@
 the mixed Banana + Pen suite with per-env mass randomisation (configs[3]) and the 32768-env per-GPU share of
 configs[4] - oracle comparisons on small slices, size-independent properties at the full sizes with the benchmarked
 solver settings (Newton, 100 iterations, tolerance 1e-8)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -432,3 +434,61 @@ def test_settled_cache_file_roundtrip(tmp_path):
     with pytest.raises(settled_cache.SettledCacheError, match="mass_scale_sha256"):
         e.load_settled_cache(path)
     e.close()
+
+
+def test_config0_single_env_500_random_steps(blobs):
+    """BASELINE.json configs[0]: `create_task_env('SO100HandOverBanana', time_limit=10.0, random_state=0)`, ONE env, 500
+    uniform random actions through the reference's own Python surface.  The oracle's env layer, started from the same
+    reset state, runs beside it for the first steps (arm joints to 1e-4 until the arm touches something, 5e-3 for five more
+    steps): exact task outputs and the observation delay line throughout; the episode must end with LAST on control step 500 (or earlier on a physics error /
+    success, discount 0) and auto-reset."""
+    from so101_sim_amd import task_suite
+    cwd = os.getcwd()
+    os.chdir(os.path.dirname(os.path.abspath(__file__)))       # no calibration/red_arm.json here: offsets are zero
+    try:
+        env = task_suite.create_task_env("SO100HandOverBanana", time_limit=10.0, random_state=0)
+    finally:
+        os.chdir(cwd)
+    spec = env.action_spec()
+    ts = env.reset()
+    assert ts.first() and ts.reward is None and ts.discount is None
+    assert list(ts.observation) == ["commanded_joints_pos", "joints_pos", "joints_vel", "physics_state", "undelayed_joints_pos",
+                                    "undelayed_joints_vel", "delayed_physics_state"]
+    state0 = np.asarray(ts.observation["physics_state"], dtype=np.float64)
+    o = Oracle(blobs["f64"])
+    o.env_config(last_step=500)
+    o.set_state(state0[:20], state0[20:], np.zeros(18))
+    o.set_ctrl(np.asarray(ts.observation["commanded_joints_pos"], dtype=np.float64))
+    o.env_begin()
+    rng = np.random.RandomState(0)
+    undelayed, compared, touched, budget, ended = [], 0, False, 5, None
+    for t in range(1, 501):
+        a = rng.uniform(spec.minimum, spec.maximum).astype(np.float32)
+        ts = env.step(a)
+        ob = ts.observation
+        assert ob["joints_pos"].shape == (6,) and ob["joints_vel"].shape == (0,) and ob["physics_state"].shape == (38,)
+        assert np.all(np.isfinite(ob["physics_state"])) and ts.reward in (0.0, 1.0)
+        np.testing.assert_array_equal(ob["commanded_joints_pos"], a.astype(np.float64))        # unclamped ctrl, zero offsets
+        np.testing.assert_array_equal(ob["undelayed_joints_pos"], ob["physics_state"][:6])
+        undelayed.append(ob["undelayed_joints_pos"].copy())
+        want = undelayed[t - 6] if t >= 6 else np.zeros(6)                                   # value of control step t - 5
+        np.testing.assert_array_equal(ob["joints_pos"], want)
+        if budget > 0 and not ts.last():
+            # full-range random targets drive the arm into the table or itself within a step or two; from then on the
+            # trajectories separate chaotically, so the comparison loosens and stops five steps later
+            oo, orew, odisc, ost = o.env_step(a.astype(np.float64))
+            touched = touched or any(pc._arm_geom(c["geom1"]) or pc._arm_geom(c["geom2"]) for c in o.contacts())
+            np.testing.assert_allclose(ob["undelayed_joints_pos"], oo[6:12], atol=5e-3 if touched else 1e-4)
+            assert (float(ts.reward), float(ts.discount)) == (orew, odisc)
+            compared += 1
+            budget -= 1 if touched else 0
+        if ts.last():
+            ended = t
+            break
+        assert ts.mid() and ts.discount == 1.0
+    assert compared >= 5, compared
+    assert ended is not None and (ended == 500 or ts.discount == 0.0), (ended, ts.discount)
+    if ended == 500:
+        assert ts.discount == 1.0 and ts.reward == 0.0
+    assert env.step(np.zeros(6, dtype=np.float32)).first()
+    env.close()
