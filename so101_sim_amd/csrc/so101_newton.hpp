@@ -115,18 +115,24 @@ DEV float row_cost(const Row1& r, float jar, float* force, float* h) {
 }
 
 // the contact's Jacobian and parameters, from the LDS record into the lane's registers
+// coordinate groups a contact touches (0 arm, 1 object, 2 container; -1 none; g0 < g1 when both are present)
+DEV void contact_groups(const Contact& c, int* g0, int* g1) {
+  int a = c.armslot >= 0 ? 0 : 3, f1 = c.d1 >= NARM ? c.d1 - NARM + 1 : 3, f2 = c.d2 >= NARM ? c.d2 - NARM + 1 : 3;   // 3 = none
+  int lo = min(a, min(f1, f2)), hi = max(a == 3 ? -1 : a, max(f1 == 3 ? -1 : f1, f2 == 3 ? -1 : f2));
+  *g0 = lo == 3 ? -1 : lo;
+  *g1 = hi > lo ? hi : -1;
+}
+
+template <bool SINGLE>
 DEV void conreg_load(const EnvLDS& L, const Contact& c, ConReg& r) {
   r.dim = c.dim; r.mu = c.mu;
   r.fr[0] = c.fric[0]; r.fr[1] = c.fric[0]; r.fr[2] = c.fric[1]; r.fr[3] = c.fric[2]; r.fr[4] = c.fric[2];
   r.Dj[0] = 1.f / c.R[0]; r.Dj[1] = 1.f / c.R[1]; r.Dj[2] = r.Dj[1]; r.Dj[3] = 1.f / c.R[2]; r.Dj[4] = 1.f / c.R[3]; r.Dj[5] = r.Dj[4];
 #pragma unroll
   for (int j = 0; j < 6; j++) r.aref[j] = c.aref[j];
-  int a = c.armslot >= 0 ? 0 : 3, f1 = c.d1 >= NARM ? c.d1 - NARM + 1 : 3, f2 = c.d2 >= NARM ? c.d2 - NARM + 1 : 3;   // 3 = none
-  int lo = min(a, min(f1, f2)), hi = max(a == 3 ? -1 : a, max(f1 == 3 ? -1 : f1, f2 == 3 ? -1 : f2));
-  r.g0 = lo == 3 ? -1 : lo;
-  r.g1 = hi > lo ? hi : -1;
+  contact_groups(c, &r.g0, &r.g1);
 #pragma unroll
-  for (int s = 0; s < 2; s++) {
+  for (int s = 0; s < (SINGLE ? 1 : 2); s++) {
     int g = s == 0 ? r.g0 : r.g1;
     if (g == 0) {
       const ArmCon& ac = L.armcon[c.armslot];
@@ -186,7 +192,11 @@ DEV float mass_entry(const DevModel* m, const EnvLDS& L, int a, int b) {
   return 0.f;
 }
 
-template <bool ROW0>
+// SINGLE: no contact couples two coordinate groups (g1 < 0 everywhere), so H = M + J' Hc J is block diagonal - three
+// independent 6x6 systems.  Slot 1 of every ConReg is never touched (half the Jacobian registers and products), lane
+// i keeps only the six entries of row i inside its block, and the three blocks are factorised and solved side by side:
+// six pivot steps instead of eighteen on the dependent chain.
+template <bool ROW0, bool SINGLE>
 DEV void solve_newton_impl(const DevModel* m, EnvLDS& L, int max_iter, float tolerance) {
   int lane = wave_lane();
   int nrow = L.nrow, ncon = L.ncon;
@@ -214,7 +224,7 @@ DEV void solve_newton_impl(const DevModel* m, EnvLDS& L, int max_iter, float tol
   for (int j = 0; j < 6; j++) { C.Dj[j] = 0.f; C.aref[j] = 0.f; }
 #pragma unroll
   for (int j = 0; j < 5; j++) C.fr[j] = 0.f;
-  if (has_con) conreg_load(L, L.con[lane], C);
+  if (has_con) conreg_load<SINGLE>(L, L.con[lane], C);
 #ifdef SO101_EMU_TRACE
   if (has_con) fprintf(stderr, "  con %d dim %d g %d %d R %.6g %.6g %.6g %.6g aref %.6g %.6g %.6g %.6g %.6g %.6g mu %.6g\n", lane, C.dim, C.g0, C.g1,
                        L.con[lane].R[0], L.con[lane].R[1], L.con[lane].R[2], L.con[lane].R[3], C.aref[0], C.aref[1], C.aref[2], C.aref[3], C.aref[4], C.aref[5], C.mu);
@@ -253,7 +263,7 @@ DEV void solve_newton_impl(const DevModel* m, EnvLDS& L, int max_iter, float tol
     for (int q = 0; q < 6; q++) {
       float x0 = x[o0 + q], x1 = x[o1 + q];
 #pragma unroll
-      for (int j = 0; j < 6; j++) out6[j] += C.J[q][j] * x0 + C.J[6 + q][j] * x1;
+      for (int j = 0; j < 6; j++) { if constexpr (SINGLE) out6[j] += C.J[q][j] * x0; else out6[j] += C.J[q][j] * x0 + C.J[6 + q][j] * x1; }
     }
   };
   // total cost at x; leaves this lane's residuals (jar, rjar), forces and block Hessians in registers
@@ -290,18 +300,25 @@ DEV void solve_newton_impl(const DevModel* m, EnvLDS& L, int max_iter, float tol
   // no block changes its zone and no contact sits in the middle zone of its cone (the only zone whose Hessian depends on
   // x), H is the same matrix and is neither assembled nor factorised again - resting props take their two or three
   // iterations on one factorisation.
-  float h[NVS], mxs = 1.f;
+  constexpr int HW = SINGLE ? 6 : NVS;              // entries of row `lane` kept in registers
+  const int grp = lane / 6, sub = lane % 6;         // SINGLE: block and row inside the block
+  // value of v at lane 6 * (own block) + b
+  auto gget = [&](float v, int b) -> float {
+    float a0 = wave_get_f(v, b), a1 = wave_get_f(v, 6 + b), a2 = wave_get_f(v, 12 + b);
+    return grp == 0 ? a0 : (grp == 1 ? a1 : a2);
+  };
+  float h[HW], mxs = 1.f;
 #pragma unroll
-  for (int b = 0; b < NVS; b++) h[b] = 0.f;
+  for (int b = 0; b < HW; b++) h[b] = 0.f;
   int zone_prev = -1;
   bool rquad_prev = false;
   int it = 0;
   NPROF(0)
   for (; it < max_iter; it++) {
     // ---- gradient g = M (x - x_s) - J' f, lane d keeps g_d
-    float jl[12];
+    float jl[SINGLE ? 6 : 12];
 #pragma unroll
-    for (int c = 0; c < 12; c++) {
+    for (int c = 0; c < (SINGLE ? 6 : 12); c++) {
       float s = 0.f;
 #pragma unroll
       for (int j = 0; j < 6; j++) s += C.J[c][j] * force[j];
@@ -312,7 +329,8 @@ DEV void solve_newton_impl(const DevModel* m, EnvLDS& L, int max_iter, float tol
     for (int d = 0; d < NVS; d++) {
       const int G = d / 6, q = d % 6;
       if (anyG[G] || G == 0) {
-        float v = (C.g0 == G) ? jl[q] : ((C.g1 == G) ? jl[6 + q] : 0.f);
+        float v;
+        if constexpr (SINGLE) v = (C.g0 == G) ? jl[q] : 0.f; else v = (C.g0 == G) ? jl[q] : ((C.g1 == G) ? jl[6 + q] : 0.f);
         if (G == 0) v += (has_row && rreg.dof == q) ? rreg.sign * rforce : 0.f;
         float tot = csum(v);
         if (lane == d) grad -= tot;
@@ -323,6 +341,91 @@ DEV void solve_newton_impl(const DevModel* m, EnvLDS& L, int max_iter, float tol
     bool rquad = rh != 0.f;
     bool same = wave_ballot((has_con && (zone != zone_prev || zone == 2)) || (has_row && rquad != rquad_prev)) == 0ull;
     zone_prev = zone; rquad_prev = rquad;
+    if constexpr (SINGLE) {
+    if (!(it > 0 && same)) {
+#pragma unroll
+      for (int b = 0; b < 6; b++) h[b] = lane < NVS ? mass_entry(m, L, lane, 6 * grp + b) : 0.f;
+#pragma unroll
+      for (int q = 0; q < NARM; q++) {                       // scalar rows: J = +-e_dof, Hc = D when quadratic
+        float tot = csum((has_row && rreg.dof == q) ? rh : 0.f);
+        if (lane == q) h[q] += tot;
+      }
+      bool actG[3];
+      {
+        bool on = has_con && zone != 0;
+#pragma unroll
+        for (int G = 0; G < 3; G++) actG[G] = wave_ballot(on && C.g0 == G) != 0ull;
+      }
+      if (actG[0] || actG[1] || actG[2]) {
+#pragma unroll
+        for (int b = 0; b < 6; b++) {
+          float W0[6];
+#pragma unroll
+          for (int i = 0; i < 6; i++) {
+            float s0 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; j++) s0 += Hc[i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i] * C.J[b][j];
+            W0[i] = s0;
+          }
+#pragma unroll
+          for (int a = 0; a <= b; a++) {
+            float s0 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 6; j++) s0 += C.J[a][j] * W0[j];
+#pragma unroll
+            for (int G = 0; G < 3; G++) {
+              if (actG[G]) {
+                float tot = csum((C.g0 == G) ? s0 : 0.f);
+                if (lane == 6 * G + a) h[b] += tot;
+                if (a != b && lane == 6 * G + b) h[a] += tot;
+              }
+            }
+          }
+        }
+      }
+      // diagonal scaling, then the three 6x6 Cholesky factorisations side by side (lane 6 G + i: row i of block G)
+      float dg = 1.f;
+#pragma unroll
+      for (int b = 0; b < 6; b++) dg = (lane < NVS && sub == b) ? h[b] : dg;
+      mxs = 1.f / sqrtf(fmaxf(dg, 1e-30f));
+#pragma unroll
+      for (int b = 0; b < 6; b++) h[b] *= mxs * gget(mxs, b);
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        float d = sqrtf(fmaxf(gget(h[j], j), 1e-7f));
+        float l = (sub == j) ? d : h[j] / d;
+        h[j] = l;
+#pragma unroll
+        for (int k = j + 1; k < 6; k++) h[k] -= l * gget(l, k);
+      }
+      if (lane < NVS) {
+#pragma unroll
+        for (int b = 0; b < 6; b++) W.H[lane][b] = h[b];
+      }
+      wave_sync();
+      NPROF(3)
+    }   // (assembly + factorisation)
+    }
+    float y = 0.f;
+    if constexpr (SINGLE) {
+      y = lane < NVS ? -grad * mxs : 0.f;
+#pragma unroll
+      for (int i = 0; i < 6; i++) {            // forward substitution, the three blocks in lock step
+        float yi = gget(y, i) / gget(h[i], i);
+        if (sub == i) y = yi;
+        else if (sub > i) y -= h[i] * yi;
+      }
+      float t[6];
+#pragma unroll
+      for (int i = 0; i < 6; i++) t[i] = lane < NVS ? W.H[6 * grp + i][sub] : 0.f;
+#pragma unroll
+      for (int i = 5; i >= 0; i--) {           // L' x = y
+        float xi = gget(y, i) / gget(h[i], i);
+        if (sub == i) y = xi;
+        else if (sub < i) y -= t[i] * xi;
+      }
+    }
+    if constexpr (!SINGLE) {
     if (!(it > 0 && same)) {
 #pragma unroll
     for (int b = 0; b < NVS; b++) h[b] = lane < NVS ? mass_entry(m, L, lane, b) : 0.f;
@@ -415,7 +518,7 @@ DEV void solve_newton_impl(const DevModel* m, EnvLDS& L, int max_iter, float tol
     wave_sync();
     NPROF(3)
     }   // (assembly + factorisation)
-    float y = lane < NVS ? -grad * mxs : 0.f;
+    y = lane < NVS ? -grad * mxs : 0.f;
 #pragma unroll
     for (int i = 0; i < NVS; i++) {          // forward substitution L y = b
       float yi = wave_get_f(y, i) / wave_get_f(h[i], i);
@@ -430,6 +533,7 @@ DEV void solve_newton_impl(const DevModel* m, EnvLDS& L, int max_iter, float tol
       float xi = wave_get_f(y, i) / wave_get_f(h[i], i);
       if (lane == i) y = xi;
       else if (lane < i) y -= t[i] * xi;
+    }
     }
     float sv = y * mxs;
     if (lane < NVS) W.search[lane] = sv;
@@ -501,11 +605,19 @@ DEV void solve_newton_impl(const DevModel* m, EnvLDS& L, int max_iter, float tol
   wave_sync();
 }
 
-// Two instances: with at most 16 contacts (and 16 scalar rows) every sum over contact lanes is a single-row sum
-// (wave.hpp wave_sum_rows_f) - same bits, ~100-200 fewer v_readlane + adds per iteration.  A run-time flag inside one
-// instance was slower than no shortcut at all (650 k against 680 k env-steps/s: the scalar branch around each sum stops
-// the scheduler from overlapping neighbouring sums).
+// Instances: with at most 16 contacts (and 16 scalar rows) every sum over contact lanes is a single-row sum (wave.hpp
+// wave_sum_rows_f) - same bits, ~100-200 fewer v_readlane + adds per iteration; a run-time flag inside one instance was
+// slower than no shortcut at all (650 k against 680 k env-steps/s: the scalar branch around each sum stops the scheduler
+// from overlapping neighbouring sums).  Among those, envs whose contacts never couple two coordinate groups (props
+// resting on the table, the arm in free space or on the table - most envs of the hand-over workload) take the
+// block-diagonal instance.
 DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float tolerance) {
-  if (wave_uniform_i((int)(L.ncon <= 16 && L.nrow <= 16))) solve_newton_impl<true>(m, L, max_iter, tolerance);
-  else solve_newton_impl<false>(m, L, max_iter, tolerance);
+  int lane = wave_lane();
+  bool coupled = false;
+  if (lane < L.ncon) { int g0, g1; contact_groups(L.con[lane], &g0, &g1); coupled = g1 >= 0; }
+  bool cross = wave_ballot(coupled) != 0ull;
+  if (wave_uniform_i((int)(L.ncon <= 16 && L.nrow <= 16))) {
+    if (!cross) solve_newton_impl<true, true>(m, L, max_iter, tolerance);
+    else solve_newton_impl<true, false>(m, L, max_iter, tolerance);
+  } else solve_newton_impl<false, false>(m, L, max_iter, tolerance);
 }

@@ -171,13 +171,19 @@ def test_properties_at_benchmark_size(make_sim, blobs):
     hi = np.array([np.pi, 3.14158, 3.14158, 3.14158, 3.14158, 0.08], dtype=np.float32)
     rng = np.random.RandomState(2)
     total = np.zeros(n)
+    prev_err = np.zeros(n, dtype=bool)
     for t in range(10):
         act = rng.uniform(lo, hi, size=(n, 6)).astype(np.float32)
         obs, rew, disc, st = sim.step(act)
         total += rew
-        assert set(np.unique(rew)) <= {0.0, 1.0} and set(np.unique(st)) <= {1, 2}
-        assert np.all(disc[rew == 0] == 1.0)
-        np.testing.assert_array_equal(obs[:, 12:18], act)
+        assert set(np.unique(rew)) <= {0.0, 1.0} and set(np.unique(st[~prev_err])) <= {1, 2} and np.all(st[prev_err] == 0)
+        # discount 0 without reward = physics error (full-range random targets spin a prop up now and then: ~1e-4 per
+        # env-step): rare, flagged, ends the episode
+        err = (disc == 0) & (rew == 0)
+        assert err.sum() <= 4 and np.all(st[err] == 2) and np.all(sim.get_diag()[err, 4] & 8)
+        assert np.all(disc[(rew == 0) & ~err] == 1.0)
+        np.testing.assert_array_equal(obs[~prev_err, 12:18], act[~prev_err])      # (a FIRST step ignores its action)
+        prev_err = err
     q, v, _ = sim.get_state()
     assert np.all(np.isfinite(q)) and np.all(np.isfinite(v))
     rlo = np.array([-2.2, -3.14158, 0, -2, -3.14158, -0.2])[:, None]
@@ -186,9 +192,10 @@ def test_properties_at_benchmark_size(make_sim, blobs):
     # arriving at up to ~90 rad/s: the overshoot is v / sqrt(k) ~ 1.7 rad at worst, bounded but not small
     assert np.all(q[:6] > rlo - 2.5) and np.all(q[:6] < rhi + 2.5)
     d = sim.get_diag()
-    assert np.all(d[:, 4] == 0), "contact/candidate overflow at benchmark size"
+    assert np.all(d[:, 4] & 7 == 0), "contact/candidate overflow at benchmark size"
     ep = sim._get(sim.ep_return)
-    np.testing.assert_array_equal(ep, total.astype(np.float32))
+    alive = sim._get(sim.step_count) == 10               # (an env that ended early has been reset: its return restarted)
+    np.testing.assert_array_equal(ep[alive], total.astype(np.float32)[alive])
 
 
 def test_divergence_handling(make_sim, blobs):
