@@ -106,7 +106,8 @@ DEV void env_reset(const DevModel* m, EnvLDS& L, const StepParams& P, const DevB
   int lane = wave_lane(), N = P.n_envs;
   unsigned int episode = (unsigned int)B.episode[e];
   load_env_constants(L, B, e, N);
-  bool cached = C.tag && __atomic_load_n(&C.tag[e], __ATOMIC_ACQUIRE) == (int)episode;
+  const size_t slot = episode & 1u;
+  bool cached = C.tag && __atomic_load_n(&C.tag[slot * N + e], __ATOMIC_ACQUIRE) == (int)episode;
   if (C.pool_size > 0) {
     // reset pool: the episode starts from a caller-provided state (pre-grasp pools, checkpoints) instead of
     // placement + settle; the entry is a pure function of (seed, global env id, episode)
@@ -127,10 +128,10 @@ DEV void env_reset(const DevModel* m, EnvLDS& L, const StepParams& P, const DevB
     if (lane == 0) { L.ncon = 0; L.nrow = 0; L.iters = 0; L.ncand = 0; L.overflow |= C.store_flags[k * N + o]; }
     wave_sync();
   } else if (cached) {
-    if (lane < NQ) L.qpos[lane] = C.qpos[(size_t)lane * N + e];
-    if (lane < NV) { L.qvel[lane] = C.qvel[(size_t)lane * N + e]; L.warm[lane] = C.warm[(size_t)lane * N + e]; }
+    if (lane < NQ) L.qpos[lane] = C.qpos[(slot * NQ + lane) * N + e];
+    if (lane < NV) { L.qvel[lane] = C.qvel[(slot * NV + lane) * N + e]; L.warm[lane] = C.warm[(slot * NV + lane) * N + e]; }
     if (lane < NU) L.ctrl[lane] = m->home_ctrl[lane] + P.action_offset[lane];
-    if (lane == 0) { L.ncon = 0; L.nrow = 0; L.iters = 0; L.ncand = 0; L.overflow |= C.flags[e]; }
+    if (lane == 0) { L.ncon = 0; L.nrow = 0; L.iters = 0; L.ncand = 0; L.overflow |= C.flags[slot * N + e]; }
     wave_sync();
   } else {
     env_settle<SOLVER>(m, L, P, e, episode);

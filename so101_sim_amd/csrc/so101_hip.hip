@@ -403,9 +403,9 @@ int so101_create(const void* blob, size_t bytes, int n_envs, int device, uint64_
   }
   if (rc == SO101_OK) {
     PrepBuffers& C = s->prep;
-    bool ok = dev_alloc(s, &C.qpos, NQ * n, 0, "hipMalloc(prep)") && dev_alloc(s, &C.qvel, NV * n, 0, "hipMalloc(prep)") &&
-              dev_alloc(s, &C.warm, NV * n, 0, "hipMalloc(prep)") && dev_alloc(s, &C.tag, n, 0xFF, "hipMalloc(prep)") &&
-              dev_alloc(s, &C.cursor, (size_t)1, 0, "hipMalloc(prep)") && dev_alloc(s, &C.flags, n, 0, "hipMalloc(prep)");
+    bool ok = dev_alloc(s, &C.qpos, 2 * NQ * n, 0, "hipMalloc(prep)") && dev_alloc(s, &C.qvel, 2 * NV * n, 0, "hipMalloc(prep)") &&
+              dev_alloc(s, &C.warm, 2 * NV * n, 0, "hipMalloc(prep)") && dev_alloc(s, &C.tag, 2 * n, 0xFF, "hipMalloc(prep)") &&
+              dev_alloc(s, &C.cursor, (size_t)1, 0, "hipMalloc(prep)") && dev_alloc(s, &C.flags, 2 * n, 0, "hipMalloc(prep)");
     int lo = 0, hi = 0;
     ok = ok && hip_ok(s, hipDeviceGetStreamPriorityRange(&lo, &hi), "hipDeviceGetStreamPriorityRange") &&
          hip_ok(s, hipStreamCreateWithPriority(&s->prep_stream, hipStreamNonBlocking, lo), "hipStreamCreateWithPriority") &&
@@ -460,7 +460,7 @@ int so101_configure(so101_sim* s, const so101_config* cfg) {
   GUARD_DEVICE(s);
   // cached initial states were settled under the old configuration
   if (!drain_prepare(s)) return SO101_ERR_HIP;
-  if (s->prep.tag && !hip_ok(s, hipMemset(s->prep.tag, 0xFF, sizeof(int) * (size_t)s->n_envs), "hipMemset(prep)")) return SO101_ERR_HIP;
+  if (s->prep.tag && !hip_ok(s, hipMemset(s->prep.tag, 0xFF, sizeof(int) * 2 * (size_t)s->n_envs), "hipMemset(prep)")) return SO101_ERR_HIP;
   s->cfg = *cfg;
   s->generation++;
   return SO101_OK;
@@ -475,7 +475,7 @@ int so101_bind_state(so101_sim* s, const so101_buffers* b) {
   // a prefetch in flight reads the OLD episode buffer: let it finish before the pointers change, and forget what it
   // cached (the new buffers carry their own episode counters)
   if (!drain_prepare(s)) return SO101_ERR_HIP;
-  if (s->bound && s->prep.tag && !hip_ok(s, hipMemset(s->prep.tag, 0xFF, sizeof(int) * (size_t)s->n_envs), "hipMemset(prep)")) return SO101_ERR_HIP;
+  if (s->bound && s->prep.tag && !hip_ok(s, hipMemset(s->prep.tag, 0xFF, sizeof(int) * 2 * (size_t)s->n_envs), "hipMemset(prep)")) return SO101_ERR_HIP;
   s->buf.qpos = b->qpos; s->buf.qvel = b->qvel; s->buf.ctrl = b->ctrl; s->buf.warm = b->warmstart; s->buf.ring = b->obs_ring;
   s->buf.ep_return = b->ep_return; s->buf.step_count = b->step_count; s->buf.episode = b->episode;
   s->buf.mass_scale = b->mass_scale;

@@ -15,20 +15,27 @@ __global__ void __launch_bounds__(64, 2) k_prepare(const DevModel* m, StepParams
     if (lane == 0) e = atomicAdd(C.cursor, 1);
     e = wave_uniform_i(e);
     if (e >= N) break;
-    int target = __atomic_load_n(&B.episode[e], __ATOMIC_ACQUIRE);
-    if (__atomic_load_n(&C.tag[e], __ATOMIC_ACQUIRE) == target) continue;
-    if ((unsigned int)target - (unsigned int)C.store_first < (unsigned int)C.store_count) continue;     // in the settled-state store
-    if (lane == 0) { L.overflow = 0; L.t_collision = 0; L.t_solve = 0; }
-    load_env_constants(L, B, e, N);
-    env_settle<SOLVER>(m, L, P, e, (unsigned int)target);
-    wave_sync();
-    if (lane < NQ) C.qpos[(size_t)lane * N + e] = L.qpos[lane];
-    if (lane < NV) { C.qvel[(size_t)lane * N + e] = L.qvel[lane]; C.warm[(size_t)lane * N + e] = L.warm[lane]; }
-    if (lane == 0) C.flags[e] = L.overflow;
-    __threadfence();
-    wave_sync();
-    if (lane == 0) __atomic_store_n(&C.tag[e], target, __ATOMIC_RELEASE);
-    wave_sync();
+    // the next episode and the one after it; an entry is only overwritten when its episode lies behind the env's
+    // counter, i.e. after env_reset() has consumed it (the counter is bumped after the entry has been read)
+    int next = __atomic_load_n(&B.episode[e], __ATOMIC_ACQUIRE);
+#pragma unroll 1
+    for (int ahead = 0; ahead < 2; ahead++) {
+      int target = next + ahead;
+      size_t slot = (unsigned int)target & 1u;
+      if (__atomic_load_n(&C.tag[slot * N + e], __ATOMIC_ACQUIRE) == target) continue;
+      if ((unsigned int)target - (unsigned int)C.store_first < (unsigned int)C.store_count) continue;     // in the settled-state store
+      if (lane == 0) { L.overflow = 0; L.t_collision = 0; L.t_solve = 0; }
+      load_env_constants(L, B, e, N);
+      env_settle<SOLVER>(m, L, P, e, (unsigned int)target);
+      wave_sync();
+      if (lane < NQ) C.qpos[(slot * NQ + lane) * N + e] = L.qpos[lane];
+      if (lane < NV) { C.qvel[(slot * NV + lane) * N + e] = L.qvel[lane]; C.warm[(slot * NV + lane) * N + e] = L.warm[lane]; }
+      if (lane == 0) C.flags[slot * N + e] = L.overflow;
+      __threadfence();
+      wave_sync();
+      if (lane == 0) __atomic_store_n(&C.tag[slot * N + e], target, __ATOMIC_RELEASE);
+      wave_sync();
+    }
   }
 }
 

@@ -135,10 +135,15 @@ struct DevBuffers {
 // episode that is about to start; otherwise env_reset() settles in place.  Either way the result is the same
 // bits, only the time at which the work is done differs.
 struct PrepBuffers {
-  float *qpos, *qvel, *warm;   // [NQ|NV|NV][n_envs]
-  int *tag;                    // episode index the entry belongs to, -1 = empty
+  // Two entries per env (slot = episode & 1): the next episode's settled state and the one after it.  When every env
+  // passes its time limit on the same control step, the whole cache is consumed at once and refilling it takes ~2 s in
+  // the background; an env whose physics diverge inside that window resets a second time, and with one entry per env it
+  // had to settle inside the step call (one wavefront, 1000 substeps, ~130 ms - measured 42 ms per control step over the
+  // 50 steps after a mass reset).  The second entry covers that reset.
+  float *qpos, *qvel, *warm;   // [2][NQ|NV|NV][n_envs]
+  int *tag;                    // [2][n_envs] episode index the entry belongs to, -1 = empty
   int *cursor;                 // work-queue head of k_prepare
-  int *flags;                  // [n_envs] flag word of the settle that produced the entry (placement / settle failures)
+  int *flags;                  // [2][n_envs] flag word of the settle that produced the entry (placement / settle failures)
   // Reset pool (so101_set_reset_pool): when pool_size > 0 an episode starts from pool entry
   // floor(u * pool_size), u = rng_uniform(seed, env id, episode, draw 1000), instead of placement + settle
   const float *pool_qpos, *pool_qvel, *pool_ctrl;   // [NQ|NV|NU][pool_size]
