@@ -284,7 +284,7 @@ def main():
                              "wait_fraction": pmc.get("wait_fraction"), "source": f"profiles/pmc_{build_hash}.json"},
                          "note": "HBM fraction as the metric asks: algorithmic bytes (620 B/env-step x envs) / device time of the step's launch "
                                  "chain / MEASURED device-to-device copy bandwidth of this GPU; the path is bound by dependent-issue latency of "
-                                 "wave-level geometry / solver code, not by HBM (DESIGN.md section 6); `compute` = VALU wave-instructions x 64 lanes "
+                                 "wave-level geometry / solver code, not by HBM (DESIGN.md section 7); `compute` = VALU wave-instructions x 64 lanes "
                                  "x 2 flop over the same time against the fp32 vector peak, from the PMC pass of this exact build when one is committed"},
             "diag_mean": {k2: float(stats[k]) / max(stats["samples"], 1) for k, k2 in (("ncon", "contacts"), ("nefc", "constraint_rows"), ("iters", "solver_iterations"), ("ncand", "narrowphase_candidates"))},
             "events_per_env_step": {k: v / env_steps for k, v in events.items()},
