@@ -44,7 +44,9 @@ for lo_, hi_ in ((1, 5), (5, 9), (9, 13), (13, 20), (20, 33), (33, 65)):
 nc_ = torch.zeros(N, dtype=torch.int32, device=s.dev); cand_ = torch.zeros(N, 256, dtype=torch.int32, device=s.dev)
 tk_ = torch.zeros(N, 256, dtype=torch.int32, device=s.dev); cr_ = torch.zeros(N, 256, 24, device=s.dev)
 s.sim.debug_candidates(nc_.data_ptr(), cand_.data_ptr(), tk_.data_ptr(), cr_.data_ptr()); torch.cuda.synchronize()
-ph = tk_.cpu().numpy()[:, 248:256].astype(np.int64) * 1e-2
+ph = tk_.cpu().numpy()[:, 240:256].astype(np.int64) * 1e-2
 print("solver phases (us per env-substep, mean; per iteration): setup gradient hessian factor solve linesearch cost")
 print("   mean  ", " ".join("%6.2f" % x for x in ph[:, :7].mean(0)), " total %.1f" % ph[:, :7].sum(1).mean())
 print("   /iter ", " ".join("%6.2f" % x for x in (ph[:, :7] / np.maximum(it, 1)[:, None]).mean(0)))
+print("next-substep phase (us, mean): state store %.2f  kinematics %.2f  geom boxes %.2f  pair list %.2f  oriented boxes %.2f  publish %.2f" % tuple(ph[:, 8:14].mean(0)))
+print("pair list split (us, mean): burst load of the pair words %.2f  box tests %.2f  (compaction = pair list - both)" % tuple(ph[:, 14:16].mean(0)))

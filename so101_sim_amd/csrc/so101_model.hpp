@@ -96,7 +96,8 @@ struct NewtonScratch {          // LDS working set of solve_newton(): the vector
   float H[NVS][NVS + 1];
   float x[NVS], xs[NVS], xw[NVS], tmp[NVS], search[NVS];
 #ifdef SO101_DEBUG_CLOCKS
-  unsigned int prof[8];        // profiling builds: wall-clock ticks per solver phase (setup, gradient, Hessian, factor, solve, line search, cost, -)
+  unsigned int prof[16];       // profiling builds: wall-clock ticks per solver phase (setup, gradient, Hessian, factor, solve, line search, cost, -)
+                               // and, [8..], of the next substep's broadphase (state store, kinematics, geom boxes, pair list, oriented boxes, publish)
 #endif
 };
 
@@ -111,7 +112,10 @@ struct EnvLDS {
   // collision-phase scratch (geom boxes, broadphase candidates) shares storage with the arm-contact Jacobian
   // pool: the pool is first written by make_constraints(), after collision() has consumed boxes and candidates
   union {
-    struct { float aabb[MAXGEOM][8]; unsigned short cand[MAXCAND][2]; };     // lo xyz, pad, hi xyz, pad: two 16-byte reads per geom
+    // world boxes component-major (lo xyz, hi xyz): lanes test consecutive geoms, so consecutive lanes read consecutive
+    // banks (geom-major rows of 32 bytes were read with ds_read_b32 at a 32-byte lane stride: 8-way bank conflicts,
+    // 11.5 of the 13.5 us the pair list cost per env-substep)
+    struct { float aabb[6][MAXGEOM]; unsigned short cand[MAXCAND][2]; };
     ArmCon armcon[MAXARMCON];
   };
   Contact con[MAXCON];

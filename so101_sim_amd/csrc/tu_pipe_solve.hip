@@ -112,14 +112,20 @@ __global__ void __launch_bounds__(64, 2) k_pipe_solve(const DevModel* m, StepPar
   if (!last) {
     store_state_aos(L, W, e);
     if (!diverged) {
+      unsigned long long q0 = SO101_CLOCK();
       kinematics(m, L);
+      unsigned long long q1 = SO101_CLOCK();
       broadphase(m, L);
+      unsigned long long q2 = SO101_CLOCK();
       publish_candidates(L, W, e, N, s + 1);
+#ifdef SO101_DEBUG_CLOCKS
+      if (lane == 0) { L.nw.prof[8] = (unsigned int)(q0 - c5); L.nw.prof[9] = (unsigned int)(q1 - q0); L.nw.prof[13] = (unsigned int)(SO101_CLOCK() - q2); }
+#endif
     } else if (lane == 0) W.ncand[e] = 0;
     if (lane == 0) {
       if (L.overflow) E.flags[e] |= L.overflow;          // rare; summed into the event counters by finish_step()
 #ifdef SO101_DEBUG_CLOCKS
-      for (int k = 0; k < 8; k++) W.ticks[(size_t)e * MAXCAND + 248 + k] = L.nw.prof[k];      // (solver phases; slots of candidates 248+ are idle)
+      for (int k = 0; k < 16; k++) W.ticks[(size_t)e * MAXCAND + 240 + k] = L.nw.prof[k];      // (solver / broadphase phases; slots of candidates 240+ are idle)
 #endif
       if (SO101_CLOCKS_ON) {
         unsigned int* st = W.stage + (size_t)e * 8;
