@@ -238,24 +238,45 @@ DEV void crba_arm(const DevModel* m, EnvLDS& L) {
 #pragma unroll
     for (int i = 0; i < 6; i++) Ic[k][i] = cI[i];
   }
-  // M[j][k], k<=j: lane e owns entry e of the packed lower triangle (21 entries)
+  // M[j][k], k <= j: lane e computes entry e of the packed lower triangle (21 entries) from the composites, which lane 0
+  // parks in LDS (the Newton scratch is idle here).  Every lane used to compute all 21 entries on identical values.
+  float* park = &L.nw.H[0][0];                       // [NARM][10]: mass, COM, inertia of sub-chain j..5
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < NARM; j++) {
+      park[10 * j] = mc[j];
+#pragma unroll
+      for (int i = 0; i < 3; i++) park[10 * j + 1 + i] = Cc[j][i];
+#pragma unroll
+      for (int i = 0; i < 6; i++) park[10 * j + 4 + i] = Ic[j][i];
+    }
+  }
+  wave_sync();
+  if (lane < NARM * (NARM + 1) / 2) {
+    int j = 0;
+#pragma unroll
+    for (int t = 1; t < NARM; t++) j += lane >= t * (t + 1) / 2 ? 1 : 0;
+    int k = lane - j * (j + 1) / 2;
+    const float* pj = park + 10 * j;
+    float mcj = pj[0], Ccj[3] = {pj[1], pj[2], pj[3]}, Icj[6] = {pj[4], pj[5], pj[6], pj[7], pj[8], pj[9]};
+    float ak[3] = {L.axis[k][0], L.axis[k][1], L.axis[k][2]};
+    float aj[3] = {L.axis[j][0], L.axis[j][1], L.axis[j][2]};
+    float rk[3] = {Ccj[0] - L.xpos[k][0], Ccj[1] - L.xpos[k][1], Ccj[2] - L.xpos[k][2]};
+    float rj[3] = {Ccj[0] - L.xpos[j][0], Ccj[1] - L.xpos[j][1], Ccj[2] - L.xpos[j][2]};
+    float hl[3]; cross3(hl, ak, rk);
+    hl[0] *= mcj; hl[1] *= mcj; hl[2] *= mcj;
+    float ha[3]; symvec3(ha, Icj, ak);
+    float t3[3]; cross3(t3, rj, hl);
+    float v = aj[0] * (ha[0] + t3[0]) + aj[1] * (ha[1] + t3[1]) + aj[2] * (ha[2] + t3[2]);
+    if (j == k) v += m->armature[j];
+    L.Marm[j][k] = v; L.Marm[k][j] = v;
+  }
+  wave_sync();
   float Mfull[NARM][NARM];
 #pragma unroll
   for (int j = 0; j < NARM; j++)
 #pragma unroll
-    for (int k = 0; k <= j; k++) {
-      float ak[3] = {L.axis[k][0], L.axis[k][1], L.axis[k][2]};
-      float aj[3] = {L.axis[j][0], L.axis[j][1], L.axis[j][2]};
-      float rk[3] = {Cc[j][0] - L.xpos[k][0], Cc[j][1] - L.xpos[k][1], Cc[j][2] - L.xpos[k][2]};
-      float rj[3] = {Cc[j][0] - L.xpos[j][0], Cc[j][1] - L.xpos[j][1], Cc[j][2] - L.xpos[j][2]};
-      float hl[3]; cross3(hl, ak, rk);
-      hl[0] *= mc[j]; hl[1] *= mc[j]; hl[2] *= mc[j];
-      float ha[3]; symvec3(ha, Ic[j], ak);
-      float t[3]; cross3(t, rj, hl);
-      float v = aj[0] * (ha[0] + t[0]) + aj[1] * (ha[1] + t[1]) + aj[2] * (ha[2] + t[2]);
-      if (j == k) v += m->armature[j];
-      Mfull[j][k] = v; Mfull[k][j] = v;
-    }
+    for (int k = 0; k <= j; k++) { float v = L.Marm[j][k]; Mfull[j][k] = v; Mfull[k][j] = v; }
   // Cholesky (uniform) then lane c solves for column c of the inverse
   float Lc[NARM][NARM];
 #pragma unroll
@@ -292,12 +313,6 @@ DEV void crba_arm(const DevModel* m, EnvLDS& L) {
     }
 #pragma unroll
     for (int i = 0; i < NARM; i++) L.Minv[i][lane] = x[i];
-  }
-  if (lane == 0) {          // constant indices only: a lane-indexed read would push Mfull into scratch memory
-#pragma unroll
-    for (int i = 0; i < NARM; i++)
-#pragma unroll
-      for (int j = 0; j < NARM; j++) L.Marm[i][j] = Mfull[i][j];
   }
   wave_sync();
 }
@@ -1291,44 +1306,55 @@ DEV void arm_jac_row(const EnvLDS& L, int link, const float* p, const float* u, 
 // joint-space Jacobian rows in the LDS pool.  What only PGS needs (the diagonal blocks of A) is built by solve_pgs().
 DEV void make_constraints(const DevModel* m, EnvLDS& L) {
   int lane = wave_lane();
-  // ---- scalar rows: frictionloss (dof order) then active joint limits (joint order) — lane 0 builds the list
-  if (lane == 0) {
-    int n = 0;
-    for (int d = 0; d < NARM; d++) if (m->frictionloss[d] > 0.f) {
-      Row1& r = L.row[n++];
-      float imp = impedance(m->dof_solimp, 0.f), K, B;
-      kb_from_solref(m, m->dof_solref, m->dof_solimp, &K, &B);
-      r.dof = d; r.sign = 1.f; r.floss = m->frictionloss[d];
-      r.R = fmaxf(MINVAL_F, (1.f - imp) * m->dof_invweight0[d] / imp);
-      r.aref = -B * L.qvel[d];
-      r.f = 0.f; r.Ainv = 1.f / (L.Minv[d][d] + r.R);
-    }
-    for (int h = 0; h < NARM; h++) if (m->limited[h]) {
-      float q = L.qpos[h];
-      for (int side = 0; side < 2; side++) {
+  // ---- scalar rows: frictionloss (dof order) then active joint limits (joint order).  Lane d < 6 proposes dof d's
+  // frictionloss row, lane 8 + 2 h + side the limit row of joint h; the active ones are compacted in lane order, which is
+  // the list order above.  (One lane used to build the list in a loop: six impedance / solref evaluations in series.)
+  {
+    bool active = false;
+    Row1 r; r.dof = 0; r.sign = 0.f; r.R = 1.f; r.aref = 0.f; r.floss = 0.f; r.f = 0.f; r.Ainv = 0.f; r.pad = 0.f;
+    if (lane < NARM) {
+      int d = lane;
+      if (m->frictionloss[d] > 0.f) {
+        float imp = impedance(m->dof_solimp, 0.f), K, B;
+        kb_from_solref(m, m->dof_solref, m->dof_solimp, &K, &B);
+        r.dof = d; r.sign = 1.f; r.floss = m->frictionloss[d];
+        r.R = fmaxf(MINVAL_F, (1.f - imp) * m->dof_invweight0[d] / imp);
+        r.aref = -B * L.qvel[d];
+        r.f = 0.f; r.Ainv = 1.f / (L.Minv[d][d] + r.R);
+        active = true;
+      }
+    } else if (lane >= 8 && lane < 8 + 2 * NARM) {
+      int h = (lane - 8) >> 1, side = (lane - 8) & 1;
+      if (m->limited[h]) {
+        float q = L.qpos[h];
         float pos = side == 0 ? q - m->range[h][0] : m->range[h][1] - q;
         if (pos < 0.f) {
-          Row1& r = L.row[n++];
           float imp = impedance(m->jnt_solimp, pos), K, B;
           kb_from_solref(m, m->jnt_solref, m->jnt_solimp, &K, &B);
           r.dof = h; r.sign = side == 0 ? 1.f : -1.f; r.floss = 0.f;
           r.R = fmaxf(MINVAL_F, (1.f - imp) * m->dof_invweight0[h] / imp);
           r.aref = -B * r.sign * L.qvel[h] - K * imp * pos;
           r.f = 0.f; r.Ainv = 1.f / (L.Minv[h][h] + r.R);
+          active = true;
         }
       }
     }
-    L.nrow = n;
-    // arm-pool slots for contacts that touch an arm link (in contact order)
-    int slots = 0;
-    for (int k = 0; k < L.ncon; k++) {
-      Contact& c = L.con[k];
-      if ((c.d1 >= 0 && c.d1 < NARM) || (c.d2 >= 0 && c.d2 < NARM)) {
-        if (slots < MAXARMCON) c.armslot = slots++;
-        else { c.armslot = -2; L.overflow |= 4; }    // pool exhausted: contact is dropped below
-      }
+    unsigned long long mask = wave_ballot(active);
+    if (active) L.row[wave_prefix(mask)] = r;
+    // arm-pool slots for contacts that touch an arm link (in contact order): lane = contact
+    bool arm = false;
+    if (lane < L.ncon) { const Contact& c = L.con[lane]; arm = (c.d1 >= 0 && c.d1 < NARM) || (c.d2 >= 0 && c.d2 < NARM); }
+    unsigned long long amask = wave_ballot(arm);
+    if (arm) {
+      int slot = wave_prefix(amask);
+      L.con[lane].armslot = slot < MAXARMCON ? slot : -2;      // pool exhausted: the contact is dropped below
     }
-    L.narmcon = slots;
+    int narm = __popcll(amask);
+    if (lane == 0) {
+      L.nrow = __popcll(mask);
+      L.narmcon = narm < MAXARMCON ? narm : MAXARMCON;
+      if (narm > MAXARMCON) L.overflow |= 4;
+    }
   }
   wave_sync();
   // ---- contact rows: lane = contact
