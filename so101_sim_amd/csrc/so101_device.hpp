@@ -144,6 +144,28 @@ DEV void rotsym(float* o, const float* R, const float* s) {
 }
 DEV int tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
+// world inertia of every dynamic body (lane-parallel)
+DEV void world_inertias(const DevModel* m, EnvLDS& L) {
+  int lane = wave_lane();
+  if (lane < NDYN) {
+    const float* Ib = lane < NARM ? m->arm_Ib[lane] : m->free_Ib[lane - NARM];
+    float sc = lane < NARM ? 1.f : L.fscale[lane - NARM];      // per-env prop mass scale: mass and inertia scale together
+    float o[6]; rotsym(o, L.xmat[lane], Ib);
+#pragma unroll
+    for (int i = 0; i < 6; i++) L.Iw[lane][i] = sc * o[i];
+    if (lane >= NARM) {
+      int f = lane - NARM;
+      float oi[6]; rotsym(oi, L.xmat[lane], m->free_Ibinv[f]);
+      float isc = 1.f / sc;
+#pragma unroll
+      for (int i = 0; i < 6; i++) L.fIinv[f][i] = isc * oi[i];
+      L.fmass[f] = sc * m->free_mass[f];
+      L.fminv[f] = 1.f / L.fmass[f];
+    }
+  }
+  wave_sync();
+}
+
 // ------------------------------------------------------------------ kinematics (uniform)
 DEV void kinematics(const DevModel* m, EnvLDS& L) {
   int lane = wave_lane();
@@ -184,24 +206,41 @@ DEV void kinematics(const DevModel* m, EnvLDS& L) {
     for (int i = 0; i < 9; i++) L.xmat[b][i] = Rf[i];
   }
   wave_sync();
-  // world inertia of every dynamic body (lane-parallel)
-  if (lane < NDYN) {
-    const float* Ib = lane < NARM ? m->arm_Ib[lane] : m->free_Ib[lane - NARM];
-    float sc = lane < NARM ? 1.f : L.fscale[lane - NARM];      // per-env prop mass scale: mass and inertia scale together
-    float o[6]; rotsym(o, L.xmat[lane], Ib);
-#pragma unroll
-    for (int i = 0; i < 6; i++) L.Iw[lane][i] = sc * o[i];
-    if (lane >= NARM) {
-      int f = lane - NARM;
-      float oi[6]; rotsym(oi, L.xmat[lane], m->free_Ibinv[f]);
-      float isc = 1.f / sc;
-#pragma unroll
-      for (int i = 0; i < 6; i++) L.fIinv[f][i] = isc * oi[i];
-      L.fmass[f] = sc * m->free_mass[f];
-      L.fminv[f] = 1.f / L.fmass[f];
-    }
+  world_inertias(m, L);
+}
+
+// Kinematics of a state whose body poses are already known (the pipelined step publishes them for the narrowphase at
+// the end of the previous kernel): poses from global memory, then the derived quantities one body per lane - joint axes,
+// COM positions, world inertias - with the same expressions kinematics() uses, so the bits are the same.  Replaces the
+// serial walk down the arm (every lane on identical values, ~900 dependent instructions) by ~50.
+DEV void kinematics_from_pose(const DevModel* m, EnvLDS& L, const float* pose /* [NDYN][12]: xpos, xmat */) {
+  int lane = wave_lane();
+  for (int i = lane; i < NDYN * 12; i += WAVE) {
+    int b = i / 12, j = i % 12;
+    float v = pose[i];
+    if (j < 3) L.xpos[b][j] = v; else L.xmat[b][j - 3] = v;
   }
   wave_sync();
+  if (lane < NARM) {
+    int k = lane;
+    float R[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) R[i] = L.xmat[k][i];
+    float ax[3]; matvec3(ax, R, m->arm_axis[k]);
+    float ip[3]; matvec3(ip, R, m->arm_ipos[k]);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { L.axis[k][i] = ax[i]; L.xipos[k][i] = L.xpos[k][i] + ip[i]; }
+  } else if (lane < NDYN) {
+    int f = lane - NARM, b = lane;
+    float Rf[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) Rf[i] = L.xmat[b][i];
+    float ip[3]; matvec3(ip, Rf, m->free_ipos[f]);
+#pragma unroll
+    for (int i = 0; i < 3; i++) L.xipos[b][i] = L.xpos[b][i] + ip[i];
+  }
+  wave_sync();
+  world_inertias(m, L);
 }
 
 // ------------------------------------------------------------------ CRBA + inverse of the arm block

@@ -89,7 +89,10 @@ __global__ void __launch_bounds__(64, 2) k_pipe_solve(const DevModel* m, StepPar
   load_state_aos(L, B, W, e, N);
   bool diverged = act == 2;
   if (!diverged) {
-    forward_smooth(m, L);
+    // (the poses of this state were published for the narrowphase by the kernel that produced it)
+    kinematics_from_pose(m, L, W.pose + (size_t)e * (NDYN * 12));
+    crba_arm(m, L);
+    smooth_dynamics(m, L);
     c1 = SO101_CLOCK();
     gather_contacts(m, L, W, e);
     c2 = SO101_CLOCK();
