@@ -33,3 +33,10 @@ for a, b, x in zip(g1, g2, t):
     agg[k][0] += 1; agg[k][1] += x
 for k, (n, tot) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
     print("  %-50s n %6d  total %.1f ms  mean %.2f us" % (k, n, tot * 1e-3, tot / n))
+
+ph = tk[:, 224:230].astype(np.float64)
+tot = ph.sum(0)                      # accumulated over every substep of the run
+whole = tot[0] + tot[5]
+print("narrowphase time by phase (share of fetch + narrow_pair): fetch of the work item and both geoms %.1f %% | hull vertices into registers %.1f %% | "
+      "flat-face scan incl. patch pass %.1f %% | MPR %.1f %% | contact output %.1f %%" % (100 * tot[0] / whole, 100 * tot[1] / whole, 100 * tot[2] / whole,
+      100 * tot[3] / whole, 100 * (tot[5] - tot[1] - tot[2] - tot[3]) / whole))

@@ -1049,12 +1049,20 @@ DEV void support_patch(const DevModel* m, const GeomW& G, const float* f, const 
       if (s > best[k]) { best[k] = s; bi[k] = i; }
     }
   }
+  // the five reductions first, then the five winners' coordinates in one burst of loads (fetching each winner right
+  // after its reduction put five L2 round trips in series), then the transforms
+#pragma unroll
+  for (int k = 0; k < NCPP; k++) GP::argmax(best[k], bi[k]);
+  float loc[NCPP][3];
 #pragma unroll
   for (int k = 0; k < NCPP; k++) {
-    GP::argmax(best[k], bi[k]);
     int w = (unsigned int)bi[k] < (unsigned int)G.vnum ? bi[k] : 0;       // (a non-finite direction selects nothing)
-    float loc[3] = {x[w], y[w], z[w]}, wv[3];
-    matvec3(wv, G.R, loc);
+    loc[k][0] = x[w]; loc[k][1] = y[w]; loc[k][2] = z[w];
+  }
+#pragma unroll
+  for (int k = 0; k < NCPP; k++) {
+    float wv[3];
+    matvec3(wv, G.R, loc[k]);
     P.p[k][0] = G.p[0] + wv[0]; P.p[k][1] = G.p[1] + wv[1]; P.p[k][2] = G.p[2] + wv[2];
   }
 }
@@ -1182,6 +1190,8 @@ DEV void scan_faces(const DevModel* m, const GeomW& GR, const GeomW& GI, const C
 #pragma unroll
     for (int k = 0; k < 3; k++) { R.f[k] = f[k]; R.c[k] = c[k]; R.u[k] = u[k]; R.v[k] = v[k]; }
     // the face is (so far) the reference face: its five patch samples in one more pass over the incident hull
+    // (taking them in the same pass that finds a0 for the face visited first measured no faster: 1.257 M vs 1.261 M
+    // env-steps/s at 32768 envs - the passes over the hull are not what a candidate's 5-10 us go into)
     Patch5 P;
     support_patch<Cache, GP>(m, GI, f, u, v, P, HI);
 #pragma unroll
@@ -1191,10 +1201,19 @@ DEV void scan_faces(const DevModel* m, const GeomW& GR, const GeomW& GI, const C
 
 // Narrowphase of one candidate pair (geom types ordered): up to NCPP contacts sharing one normal (geom1 -> geom2),
 // each with its penetration distance (< 0) and position.
+#ifdef SO101_DEBUG_CLOCKS
+#define QPROF(k) { unsigned long long qn_ = SO101_CLOCK(); if (prof && wave_lane() == 0) atomicAdd(&prof[k], (unsigned int)(qn_ - qp_)); qp_ = qn_; }
+#else
+#define QPROF(k)
+#endif
 template <class Cache, class GP = G64>
-DEV void narrow_pair(const DevModel* m, const GeomW& G1, const GeomW& G2, int g1, int g2, PairContacts& out) {
+DEV void narrow_pair(const DevModel* m, const GeomW& G1, const GeomW& G2, int g1, int g2, PairContacts& out, unsigned int* prof = nullptr) {
+#ifdef SO101_DEBUG_CLOCKS
+  unsigned long long qp_ = SO101_CLOCK();
+#endif
   Cache H1, H2;
   hull_load<GP>(m, G1, H1); hull_load<GP>(m, G2, H2);
+  QPROF(1)
   out.valid = 0u; out.nrm[0] = out.nrm[1] = out.nrm[2] = 0.f;
 #pragma unroll
   for (int j = 0; j < NCPP; j++) { out.dist[j] = 0.f; out.pos[j][0] = out.pos[j][1] = out.pos[j][2] = 0.f; }
@@ -1216,6 +1235,7 @@ DEV void narrow_pair(const DevModel* m, const GeomW& G1, const GeomW& G2, int g1
   for (int k = 0; k < NCPP; k++) { best.P.p[k][0] = 0.f; best.P.p[k][1] = 0.f; best.P.p[k][2] = 0.f; }
   scan_faces<Cache, GP>(m, G1, G2, H2, 0, best);
   if (!best.separated && !best.exact) scan_faces<Cache, GP>(m, G2, G1, H1, 1, best);
+  QPROF(2)
   if (best.separated) return;
   float depth = 0.f, nrm[3] = {0.f, 0.f, 0.f}, pos[3] = {0.f, 0.f, 0.f};
   if (!best.exact) {
@@ -1226,6 +1246,7 @@ DEV void narrow_pair(const DevModel* m, const GeomW& G1, const GeomW& G2, int g1
     if (!ok || !(depth > 0.f)) return;
     if (best.side >= 0 && !(best.depth <= depth * (1.f + FACE_DEPTH_REL) + FACE_DEPTH_ABS)) best.side = -1;
   }
+  QPROF(3)
   int ref = best.side;
   bool patched = false;
   if (ref >= 0) patched = face_patch(best.P, best.f, best.c, best.u, best.v, best.hu, best.hv, PATCH_DUP * fminf(rb1, rb2), out);

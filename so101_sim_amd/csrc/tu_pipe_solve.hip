@@ -39,7 +39,15 @@ __global__ void __launch_bounds__(64, 2) k_narrow(const DevModel* m, int N, Pipe
       GeomW G1, G2;
       load_geom_at(m, g1, p1, p1 + 3, G1); load_geom_at(m, g2, p2, p2 + 3, G2);
       PairContacts pc;
+#ifdef SO101_DEBUG_CLOCKS
+      unsigned int* nprof = W.ticks + (size_t)e * MAXCAND + 224;      // per-env sums: [0] fetch, [1] hull load, [2] face scan, [3] MPR, [4] rest
+      if (lane == 0) atomicAdd(&nprof[0], (unsigned int)(SO101_CLOCK() - t0));
+      unsigned long long t1 = SO101_CLOCK();
+      narrow_pair<HullCache>(m, G1, G2, g1, g2, pc, nprof);
+      if (lane == 0) atomicAdd(&nprof[5], (unsigned int)(SO101_CLOCK() - t1));
+#else
       narrow_pair<HullCache>(m, G1, G2, g1, g2, pc);
+#endif
       if (lane == 0) {
         float* r = W.conres + (size_t)w * CONRES_DIM;
         r[0] = (float)__popc(pc.valid); r[1] = pc.nrm[0]; r[2] = pc.nrm[1]; r[3] = pc.nrm[2];
