@@ -35,46 +35,55 @@ VALU_PEAK_TFLOPS = 157.3           # MI355X_MICROARCH.md: fp32 vector peak (256 
 DEFAULT_ENVS = {"handover": 4096, "pickplace": 16384, "mixed": 32768}
 
 
-def cpu_baseline(seconds_budget: float = 12.0):
-    """The fp64 oracle (a port: MuJoCo is not installable here) stepping the handover workload on the host: 1 env
-    on ONE core, then one env per core on ALL cores (ctypes releases the GIL, one oracle handle per thread)."""
-    import threading
+def cpu_baseline(envs_per_worker: int = 64, steps: int = 6, reps: int = 5):
+    """The fp64 oracle (a port: MuJoCo is not installable here) on the host cores: C++ threads inside the oracle
+    library (oracle/so101_oracle.cpp orc_bench_rollout), `envs_per_worker` envs per thread, 1 thread and then one thread
+    per core.  Times placement + settle of every env, then `reps` repetitions of `steps` control steps of every env
+    under uniform random actions, for two solver settings: the GPU's (Newton, 100 iterations, tolerance 1e-8) and a
+    fixed-iteration one (Newton, 4 iterations, tolerance 0: above the GPU's measured mean of 2.5-3.2).  `value` =
+    env-steps/s on all cores at the GPU's setting with the reset amortised over 500-step episodes."""
+    import ctypes as C
     import numpy as np
     from so101_sim_amd.model import scenes
-    from oracle.oracle import Oracle
+    from oracle import oracle as orc
     raw64, _ = scenes.load_blob("banana", "f64")
-    lo = np.array([-np.pi, -3.14158, -3.14158, -3.14158, -3.14158, 0.0])
-    hi = np.array([np.pi, 3.14158, 3.14158, 3.14158, 3.14158, 0.08])
-
-    def worker(idx, budget, out):
-        o = Oracle(raw64)
-        o.env_config(seed=0, env_id=idx, last_step=500)
-        rng = np.random.RandomState(1 + idx)
-        t0 = time.perf_counter()
-        o.env_reset()
-        steps = 0
-        while time.perf_counter() - t0 < budget:          # episodes follow each other through the auto-reset
-            o.env_step(rng.uniform(lo, hi))
-            steps += 1
-        out[idx] = (steps, time.perf_counter() - t0)
-
-    one = {}
-    worker(0, seconds_budget, one)
+    L = orc.lib()
+    L.orc_bench_rollout.restype = C.c_longlong
+    L.orc_bench_rollout.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int),
+                                    C.POINTER(C.c_double), C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    settings = [("newton_100it_tol1e-8", 100, 1e-8), ("newton_fixed_4it", 4, 0.0)]
+    its = (C.c_int * 2)(*[x[1] for x in settings])
+    tol = (C.c_double * 2)(*[x[2] for x in settings])
     ncpu = os.cpu_count() or 1
-    many = {}
-    th = [threading.Thread(target=worker, args=(i, seconds_budget, many)) for i in range(ncpu)]
-    t0 = time.perf_counter()
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    wall = time.perf_counter() - t0
-    total = sum(s for s, _ in many.values())
-    return {"value": total / wall, "unit": "env-steps/s", "cores": ncpu, "kind": "port",
-            "single_core_value": one[0][0] / one[0][1], "nproc": ncpu,
-            "sample": f"handover workload (uniform random actions, 500-step episodes, auto-reset + settle included), fp64 oracle, Newton "
-                      f"solver: 1 env on 1 core for {one[0][1]:.1f} s ({one[0][0]} steps), then 1 env per core on {ncpu} cores for {wall:.1f} s "
-                      f"({total} steps)"}
+
+    def leg(threads):
+        rs = C.c_double(0.0)
+        rep = (C.c_double * (2 * reps))()
+        n = L.orc_bench_rollout(raw64, len(raw64), threads, envs_per_worker, steps, reps, 2, its, tol, 0, C.byref(rs), rep)
+        if n <= 0:
+            raise RuntimeError("orc_bench_rollout failed")
+        out = {"threads": threads, "envs": threads * envs_per_worker, "reset_seconds": rs.value,
+               "reset_seconds_per_env_per_core": rs.value / envs_per_worker}
+        for k, (name, _, _) in enumerate(settings):
+            r = np.array([n / rep[k * reps + j] for j in range(reps)])
+            # one 500-step episode of one env costs 500 steps + one reset on its core
+            step_s = threads / r.mean()                      # seconds of one core per env-step
+            amort = threads * 500.0 / (500.0 * step_s + rs.value / envs_per_worker)
+            out[name] = {"env_steps_per_s_mean": float(r.mean()), "env_steps_per_s_std": float(r.std()), "reps": reps,
+                         "with_reset_amortised_over_500_steps": float(amort)}
+        return out
+
+    one, many = leg(1), leg(ncpu)
+    key = settings[0][0]
+    eff = many[key]["env_steps_per_s_mean"] / (ncpu * one[key]["env_steps_per_s_mean"])
+    return {"value": many[key]["with_reset_amortised_over_500_steps"], "unit": "env-steps/s", "cores": ncpu, "kind": "port",
+            "label": "CPU restatement baseline (MuJoCo unavailable)",
+            "single_core_value": one[key]["with_reset_amortised_over_500_steps"], "parallel_efficiency": eff,
+            "one_thread": one, "all_threads": many,
+            "sample": f"handover workload, fp64 oracle, C++ threads, {envs_per_worker} envs per thread: placement + settle of every env "
+                      f"(timed on its own), then {reps} repetitions of {steps} control steps of every env under uniform random actions "
+                      f"per solver setting (first steps of the episode: ~9 contacts per env); 1 thread, then {ncpu} threads; "
+                      f"value = all threads, GPU solver setting, reset amortised over 500-step episodes; mean +- std over the repetitions inside"}
 
 
 def measure_hbm_copy(torch, dev, mib=2048, reps=5):
@@ -106,6 +115,40 @@ def load_pmc(build_hash):
     return None
 
 
+def spawn_ranks(n: int) -> int:
+    """`bench.py --gpus N` launched plainly: start N fresh rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set, one GPU each, RCCL or gloo rendezvous on 127.0.0.1), wait for them and relay rank 0's JSON line.  This
+    parent never imports torch and never touches HIP; nothing re-execs."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True if r == 0 else None))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [q.wait() for q in procs[1:]]
+    sys.stdout.write(out or "")
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
+    if bad:
+        sys.stderr.write(f"bench.py: rank(s) failed: {bad}\n")
+        return 1
+    return 0
+
+
+def resolve_factory(spec: str):
+    """`module:callable` -> callable(name, n_envs, env_id_base, device, **kw) (tests stub the env with it)."""
+    import importlib
+    mod, _, fn = spec.partition(":")
+    return getattr(importlib.import_module(mod), fn)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,76 +165,119 @@ def main():
     ap.add_argument("--solver-tolerance", type=float, default=-1.0, help="<0 = model default (1e-8)")
     ap.add_argument("--pool-size", type=int, default=4096, help="pickplace: states in the pre-grasp pool")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--repeats", type=int, default=5, help="timed windows of --steps steps; `value` is the first one, all are in `repeats`")
+    ap.add_argument("--device", choices=("cuda", "cpu"), default="cuda", help="cpu: tests only (gloo, needs --env-factory)")
+    ap.add_argument("--env-factory", default="", help="module:callable replacing task_suite.create_task_env (tests)")
     args = ap.parse_args()
+
+    # A plain `bench.py --gpus N` (no torchrun environment) launches its own N ranks before anything touches the GPU
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     from so101_sim_amd import distributed as sdist
 
     rank, local_rank, world = sdist.rank_info()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if world != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}\n")
+        sys.exit(2)
+    on_gpu = args.device == "cuda"
+    if on_gpu:
+        if torch.cuda.device_count() <= local_rank:
+            sys.stderr.write(f"bench.py: rank {rank} needs GPU {local_rank} but only {torch.cuda.device_count()} device(s) are visible\n")
+            sys.exit(3)
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        dev = torch.device("cpu")
     sdist.init(dev)
+    assert (not torch.distributed.is_initialized() and world == 1) or torch.distributed.get_world_size() == args.gpus
 
     from so101_sim_amd import build as sbuild
-    from so101_sim_amd import task_suite
     # roofline denominator first: a few seconds of streaming copies, which also take the GPU out of its idle power state
     # before anything is timed (a fresh box otherwise spends the first timed steps ramping its clocks)
-    hbm_measured = measure_hbm_copy(torch, dev, reps=20) if rank == 0 else None
+    hbm_measured = measure_hbm_copy(torch, dev, reps=20) if (rank == 0 and on_gpu) else None
     N = args.envs_per_gpu or DEFAULT_ENVS[args.workload]
     cwd = os.getcwd()
     os.chdir("/tmp")          # calibration offsets OFF (reference looks the JSON up relative to the CWD)
     kw = dict(time_limit=10.0, random_state=0, device=dev, solver_iterations=args.solver_iterations,
               solver_tolerance=args.solver_tolerance, solver=args.solver, prefetch_resets=not args.no_prefetch)
+    if args.env_factory:
+        make = resolve_factory(args.env_factory)
+    else:
+        from so101_sim_amd import task_suite
+        make = task_suite.create_task_env
     if args.workload == "mixed":
         half = N // 2
-        envs = [task_suite.create_task_env("SO100HandOverBanana", n_envs=half, env_id_base=sdist.shard_base(rank, N), **kw),
-                task_suite.create_task_env("SO100HandOverPen", n_envs=N - half, env_id_base=sdist.shard_base(rank, N) + half, **kw)]
+        envs = [make("SO100HandOverBanana", n_envs=half, env_id_base=sdist.shard_base(rank, N), **kw),
+                make("SO100HandOverPen", n_envs=N - half, env_id_base=sdist.shard_base(rank, N) + half, **kw)]
     else:
-        envs = [task_suite.create_task_env("SO100HandOverBanana", n_envs=N, env_id_base=sdist.shard_base(rank, N), **kw)]
+        envs = [make("SO100HandOverBanana", n_envs=N, env_id_base=sdist.shard_base(rank, N), **kw)]
     os.chdir(cwd)
     for env in envs:
         if args.fused:
             env.sim.configure(pipeline=0)
         if args.groups:
             env.sim.configure(groups=args.groups)
-    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in envs[1:]]
+
+    # Every env steps on its own non-default stream (the library captures its launch sequence into a HIP graph, which the
+    # legacy null stream cannot do); resets, tapes and statistics of an env are produced and consumed on that stream only.
+    class _NoStream:
+        def wait_stream(self, other): pass
+        def synchronize(self): pass
+    if on_gpu:
+        streams = [torch.cuda.Stream(dev) for _ in envs]
+        on_stream = torch.cuda.stream
+        sync = lambda: torch.cuda.synchronize(dev)
+        class Tick:
+            def __init__(self, stream):
+                self.ev = torch.cuda.Event(enable_timing=True); self.ev.record(stream)
+            def ms_until(self, other):
+                return self.ev.elapsed_time(other.ev)
+    else:
+        import contextlib
+        streams = [_NoStream() for _ in envs]
+        on_stream = lambda s: contextlib.nullcontext()
+        sync = lambda: None
+        class Tick:
+            def __init__(self, stream):
+                self.t = time.perf_counter()
+            def ms_until(self, other):
+                return 1e3 * (other.t - self.t)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1 + rank)
     total = args.warmup + args.steps
 
-    if args.workload == "mixed":
-        for env in envs:          # per-env domain randomisation of the props' mass (pose randomisation is the reset's)
-            env.set_mass_scale(0.5 + torch.rand(2, env.n_envs, device=dev, generator=gen))
-    if args.workload == "pickplace":
-        from so101_sim_amd import pregrasp
-        pool = pregrasp.build_pickplace_pool(envs[0], pool_size=args.pool_size, seed=rank)
-        envs[0].set_reset_pool(*pool)
-
     spec = envs[0].action_spec()
     lo = torch.tensor(spec.minimum, device=dev)
     hi = torch.tensor(spec.maximum, device=dev)
-    if args.workload == "pickplace":
-        noise = [0.05 * torch.randn(total, env.n_envs, 6, device=dev, generator=gen) for env in envs]
-        hold = [torch.zeros(env.n_envs, 6, device=dev) for env in envs]
-    else:
-        tapes = [lo + (hi - lo) * torch.rand(total, env.n_envs, 6, device=dev, generator=gen) for env in envs]   # actions resident in HBM
-
-    for env in envs:
-        env.reset_all()
-    if args.workload == "pickplace":
-        hold[0].copy_(envs[0].obs[:, 12:18])
-
-    stats = {k: torch.zeros((), device=dev) for k in ("reward_sum", "ncon", "nefc", "iters", "ncand")}
-    stats["samples"] = 0
+    tapes, noise, hold = [None] * len(envs), [None] * len(envs), [None] * len(envs)
+    stats = [{k: torch.zeros((), device=dev) for k in ("reward_sum", "ncon", "nefc", "iters", "ncand")} for _ in envs]
+    samples = [0]
+    for k, env in enumerate(envs):
+        with on_stream(streams[k]):
+            if args.workload == "mixed":      # per-env domain randomisation of the props' mass (pose randomisation is the reset's)
+                env.set_mass_scale(0.5 + torch.rand(2, env.n_envs, device=dev, generator=gen))
+            if args.workload == "pickplace":
+                from so101_sim_amd import pregrasp
+                env.set_reset_pool(*pregrasp.build_pickplace_pool(env, pool_size=args.pool_size, seed=rank))
+                noise[k] = 0.05 * torch.randn(total, env.n_envs, 6, device=dev, generator=gen)
+            else:
+                tapes[k] = lo + (hi - lo) * torch.rand(total, env.n_envs, 6, device=dev, generator=gen)   # actions resident in HBM
+            env.reset_all()
+            if args.workload == "pickplace":
+                hold[k] = env.obs[:, 12:18].clone()
+    sync()
 
     def one_step(i, timed, sample=None):
-        # `sample`: read the per-env diagnostics after this step.  The first warm-up step does it too (result discarded),
-        # so that every torch kernel the sampling needs is loaded before the timed region starts - on a fresh box the
-        # lazy load of one kernel costs more than a control step.
+        # `i` indexes the action tape (warm-up part, then the K-step window: every repeat replays the window's actions on
+        # whatever states the envs are in).  `sample`: read the per-env diagnostics after this step.  The first warm-up
+        # step does it too (result discarded), so that every torch kernel the sampling needs is loaded before the timed
+        # region starts - on a fresh box the lazy load of one kernel costs more than a control step.
         if sample is None:
             sample = timed and (i - args.warmup) % 10 == 0
         for k, env in enumerate(envs):
-            with torch.cuda.stream(streams[k]):
+            with on_stream(streams[k]):
                 if args.workload == "pickplace":
                     # hold pose of the episode (= commanded pose at FIRST) + small noise, jaw driven 0.3 rad past closed
                     first = (env.step_type == 0).unsqueeze(1)
@@ -202,53 +288,67 @@ def main():
                     act = tapes[k][i]
                 env.step_tensor(act)
                 if (timed or sample) and args.workload != "handover":      # (the headline workload never reaches reward 1: no extra launches there)
-                    stats["reward_sum"] += env.reward.sum()
-        if sample:
-            for k, env in enumerate(envs):
-                with torch.cuda.stream(streams[k]):
+                    stats[k]["reward_sum"] += env.reward.sum()
+                if sample:
                     d = env.diagnostics().float()
-                    stats["ncon"] += d[:, 0].sum()
-                    stats["nefc"] += d[:, 1].sum()
-                    stats["iters"] += d[:, 2].sum()
-                    stats["ncand"] += d[:, 3].sum()
-            stats["samples"] += sum(e.n_envs for e in envs)
+                    stats[k]["ncon"] += d[:, 0].sum()
+                    stats[k]["nefc"] += d[:, 1].sum()
+                    stats[k]["iters"] += d[:, 2].sum()
+                    stats[k]["ncand"] += d[:, 3].sum()
+        if sample:
+            samples[0] += sum(e.n_envs for e in envs)
 
     for i in range(args.warmup):
         one_step(i, False, sample=(i == 0))
-    for s in streams[1:]:
-        streams[0].wait_stream(s)
-    torch.cuda.synchronize(dev)
-    for k in stats:
-        stats[k] = 0 if k == "samples" else torch.zeros((), device=dev)
+    sync()
+    for st in stats:
+        for k in st:
+            st[k].zero_()
+    samples[0] = 0
     for env in envs:
         env.events(clear=True)
-    sdist.barrier()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    t0 = time.perf_counter()
-    ev[0].record(streams[0])
-    for s in streams[1:]:
-        s.wait_stream(streams[0])
-    for i in range(args.steps):
-        one_step(args.warmup + i, True)
-    for s in streams[1:]:
-        streams[0].wait_stream(s)
-    ev[1].record(streams[0])
-    torch.cuda.synchronize(dev)
-    sdist.barrier()
-    elapsed = time.perf_counter() - t0
-    # device time of one control step on the stream(s) the kernels are launched on (torch's current stream, which
-    # so101_step receives and on which the library's internal slice streams are joined)
-    kernel_ms = ev[0].elapsed_time(ev[1]) / args.steps
+
+    def timed_window(segment=0):
+        """EXACTLY --steps steps bracketed by barrier + synchronize on both sides.  Returns (host seconds, device ms per
+        step on the launch streams, [device ms of each `segment`-step slice])."""
+        sync()
+        sdist.barrier()
+        t0 = time.perf_counter()
+        ticks = [[Tick(s)] for s in streams]
+        for i in range(args.steps):
+            one_step(args.warmup + i, True)
+            if segment and (i + 1) % segment == 0 and i + 1 < args.steps:
+                for k, s in enumerate(streams):
+                    ticks[k].append(Tick(s))
+        for k, s in enumerate(streams):
+            ticks[k].append(Tick(s))
+        sync()
+        sdist.barrier()
+        host = time.perf_counter() - t0
+        dev_ms = max(t[0].ms_until(t[-1]) for t in ticks) / args.steps
+        segs = [max(t[j].ms_until(t[j + 1]) for t in ticks) for j in range(len(ticks[0]) - 1)] if segment else []
+        return host, dev_ms, segs
+
+    elapsed, kernel_ms, segments = timed_window(segment=100 if args.steps >= 500 else 0)
+    elapsed = sdist.max_over_ranks(elapsed, dev)
+    events_first = {}
+    for env in envs:
+        for k, v in env.events().items():
+            events_first[k] = events_first.get(k, 0) + v
+    stats_first = {k: sum(float(st[k]) for st in stats) for k in stats[0]}
+    stats_first["samples"] = samples[0]
+    # further windows of the same length: spread of the measurement (box clocks, episode phase)
+    rep_elapsed = [elapsed]
+    for _ in range(max(args.repeats, 1) - 1):
+        e2, _, _ = timed_window()
+        rep_elapsed.append(sdist.max_over_ranks(e2, dev))
 
     # logging-only exchange: episode returns all-gathered over RCCL/xGMI (not in the timed region)
     returns = torch.cat([env.episode_returns() for env in envs])
     all_returns = sdist.all_gather_returns(returns)
-    elapsed = sdist.max_over_ranks(elapsed, dev)
-    events = {}
-    for env in envs:
-        for k, v in env.events().items():
-            events[k] = events.get(k, 0) + v
+    events = events_first
     n_local = sum(e.n_envs for e in envs)
+    stats = stats_first
 
     if rank == 0:
         build_hash = sbuild.source_hash()
@@ -272,7 +372,7 @@ def main():
                        "solver_tolerance": args.solver_tolerance if args.solver_tolerance >= 0 else 1e-8,
                        "parallelism": f"env-shard x{world}", "build": build_hash},
             "roofline": {"bound": "latency/valu", "achieved": achieved, "peak": hbm_measured, "unit": "GB/s",
-                         "frac": achieved / hbm_measured, "traffic": (pmc or {}).get("hbm_bytes_per_step"),
+                         "frac": achieved / hbm_measured if hbm_measured else None, "traffic": (pmc or {}).get("hbm_bytes_per_step"),
                          "peak_spec": HBM_SPEC_GBS, "frac_of_spec": achieved / HBM_SPEC_GBS,
                          "kernel": "k_step" if args.fused else f"k_order + {args.groups or 4} env slices x (k_pipe_begin + substeps x (k_narrow + k_pipe_solve))",
                          "kernel_ms": kernel_ms, "launches_per_step": 1 if args.fused else 1 + (args.groups or 4) * 21,
@@ -292,7 +392,21 @@ def main():
             "mean_reward_per_env_step": float(stats["reward_sum"]) / env_steps,
             "mean_episode_return": float(all_returns.mean().item()),
         }
-        if not args.no_cpu_baseline and world == 1:
+        import statistics
+        rep_values = [world * n_local * args.steps / e for e in rep_elapsed]
+        out["repeats"] = {"n": len(rep_values), "values": rep_values, "mean": statistics.fmean(rep_values),
+                          "std": statistics.pstdev(rep_values) if len(rep_values) > 1 else 0.0,
+                          "note": "`value` is the first window (the --steps steps that follow the warm-up); the others are further "
+                                  "windows of the same length on the same envs, each bracketed by barrier + synchronize"}
+        if segments:
+            seg_rates = [n_local * 100 / (ms * 1e-3) for ms in segments]
+            out["sustained"] = {"steps": args.steps, "env_steps_per_s": value, "per_100_steps_env_steps_per_s": seg_rates,
+                                "min": min(seg_rates), "max": max(seg_rates),
+                                "note": "one window long enough for every env to pass its time limit (auto-reset inside); device time "
+                                        "of each 100-step slice on rank 0, the way the reference logs its step time (run_eval.py:103-124)"}
+        if hasattr(envs[0], "sim") and hasattr(envs[0].sim, "info"):
+            out["config"]["step_path"] = envs[0].sim.info()
+        if not args.no_cpu_baseline and world == 1 and on_gpu:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     sdist.finalize()

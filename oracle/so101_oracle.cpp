@@ -7,8 +7,12 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
+#include <condition_variable>
 #include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -1610,4 +1614,79 @@ void orc_env_step(orc_sim* s, const double* action, double* obs, double* rew, do
   if (*st == 2) s->need_reset = true;
 }
 double orc_rng_uniform(uint64_t seed, uint64_t env, uint64_t ep, uint32_t draw) { return rng_uniform(seed, env, ep, draw); }
+
+// ---- bench.py's cpu_baseline leg: the handover workload on host threads (one orc_sim per env, envs_per_thread envs per
+// thread, every thread steps its envs one after the other - a CPU simulator's natural batching).  Phase 0 (timed on its
+// own): placement + settle of every env.  Then, per solver setting, `reps` repetitions of `steps` control steps of
+// every env with uniform random actions over the action spec (so100_task.py:232-251), all threads released together
+// and the repetition's time taken when the last thread is done.  Returns the env-steps of one repetition.
+namespace {
+struct BenchBarrier {
+  std::mutex mu; std::condition_variable cv; int n, waiting = 0; unsigned long gen = 0;
+  explicit BenchBarrier(int n_) : n(n_) {}
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    unsigned long g = gen;
+    if (++waiting == n) { waiting = 0; gen++; cv.notify_all(); } else cv.wait(lk, [&] { return gen != g; });
+  }
+};
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
+long long orc_bench_rollout(const void* blob, size_t bytes, int n_threads, int envs_per_thread, int steps, int reps, int n_settings,
+                            const int* iterations, const double* tolerance, uint64_t seed, double* reset_seconds,
+                            double* rep_seconds /*[n_settings][reps]*/) {
+  if (n_threads <= 0 || envs_per_thread <= 0 || steps <= 0 || reps <= 0 || n_settings <= 0) return -1;
+  static const double lo[6] = {-3.14159265358979, -3.14158, -3.14158, -3.14158, -3.14158, 0.0};
+  static const double hi[6] = {3.14159265358979, 3.14158, 3.14158, 3.14158, 3.14158, 0.08};
+  BenchBarrier bar(n_threads + 1);
+  std::vector<int> failed(n_threads, 0);
+  auto worker = [&](int t) {
+    std::vector<orc_sim*> envs;
+    for (int i = 0; i < envs_per_thread; i++) {
+      orc_sim* s = orc_create(blob, bytes);
+      if (!s) { failed[t] = 1; break; }
+      orc_env_cfg c{};
+      c.last_step = 500; c.settle_max_substeps = 1000; c.seed = seed; c.env_id = (uint64_t)t * envs_per_thread + i;
+      orc_env_config(s, &c);
+      orc_set_solver_type(s, 1);
+      envs.push_back(s);
+    }
+    uint64_t lcg = 0x9E3779B97F4A7C15ull * (uint64_t)(t + 1) + seed;
+    auto uni = [&]() { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; return (double)(lcg >> 11) * (1.0 / 9007199254740992.0); };
+    bar.wait();                                   // ---- reset phase
+    for (orc_sim* s : envs) orc_env_reset(s);
+    bar.wait();
+    for (int k = 0; k < n_settings; k++) {
+      for (orc_sim* s : envs) orc_set_solver(s, iterations[k], tolerance[k]);
+      for (int r = 0; r < reps; r++) {
+        bar.wait();
+        for (int i = 0; i < steps; i++)
+          for (orc_sim* s : envs) {
+            double a[6], obs[18], rew, disc; int st;
+            for (int j = 0; j < 6; j++) a[j] = lo[j] + (hi[j] - lo[j]) * uni();
+            orc_env_step(s, a, obs, &rew, &disc, &st);
+          }
+        bar.wait();
+      }
+    }
+    for (orc_sim* s : envs) orc_destroy(s);
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < n_threads; t++) th.emplace_back(worker, t);
+  bar.wait();
+  double t0 = now_s();
+  bar.wait();
+  if (reset_seconds) *reset_seconds = now_s() - t0;
+  for (int k = 0; k < n_settings; k++)
+    for (int r = 0; r < reps; r++) {
+      bar.wait();
+      double t1 = now_s();
+      bar.wait();
+      rep_seconds[k * reps + r] = now_s() - t1;
+    }
+  for (auto& x : th) x.join();
+  for (int f : failed) if (f) return -1;
+  return (long long)n_threads * envs_per_thread * steps;
+}
 }

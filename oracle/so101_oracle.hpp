@@ -104,4 +104,11 @@ double orc_env_return(const orc_sim*);
 
 // uniform(0,1) of the shared counter RNG (so tests can pin the GPU's reset draws)
 double orc_rng_uniform(uint64_t seed, uint64_t env_id, uint64_t episode, uint32_t draw);
+
+// bench.py cpu_baseline: the handover workload on `n_threads` host threads with `envs_per_thread` envs each.  Times the
+// reset (placement + settle of every env) and, per solver setting k (iterations[k], tolerance[k]; Newton), `reps`
+// repetitions of `steps` control steps of every env under uniform random actions.  Returns env-steps per repetition.
+long long orc_bench_rollout(const void* blob, size_t bytes, int n_threads, int envs_per_thread, int steps, int reps, int n_settings,
+                            const int* iterations, const double* tolerance, uint64_t seed, double* reset_seconds,
+                            double* rep_seconds /*[n_settings][reps]*/);
 }

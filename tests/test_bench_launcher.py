@@ -1,0 +1,47 @@
+"""`python bench.py --gpus 2` launched PLAINLY (no torchrun environment) must start two ranks itself: the real bench.py
+main runs here on CPU with gloo and a stub env factory (tests/bench_stub.py) in place of the GPU env."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra, env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--device", "cpu", "--env-factory", "tests.bench_stub:make",
+                           "--no-cpu-baseline", *extra], env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+
+
+def test_gpus_2_spawns_two_ranks_and_reports_the_whole_job():
+    r = _run(["--gpus", "2", "--steps", "4", "--warmup", "1", "--envs-per-gpu", "8", "--repeats", "2"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(line) == 1, r.stdout
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 1
+    assert out["config"]["global_envs"] == 16 and out["config"]["envs_per_gpu"] == 8
+    # MAX over ranks: rank 1 sleeps 30 ms per step, rank 0 10 ms; the job time is rank 1's
+    assert out["ms_per_step"] >= 30.0 * 0.9
+    assert abs(out["value"] - 16 * 4 / (out["ms_per_step"] * 4e-3)) < 1e-6 * out["value"]
+    assert out["repeats"]["n"] == 2 and out["repeats"]["values"][0] == out["value"]
+    # returns gathered in rank order over global env ids 0..15: (warm-up 1 + 2 windows x 4 steps) x id; mean id = 7.5
+    assert abs(out["mean_episode_return"] - 9 * 7.5) < 1e-4
+
+
+def test_world_size_mismatch_is_refused():
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
+
+
+def test_single_rank_line_has_the_contract_keys():
+    r = _run(["--steps", "3", "--warmup", "1", "--envs-per-gpu", "4", "--repeats", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "repeats"):
+        assert k in out
+    assert out["n_gpus"] == 1 and out["vs_baseline"] is None and out["scaling"] == "weak"
