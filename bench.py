@@ -160,6 +160,8 @@ def main():
                     help="newton = MuJoCo's default, which the reference scene uses (it sets no <option solver>)")
     ap.add_argument("--no-prefetch", action="store_true", help="settle auto-resets inside the step call")
     ap.add_argument("--fused", action="store_true", help="one fused k_step launch per control step instead of the pipeline")
+    ap.add_argument("--pipeline", type=int, default=-1, help="step path: 2 per-env chained (library default), 1 launch chains, 0 fused")
+    ap.add_argument("--chain-waves", type=int, default=0, help="pipeline 2: persistent wavefronts (0 = library default)")
     ap.add_argument("--groups", type=int, default=0, help="env slices of the pipelined step (0 = library default)")
     ap.add_argument("--solver-iterations", type=int, default=0, help="iteration cap; 0 = model default (100)")
     ap.add_argument("--solver-tolerance", type=float, default=-1.0, help="<0 = model default (1e-8)")
@@ -217,6 +219,10 @@ def main():
     for env in envs:
         if args.fused:
             env.sim.configure(pipeline=0)
+        elif args.pipeline >= 0:
+            env.sim.configure(pipeline=args.pipeline)
+        if args.chain_waves:
+            env.sim.configure(chain_waves=args.chain_waves)
         if args.groups:
             env.sim.configure(groups=args.groups)
 
@@ -350,11 +356,12 @@ def main():
     n_local = sum(e.n_envs for e in envs)
     stats = stats_first
 
+    path = 0 if args.fused else (args.pipeline if args.pipeline >= 0 else 2)
     if rank == 0:
         build_hash = sbuild.source_hash()
         value = world * n_local * args.steps / elapsed
         achieved = ALGO_BYTES_PER_ENV_STEP * n_local / (kernel_ms * 1e-3) / 1e9
-        pmc = load_pmc(build_hash) if args.workload == "handover" and N == 4096 and not args.fused else None
+        pmc = load_pmc(build_hash) if args.workload == "handover" and N == 4096 and path == 2 else None
         env_steps = n_local * args.steps
         names = {"handover": "SO100HandOverBanana, uniform random actions, 500-step episodes with the reference reset (placement + settle, prefetched)",
                  "pickplace": f"SO100HandOverBanana pick-and-place, episodes from a scripted pre-grasp pool of {args.pool_size} states, hold pose + N(0,0.05) actions with the jaw closing",
@@ -367,15 +374,16 @@ def main():
             "config": {"workload": f"{names[args.workload]}; {n_local} lock-step envs per GPU, proprioceptive obs"
                                    + (f" (BASELINE.json configs[{cfg_index}]" + (" per-GPU share)" if cfg_index == 4 else ")") if cfg_index else ""),
                        "envs_per_gpu": n_local, "global_envs": world * n_local, "substeps_per_step": 10,
-                       "solver": args.solver, "reset_prefetch": not args.no_prefetch, "pipeline": not args.fused,
+                       "solver": args.solver, "reset_prefetch": not args.no_prefetch, "pipeline": path,
                        "solver_iterations": args.solver_iterations or 100,
                        "solver_tolerance": args.solver_tolerance if args.solver_tolerance >= 0 else 1e-8,
                        "parallelism": f"env-shard x{world}", "build": build_hash},
             "roofline": {"bound": "latency/valu", "achieved": achieved, "peak": hbm_measured, "unit": "GB/s",
                          "frac": achieved / hbm_measured if hbm_measured else None, "traffic": (pmc or {}).get("hbm_bytes_per_step"),
                          "peak_spec": HBM_SPEC_GBS, "frac_of_spec": achieved / HBM_SPEC_GBS,
-                         "kernel": "k_step" if args.fused else f"k_order + {args.groups or 4} env slices x (k_pipe_begin + substeps x (k_narrow + k_pipe_solve))",
-                         "kernel_ms": kernel_ms, "launches_per_step": 1 if args.fused else 1 + (args.groups or 4) * 21,
+                         "kernel": {0: "k_step", 1: f"k_order + {args.groups or 4} env slices x (k_pipe_begin + substeps x (k_narrow + k_pipe_solve))",
+                                    2: "k_order + k_pipe_begin + k_chain (persistent: narrowphase chunks and per-env solve items from device-side queues)"}[path],
+                         "kernel_ms": kernel_ms, "launches_per_step": {0: 1, 1: 1 + (args.groups or 4) * 21, 2: 3}[path],
                          "compute": None if not pmc else {
                              "valu_tflops_equiv": pmc.get("valu_insts_per_step", 0) * 64 * 2 / (kernel_ms * 1e-3) / 1e12,
                              "peak_tflops": VALU_PEAK_TFLOPS,

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SO101_ABI_VERSION 6
+#define SO101_ABI_VERSION 7
 #define SO101_OBS_DIM 18      /* joints_pos(6, delayed) | undelayed_joints_pos(6) | commanded_joints_pos(6) */
 #define SO101_ACT_DIM 6
 #define SO101_SOLVER_PGS 0
@@ -83,8 +83,12 @@ typedef struct {
   int32_t prefetch_resets; /* 1 (default): settle the next episode's initial state of every env ahead of time on an
                               internal low-priority stream, so that auto-resets inside so101_step cost a copy;
                               0: always settle inside the call.  Results are identical either way. */
-  int32_t pipeline;        /* 1 (default): so101_step runs every substep as narrowphase (one wavefront per candidate pair)
-                              + solve (one wavefront per env) launches; 0: one fused launch, one wavefront per env. */
+  int32_t pipeline;        /* 2 (default): per-env chained step - cost order, prologue and ONE persistent launch in which
+                              wavefronts pull narrowphase chunks and per-env solve items from device-side queues, every
+                              env advancing on its own dependencies (csrc/so101_chain.hpp);
+                              1: launch chains - every substep is a narrowphase launch (one wavefront per candidate pair)
+                              and a solve launch (one wavefront per env) per env slice, 21 launches per slice;
+                              0: one fused launch, one wavefront per env.  Same device functions, same results. */
   int32_t groups;          /* pipelined step: the envs, sorted by the solver time of their previous step, are cut into 1..8
                               slices whose launch chains run on separate internal streams and fill each other's tails;
                               0 (default) = 4 when GPU_MAX_HW_QUEUES >= 6 was set before HIP initialised, else 3 (the
@@ -93,6 +97,8 @@ typedef struct {
   int32_t use_graph;       /* 1 (default): the launch sequence of the pipelined step is captured once into a HIP graph and
                               replayed with one hipGraphLaunch per step (re-captured when configuration, bound buffers,
                               pool or the step's I/O pointers change); 0: plain launches.  Same kernels either way. */
+  int32_t chain_waves;     /* pipeline = 2: persistent wavefronts of the step kernel; 0 (default) = 2048 (2 per SIMD on
+                              256 CUs), capped at 2 * N + 6 */
 } so101_config;
 
 int so101_version(void);
@@ -187,6 +193,7 @@ int so101_get_diag(so101_sim* sim, int32_t* out, void* hip_stream);
  *   4 reset: the container placer's 20 attempts all collided (dm_control's PropPlacer raises RuntimeError there;
  *     here the last sample is kept and the event is counted)         5 reset: the settle did not converge within
  *     settle_max_substeps (dm_control warns, examples/so101_rl_breakdown.ipynb:50-55)
+ *   6 the chained step's watchdog ended a launch (scheduler protocol error: results of that step are invalid)
  * The same bits appear per env in diag word 4 for the most recent substep. */
 #define SO101_NEVENTS 8
 int so101_get_events(so101_sim* sim, uint64_t* out, int clear, void* hip_stream);
@@ -204,6 +211,21 @@ int so101_debug_forward(so101_sim* sim, float* out, void* hip_stream);
 int so101_debug_stages(so101_sim* sim, uint32_t* stage, void* hip_stream);
 
 int so101_debug_candidates(so101_sim* sim, int32_t* ncand, uint32_t* cand, uint32_t* ticks, float* conres, void* hip_stream);
+
+/* Facts about the handle for logs and tests (host value, synchronises `hip_stream` for the device-side ones):
+ *   SO101_INFO_GRAPH_ACTIVE   1 when the last so101_step replayed a captured HIP graph
+ *   SO101_INFO_STEP_PATH      0 fused, 1 launch chains, 2 per-env chained: what the last so101_step ran
+ *   SO101_INFO_CHAINS         launch chains of the last pipeline = 1 step
+ *   SO101_INFO_HW_QUEUES      GPU_MAX_HW_QUEUES as the library read it (4 when unset)
+ *   SO101_INFO_SCHED_ABORTS   times the chained step's watchdog ended a launch (a protocol error; also event 6)
+ *   SO101_INFO_SCRATCH_BYTES  library-owned device memory of this handle */
+#define SO101_INFO_GRAPH_ACTIVE 0
+#define SO101_INFO_STEP_PATH 1
+#define SO101_INFO_CHAINS 2
+#define SO101_INFO_HW_QUEUES 3
+#define SO101_INFO_SCHED_ABORTS 4
+#define SO101_INFO_SCRATCH_BYTES 5
+long long so101_get_info(so101_sim* sim, int what, void* hip_stream);
 
 const char* so101_last_error(const so101_sim* sim);
 

@@ -213,11 +213,12 @@ DEV void kinematics(const DevModel* m, EnvLDS& L) {
 // the end of the previous kernel): poses from global memory, then the derived quantities one body per lane - joint axes,
 // COM positions, world inertias - with the same expressions kinematics() uses, so the bits are the same.  Replaces the
 // serial walk down the arm (every lane on identical values, ~900 dependent instructions) by ~50.
+template <bool AG = false>       // AG: the poses were stored by another wavefront of this launch (wave.hpp, agent-scope loads)
 DEV void kinematics_from_pose(const DevModel* m, EnvLDS& L, const float* pose /* [NDYN][12]: xpos, xmat */) {
   int lane = wave_lane();
   for (int i = lane; i < NDYN * 12; i += WAVE) {
     int b = i / 12, j = i % 12;
-    float v = pose[i];
+    float v = AG ? ld_agent(&pose[i]) : pose[i];
     if (j < 3) L.xpos[b][j] = v; else L.xmat[b][j - 3] = v;
   }
   wave_sync();

@@ -40,11 +40,12 @@ DEV void store_diag(const EnvLDS& L, int* diag, int e) {
 }
 
 // adds this env's flag word (ORed with what earlier substeps of the control step left in E.flags) to the counters
+template <bool AG = false>       // AG: E.flags[e] was last written by another wavefront of this launch (wave.hpp)
 DEV void count_events(const EnvLDS& L, const EventBuffers& E, int e) {
   if (wave_lane() == 0) {
-    int f = E.flags[e] | L.overflow;
+    int f = (AG ? ld_agent(&E.flags[e]) : E.flags[e]) | L.overflow;
     if (f) {
-      E.flags[e] = 0;
+      if constexpr (AG) st_agent(&E.flags[e], 0); else E.flags[e] = 0;
       for (int b = 0; b < SO101_NEVENTS; b++) if ((f >> b) & 1) atomicAdd(&E.events[b], 1ull);
     }
   }
@@ -161,6 +162,7 @@ DEV void write_first(const EnvLDS& L, int e, float* obs, float* reward, float* d
 // End of a control step: observables with the 5-step joints_pos delay line (so100_task.py:189-210,323-368), reward
 // (so100_hand_over.py:238-275), discount / termination (so100_task.py:292-302), time limit (task_suite.py:151).
 // `sc` = control steps since reset including this one.  Needs the post-step state in LDS.
+template <bool AG = false>
 DEV void finish_step(const DevModel* m, EnvLDS& L, const StepParams& P, const DevBuffers& B, int e, int sc, bool diverged,
                      float* obs, float* reward, float* discount, unsigned char* step_type, unsigned char* need_reset,
                      int* diag, const EventBuffers& E) {
@@ -187,5 +189,5 @@ DEV void finish_step(const DevModel* m, EnvLDS& L, const StepParams& P, const De
     step_type[e] = st; need_reset[e] = st == 2;
     B.step_count[e] = sc; B.ep_return[e] += r;
   }
-  count_events(L, E, e);
+  count_events<AG>(L, E, e);
 }

@@ -95,6 +95,11 @@ struct so101_sim {
   hipEvent_t prep_done = nullptr, main_ev = nullptr;
   bool prep_pending = false;
   int prep_waves = 0;
+  ChainQueues chain{};         // queues of the per-env chained step (pipeline = 2)
+  unsigned char* chain_cls = nullptr;
+  ChainParams* chain_params = nullptr;     // device copy of k_chain's parameter block
+  ChainParams chain_host{};                // what it holds
+  bool chain_params_valid = false;
   PipeBuffers pipe{};          // scratch of the pipelined step (group 0's view; the groups differ in work/counters)
   static constexpr int MAXGROUPS = 8;
   hipStream_t group_stream[MAXGROUPS] = {};
@@ -106,6 +111,10 @@ struct so101_sim {
   so101::StepIO graph_io{};
   unsigned long long generation = 1, graph_gen = 0;     // bumped by configure / bind_state / set_reset_pool
   bool graph_failed = false;
+  hipStream_t graph_failed_stream = nullptr;            // capture is retried when the caller moves to another stream
+  int last_path = -1, last_chains = 0;                  // so101_get_info
+  bool last_graph = false;
+  size_t scratch_bytes = 0;
   std::string err;
 };
 
@@ -360,6 +369,7 @@ bool dev_alloc(so101_sim* s, T** out, size_t count, int fill, const char* what) 
   size_t bytes = sizeof(T) * (count ? count : 1);
   if (!hip_ok(s, hipMalloc(&p, bytes), what)) return false;
   s->owned.push_back(p);
+  s->scratch_bytes += bytes;
   if (!hip_ok(s, hipMemset(p, fill, bytes), what)) return false;
   *out = (T*)p;
   return true;
@@ -379,7 +389,7 @@ int so101_default_config(so101_config* cfg) {
   memset(cfg, 0, sizeof *cfg);
   cfg->last_step = 1 << 30; cfg->n_substeps = 10; cfg->solver_iterations = 0; cfg->solver_tolerance = -1.f;
   cfg->settle_max_substeps = 1000; cfg->terminate_on_success = 1; cfg->env_id_base = 0; cfg->solver = SO101_SOLVER_NEWTON;
-  cfg->prefetch_resets = 1; cfg->pipeline = 1; cfg->groups = 0; cfg->use_graph = 1;
+  cfg->prefetch_resets = 1; cfg->pipeline = 2; cfg->groups = 0; cfg->use_graph = 1; cfg->chain_waves = 0;
   return SO101_OK;
 }
 
@@ -422,7 +432,18 @@ int so101_create(const void* blob, size_t bytes, int n_envs, int device, uint64_
               dev_alloc(s, &W.conres, CONRES_DIM * MAXCAND * n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.active, n, 0, "hipMalloc(pipe)") &&
               dev_alloc(s, &W.ticks, MAXCAND * n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.stage, 8 * n, 0, "hipMalloc(pipe)") &&
               dev_alloc(s, &W.cost, n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.order, n, 0, "hipMalloc(pipe)") &&
-              dev_alloc(s, &W.state, STATE_AOS * n, 0, "hipMalloc(pipe)");
+              dev_alloc(s, &W.state, STATE_AOS * n, 0, "hipMalloc(pipe)") &&
+              dev_alloc(s, &s->chain.pending, n, 0, "hipMalloc(chain)") && dev_alloc(s, &s->chain_cls, n, 0, "hipMalloc(chain)") &&
+              dev_alloc(s, &s->chain.qctl, (size_t)4 * 64, 0, "hipMalloc(chain)") && dev_alloc(s, &s->chain.chain_ctl, (size_t)64, 0, "hipMalloc(chain)") &&
+              dev_alloc(s, &s->chain_params, (size_t)1, 0, "hipMalloc(chain)");
+    s->chain.cls = s->chain_cls;
+    // work queues of the chained step: narrow chunks (at most MAXCAND / NARROW_CHUNK outstanding per env), solve items (one per env)
+    for (int q = 0; q < 4 && ok; q++) {
+      size_t need = q < Q_SOLVE ? n * (MAXCAND / NARROW_CHUNK) : n, cap = 64;
+      while (cap < need) cap <<= 1;
+      ok = dev_alloc(s, &s->chain.qslot[q], cap, 0, "hipMalloc(chain)");
+      s->chain.qmask[q] = (unsigned int)(cap - 1);
+    }
     W.work_cap = 0u;
     for (int g = 0; g < so101_sim::MAXGROUPS && ok; g++)
       ok = hip_ok(s, hipStreamCreateWithFlags(&s->group_stream[g], hipStreamNonBlocking), "hipStreamCreate") &&
@@ -559,6 +580,7 @@ static int enqueue_pipelined(so101_sim* s, hipStream_t st, const so101::StepIO& 
   if (G > so101_sim::MAXGROUPS) G = so101_sim::MAXGROUPS;
   int n = s->n_envs;
   if (n < 64) G = 1;
+  s->last_chains = G;
   // Slices of the cost-sorted env order (most expensive first), one launch chain each: 2 chains split at n/2, 3 at n/4
   // and 5n/8, 4 and more in equal parts (re-measured in round 2 at 4096 envs: 1 chain 515 k, 2 618 k, 3 653 k, 4 672 k
   // with enough hardware queues, 5-6 650 k env-steps/s; unequal 4-way splits are 1-2 % slower)
@@ -576,7 +598,7 @@ static int enqueue_pipelined(so101_sim* s, hipStream_t st, const so101::StepIO& 
     bounds[++G] = n;
   }
 #endif
-  so101::launch_order(st, s->pipe.cost, s->pipe.order, n);
+  so101::launch_order(st, s->pipe.cost, s->pipe.order, s->chain_cls, n);
   LAUNCH_CHECK(s, "k_order");
   if (G > 1 && !hip_ok(s, hipEventRecord(s->step_begin, st), "hipEventRecord")) return SO101_ERR_HIP;
   for (int g = 0; g < G; g++) {
@@ -604,6 +626,43 @@ static int enqueue_pipelined(so101_sim* s, hipStream_t st, const so101::StepIO& 
   return SO101_OK;
 }
 
+// The per-env chained step (pipeline = 2, csrc/so101_chain.hpp): cost order + classes, prologue, ONE persistent launch.
+// k_chain reads its parameters from a device-memory block; sync_chain_params() brings it up to date on `st` BEFORE any
+// capture starts (an upload from host memory must not become a graph node).
+static ChainParams chain_params_now(so101_sim* s, const so101::StepIO& io) {
+  ChainParams cp;
+  memset(&cp, 0, sizeof cp);
+  cp.m = s->dm; cp.P = make_params(s); cp.B = s->buf; cp.E = s->ev; cp.W = s->pipe; cp.Q = s->chain;
+  cp.io = SolveIO{io.obs, io.reward, io.discount, io.step_type, s->need_reset, s->diag};
+  return cp;
+}
+static bool sync_chain_params(so101_sim* s, hipStream_t st, const so101::StepIO& io) {
+  ChainParams cp = chain_params_now(s, io);
+  if (s->chain_params_valid && memcmp(&cp, &s->chain_host, sizeof cp) == 0) return true;
+  // the previous contents may still be in use by a step in flight on another stream of the caller: drain first (rare)
+  if (!hip_ok(s, hipDeviceSynchronize(), "hipDeviceSynchronize(chain params)")) return false;
+  s->chain_host = cp;
+  if (!hip_ok(s, hipMemcpy(s->chain_params, &s->chain_host, sizeof cp, hipMemcpyHostToDevice), "hipMemcpy(chain params)")) return false;
+  s->chain_params_valid = true;
+  return true;
+}
+static int enqueue_chained(so101_sim* s, hipStream_t st, const so101::StepIO& io) {
+  StepParams P = make_params(s);
+  PrepBuffers C = prep_view(s);
+  int n = s->n_envs;
+  so101::launch_order(st, s->pipe.cost, s->pipe.order, s->chain_cls, n);
+  LAUNCH_CHECK(s, "k_order");
+  if (!hip_ok(s, hipMemsetAsync(s->chain.chain_ctl, 0, sizeof(unsigned int), st), "hipMemsetAsync(chain)")) return SO101_ERR_HIP;
+  so101::launch_pipe_begin(n, st, s->dm, P, s->buf, C, s->ev, s->pipe, io, s->need_reset, s->diag, 0, s->chain_params);
+  LAUNCH_CHECK(s, "k_pipe_begin");
+  // persistent wavefronts: what fills the machine at 2 per SIMD (8 per CU x 256 CUs), fewer for small batches
+  int waves = s->cfg.chain_waves > 0 ? s->cfg.chain_waves : 2048;
+  if (waves > 2 * n + 6) waves = 2 * n + 6;
+  so101::launch_chain(waves, st, s->chain_params);
+  LAUNCH_CHECK(s, "k_chain");
+  return SO101_OK;
+}
+
 static void drop_graph(so101_sim* s) {
   if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
 }
@@ -616,40 +675,70 @@ int so101_step(so101_sim* s, const float* action, float* obs, float* reward, flo
   so101::StepIO io{action, obs, reward, discount, step_type};
   // the pipelined step is a Newton path; PGS (107 ms per control step at 4096 envs) runs the fused kernel
   if (s->cfg.pipeline && s->cfg.n_substeps <= MAXSUB && s->cfg.solver == SO101_SOLVER_NEWTON) {
-    // The launch sequence of a control step (~90 kernels, memsets and event edges over 5 streams) depends only on the
-    // configuration and the caller's pointers: it is captured ONCE into a HIP graph and replayed with one call per
-    // step - the host thread issues 1 API call instead of ~110 (with 8 ranks on one host, or a cold host, the
-    // launch loop was the bottleneck).  Any change of configuration, bound buffers, pool or I/O pointers re-captures.
-    if (s->cfg.use_graph && !s->graph_failed) {
+    const bool chained = s->cfg.pipeline == 2;
+    s->last_path = chained ? 2 : 1;
+    if (chained && !sync_chain_params(s, st, io)) return SO101_ERR_HIP;
+    // The launch sequence of a control step (launch chains: ~90 kernels, memsets and event edges over 5 streams; chained: 3
+    // kernels and a memset) depends only on the configuration and the caller's pointers: it is captured ONCE into a HIP
+    // graph and replayed with one call per step.  Any change of configuration, bound buffers, pool or I/O pointers
+    // re-captures.  The legacy null stream cannot capture: the step then runs as plain launches, and capture is tried again
+    // when the caller comes with another stream.
+    if (s->cfg.use_graph && !(s->graph_failed && s->graph_failed_stream == st)) {
       bool same = s->graph_exec && s->graph_gen == s->generation && s->graph_io.action == io.action && s->graph_io.obs == io.obs &&
                   s->graph_io.reward == io.reward && s->graph_io.discount == io.discount && s->graph_io.step_type == io.step_type;
       if (!same) {
         drop_graph(s);
         hipGraph_t g = nullptr;
+        bool ok = false;
         if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-          int rc = enqueue_pipelined(s, st, io);
+          int rc = chained ? enqueue_chained(s, st, io) : enqueue_pipelined(s, st, io);
           hipError_t e = hipStreamEndCapture(st, &g);
           if (rc == SO101_OK && e == hipSuccess && g && hipGraphInstantiate(&s->graph_exec, g, nullptr, nullptr, 0) == hipSuccess) {
-            s->graph_gen = s->generation; s->graph_io = io;
-          } else { s->graph_exec = nullptr; s->graph_failed = true; (void)hipGetLastError(); }
+            s->graph_gen = s->generation; s->graph_io = io; ok = true;
+          } else s->graph_exec = nullptr;
           if (g) (void)hipGraphDestroy(g);
-        } else { s->graph_failed = true; (void)hipGetLastError(); }
+        }
+        s->graph_failed = !ok; s->graph_failed_stream = st;
+        if (!ok) (void)hipGetLastError();
       }
       if (s->graph_exec) {
         if (!hip_ok(s, hipGraphLaunch(s->graph_exec, st), "hipGraphLaunch")) return SO101_ERR_HIP;
+        s->last_graph = true;
         launch_prepare(s, st);
         return SO101_OK;
       }
     }
-    int rc = enqueue_pipelined(s, st, io);
+    s->last_graph = false;
+    int rc = chained ? enqueue_chained(s, st, io) : enqueue_pipelined(s, st, io);
     if (rc != SO101_OK) return rc;
     launch_prepare(s, st);
     return SO101_OK;
   }
+  s->last_path = 0; s->last_graph = false;
   so101::launch_step(s->cfg.solver, s->n_envs, st, s->dm, make_params(s), s->buf, prep_view(s), s->ev, io, s->need_reset, s->diag);
   LAUNCH_CHECK(s, "k_step");
   launch_prepare(s, st);
   return SO101_OK;
+}
+
+long long so101_get_info(so101_sim* s, int what, void* stream) {
+  if (!s) return -1;
+  switch (what) {
+    case SO101_INFO_GRAPH_ACTIVE: return s->last_graph ? 1 : 0;
+    case SO101_INFO_STEP_PATH: return s->last_path;
+    case SO101_INFO_CHAINS: return s->last_chains;
+    case SO101_INFO_HW_QUEUES: return getenv("GPU_MAX_HW_QUEUES") ? atoi(getenv("GPU_MAX_HW_QUEUES")) : 4;
+    case SO101_INFO_SCRATCH_BYTES: return (long long)s->scratch_bytes;
+    case SO101_INFO_SCHED_ABORTS: {
+      DeviceGuard guard(s);
+      unsigned int v = 0;
+      if (!guard.ok || !s->chain.chain_ctl) return -1;
+      if (hipMemcpyAsync(&v, s->chain.chain_ctl + 32, sizeof v, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return -1;
+      if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return -1;
+      return (long long)v;
+    }
+    default: return -1;
+  }
 }
 
 int so101_physics(so101_sim* s, int nsub, int freeze, void* stream) {

@@ -27,12 +27,16 @@ void launch_begin(int n_envs, hipStream_t st, const DevModel* m, const StepParam
 void launch_reward(int n_envs, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B, float* reward);
 
 // pipelined step (Newton) -----------------------------------------------------------------------------------------
-void launch_order(hipStream_t st, const unsigned int* cost, int* order, int n_envs);
+void launch_order(hipStream_t st, const unsigned int* cost, int* order, unsigned char* cls, int n_envs);
 void launch_pipe_begin(int n_group, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B, const PrepBuffers& C,
-                       const EventBuffers& E, const PipeBuffers& W, const StepIO& io, unsigned char* need_reset, int* diag, int e0);
+                       const EventBuffers& E, const PipeBuffers& W, const StepIO& io, unsigned char* need_reset, int* diag, int e0,
+                       const ChainParams* chain = nullptr);
 void launch_narrow(int waves, hipStream_t st, const DevModel* m, int n_envs, const PipeBuffers& W, int substep);
 void launch_pipe_solve(int n_group, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B, const EventBuffers& E,
                        const PipeBuffers& W, int substep, int last, const StepIO& io, unsigned char* need_reset, int* diag, int e0);
+
+// per-env chained step (so101_chain.hpp): k_order + k_pipe_begin + ONE persistent launch
+void launch_chain(int waves, hipStream_t st, const ChainParams* params /* device memory */);
 
 // the PGS instantiations live in their own files
 void launch_reset_pgs(int n_envs, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B, const PrepBuffers& C,

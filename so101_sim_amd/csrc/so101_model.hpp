@@ -192,7 +192,24 @@ struct PipeBuffers {
                           // pipelined step (the caller's buffers are env-fastest struct-of-arrays: with one env per
                           // wavefront every scalar is its own 64-byte line; they are read once and written once per call)
 };
+
+// ---- per-env chaining (pipeline = 2, so101_chain.hpp): work queues of the persistent step kernel
+struct ChainQueues {
+  unsigned int* pending;  // [N] substep << 16 | narrowphase chunks of that substep still outstanding
+  const unsigned char* cls;   // [N] 1 = among the most expensive eighth of the previous control step (served first), by k_order
+  unsigned int* qctl;     // [4][64] per queue (narrow lo, narrow hi, solve lo, solve hi): word 0 head, word 32 tail
+  unsigned long long* qslot[4];   // ring slots: item | (ticket + 1) << 32
+  unsigned int qmask[4];
+  unsigned int* chain_ctl;        // [0] envs that finished this control step, [32] watchdog aborts
+};
+struct SolveIO { float* obs; float* reward; float* discount; unsigned char* step_type; unsigned char* need_reset; int* diag; };
 #define STATE_AOS 64
+#define NARROW_CHUNK 4     // candidate pairs per narrowphase work item
+#define Q_NARROW 0         // queue index = type + class
+#define Q_SOLVE 2
+
+// launch parameters of k_chain, kept in device memory (tu_chain.hip)
+struct ChainParams { const DevModel* m; StepParams P; DevBuffers B; EventBuffers E; PipeBuffers W; ChainQueues Q; SolveIO io; };
 
 // debug dump layout (floats) of so101_debug_forward
 #define DBG_M 0          // 36  arm mass matrix

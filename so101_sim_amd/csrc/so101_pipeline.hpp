@@ -23,7 +23,14 @@
 
 #include "so101_env.hpp"
 
+// Memory policy AG (all functions below): false = the data was produced by an EARLIER launch (launch chains, pipeline = 1);
+// true = it was produced by another wavefront of THIS launch (per-env chaining, pipeline = 2, so101_chain.hpp): every
+// store and load of handed-off bytes is then an agent-scope (sc1) access, see wave.hpp.
+template <bool AG, class T> DEV T pld(const T* p) { if constexpr (AG) return ld_agent(p); else return *p; }
+template <bool AG, class T> DEV void pst(T* p, T v) { if constexpr (AG) st_agent(p, v); else *p = v; }
+
 // the env's integrated state as one contiguous 256-byte record (substep round trips of the pipelined step)
+template <bool AG = false>
 DEV void store_state_aos(const EnvLDS& L, const PipeBuffers& W, int e) {
   int lane = wave_lane();
   float v = 0.f;
@@ -31,12 +38,13 @@ DEV void store_state_aos(const EnvLDS& L, const PipeBuffers& W, int e) {
   else if (lane < NQ + NV) v = L.qvel[lane - NQ];
   else if (lane < NQ + 2 * NV) v = L.warm[lane - NQ - NV];
   else if (lane < NQ + 2 * NV + NU) v = L.ctrl[lane - NQ - 2 * NV];
-  W.state[(size_t)e * STATE_AOS + lane] = v;
+  pst<AG>(&W.state[(size_t)e * STATE_AOS + lane], v);
 }
+template <bool AG = false>
 DEV void load_state_aos(EnvLDS& L, const DevBuffers& B, const PipeBuffers& W, int e, int N) {
   int lane = wave_lane();
   load_env_constants(L, B, e, N);
-  float v = W.state[(size_t)e * STATE_AOS + lane];
+  float v = pld<AG>(&W.state[(size_t)e * STATE_AOS + lane]);
   if (lane < NQ) L.qpos[lane] = v;
   else if (lane < NQ + NV) L.qvel[lane - NQ] = v;
   else if (lane < NQ + 2 * NV) L.warm[lane - NQ - NV] = v;
@@ -68,14 +76,15 @@ DEV void publish_candidates(const EnvLDS& L, const PipeBuffers& W, int e, int N,
 
 // contacts of this env for the current substep, in candidate order (a pair's contacts stay together, in the order the
 // narrowphase produced them), truncated at MAXCON like the fused loop.  lane = candidate.
+template <bool AG = false>
 DEV void gather_contacts(const DevModel* m, EnvLDS& L, const PipeBuffers& W, int e) {
   int lane = wave_lane();
-  int info = W.ncand[e], ncand = info & 0xffff, ncon = 0;
+  int info = pld<AG>(&W.ncand[e]), ncand = info & 0xffff, ncon = 0;
   for (int k0 = 0; k0 < ncand; k0 += WAVE) {
     int k = k0 + lane;
     size_t w = (size_t)e * MAXCAND + k;
     const float* r = W.conres + w * CONRES_DIM;
-    int cnt = k < ncand ? (int)r[0] : 0;
+    int cnt = k < ncand ? (int)pld<AG>(&r[0]) : 0;
     // exclusive prefix of the per-candidate contact counts (at most NCPP each): one ballot per possible count bit
     int idx = ncon, total = 0;
 #pragma unroll
@@ -85,12 +94,12 @@ DEV void gather_contacts(const DevModel* m, EnvLDS& L, const PipeBuffers& W, int
       total += __popcll(mask) << b;
     }
     if (cnt > 0) {
-      unsigned int c = W.cand[w];
-      float nrm[3] = {r[1], r[2], r[3]};
+      unsigned int c = pld<AG>(&W.cand[w]);
+      float nrm[3] = {pld<AG>(&r[1]), pld<AG>(&r[2]), pld<AG>(&r[3])};
       for (int j = 0; j < cnt; j++) {
         if (idx + j < MAXCON) {
-          float pos[3] = {r[5 + 4 * j], r[6 + 4 * j], r[7 + 4 * j]};
-          contact_init(m, L.con[idx + j], (int)(c & 0xffffu), (int)(c >> 16), r[4 + 4 * j], nrm, pos);
+          float pos[3] = {pld<AG>(&r[5 + 4 * j]), pld<AG>(&r[6 + 4 * j]), pld<AG>(&r[7 + 4 * j])};
+          contact_init(m, L.con[idx + j], (int)(c & 0xffffu), (int)(c >> 16), pld<AG>(&r[4 + 4 * j]), nrm, pos);
         }
       }
     }
@@ -103,4 +112,69 @@ DEV void gather_contacts(const DevModel* m, EnvLDS& L, const PipeBuffers& W, int
     L.ncon = ncon > MAXCON ? MAXCON : ncon;
   }
   wave_sync();
+}
+
+// One substep of one env on the solve side of the pipeline: smooth dynamics from the published poses, contact gather,
+// constraint rows, Newton, Euler step; then, unless this was the last substep, the integrated state goes back to its
+// record and the next substep's broadphase runs (candidates left in L.cand for the caller to publish); the last substep
+// ends with the task logic (finish_step).  Returns true when candidates for substep s + 1 are in L (false: last
+// substep, or the env has diverged - then W.ncand[e] = 0 has been stored).  Shared by k_pipe_solve and k_chain.
+template <bool AG>
+DEV bool pipe_solve_env(const DevModel* m, EnvLDS& L, const StepParams& P, const DevBuffers& B, const EventBuffers& E, const PipeBuffers& W,
+                        int e, int s, int last, int act, const SolveIO& io) {
+  int lane = wave_lane(), N = P.n_envs;
+  int sc = B.step_count[e] + 1;
+  unsigned long long c0 = SO101_CLOCK(), c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0;
+  load_state_aos<AG>(L, B, W, e, N);
+  bool diverged = act == 2;
+  if (!diverged) {
+    // (the poses of this state were published for the narrowphase by the kernel / wavefront that produced it)
+    kinematics_from_pose<AG>(m, L, W.pose + (size_t)e * (NDYN * 12));
+    crba_arm(m, L);
+    smooth_dynamics(m, L);
+    c1 = SO101_CLOCK();
+    gather_contacts<AG>(m, L, W, e);
+    c2 = SO101_CLOCK();
+    unsigned long long t_solve0 = wall_clock64();            // scheduling hint of k_order: always measured
+    make_constraints(m, L);
+    c3 = SO101_CLOCK();
+    solve_newton(m, L, P.iterations, P.tolerance);
+    c4 = SO101_CLOCK();
+    forward_accelerations(L);
+    if (lane == 0) { unsigned int dt = (unsigned int)(wall_clock64() - t_solve0); L.t_solve += dt; W.cost[e] = dt; }
+    euler(m, L);
+    diverged = check_divergence(L);
+    if (diverged && lane == 0) { if constexpr (AG) st_agent8(&W.active[e], (unsigned char)2); else W.active[e] = 2; }
+    c5 = SO101_CLOCK();
+  } else {
+    if (lane == 0) { L.ncon = 0; L.nrow = 0; L.iters = 0; L.ncand = 0; L.overflow = 8; }
+    wave_sync();
+  }
+  int ncon_solved = L.ncon, iters_solved = L.iters;      // (the next broadphase clears the counts)
+  if (!last) {
+    store_state_aos<AG>(L, W, e);
+    if (!diverged) {
+      unsigned long long q0 = SO101_CLOCK();
+      kinematics(m, L);
+      unsigned long long q1 = SO101_CLOCK();
+      broadphase(m, L);
+#ifdef SO101_DEBUG_CLOCKS
+      if (lane == 0) { L.nw.prof[8] = (unsigned int)(q0 - c5); L.nw.prof[9] = (unsigned int)(q1 - q0); }
+#endif
+    } else if (lane == 0) pst<AG>(&W.ncand[e], 0);
+    if (lane == 0) {
+      if (L.overflow) pst<AG>(&E.flags[e], pld<AG>(&E.flags[e]) | L.overflow);      // rare; summed into the event counters by finish_step()
+#ifdef SO101_DEBUG_CLOCKS
+      for (int k = 0; k < 16; k++) W.ticks[(size_t)e * MAXCAND + 240 + k] = L.nw.prof[k];      // (solver / broadphase phases; slots of candidates 240+ are idle)
+#endif
+      if (SO101_CLOCKS_ON) {
+        unsigned int* st = W.stage + (size_t)e * 8;
+        st[0] = (unsigned int)(c1 - c0); st[1] = (unsigned int)(c2 - c1); st[2] = (unsigned int)(c3 - c2); st[3] = (unsigned int)(c4 - c3);
+        st[4] = (unsigned int)(c5 - c4); st[5] = (unsigned int)(SO101_CLOCK() - c5); st[6] = (unsigned int)ncon_solved; st[7] = (unsigned int)iters_solved;
+      }
+    }
+    return !diverged;
+  }
+  finish_step<AG>(m, L, P, B, e, sc, diverged, io.obs, io.reward, io.discount, io.step_type, io.need_reset, io.diag, E);
+  return false;
 }

@@ -1,0 +1,81 @@
+// Translation unit: the persistent kernel of the per-env chained control step (so101_chain.hpp).
+#define SO101_OPAQUE_LANE 1
+#include "so101_chain.hpp"
+#include "so101_launch.hpp"
+
+// Every wavefront of the grid loops: solve item of the expensive class, narrow chunk of the expensive class, solve item,
+// narrow chunk, else look at the done counter / abort flag and sleep.  2 waves per SIMD (the narrowphase keeps both hulls
+// in registers), 20 KB of LDS per wavefront for the solve items.
+//
+// The launch parameters live in a device-memory block (ChainParams) instead of the kernel argument segment, and every
+// phase loads the part it needs through a laundered pointer: as kernel arguments the ~70 pointers and scalars stayed in
+// SGPRs across the whole loop, and the narrowphase (252 VGPRs on its own) had no room left for the registers their spills
+// need (first build: 116 spilled VGPRs, 448 B of scratch per lane).
+// The narrowphase chunk as a real function call: its 252 VGPRs (both hulls in registers) are allocated on their own.  Inlined
+// next to the solver, whose ~430 spilled SGPRs reserve VGPRs for the WHOLE kernel, it spilled 116-168 VGPRs to scratch.
+// Nothing but the parameter pointer and the clock is live across the call.
+#ifdef CHAIN_NARROW_CALL
+SO101_NOINLINE __device__ void chain_narrow_call(const ChainParams* cp_in, unsigned int item_in) {
+  const ChainParams* cp = uniform_ptr(cp_in);
+  unsigned int item = (unsigned int)wave_uniform_i((int)item_in);
+  chain_narrow(ldc(&cp->m), ldc_obj(&cp->W), ldc_obj(&cp->Q), item);
+}
+#endif
+
+__global__ void __launch_bounds__(64, 2) k_chain(const ChainParams* cp0) {
+  BLOCK_SHARED(EnvLDS, L);
+  int lane = wave_lane();
+  unsigned long long t_idle = wall_clock64();
+  for (;;) {
+    unsigned int item = 0;
+    int kind = -1;
+    {
+      const ChainParams* cp = cp0; LAUNDER_UNIFORM(cp);
+      ChainQueues Q = ldc_obj(&cp->Q);
+      if (q_pop(chain_queue(Q, Q_SOLVE + 1), &item)) kind = 1;
+      else if (q_pop(chain_queue(Q, Q_NARROW + 1), &item)) kind = 0;
+      else if (q_pop(chain_queue(Q, Q_SOLVE + 0), &item)) kind = 1;
+      else if (q_pop(chain_queue(Q, Q_NARROW + 0), &item)) kind = 0;
+    }
+    if (kind == 1) {
+      const ChainParams* cp = cp0; LAUNDER_UNIFORM(cp);
+      chain_solve(ldc(&cp->m), L, ldc_obj(&cp->P), ldc_obj(&cp->B), ldc_obj(&cp->E), ldc_obj(&cp->W), ldc_obj(&cp->Q), item, ldc_obj(&cp->io));
+      wave_sync();
+      t_idle = wall_clock64();
+      continue;
+    }
+    if (kind == 0) {
+#ifdef CHAIN_NARROW_CALL
+      chain_narrow_call(cp0, item);
+#else
+      const ChainParams* cp = cp0; LAUNDER_UNIFORM(cp);
+      chain_narrow(ldc(&cp->m), ldc_obj(&cp->W), ldc_obj(&cp->Q), item);
+#endif
+      t_idle = wall_clock64();
+      continue;
+    }
+    int stop = 0;
+    {
+      const ChainParams* cp = cp0; LAUNDER_UNIFORM(cp);
+      unsigned int* ctl = ldc(&cp->Q.chain_ctl);
+      if (lane == 0) {
+        if (ld_agent(&ctl[0]) >= (unsigned int)ldc(&cp->P.n_envs) || ld_agent(&ctl[32]) != 0u) stop = 1;
+        else if (wall_clock64() - t_idle > CHAIN_WATCHDOG_TICKS) {
+          if (atom_add_agent(&ctl[32], 1u) == 0u) atomicAdd(ldc(&cp->E.events) + 6, 1ull);
+          stop = 1;
+        }
+      }
+    }
+    if (wave_uniform_i(stop)) break;
+    idle_sleep();
+  }
+}
+
+namespace so101 {
+void launch_chain(int waves, hipStream_t st, const ChainParams* params) {
+#ifdef SO101_EMU
+  waves = waves < 3 ? waves : 3;           // OS threads: three wavefronts alive at once exercise every hand-off
+#endif
+  SO101_LAUNCH_CONCURRENT(k_chain, dim3(waves), dim3(64), st, params);
+}
+}  // namespace so101

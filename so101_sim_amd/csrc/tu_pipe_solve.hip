@@ -10,7 +10,6 @@
 // wavefront.  It is SLOWER (4096-env bench 490-509 k against 635 k env-steps/s): ~70 % of a query's instructions are
 // the lane-parallel hull scans, not the uniform portal math, and a row caches only 128 vertices of a hull in registers
 // (the arm links have 400-525), so every support call of a big hull goes back to L2.
-#define NARROW_CHUNK 4
 __global__ void __launch_bounds__(64, 2) k_narrow(const DevModel* m, int N, PipeBuffers W, int s) {
   int lane = wave_lane();
   // Scalar load on purpose.  The count shares its cache line with the cursor every wave of this launch does atomics on; when the
@@ -65,7 +64,7 @@ __global__ void __launch_bounds__(64, 2) k_narrow(const DevModel* m, int N, Pipe
 // counts: mean 2.7, max ~19) and workgroups are dispatched in index order, so envs that were expensive in the
 // previous control step go first: counting sort of the group's envs by log2(cost), descending.  The order only
 // changes WHEN an env is processed, never its result.  One workgroup for the whole batch.
-__global__ void __launch_bounds__(1024) k_order(const unsigned int* cost, int* order, int e0, int ng) {   // e0 = 0, ng = N
+__global__ void __launch_bounds__(1024) k_order(const unsigned int* cost, int* order, unsigned char* cls, int e0, int ng) {   // e0 = 0, ng = N
   __shared__ int hist[32], start[32];
   int t = threadIdx.x;
   if (t < 32) hist[t] = 0;
@@ -81,7 +80,9 @@ __global__ void __launch_bounds__(1024) k_order(const unsigned int* cost, int* o
   for (int i = t; i < ng; i += 1024) {
     unsigned int c = cost[e0 + i];
     int b = c ? __clz((int)c) : 31;
-    order[e0 + atomicAdd(&start[b], 1)] = e0 + i;
+    int pos = atomicAdd(&start[b], 1);
+    order[e0 + pos] = e0 + i;
+    cls[e0 + i] = pos < ng / 8 ? 1 : 0;        // the expensive eighth: served first by the chained step (so101_chain.hpp)
   }
 }
 
@@ -89,69 +90,22 @@ __global__ void __launch_bounds__(64, 2) k_pipe_solve(const DevModel* m, StepPar
                                                    float* obs, float* reward, float* discount, unsigned char* step_type,
                                                    unsigned char* need_reset, int* diag, int e0) {
   __shared__ EnvLDS L;
-  int e = wave_uniform_i(W.order[e0 + blockIdx.x]), lane = wave_lane(), N = P.n_envs;
+  int e = wave_uniform_i(W.order[e0 + blockIdx.x]);
   int act = W.active[e];
   if (act == 0) return;
-  int sc = B.step_count[e] + 1;
-  unsigned long long c0 = SO101_CLOCK(), c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0;
-  load_state_aos(L, B, W, e, N);
-  bool diverged = act == 2;
-  if (!diverged) {
-    // (the poses of this state were published for the narrowphase by the kernel that produced it)
-    kinematics_from_pose(m, L, W.pose + (size_t)e * (NDYN * 12));
-    crba_arm(m, L);
-    smooth_dynamics(m, L);
-    c1 = SO101_CLOCK();
-    gather_contacts(m, L, W, e);
-    c2 = SO101_CLOCK();
-    unsigned long long t_solve0 = wall_clock64();            // scheduling hint of k_order: always measured
-    make_constraints(m, L);
-    c3 = SO101_CLOCK();
-    solve_newton(m, L, P.iterations, P.tolerance);
-    c4 = SO101_CLOCK();
-    forward_accelerations(L);
-    if (lane == 0) { unsigned int dt = (unsigned int)(wall_clock64() - t_solve0); L.t_solve += dt; W.cost[e] = dt; }
-    euler(m, L);
-    diverged = check_divergence(L);
-    if (diverged && lane == 0) W.active[e] = 2;
-    c5 = SO101_CLOCK();
-  } else {
-    if (lane == 0) { L.ncon = 0; L.nrow = 0; L.iters = 0; L.ncand = 0; L.overflow = 8; }
-    wave_sync();
-  }
-  int ncon_solved = L.ncon, iters_solved = L.iters;      // (the next broadphase clears the counts)
-  if (!last) {
-    store_state_aos(L, W, e);
-    if (!diverged) {
-      unsigned long long q0 = SO101_CLOCK();
-      kinematics(m, L);
-      unsigned long long q1 = SO101_CLOCK();
-      broadphase(m, L);
-      unsigned long long q2 = SO101_CLOCK();
-      publish_candidates(L, W, e, N, s + 1);
+  SolveIO io{obs, reward, discount, step_type, need_reset, diag};
+  if (pipe_solve_env<false>(m, L, P, B, E, W, e, s, last, act, io)) {
+    unsigned long long q2 = SO101_CLOCK();
+    publish_candidates(L, W, e, P.n_envs, s + 1);
 #ifdef SO101_DEBUG_CLOCKS
-      if (lane == 0) { L.nw.prof[8] = (unsigned int)(q0 - c5); L.nw.prof[9] = (unsigned int)(q1 - q0); L.nw.prof[13] = (unsigned int)(SO101_CLOCK() - q2); }
+    if (wave_lane() == 0) W.ticks[(size_t)e * MAXCAND + 240 + 13] = (unsigned int)(SO101_CLOCK() - q2);
 #endif
-    } else if (lane == 0) W.ncand[e] = 0;
-    if (lane == 0) {
-      if (L.overflow) E.flags[e] |= L.overflow;          // rare; summed into the event counters by finish_step()
-#ifdef SO101_DEBUG_CLOCKS
-      for (int k = 0; k < 16; k++) W.ticks[(size_t)e * MAXCAND + 240 + k] = L.nw.prof[k];      // (solver / broadphase phases; slots of candidates 240+ are idle)
-#endif
-      if (SO101_CLOCKS_ON) {
-        unsigned int* st = W.stage + (size_t)e * 8;
-        st[0] = (unsigned int)(c1 - c0); st[1] = (unsigned int)(c2 - c1); st[2] = (unsigned int)(c3 - c2); st[3] = (unsigned int)(c4 - c3);
-        st[4] = (unsigned int)(c5 - c4); st[5] = (unsigned int)(SO101_CLOCK() - c5); st[6] = (unsigned int)ncon_solved; st[7] = (unsigned int)iters_solved;
-      }
-    }
-    return;
   }
-  finish_step(m, L, P, B, e, sc, diverged, obs, reward, discount, step_type, need_reset, diag, E);
 }
 
 namespace so101 {
-void launch_order(hipStream_t st, const unsigned int* cost, int* order, int n_envs) {
-  hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, cost, order, 0, n_envs);
+void launch_order(hipStream_t st, const unsigned int* cost, int* order, unsigned char* cls, int n_envs) {
+  hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, cost, order, cls, 0, n_envs);
 }
 void launch_narrow(int waves, hipStream_t st, const DevModel* m, int n_envs, const PipeBuffers& W, int substep) {
   hipLaunchKernelGGL(k_narrow, dim3(waves), dim3(64), 0, st, m, n_envs, W, substep);

@@ -8,8 +8,24 @@
 #include <hip/hip_runtime.h>
 
 #define WAVE 64
+#define BLOCK_SHARED(T, name) __shared__ T name
+#define SO101_LAUNCH_CONCURRENT(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
 
-__device__ __forceinline__ int wave_lane() { return threadIdx.x; }
+// SO101_OPAQUE_LANE (tu_chain.hip): the lane index comes out of a volatile asm, once per call site.  In the persistent
+// kernel everything derived from threadIdx.x is invariant with respect to the work loop; LLVM hoisted hundreds of lane
+// predicates and lane-derived addresses of BOTH phases in front of the loop and kept them live across it (first build: 168
+// spilled VGPRs, 720 B of scratch per lane).  An asm result cannot be hoisted or merged, so lane-derived values live where
+// the source computes them; two VALU instructions per call site.
+__device__ __forceinline__ int wave_lane() {
+#ifdef SO101_OPAQUE_LANE
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  __builtin_assume(l >= 0 && l < 64);
+  return l;
+#else
+  return threadIdx.x;
+#endif
+}
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
 
 // DPP controls (GFX9 encoding)
@@ -96,6 +112,26 @@ __device__ __forceinline__ int wave_prefix(unsigned long long mask) {
 template <class T>
 __device__ __forceinline__ T ldc(const T* p) { return *(const __attribute__((address_space(4))) T*)(unsigned long long)p; }
 
+// a whole (trivially copyable) object from memory that no kernel writes, through scalar loads
+template <class T>
+__device__ __forceinline__ T ldc_obj(const T* p) {
+  T out;
+  // (typed source pointer: with a void* the copy has alignment 1 and becomes VECTOR loads)
+  __builtin_memcpy(&out, (const __attribute__((address_space(4))) T*)(unsigned long long)p, sizeof(T));
+  return out;
+}
+// a pointer that is the same in every lane but arrived in vector registers (argument of a non-inlined device function)
+template <class T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+  unsigned long long v = (unsigned long long)p;
+  unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)v), hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(v >> 32));
+  return (T*)(((unsigned long long)hi << 32) | lo);
+}
+#define SO101_NOINLINE __attribute__((noinline))
+// makes the compiler forget what it knows about a wave-uniform pointer: loads through it are issued where the source has them
+// instead of being hoisted to the top of the kernel and kept in registers across everything in between
+#define LAUNDER_UNIFORM(p) asm volatile("" : "+s"(p))
+
 // tells the compiler that v is the same in every lane (keeps it in an SGPR: scalar loads, scalar branches)
 __device__ __forceinline__ int wave_uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -144,4 +180,34 @@ __device__ __forceinline__ void row_argmax3(float& val, int& idx, float& x, floa
   row_argmax3_step<DPP_ROW_HALF_MIRROR>(val, idx, x, y, z);
   row_argmax3_step<DPP_ROW_MIRROR>(val, idx, x, y, z);
 }
+// ---- agent-scope memory operations: hand-offs between wavefronts INSIDE one launch (so101_chain.hpp) ------------------
+// Per-XCD L2s are not coherent with each other and a CU's vector L1 is never refreshed by another CU's stores
+// (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility").  Bytes that one wavefront hands
+// to another within a launch are therefore written with `sc1` (write-through) stores, drained with s_waitcnt vmcnt(0)
+// before the flag / queue slot / counter that announces them, and read with `sc1` loads (L1 bypassed) - every store and
+// every load of those bytes, no exceptions.  The relaxed agent-scope atomics below compile to exactly those forms
+// (global_load/store ... sc1); no cache-wide release / acquire fence is needed with this discipline.
+template <class T>
+__device__ __forceinline__ T ld_agent(const T* p) {
+  static_assert(sizeof(T) == 4, "ld_agent: 4-byte types");
+  int v = __hip_atomic_load((const int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __builtin_bit_cast(T, v);
+}
+template <class T>
+__device__ __forceinline__ void st_agent(T* p, T v) {
+  static_assert(sizeof(T) == 4, "st_agent: 4-byte types");
+  __hip_atomic_store((int*)p, __builtin_bit_cast(int, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ld_agent64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent64(unsigned long long* p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned char ld_agent8(const unsigned char* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent8(unsigned char* p, unsigned char v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// every store this wavefront has issued has reached the coherence point (on gfx9 vmcnt counts stores as well as loads)
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned int atom_add_agent(unsigned int* p, unsigned int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned int atom_cas_agent(unsigned int* p, unsigned int expect, unsigned int desired) {
+  __hip_atomic_compare_exchange_strong(p, &expect, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return expect;                       // the value found: == the caller's `expect` when the exchange happened
+}
+__device__ __forceinline__ void idle_sleep() { __builtin_amdgcn_s_sleep(32); }      // ~2 k cycles off the issue port
 #endif  // SO101_WAVE_HPP_

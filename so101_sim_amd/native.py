@@ -18,7 +18,8 @@ RING_DEPTH = 5
 DIAG_DIM = 8
 NEVENTS = 8
 EVENT_NAMES = ("candidate_overflow", "contact_overflow", "arm_pool_overflow", "diverged", "placement_rejected",
-               "settle_not_converged")
+               "settle_not_converged", "scheduler_abort")
+INFO = dict(graph_active=0, step_path=1, chains=2, hw_queues=3, scheduler_aborts=4, scratch_bytes=5)
 DEBUG_DIM = 2048
 MAXCON = 64
 
@@ -29,7 +30,7 @@ DBG = dict(M=0, MINV=36, BIAS=72, SMOOTH=78, QACC=96, COUNTS=114, XPOS=120, CON=
 EXPORTS = (
     "so101_version", "so101_max_contacts", "so101_create", "so101_destroy", "so101_default_config",
     "so101_configure", "so101_bind_state", "so101_set_reset_pool", "so101_compute_settled", "so101_set_settled_store", "so101_reset", "so101_settle", "so101_begin_episode", "so101_step", "so101_physics", "so101_reward",
-    "so101_get_returns", "so101_get_diag", "so101_get_events", "so101_debug_forward", "so101_debug_candidates", "so101_debug_stages", "so101_last_error",
+    "so101_get_returns", "so101_get_diag", "so101_get_events", "so101_debug_forward", "so101_debug_candidates", "so101_debug_stages", "so101_get_info", "so101_last_error",
 )
 
 
@@ -44,7 +45,7 @@ class Config(C.Structure):
                 ("solver_iterations", C.c_int32), ("solver_tolerance", C.c_float),
                 ("settle_max_substeps", C.c_int32), ("terminate_on_success", C.c_int32),
                 ("env_id_base", C.c_uint64), ("solver", C.c_int32), ("prefetch_resets", C.c_int32), ("pipeline", C.c_int32),
-                ("groups", C.c_int32), ("use_graph", C.c_int32)]
+                ("groups", C.c_int32), ("use_graph", C.c_int32), ("chain_waves", C.c_int32)]
 
 
 _libs: dict[str, C.CDLL] = {}
@@ -89,6 +90,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.so101_debug_forward.argtypes = [vp, vp, vp]
     L.so101_debug_candidates.argtypes = [vp, vp, vp, vp, vp, vp]
     L.so101_debug_stages.argtypes = [vp, vp, vp]
+    L.so101_get_info.restype = C.c_longlong
+    L.so101_get_info.argtypes = [vp, C.c_int, vp]
     L.so101_last_error.restype = C.c_char_p
     L.so101_last_error.argtypes = [vp]
     _libs[path] = L
@@ -136,6 +139,10 @@ class Sim:
                     raise AttributeError(k)
                 setattr(self.cfg, k, v)
         self._check(self.L.so101_configure(self.h, C.byref(self.cfg)), "so101_configure")
+
+    def info(self, stream=0) -> dict:
+        """Facts about the handle (so101_get_info): which step path ran, graph replay, scheduler aborts, scratch size."""
+        return {k: int(self.L.so101_get_info(self.h, v, C.c_void_p(stream))) for k, v in INFO.items()}
 
     def bind(self, qpos, qvel, ctrl, warmstart, obs_ring, ep_return, step_count, episode, mass_scale=None):
         b = Buffers(qpos, qvel, ctrl, warmstart, obs_ring, ep_return, step_count, episode, mass_scale)

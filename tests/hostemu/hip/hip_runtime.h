@@ -4,6 +4,7 @@
 // loaded by the product package (so101_sim_amd/native.py only loads libso101_hip.so).
 #pragma once
 #include <pthread.h>
+#include <time.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -24,11 +25,23 @@ struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c 
 struct emu_idx { unsigned x, y, z; };
 extern thread_local emu_idx threadIdx;
 extern thread_local emu_idx blockIdx;
-extern pthread_barrier_t emu_barrier;
-extern pthread_barrier_t emu_row_barrier[4];      // one per DPP row of 16 lanes: rows of a wave may diverge (k_narrow)
-extern float emu_xchg_f[64];
-extern int emu_xchg_i[64];
-extern unsigned long long emu_xchg_u;
+// Per-block context: barrier, cross-lane exchange buffers, "LDS".  Blocks normally run one after the other
+// (emu_launch); the persistent scheduler kernel (k_chain) needs several blocks alive at once (emu_launch_concurrent),
+// so nothing block-local may be a process-wide global.
+struct EmuBlock {
+  pthread_barrier_t barrier;
+  pthread_barrier_t row_barrier[4];      // one per DPP row of 16 lanes: rows of a wave may diverge (k_narrow)
+  float xchg_f[64];
+  int xchg_i[64];
+  float pv[64], px[64], py[64], pz[64];
+  int pi[64];
+  alignas(64) unsigned char lds[65536];  // BLOCK_SHARED storage of kernels that may run concurrently
+};
+extern thread_local EmuBlock* emu_blk;
+#define emu_barrier (emu_blk->barrier)
+#define emu_row_barrier (emu_blk->row_barrier)
+#define emu_xchg_f (emu_blk->xchg_f)
+#define emu_xchg_i (emu_blk->xchg_i)
 
 inline void __syncthreads() { pthread_barrier_wait(&emu_barrier); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
@@ -39,7 +52,7 @@ using std::min;
 typedef int hipError_t;
 typedef void* hipStream_t;
 enum { hipSuccess = 0 };
-enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToDevice = 3 };
+enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
 inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? 0 : 1; }
 inline hipError_t hipFree(void* p) { free(p); return 0; }
@@ -57,6 +70,7 @@ inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (void*)1; return 0; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+inline hipError_t hipDeviceSynchronize() { return 0; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (void*)1; return 0; }
 inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
@@ -72,7 +86,10 @@ inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*,
 inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return 1; }
 inline hipError_t hipGraphDestroy(hipGraph_t) { return 0; }
 inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return 0; }
-inline unsigned long long wall_clock64() { return 0ull; }
+inline unsigned long long wall_clock64() {        // 100 MHz like the device's s_memrealtime
+  timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (unsigned long long)ts.tv_sec * 100000000ull + (unsigned long long)ts.tv_nsec / 10ull;
+}
 // v_readlane: value of lane `l`
 inline int __builtin_amdgcn_readlane(int v, int l) { emu_xchg_i[threadIdx.x] = v; __syncthreads(); int r = emu_xchg_i[l]; __syncthreads(); return r; }
 inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
@@ -81,17 +98,41 @@ inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v)
 inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline hipError_t hipGetLastError() { return 0; }
 
+inline EmuBlock* emu_block_new(unsigned threads) {
+  EmuBlock* b = new EmuBlock();
+  pthread_barrier_init(&b->barrier, nullptr, threads);
+  if (threads == 64) for (int r = 0; r < 4; r++) pthread_barrier_init(&b->row_barrier[r], nullptr, 16);
+  return b;
+}
+inline void emu_block_free(EmuBlock* b, unsigned threads) {
+  pthread_barrier_destroy(&b->barrier);
+  if (threads == 64) for (int r = 0; r < 4; r++) pthread_barrier_destroy(&b->row_barrier[r]);
+  delete b;
+}
 template <typename K, typename... A>
 void emu_launch(K kernel, dim3 grid, dim3 block, A... args) {
   for (unsigned b = 0; b < grid.x; b++) {
-    pthread_barrier_init(&emu_barrier, nullptr, block.x);
-    if (block.x == 64) for (int r = 0; r < 4; r++) pthread_barrier_init(&emu_row_barrier[r], nullptr, 16);
+    EmuBlock* blk = emu_block_new(block.x);
     std::vector<std::thread> th;
     for (unsigned t = 0; t < block.x; t++)
-      th.emplace_back([=]() { threadIdx = {t, 0, 0}; blockIdx = {b, 0, 0}; kernel(args...); });
+      th.emplace_back([=]() { threadIdx = {t, 0, 0}; blockIdx = {b, 0, 0}; emu_blk = blk; kernel(args...); });
     for (auto& x : th) x.join();
-    pthread_barrier_destroy(&emu_barrier);
-    if (block.x == 64) for (int r = 0; r < 4; r++) pthread_barrier_destroy(&emu_row_barrier[r]);
+    emu_block_free(blk, block.x);
   }
 }
+// all blocks of the grid alive at once (persistent kernels whose blocks hand work to each other)
+template <typename K, typename... A>
+void emu_launch_concurrent(K kernel, dim3 grid, dim3 block, A... args) {
+  std::vector<EmuBlock*> blks;
+  std::vector<std::thread> th;
+  for (unsigned b = 0; b < grid.x; b++) {
+    EmuBlock* blk = emu_block_new(block.x);
+    blks.push_back(blk);
+    for (unsigned t = 0; t < block.x; t++)
+      th.emplace_back([=]() { threadIdx = {t, 0, 0}; blockIdx = {b, 0, 0}; emu_blk = blk; kernel(args...); });
+  }
+  for (auto& x : th) x.join();
+  for (EmuBlock* blk : blks) emu_block_free(blk, block.x);
+}
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) emu_launch(kernel, grid, block, __VA_ARGS__)
+#define SO101_LAUNCH_CONCURRENT(kernel, grid, block, stream, ...) emu_launch_concurrent(kernel, grid, block, __VA_ARGS__)

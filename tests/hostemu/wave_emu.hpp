@@ -6,7 +6,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <sched.h>
 #define WAVE 64
+#define SO101_EMU 1
+// block-shared storage of kernels whose blocks may be alive concurrently under emulation (k_chain)
+#define BLOCK_SHARED(T, name) static_assert(sizeof(T) <= sizeof(EmuBlock::lds), "LDS"); T& name = *reinterpret_cast<T*>(emu_blk->lds)
 inline int wave_lane() { return threadIdx.x; }
 inline void wave_sync() { __syncthreads(); }
 inline float wave_max_f(float v) {
@@ -49,6 +53,10 @@ inline int wave_prefix(unsigned long long mask) { return __builtin_popcountll(ma
 // readfirstlane: every lane gets lane 0's value
 inline int wave_uniform_i(int v) { emu_xchg_i[threadIdx.x] = v; __syncthreads(); int r = emu_xchg_i[0]; __syncthreads(); return r; }
 template <class T> inline T ldc(const T* p) { return *p; }
+template <class T> inline T ldc_obj(const T* p) { return *p; }
+#define LAUNDER_UNIFORM(p) (void)(p)
+template <class T> inline T* uniform_ptr(T* p) { return p; }
+#define SO101_NOINLINE
 inline float wave_get_f(float v, int src) { emu_xchg_f[threadIdx.x] = v; __syncthreads(); float r = emu_xchg_f[src]; __syncthreads(); return r; }
 inline float wave_bcast_f(float v, int src) { emu_xchg_f[threadIdx.x] = v; __syncthreads(); float r = emu_xchg_f[src]; __syncthreads(); return r; }
 inline int wave_bcast_i(int v, int src) { emu_xchg_i[threadIdx.x] = v; __syncthreads(); int r = emu_xchg_i[src]; __syncthreads(); return r; }
@@ -64,7 +72,7 @@ inline int wave_min_i(int v) {
   __syncthreads(); return m;
 }
 inline void wave_argmax3(float& val, int& idx, float& x, float& y, float& z) {
-  static float px[64], py[64], pz[64];
+  float *px = emu_blk->px, *py = emu_blk->py, *pz = emu_blk->pz;
   emu_xchg_f[threadIdx.x] = val; emu_xchg_i[threadIdx.x] = idx; px[threadIdx.x] = x; py[threadIdx.x] = y; pz[threadIdx.x] = z;
   __syncthreads();
   float m = emu_xchg_f[0]; for (int i = 1; i < 64; i++) m = std::fmax(m, emu_xchg_f[i]);
@@ -79,8 +87,8 @@ inline void wave_argmax3(float& val, int& idx, float& x, float& y, float& z) {
 // row-local argmax with payload: the 16 lanes of a DPP row agree on (max value, smallest index, winner's payload).
 // Rows of a wave may diverge (k_narrow runs one geom pair per row), so the exchange synchronises the row only.
 inline void row_argmax3(float& val, int& idx, float& x, float& y, float& z) {
-  static float pv[64], px[64], py[64], pz[64];
-  static int pi[64];
+  float *pv = emu_blk->pv, *px = emu_blk->px, *py = emu_blk->py, *pz = emu_blk->pz;
+  int* pi = emu_blk->pi;
   int t = threadIdx.x, row = t >> 4, r0 = t & ~15, src = r0;
   pv[t] = val; pi[t] = idx; px[t] = x; py[t] = y; pz[t] = z;
   pthread_barrier_wait(&emu_row_barrier[row]);
@@ -90,4 +98,18 @@ inline void row_argmax3(float& val, int& idx, float& x, float& y, float& z) {
   pthread_barrier_wait(&emu_row_barrier[row]);
   val = ov; idx = oi; x = ox; y = oy; z = oz;
 }
+// agent-scope memory operations (wave.hpp): sequentially consistent host atomics
+template <class T> inline T ld_agent(const T* p) { int v = __atomic_load_n((const int*)p, __ATOMIC_SEQ_CST); T o; std::memcpy(&o, &v, 4); return o; }
+template <class T> inline void st_agent(T* p, T v) { int x; std::memcpy(&x, &v, 4); __atomic_store_n((int*)p, x, __ATOMIC_SEQ_CST); }
+inline unsigned long long ld_agent64(const unsigned long long* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
+inline void st_agent64(unsigned long long* p, unsigned long long v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
+inline unsigned char ld_agent8(const unsigned char* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
+inline void st_agent8(unsigned char* p, unsigned char v) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
+inline void drain_stores() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+inline unsigned int atom_add_agent(unsigned int* p, unsigned int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+inline unsigned int atom_cas_agent(unsigned int* p, unsigned int expect, unsigned int desired) {
+  __atomic_compare_exchange_n(p, &expect, desired, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+  return expect;
+}
+inline void idle_sleep() { sched_yield(); }
 #endif

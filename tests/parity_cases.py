@@ -319,10 +319,10 @@ def check_settled_store_identical(make_sim, n=3, settle=25, steps=9, last_step=3
     assert events[0] == events[1]                      # placement / settle flags travel with the entries
 
 
-def check_pipeline_identical(make_sim, golden, n=4, steps=3, seed=9, settle=20, exact=True, all_reset_last=True):
-    """The pipelined step (k_pipe_begin / k_narrow / k_pipe_solve per substep) and the fused k_step run the same device
-    functions in the same order: rollouts from contact-rich states, across a time-limit auto-reset, must agree
-    (bit for bit when `exact`)."""
+def check_pipeline_identical(make_sim, golden, n=4, steps=3, seed=9, settle=20, exact=True, all_reset_last=True, pipelines=(0, 1, 2), **cfg):
+    """The fused k_step (0), the launch-chain pipeline (1: k_pipe_begin / k_narrow / k_pipe_solve per substep) and the per-env
+    chained step (2: one persistent k_chain launch, device-side queues) run the same device functions in the same order:
+    rollouts from contact-rich states, across a time-limit auto-reset, must agree (bit for bit when `exact`)."""
     states = golden["contact_rich_states"]["states"]
     states = (states * (1 + n // len(states)))[:n]            # tiled: n >= 64 exercises the multi-chain launch
     Q = np.array([s["qpos"] for s in states]).T
@@ -331,8 +331,8 @@ def check_pipeline_identical(make_sim, golden, n=4, steps=3, seed=9, settle=20, 
     A = np.array([s["action"] for s in states]).T
     n = len(states)
     out = []
-    for pipeline in (0, 1):
-        sim = make_sim(n, seed=seed, settle_max_substeps=settle, last_step=steps, pipeline=pipeline, prefetch_resets=0)
+    for pipeline in pipelines:
+        sim = make_sim(n, seed=seed, settle_max_substeps=settle, last_step=steps, pipeline=pipeline, prefetch_resets=0, **cfg)
         sim.set_state(Q, V, A, W)
         sim.begin_episode()
         rng = np.random.RandomState(seed)
@@ -344,12 +344,16 @@ def check_pipeline_identical(make_sim, golden, n=4, steps=3, seed=9, settle=20, 
             assert np.all(st == 0)             # the last call was the auto-reset
         else:
             assert np.any(st == 0)             # (envs that ended early, e.g. diverged, are one episode ahead)
+        if pipeline == 2 and hasattr(sim.sim, "info"):
+            info = sim.sim.info()
+            assert info["step_path"] == 2 and info["scheduler_aborts"] == 0, info
         out.append(trace)
-    for t, (a, b) in enumerate(zip(*out)):
-        if exact:
-            np.testing.assert_array_equal(a, b, err_msg=f"step {t}")
-        else:
-            np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-4, err_msg=f"step {t}")
+    for p, other in zip(pipelines[1:], out[1:]):
+        for t, (a, b) in enumerate(zip(out[0], other)):
+            if exact:
+                np.testing.assert_array_equal(a, b, err_msg=f"pipeline {p} vs {pipelines[0]}, step {t}")
+            else:
+                np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-4, err_msg=f"pipeline {p} vs {pipelines[0]}, step {t}")
 
 
 def _compare_contact_lists(mine_list, ref_list):

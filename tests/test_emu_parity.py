@@ -51,7 +51,12 @@ def test_settled_store_is_bit_identical(make_sim):
 
 
 def test_pipelined_step_matches_fused(make_sim, golden):
-    pc.check_pipeline_identical(make_sim, golden, n=1, steps=1, settle=3)
+    pc.check_pipeline_identical(make_sim, golden, n=1, steps=1, settle=3, pipelines=(0, 1))
+
+
+def test_chained_step_matches_fused(make_sim, golden):
+    # three envs on three concurrently alive emulated wavefronts: every queue hand-off of so101_chain.hpp is exercised
+    pc.check_pipeline_identical(make_sim, golden, n=3, steps=1, settle=3, pipelines=(0, 2))
 
 
 def test_pgs_forward_matches_oracle_pgs(make_sim, blobs):

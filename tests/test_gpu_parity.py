@@ -20,7 +20,7 @@ def test_native_library_is_the_hip_build():
     import os
     from so101_sim_amd import native
     assert os.path.exists(native.LIB_PATH)
-    assert native.load_library().so101_version() == 6
+    assert native.load_library().so101_version() == 7
 
 
 def test_forward_stages(make_sim, blobs):
@@ -91,6 +91,18 @@ def test_three_launch_chains_match_fused(make_sim, golden):
     """n >= 64: so101_step cuts the cost-sorted envs into three slices on separate streams; still bit-identical to the
     fused single-launch step (different random actions per env, so the slices really differ in cost)."""
     pc.check_pipeline_identical(make_sim, golden, n=160, steps=5, seed=4, all_reset_last=False)
+
+
+def test_chained_step_matches_fused_at_4096_envs(make_sim, golden):
+    """The per-env chained step (one persistent launch, device-side queues, 2048 wavefronts on all eight XCDs) against the
+    fused step, bit for bit, at the headline batch size: any stale hand-off between wavefronts shows up here."""
+    pc.check_pipeline_identical(make_sim, golden, n=4096, steps=8, seed=11, all_reset_last=False, pipelines=(0, 2))
+
+
+def test_chained_step_with_few_wavefronts(make_sim, golden):
+    """Eight persistent wavefronts for 160 envs: every wavefront alternates between narrowphase chunks and solve items of many
+    envs (queue wrap, the CAS paths, idle polling)."""
+    pc.check_pipeline_identical(make_sim, golden, n=160, steps=5, seed=4, all_reset_last=False, pipelines=(0, 2), chain_waves=8)
 
 
 # ---- SO100HandOverPen: same kernels, second scene blob (pen + utensil holder, two overlap boxes)
