@@ -15,12 +15,14 @@
 // Classes: envs that were among the most expensive eighth of the previous control step (k_order) use their own queue
 // pair, which every wavefront looks at first - their ten substeps are the critical path of the step.
 //
-// Queues: bounded multi-producer multi-consumer rings of 8-byte granules {item, ticket + 1}.  A producer reserves
-// tickets with one atomic add on the tail and writes the granules; a consumer reads the head, checks that the granule
-// at the head carries that ticket and takes it with a compare-and-swap on the head.  Nobody ever waits for a specific
-// item: a wavefront that finds nothing goes round its loop (solve hi, narrow hi, solve lo, narrow lo, sleep), so the
-// scheme cannot deadlock whatever the dispatch order or residency of the wavefronts is.  Tickets run on across control
-// steps (32 bits, wrap-safe: a stale granule can only alias after 2^32 pushes without its slot being rewritten).
+// Queues: bounded multi-producer multi-consumer rings of 8-byte granules {item, ticket + 1}, fetch-add only.  A producer
+// reserves tickets with one atomic add on the tail, announces them with one add on the `avail` count and writes the
+// granules; a consumer takes an entitlement from `avail` (and gives it back if there was none), then a ticket from the
+// head, and reads the granule of that ticket (its producer is at most two store instructions away).  Nobody waits for
+// work that may never come: a wavefront that finds every `avail` count at zero goes round its loop (solve hi, narrow
+// hi, solve lo, narrow lo, sleep), so the scheme cannot deadlock whatever the dispatch order or residency of the
+// wavefronts is.  Tickets run on across control steps (32 bits, wrap-safe: a stale granule can only alias after 2^32
+// pushes without its slot being rewritten); head == tail and avail == 0 at the end of every step.
 //
 // Memory discipline (wave.hpp, MI355X_MICROARCH.md "inter-workgroup visibility"): every byte handed from one wavefront
 // to another inside the launch - state record, poses, candidates, contact records, flags, queue granules - is written
@@ -40,6 +42,9 @@
 #endif
 
 struct ChainQ { unsigned int* ctl; unsigned long long* slot; unsigned int mask; };
+#define QC_HEAD 0          // tickets handed to consumers
+#define QC_AVAIL 16        // (int) items announced by producers minus items claimed by consumers
+#define QC_TAIL 32         // tickets handed to producers          (each on its own 64-byte line)
 DEV ChainQ chain_queue(const ChainQueues& C, int q) { ChainQ Q; Q.ctl = C.qctl + 64 * q; Q.slot = C.qslot[q]; Q.mask = C.qmask[q]; return Q; }
 // the queue of env e's class: selects between two compile-time indices (a run-time index would put the struct on the stack)
 DEV ChainQ chain_queue_of(const ChainQueues& C, int type, int e) {
@@ -49,27 +54,25 @@ DEV ChainQ chain_queue_of(const ChainQueues& C, int type, int e) {
   return Q;
 }
 
-// one lane: take the item at the head, if there is one
-DEV bool q_pop_lane(const ChainQ& Q, unsigned int* item) {
-  for (int tries = 0; tries < 3; tries++) {
-    unsigned int h = ld_agent(&Q.ctl[0]);
+// One lane: take an item if one has been announced.  Fetch-adds only: an entitlement from the `avail` count (given back when
+// there was none), then a ticket from the head - an entitled consumer's ticket always belongs to an item whose producer has
+// at least reserved it, so the wait for the granule is bounded by that producer's two store instructions.  (The first
+// version took the head with a compare-and-swap: correct, and 180 times slower than the launch chains at 4096 envs - a
+// successful CAS needs the previous one's result, so the queue handed out one item per memory round trip.)
+DEV bool q_pop_lane(const ChainQ& Q, unsigned int* item, unsigned int* abort_flag) {
+  int old = (int)atom_add_agent(&Q.ctl[QC_AVAIL], 0xffffffffu);
+  if (old <= 0) { atom_add_agent(&Q.ctl[QC_AVAIL], 1u); return false; }
+  unsigned int h = atom_add_agent(&Q.ctl[QC_HEAD], 1u);
+  for (unsigned int spin = 0;; spin++) {
     unsigned long long v = ld_agent64(&Q.slot[h & Q.mask]);
-    if ((unsigned int)(v >> 32) != h + 1u) return false;
-    if (atom_cas_agent(&Q.ctl[0], h, h + 1u) == h) { *item = (unsigned int)v; return true; }
+    if ((unsigned int)(v >> 32) == h + 1u) { *item = (unsigned int)v; return true; }
+    if (spin > (1u << 22)) { atom_add_agent(abort_flag, 1u); return false; }      // watchdog: never seen; ends the launch instead of hanging it
   }
-  return false;
-}
-// whole wavefront: lane 0 pops, everybody gets the result
-DEV bool q_pop(const ChainQ& Q, unsigned int* item) {
-  unsigned int it = 0; int ok = 0;
-  if (wave_lane() == 0) ok = q_pop_lane(Q, &it) ? 1 : 0;
-  ok = wave_uniform_i(ok);
-  *item = (unsigned int)wave_uniform_i((int)it);
-  return ok != 0;
 }
 // one lane: push one item (the payload it announces has been drained by the caller)
 DEV void q_push_lane(const ChainQ& Q, unsigned int item) {
-  unsigned int t = atom_add_agent(&Q.ctl[32], 1u);
+  unsigned int t = atom_add_agent(&Q.ctl[QC_TAIL], 1u);
+  atom_add_agent(&Q.ctl[QC_AVAIL], 1u);
   st_agent64(&Q.slot[t & Q.mask], (unsigned long long)item | ((unsigned long long)(t + 1u) << 32));
 }
 
@@ -96,7 +99,7 @@ DEV int publish_chain(const EnvLDS& L, const PipeBuffers& W, const ChainQueues& 
   if (nch == 0) return 0;                         // (the caller goes on with this env itself: its loads follow the drain)
   ChainQ Q = chain_queue_of(C, Q_NARROW, e);
   unsigned int base = 0;
-  if (lane == 0) base = atom_add_agent(&Q.ctl[32], (unsigned int)nch);
+  if (lane == 0) { base = atom_add_agent(&Q.ctl[QC_TAIL], (unsigned int)nch); atom_add_agent(&Q.ctl[QC_AVAIL], (unsigned int)nch); }
   base = (unsigned int)wave_uniform_i((int)base);
   for (int k = lane; k < nch; k += WAVE) {
     int cnt = ncand - NARROW_CHUNK * k; cnt = cnt < NARROW_CHUNK ? cnt : NARROW_CHUNK;

@@ -32,10 +32,18 @@ __global__ void __launch_bounds__(64, 2) k_chain(const ChainParams* cp0) {
     {
       const ChainParams* cp = cp0; LAUNDER_UNIFORM(cp);
       ChainQueues Q = ldc_obj(&cp->Q);
-      if (q_pop(chain_queue(Q, Q_SOLVE + 1), &item)) kind = 1;
-      else if (q_pop(chain_queue(Q, Q_NARROW + 1), &item)) kind = 0;
-      else if (q_pop(chain_queue(Q, Q_SOLVE + 0), &item)) kind = 1;
-      else if (q_pop(chain_queue(Q, Q_NARROW + 0), &item)) kind = 0;
+      if (lane == 0) {
+        // the four `avail` counts in one round trip, then at most one claim (solve hi, narrow hi, solve lo, narrow lo)
+        int a3 = (int)ld_agent(&Q.qctl[64 * 3 + QC_AVAIL]), a1 = (int)ld_agent(&Q.qctl[64 * 1 + QC_AVAIL]);
+        int a2 = (int)ld_agent(&Q.qctl[64 * 2 + QC_AVAIL]), a0 = (int)ld_agent(&Q.qctl[64 * 0 + QC_AVAIL]);
+        unsigned int* ab = Q.chain_ctl + 32;
+        if (a3 > 0 && q_pop_lane(chain_queue(Q, 3), &item, ab)) kind = 1;
+        else if (a1 > 0 && q_pop_lane(chain_queue(Q, 1), &item, ab)) kind = 0;
+        else if (a2 > 0 && q_pop_lane(chain_queue(Q, 2), &item, ab)) kind = 1;
+        else if (a0 > 0 && q_pop_lane(chain_queue(Q, 0), &item, ab)) kind = 0;
+      }
+      kind = wave_uniform_i(kind);
+      item = (unsigned int)wave_uniform_i((int)item);
     }
     if (kind == 1) {
       const ChainParams* cp = cp0; LAUNDER_UNIFORM(cp);
