@@ -313,6 +313,8 @@ def main():
     samples[0] = 0
     for env in envs:
         env.events(clear=True)
+        if hasattr(env, "sim") and hasattr(env.sim, "chain_stats"):
+            env.sim.chain_stats(clear=True)
 
     def timed_window(segment=0):
         """EXACTLY --steps steps bracketed by barrier + synchronize on both sides.  Returns (host seconds, device ms per
@@ -414,6 +416,8 @@ def main():
                                         "of each 100-step slice on rank 0, the way the reference logs its step time (run_eval.py:103-124)"}
         if hasattr(envs[0], "sim") and hasattr(envs[0].sim, "info"):
             out["config"]["step_path"] = envs[0].sim.info()
+            if path == 2:
+                out["config"]["chain_stats"] = envs[0].sim.chain_stats()
         if not args.no_cpu_baseline and world == 1 and on_gpu:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -227,6 +227,12 @@ int so101_debug_candidates(so101_sim* sim, int32_t* ncand, uint32_t* cand, uint3
 #define SO101_INFO_SCRATCH_BYTES 5
 long long so101_get_info(so101_sim* sim, int what, void* hip_stream);
 
+/* Where the wavefronts of the chained step's persistent kernel spent their time since the last clear: out = 16 uint64 in
+ * HOST memory (the call synchronises `hip_stream`): [0] claiming work that was found, [1] looking for work that was not,
+ * [2] narrowphase chunks, [3] solve items (10 ns ticks, summed over wavefronts); [4] chunks, [5] solve items, [6] idle
+ * rounds, [7] wavefronts that ran, [8] their lifetimes (ticks). */
+int so101_debug_chain_stats(so101_sim* sim, uint64_t* out, int clear, void* hip_stream);
+
 const char* so101_last_error(const so101_sim* sim);
 
 #ifdef __cplusplus

@@ -113,12 +113,15 @@ DEV int publish_chain(const EnvLDS& L, const PipeBuffers& W, const ChainQueues& 
 // to zero hands the env to the solve queue.
 DEV void chain_narrow(const DevModel* m, const PipeBuffers& W, const ChainQueues& C, unsigned int item) {
   int lane = wave_lane();
+  unsigned long long ta = wall_clock64();
   int e = (int)(item >> 8), k0 = (int)((item >> 2) & 63u) * NARROW_CHUNK, cnt = (int)(item & 3u) + 1;
   unsigned int cl = 0;
   if (lane < cnt) cl = ld_agent(&W.cand[(size_t)e * MAXCAND + k0 + lane]);
   // the env's body poses: 96 floats over the lanes (two loads), handed to the geoms below with v_readlane
   const float* pose = W.pose + (size_t)e * (NDYN * 12);
   float pv0 = ld_agent(&pose[lane]), pv1 = lane < NDYN * 12 - WAVE ? ld_agent(&pose[WAVE + lane]) : 0.f;
+  unsigned int c_first = (unsigned int)__builtin_amdgcn_readlane((int)cl, 0);     // (waits for the loads)
+  unsigned long long tb = wall_clock64() + (c_first & 0u);
 #pragma unroll 1
   for (int j = 0; j < cnt; j++) {
     unsigned int c = (unsigned int)__builtin_amdgcn_readlane((int)cl, j);
@@ -155,12 +158,17 @@ DEV void chain_narrow(const DevModel* m, const PipeBuffers& W, const ChainQueues
     for (int i = 0; i < CONRES_DIM; i++) mine = lane == i ? rec[i] : mine;
     if (lane < CONRES_DIM) st_agent(&W.conres[((size_t)e * MAXCAND + k0 + j) * CONRES_DIM + lane], mine);
   }
+  unsigned long long tc = wall_clock64();
   drain_stores();
   ChainQ QS = chain_queue_of(C, Q_SOLVE, e);
+  unsigned int old = 0;
   if (lane == 0) {
-    unsigned int old = atom_add_agent(&C.pending[e], 0xffffffffu);           // -1
+    old = atom_add_agent(&C.pending[e], 0xffffffffu);           // -1
     if ((old & 0xffffu) == 1u) q_push_lane(QS, solve_item(e, (int)(old >> 16)));
   }
+  old = (unsigned int)wave_uniform_i((int)old);
+  unsigned long long td = wall_clock64() + (old & 0u);
+  if (lane == 0) { atomicAdd(&C.stats[9], tb - ta); atomicAdd(&C.stats[10], tc - tb); atomicAdd(&C.stats[11], td - tc); }
 }
 
 // k_pipe_solve's body for env e from substep s on: as long as a substep yields no candidate the same wavefront goes on
@@ -170,13 +178,20 @@ DEV void chain_solve(const DevModel* m, EnvLDS& L, const StepParams& P, const De
   for (;;) {
     int last = s == P.n_substeps - 1;
     int act = (int)ld_agent8(&W.active[e]);
-    bool more = pipe_solve_env<true>(m, L, P, B, E, W, e, s, last, act, io);
+    unsigned long long ts[4];
+    bool more = pipe_solve_env<true>(m, L, P, B, E, W, e, s, last, act, io, ts);
+    if (wave_lane() == 0) { atomicAdd(&C.stats[12], ts[1] - ts[0]); atomicAdd(&C.stats[13], ts[2] - ts[1]); atomicAdd(&C.stats[14], ts[3] - ts[2]); }
+    unsigned long long tp = wall_clock64();
     if (last) {
       drain_stores();
       if (wave_lane() == 0) atom_add_agent(&C.chain_ctl[0], 1u);
       return;
     }
-    if (more) { if (publish_chain(L, W, C, e, s + 1) > 0) return; }
+    if (more) {
+      int nch = publish_chain(L, W, C, e, s + 1);
+      if (wave_lane() == 0) atomicAdd(&C.stats[15], wall_clock64() - tp);
+      if (nch > 0) return;
+    }
     else drain_stores();        // diverged: state record and ncand = 0 stored; the env idles through its remaining substeps here
     wave_sync();
     s++;

@@ -435,8 +435,10 @@ int so101_create(const void* blob, size_t bytes, int n_envs, int device, uint64_
               dev_alloc(s, &W.state, STATE_AOS * n, 0, "hipMalloc(pipe)") &&
               dev_alloc(s, &s->chain.pending, n, 0, "hipMalloc(chain)") && dev_alloc(s, &s->chain_cls, n, 0, "hipMalloc(chain)") &&
               dev_alloc(s, &s->chain.qctl, (size_t)4 * 64, 0, "hipMalloc(chain)") && dev_alloc(s, &s->chain.chain_ctl, (size_t)64, 0, "hipMalloc(chain)") &&
-              dev_alloc(s, &s->chain_params, (size_t)1, 0, "hipMalloc(chain)");
+              dev_alloc(s, &s->chain_params, (size_t)1, 0, "hipMalloc(chain)") && dev_alloc(s, &s->chain.stats, (size_t)16, 0, "hipMalloc(chain)");
     s->chain.cls = s->chain_cls;
+    s->chain.idle_sleeps = getenv("SO101_CHAIN_IDLE") ? atoi(getenv("SO101_CHAIN_IDLE")) : 8;
+    s->chain.role_mode = getenv("SO101_CHAIN_ROLE") ? atoi(getenv("SO101_CHAIN_ROLE")) : 0;
     // work queues of the chained step: narrow chunks (at most MAXCAND / NARROW_CHUNK outstanding per env), solve items (one per env)
     for (int q = 0; q < 4 && ok; q++) {
       size_t need = q < Q_SOLVE ? n * (MAXCAND / NARROW_CHUNK) : n, cap = 64;
@@ -811,6 +813,15 @@ int so101_debug_candidates(so101_sim* s, int32_t* ncand, uint32_t* cand, uint32_
   if (ticks) ok = ok && hip_ok(s, hipMemcpyAsync(ticks, s->pipe.ticks, sizeof(int) * MAXCAND * n, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync(debug)");
   if (conres) ok = ok && hip_ok(s, hipMemcpyAsync(conres, s->pipe.conres, sizeof(float) * CONRES_DIM * MAXCAND * n, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync(debug)");
   return ok ? SO101_OK : SO101_ERR_HIP;
+}
+
+int so101_debug_chain_stats(so101_sim* s, uint64_t* out, int clear, void* stream) {
+  if (!s || !out) return SO101_ERR_ARG;
+  GUARD_DEVICE(s);
+  hipStream_t st = (hipStream_t)stream;
+  if (!hip_ok(s, hipMemcpyAsync(out, s->chain.stats, sizeof(uint64_t) * 16, hipMemcpyDeviceToHost, st), "hipMemcpyAsync(chain stats)")) return SO101_ERR_HIP;
+  if (clear && !hip_ok(s, hipMemsetAsync(s->chain.stats, 0, sizeof(uint64_t) * 16, st), "hipMemsetAsync(chain stats)")) return SO101_ERR_HIP;
+  return hip_ok(s, hipStreamSynchronize(st), "hipStreamSynchronize") ? SO101_OK : SO101_ERR_HIP;
 }
 
 const char* so101_last_error(const so101_sim* s) { return s ? s->err.c_str() : g_create_error.c_str(); }

@@ -201,7 +201,13 @@ struct ChainQueues {
   unsigned long long* qslot[4];   // ring slots: item | (ticket + 1) << 32
   unsigned int qmask[4];
   unsigned int* chain_ctl;        // [0] envs that finished this control step, [32] watchdog aborts
+  int idle_sleeps;                // s_sleep instructions of an idle round (each ~2 k cycles)
+  int role_mode;                  // how a wavefront picks the kind of work it looks for first (tu_chain.hip)
+  unsigned long long* stats;      // [16] wall-clock ticks (10 ns) and counts summed over the wavefronts of k_chain, see CS_*
 };
+// k_chain statistics (so101_debug_chain_stats): ticks spent claiming work that was found, looking for work that was not,
+// in narrowphase chunks, in solve items; item counts; launches; wavefront lifetimes
+enum { CS_T_POP = 0, CS_T_IDLE, CS_T_NARROW, CS_T_SOLVE, CS_N_NARROW, CS_N_SOLVE, CS_N_IDLE, CS_WAVES, CS_T_LIFE, CS_N };
 struct SolveIO { float* obs; float* reward; float* discount; unsigned char* step_type; unsigned char* need_reset; int* diag; };
 #define STATE_AOS 64
 #define NARROW_CHUNK 4     // candidate pairs per narrowphase work item

@@ -121,8 +121,9 @@ DEV void gather_contacts(const DevModel* m, EnvLDS& L, const PipeBuffers& W, int
 // substep, or the env has diverged - then W.ncand[e] = 0 has been stored).  Shared by k_pipe_solve and k_chain.
 template <bool AG>
 DEV bool pipe_solve_env(const DevModel* m, EnvLDS& L, const StepParams& P, const DevBuffers& B, const EventBuffers& E, const PipeBuffers& W,
-                        int e, int s, int last, int act, const SolveIO& io) {
+                        int e, int s, int last, int act, const SolveIO& io, unsigned long long* ts = nullptr /* [4] wall-clock stamps */) {
   int lane = wave_lane(), N = P.n_envs;
+  if (ts) ts[0] = ts[1] = ts[2] = ts[3] = wall_clock64();
   int sc = B.step_count[e] + 1;
   unsigned long long c0 = SO101_CLOCK(), c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0;
   load_state_aos<AG>(L, B, W, e, N);
@@ -135,6 +136,7 @@ DEV bool pipe_solve_env(const DevModel* m, EnvLDS& L, const StepParams& P, const
     c1 = SO101_CLOCK();
     gather_contacts<AG>(m, L, W, e);
     c2 = SO101_CLOCK();
+    if (ts) ts[1] = wall_clock64();
     unsigned long long t_solve0 = wall_clock64();            // scheduling hint of k_order: always measured
     make_constraints(m, L);
     c3 = SO101_CLOCK();
@@ -146,6 +148,7 @@ DEV bool pipe_solve_env(const DevModel* m, EnvLDS& L, const StepParams& P, const
     diverged = check_divergence(L);
     if (diverged && lane == 0) { if constexpr (AG) st_agent8(&W.active[e], (unsigned char)2); else W.active[e] = 2; }
     c5 = SO101_CLOCK();
+    if (ts) ts[2] = wall_clock64();
   } else {
     if (lane == 0) { L.ncon = 0; L.nrow = 0; L.iters = 0; L.ncand = 0; L.overflow = 8; }
     wave_sync();
@@ -173,8 +176,10 @@ DEV bool pipe_solve_env(const DevModel* m, EnvLDS& L, const StepParams& P, const
         st[4] = (unsigned int)(c5 - c4); st[5] = (unsigned int)(SO101_CLOCK() - c5); st[6] = (unsigned int)ncon_solved; st[7] = (unsigned int)iters_solved;
       }
     }
+    if (ts) ts[3] = wall_clock64();
     return !diverged;
   }
+  if (ts) ts[3] = wall_clock64();
   finish_step<AG>(m, L, P, B, e, sc, diverged, io.obs, io.reward, io.discount, io.step_type, io.need_reset, io.diag, E);
   return false;
 }

@@ -190,12 +190,18 @@ __device__ __forceinline__ void row_argmax3(float& val, int& idx, float& x, floa
 template <class T>
 __device__ __forceinline__ T ld_agent(const T* p) {
   static_assert(sizeof(T) == 4, "ld_agent: 4-byte types");
+#ifdef SO101_CHAIN_PLAIN      // EXPERIMENT ONLY (wrong results): what the sc1 accesses cost
+  return *(const volatile T*)p;
+#endif
   int v = __hip_atomic_load((const int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return __builtin_bit_cast(T, v);
 }
 template <class T>
 __device__ __forceinline__ void st_agent(T* p, T v) {
   static_assert(sizeof(T) == 4, "st_agent: 4-byte types");
+#ifdef SO101_CHAIN_PLAIN
+  *(volatile T*)p = v; return;
+#endif
   __hip_atomic_store((int*)p, __builtin_bit_cast(int, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ unsigned long long ld_agent64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

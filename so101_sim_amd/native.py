@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libso101_hip.so")
+LIB_PATH = os.environ.get("SO101_HIP_LIB") or os.path.join(_HERE, "csrc", "libso101_hip.so")      # (the variable: kernel experiments only)
 
 SOLVER_PGS, SOLVER_NEWTON = 0, 1
 OBS_DIM = 18
@@ -30,7 +30,7 @@ DBG = dict(M=0, MINV=36, BIAS=72, SMOOTH=78, QACC=96, COUNTS=114, XPOS=120, CON=
 EXPORTS = (
     "so101_version", "so101_max_contacts", "so101_create", "so101_destroy", "so101_default_config",
     "so101_configure", "so101_bind_state", "so101_set_reset_pool", "so101_compute_settled", "so101_set_settled_store", "so101_reset", "so101_settle", "so101_begin_episode", "so101_step", "so101_physics", "so101_reward",
-    "so101_get_returns", "so101_get_diag", "so101_get_events", "so101_debug_forward", "so101_debug_candidates", "so101_debug_stages", "so101_get_info", "so101_last_error",
+    "so101_get_returns", "so101_get_diag", "so101_get_events", "so101_debug_forward", "so101_debug_candidates", "so101_debug_stages", "so101_get_info", "so101_debug_chain_stats", "so101_last_error",
 )
 
 
@@ -90,6 +90,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.so101_debug_forward.argtypes = [vp, vp, vp]
     L.so101_debug_candidates.argtypes = [vp, vp, vp, vp, vp, vp]
     L.so101_debug_stages.argtypes = [vp, vp, vp]
+    L.so101_debug_chain_stats.argtypes = [vp, vp, C.c_int, vp]
     L.so101_get_info.restype = C.c_longlong
     L.so101_get_info.argtypes = [vp, C.c_int, vp]
     L.so101_last_error.restype = C.c_char_p
@@ -143,6 +144,19 @@ class Sim:
     def info(self, stream=0) -> dict:
         """Facts about the handle (so101_get_info): which step path ran, graph replay, scheduler aborts, scratch size."""
         return {k: int(self.L.so101_get_info(self.h, v, C.c_void_p(stream))) for k, v in INFO.items()}
+
+    def chain_stats(self, clear=True, stream=0) -> dict:
+        """Time accounting of the chained step's persistent kernel (so101_debug_chain_stats), seconds summed over wavefronts."""
+        buf = (C.c_uint64 * 16)()
+        self._check(self.L.so101_debug_chain_stats(self.h, C.cast(buf, C.c_void_p), int(clear), C.c_void_p(stream)), "so101_debug_chain_stats")
+        k = ("t_pop", "t_idle", "t_narrow", "t_solve", "n_narrow", "n_solve", "n_idle", "waves", "t_life",
+             "t_narrow_load", "t_narrow_pairs", "t_narrow_finish", "t_solve_load_gather", "t_solve_compute", "t_solve_store_broad", "t_solve_publish")
+        d = {n: int(buf[i]) for i, n in enumerate(k)}
+        for n in k:
+            if not n.startswith("t_"):
+                continue
+            d[n] *= 1e-8
+        return d
 
     def bind(self, qpos, qvel, ctrl, warmstart, obs_ring, ep_return, step_count, episode, mass_scale=None):
         b = Buffers(qpos, qvel, ctrl, warmstart, obs_ring, ep_return, step_count, episode, mass_scale)
