@@ -160,7 +160,7 @@ def main():
                     help="newton = MuJoCo's default, which the reference scene uses (it sets no <option solver>)")
     ap.add_argument("--no-prefetch", action="store_true", help="settle auto-resets inside the step call")
     ap.add_argument("--fused", action="store_true", help="one fused k_step launch per control step instead of the pipeline")
-    ap.add_argument("--pipeline", type=int, default=-1, help="step path: 2 per-env chained (library default), 1 launch chains, 0 fused")
+    ap.add_argument("--pipeline", type=int, default=-1, help="step path: 3 merged launches, 2 per-env chained, 1 launch chains, 0 fused (-1 = library default)")
     ap.add_argument("--chain-waves", type=int, default=0, help="pipeline 2: persistent wavefronts (0 = library default)")
     ap.add_argument("--groups", type=int, default=0, help="env slices of the pipelined step (0 = library default)")
     ap.add_argument("--solver-iterations", type=int, default=0, help="iteration cap; 0 = model default (100)")
@@ -252,7 +252,11 @@ def main():
                 return 1e3 * (other.t - self.t)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1 + rank)
-    total = args.warmup + args.steps
+    # every timed window gets its own slice of the action tape (memory permitting: 24 B per env-step)
+    n_windows = max(args.repeats, 1)
+    if (args.warmup + n_windows * args.steps) * N * 24 > 6e9:
+        n_windows = 1
+    total = args.warmup + n_windows * args.steps
 
     spec = envs[0].action_spec()
     lo = torch.tensor(spec.minimum, device=dev)
@@ -276,12 +280,11 @@ def main():
     sync()
 
     def one_step(i, timed, sample=None):
-        # `i` indexes the action tape (warm-up part, then the K-step window: every repeat replays the window's actions on
-        # whatever states the envs are in).  `sample`: read the per-env diagnostics after this step.  The first warm-up
+        # `i` indexes the action tape (warm-up part, then one K-step slice per timed window).  `sample`: read the per-env diagnostics after this step.  The first warm-up
         # step does it too (result discarded), so that every torch kernel the sampling needs is loaded before the timed
         # region starts - on a fresh box the lazy load of one kernel costs more than a control step.
         if sample is None:
-            sample = timed and (i - args.warmup) % 10 == 0
+            sample = timed and (i - args.warmup) % 10 == 0 and i < args.warmup + args.steps
         for k, env in enumerate(envs):
             with on_stream(streams[k]):
                 if args.workload == "pickplace":
@@ -316,15 +319,16 @@ def main():
         if hasattr(env, "sim") and hasattr(env.sim, "chain_stats"):
             env.sim.chain_stats(clear=True)
 
-    def timed_window(segment=0):
+    def timed_window(segment=0, window=0):
         """EXACTLY --steps steps bracketed by barrier + synchronize on both sides.  Returns (host seconds, device ms per
         step on the launch streams, [device ms of each `segment`-step slice])."""
         sync()
         sdist.barrier()
         t0 = time.perf_counter()
         ticks = [[Tick(s)] for s in streams]
+        base = args.warmup + (window % n_windows) * args.steps
         for i in range(args.steps):
-            one_step(args.warmup + i, True)
+            one_step(base + i, True)
             if segment and (i + 1) % segment == 0 and i + 1 < args.steps:
                 for k, s in enumerate(streams):
                     ticks[k].append(Tick(s))
@@ -345,11 +349,25 @@ def main():
             events_first[k] = events_first.get(k, 0) + v
     stats_first = {k: sum(float(st[k]) for st in stats) for k in stats[0]}
     stats_first["samples"] = samples[0]
-    # further windows of the same length: spread of the measurement (box clocks, episode phase)
+    # Further windows of the same length for the spread of the measurement.  They run back to back WITHOUT draining the GPU in
+    # between (device events on the launch streams at the window boundaries, one synchronize at the end): windows separated by
+    # a host synchronisation measure the clock governor, not the kernels - with the GPU idling for a moment every 20 steps the
+    # same steps ran at 630 k, 480 k, 420 k, 390 k env-steps/s against a steady 740-750 k back to back (scripts/gpu_windows.py).
     rep_elapsed = [elapsed]
-    for _ in range(max(args.repeats, 1) - 1):
-        e2, _, _ = timed_window()
-        rep_elapsed.append(sdist.max_over_ranks(e2, dev))
+    n_more = max(args.repeats, 1) - 1
+    if n_more:
+        sdist.barrier()
+        marks = [[Tick(s)] for s in streams]
+        for r in range(1, n_more + 1):
+            base = args.warmup + (r % n_windows) * args.steps
+            for i in range(args.steps):
+                one_step(base + i, True, sample=False)
+            for k, s in enumerate(streams):
+                marks[k].append(Tick(s))
+        sync()
+        sdist.barrier()
+        for r in range(n_more):
+            rep_elapsed.append(sdist.max_over_ranks(1e-3 * max(m[r].ms_until(m[r + 1]) for m in marks), dev))
 
     # logging-only exchange: episode returns all-gathered over RCCL/xGMI (not in the timed region)
     returns = torch.cat([env.episode_returns() for env in envs])
@@ -384,8 +402,9 @@ def main():
                          "frac": achieved / hbm_measured if hbm_measured else None, "traffic": (pmc or {}).get("hbm_bytes_per_step"),
                          "peak_spec": HBM_SPEC_GBS, "frac_of_spec": achieved / HBM_SPEC_GBS,
                          "kernel": {0: "k_step", 1: f"k_order + {args.groups or 4} env slices x (k_pipe_begin + substeps x (k_narrow + k_pipe_solve))",
-                                    2: "k_order + k_pipe_begin + k_chain (persistent: narrowphase chunks and per-env solve items from device-side queues)"}[path],
-                         "kernel_ms": kernel_ms, "launches_per_step": {0: 1, 1: 1 + (args.groups or 4) * 21, 2: 3}[path],
+                                    2: "k_order + k_pipe_begin + k_chain (persistent: narrowphase chunks and per-env solve items from device-side queues)",
+                                    3: f"k_order + {args.groups or 4} env slices x (k_pipe_begin + (1 + substeps) x k_pipe_merged: solve of substep s, then narrowphase chunks of s + 1)"}[path],
+                         "kernel_ms": kernel_ms, "launches_per_step": {0: 1, 1: 1 + (args.groups or 4) * 21, 2: 3, 3: 1 + (args.groups or 4) * 12}[path],
                          "compute": None if not pmc else {
                              "valu_tflops_equiv": pmc.get("valu_insts_per_step", 0) * 64 * 2 / (kernel_ms * 1e-3) / 1e12,
                              "peak_tflops": VALU_PEAK_TFLOPS,
@@ -406,8 +425,10 @@ def main():
         rep_values = [world * n_local * args.steps / e for e in rep_elapsed]
         out["repeats"] = {"n": len(rep_values), "values": rep_values, "mean": statistics.fmean(rep_values),
                           "std": statistics.pstdev(rep_values) if len(rep_values) > 1 else 0.0,
-                          "note": "`value` is the first window (the --steps steps that follow the warm-up); the others are further "
-                                  "windows of the same length on the same envs, each bracketed by barrier + synchronize"}
+                          "note": "`value` is the first window: the --steps steps that follow the warm-up, bracketed by barrier + synchronize "
+                                  "on both sides (host clock).  The others are further windows of the same length run back to back "
+                                  "behind it, timed with device events at the window boundaries (max over launch streams and ranks) and "
+                                  "one synchronize at the end"}
         if segments:
             seg_rates = [n_local * 100 / (ms * 1e-3) for ms in segments]
             out["sustained"] = {"steps": args.steps, "env_steps_per_s": value, "per_100_steps_env_steps_per_s": seg_rates,

@@ -83,12 +83,17 @@ typedef struct {
   int32_t prefetch_resets; /* 1 (default): settle the next episode's initial state of every env ahead of time on an
                               internal low-priority stream, so that auto-resets inside so101_step cost a copy;
                               0: always settle inside the call.  Results are identical either way. */
-  int32_t pipeline;        /* 2 (default): per-env chained step - cost order, prologue and ONE persistent launch in which
-                              wavefronts pull narrowphase chunks and per-env solve items from device-side queues, every
-                              env advancing on its own dependencies (csrc/so101_chain.hpp);
-                              1: launch chains - every substep is a narrowphase launch (one wavefront per candidate pair)
-                              and a solve launch (one wavefront per env) per env slice, 21 launches per slice;
-                              0: one fused launch, one wavefront per env.  Same device functions, same results. */
+  int32_t pipeline;        /* how so101_step is launched; same device functions, bit-identical results:
+                              1 (default) launch chains: per env slice, every substep is a narrowphase launch (one
+                                wavefront per candidate pair) followed by a solve launch (one wavefront per env);
+                              0 one fused launch, one wavefront per env;
+                              2 per-env chained: cost order, prologue and ONE persistent launch whose wavefronts pull
+                                narrowphase chunks and per-env solve items from device-side queues, every env advancing
+                                on its own dependencies (csrc/so101_chain.hpp);
+                              3 merged launches: like 1, with the narrowphase of substep s + 1 pulled as chunks inside
+                                the solve launch of substep s (half the launch boundaries).
+                              2 and 3 are correct and measured slower on MI355X: wavefronts that run narrowphase and
+                              solver code out of step refetch the 240 KB of code from L2 (profiles/README.md). */
   int32_t groups;          /* pipelined step: the envs, sorted by the solver time of their previous step, are cut into 1..8
                               slices whose launch chains run on separate internal streams and fill each other's tails;
                               0 (default) = 4 when GPU_MAX_HW_QUEUES >= 6 was set before HIP initialised, else 3 (the

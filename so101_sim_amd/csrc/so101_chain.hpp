@@ -63,10 +63,16 @@ DEV bool q_pop_lane(const ChainQ& Q, unsigned int* item, unsigned int* abort_fla
   int old = (int)atom_add_agent(&Q.ctl[QC_AVAIL], 0xffffffffu);
   if (old <= 0) { atom_add_agent(&Q.ctl[QC_AVAIL], 1u); return false; }
   unsigned int h = atom_add_agent(&Q.ctl[QC_HEAD], 1u);
+  unsigned long long t0 = 0;
   for (unsigned int spin = 0;; spin++) {
     unsigned long long v = ld_agent64(&Q.slot[h & Q.mask]);
     if ((unsigned int)(v >> 32) == h + 1u) { *item = (unsigned int)v; return true; }
-    if (spin > (1u << 22)) { atom_add_agent(abort_flag, 1u); return false; }      // watchdog: never seen; ends the launch instead of hanging it
+    // watchdog on the wall clock (never seen on the GPU; ends the launch instead of hanging it)
+    if ((spin & 1023u) == 1023u) {
+      unsigned long long now = wall_clock64();
+      if (t0 == 0) t0 = now;
+      else if (now - t0 > CHAIN_WATCHDOG_TICKS) { atom_add_agent(abort_flag, 1u); return false; }
+    }
   }
 }
 // one lane: push one item (the payload it announces has been drained by the caller)
@@ -111,9 +117,11 @@ DEV int publish_chain(const EnvLDS& L, const PipeBuffers& W, const ChainQueues& 
 
 // k_narrow's body for one chunk: the pairs' contact records, then the env's pending count; the wavefront that brings it
 // to zero hands the env to the solve queue.
-DEV void chain_narrow(const DevModel* m, const PipeBuffers& W, const ChainQueues& C, unsigned int item) {
+// CHAINED = false (merged launches, pipeline = 3): the records are read by the NEXT launch - plain stores, no pending count.
+template <bool CHAINED>
+DEV void narrow_chunk(const DevModel* m, const PipeBuffers& W, const ChainQueues* Cp, unsigned int item) {
   int lane = wave_lane();
-  unsigned long long ta = wall_clock64();
+  unsigned long long ta = CHAINED ? wall_clock64() : 0ull;
   int e = (int)(item >> 8), k0 = (int)((item >> 2) & 63u) * NARROW_CHUNK, cnt = (int)(item & 3u) + 1;
   unsigned int cl = 0;
   if (lane < cnt) cl = ld_agent(&W.cand[(size_t)e * MAXCAND + k0 + lane]);
@@ -121,7 +129,7 @@ DEV void chain_narrow(const DevModel* m, const PipeBuffers& W, const ChainQueues
   const float* pose = W.pose + (size_t)e * (NDYN * 12);
   float pv0 = ld_agent(&pose[lane]), pv1 = lane < NDYN * 12 - WAVE ? ld_agent(&pose[WAVE + lane]) : 0.f;
   unsigned int c_first = (unsigned int)__builtin_amdgcn_readlane((int)cl, 0);     // (waits for the loads)
-  unsigned long long tb = wall_clock64() + (c_first & 0u);
+  unsigned long long tb = CHAINED ? wall_clock64() + (c_first & 0u) : 0ull;
 #pragma unroll 1
   for (int j = 0; j < cnt; j++) {
     unsigned int c = (unsigned int)__builtin_amdgcn_readlane((int)cl, j);
@@ -156,8 +164,10 @@ DEV void chain_narrow(const DevModel* m, const PipeBuffers& W, const ChainQueues
     float mine = 0.f;
 #pragma unroll
     for (int i = 0; i < CONRES_DIM; i++) mine = lane == i ? rec[i] : mine;
-    if (lane < CONRES_DIM) st_agent(&W.conres[((size_t)e * MAXCAND + k0 + j) * CONRES_DIM + lane], mine);
+    if (lane < CONRES_DIM) pst<CHAINED>(&W.conres[((size_t)e * MAXCAND + k0 + j) * CONRES_DIM + lane], mine);
   }
+  if constexpr (!CHAINED) return;
+  const ChainQueues& C = *Cp;
   unsigned long long tc = wall_clock64();
   drain_stores();
   ChainQ QS = chain_queue_of(C, Q_SOLVE, e);
@@ -169,6 +179,80 @@ DEV void chain_narrow(const DevModel* m, const PipeBuffers& W, const ChainQueues
   old = (unsigned int)wave_uniform_i((int)old);
   unsigned long long td = wall_clock64() + (old & 0u);
   if (lane == 0) { atomicAdd(&C.stats[9], tb - ta); atomicAdd(&C.stats[10], tc - tb); atomicAdd(&C.stats[11], td - tc); }
+}
+
+DEV void chain_narrow(const DevModel* m, const PipeBuffers& W, const ChainQueues& C, unsigned int item) { narrow_chunk<true>(m, W, &C, item); }
+
+// ---- merged launches (pipeline = 3) -------------------------------------------------------------------------------------------
+// The launch chains of pipeline = 1 with the narrowphase folded into the solve launches: the wavefront that has solved
+// substep s of its env publishes the env's candidates as chunks into the CHAIN's queue and then, instead of leaving, pulls
+// chunks of substep s + 1 (anybody's) until every env of the launch has published and the queue is empty.  The contact
+// records are consumed by the next launch, so only the solve -> narrowphase hand-off (poses, candidates, queue granules)
+// happens inside a launch (agent-scope accesses, wave.hpp).  Narrowphase work fills the tail of the solves (a launch lasts
+// as long as its slowest Newton solve) and half of the launch boundaries disappear; the wavefronts of a launch still start
+// together and run the same code at about the same time, which the per-env chained kernel (k_chain) does not - its
+// desynchronised wavefronts refetch the 240 KB of code from L2 4.3 times as often and stall on it (profiles/README.md).
+// At most MERGED_LINGER wavefronts stay to poll for the chunks of the last solves; the others leave when they find the
+// queue empty, which frees their slots for the other chains' launches.
+#define MERGED_LINGER 48
+DEV ChainQ merged_queue(const PipeBuffers& W) { ChainQ Q; Q.ctl = W.mq_ctl; Q.slot = W.mq_slot; Q.mask = W.mq_mask; return Q; }
+
+// candidates of env e (in L) -> chunks in the chain's queue; poses and candidates with agent-scope stores (read by chunk
+// workers of this launch) - the next launch's solve reads the same bytes with plain loads after the launch boundary
+DEV void publish_merged(const EnvLDS& L, const PipeBuffers& W, int e) {
+  int lane = wave_lane(), ncand = L.ncand;
+  for (int i = lane; i < NDYN * 12; i += WAVE) {
+    int b = i / 12, j = i % 12;
+    st_agent(&W.pose[(size_t)e * (NDYN * 12) + i], j < 3 ? L.xpos[b][j] : L.xmat[b][j - 3]);
+  }
+  for (int k = lane; k < ncand; k += WAVE)
+    st_agent(&W.cand[(size_t)e * MAXCAND + k], (unsigned int)L.cand[k][0] | ((unsigned int)L.cand[k][1] << 16));
+  int nch = (ncand + NARROW_CHUNK - 1) / NARROW_CHUNK;
+  if (lane == 0) W.ncand[e] = ncand | ((L.overflow & 1) << 16);
+  if (nch == 0) return;
+  drain_stores();
+  ChainQ Q = merged_queue(W);
+  unsigned int base = 0;
+  if (lane == 0) { base = atom_add_agent(&Q.ctl[QC_TAIL], (unsigned int)nch); atom_add_agent(&Q.ctl[QC_AVAIL], (unsigned int)nch); }
+  base = (unsigned int)wave_uniform_i((int)base);
+  for (int k = lane; k < nch; k += WAVE) {
+    int cnt = ncand - NARROW_CHUNK * k; cnt = cnt < NARROW_CHUNK ? cnt : NARROW_CHUNK;
+    unsigned int t = base + (unsigned int)k;
+    st_agent64(&Q.slot[t & Q.mask], (unsigned long long)narrow_item(e, k, cnt) | ((unsigned long long)(t + 1u) << 32));
+  }
+}
+
+// this wavefront has passed its publish point in launch `launch` of the chain (whether or not it had anything to publish)
+DEV void merged_published(const PipeBuffers& W, int launch) {
+  drain_stores();
+  if (wave_lane() == 0) atom_add_agent(&W.mq_pub[launch], 1u);
+}
+
+// pull chunks until every env of the launch has published and the queue is empty
+DEV void merged_helper(const DevModel* m, const PipeBuffers& W, int launch, int ng) {
+  int lane = wave_lane();
+  ChainQ Q = merged_queue(W);
+  bool lingering = false;
+  unsigned long long t0 = wall_clock64();
+  for (;;) {
+    unsigned int item = 0; int got = 0, all = 0;
+    if (lane == 0) {
+      all = ld_agent(&W.mq_pub[launch]) >= (unsigned int)ng ? 1 : 0;       // read BEFORE the count: no push can follow a complete publish count
+      if ((int)ld_agent(&Q.ctl[QC_AVAIL]) > 0 && q_pop_lane(Q, &item, W.mq_pub + 127)) got = 1;
+    }
+    got = wave_uniform_i(got);
+    if (got) { narrow_chunk<false>(m, W, nullptr, (unsigned int)wave_uniform_i((int)item)); continue; }
+    int stop = wave_uniform_i(all);
+    if (!stop && !lingering) {
+      int over = 0;
+      if (lane == 0) over = atom_add_agent(&W.mq_pub[64 + launch], 1u) >= (unsigned int)MERGED_LINGER ? 1 : 0;
+      stop = wave_uniform_i(over);
+      lingering = true;
+    }
+    if (!stop && wall_clock64() - t0 > CHAIN_WATCHDOG_TICKS) stop = 1;      // (never seen: a launch cannot outlive its solves by seconds)
+    if (stop) break;
+    idle_sleep();
+  }
 }
 
 // k_pipe_solve's body for env e from substep s on: as long as a substep yields no candidate the same wavefront goes on

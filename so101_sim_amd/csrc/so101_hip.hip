@@ -95,6 +95,8 @@ struct so101_sim {
   hipEvent_t prep_done = nullptr, main_ev = nullptr;
   bool prep_pending = false;
   int prep_waves = 0;
+  unsigned long long* mq_slot = nullptr;   // merged launches (pipeline = 3): chunk rings, queue words and launch counters of the chains
+  unsigned int *mq_ctl = nullptr, *mq_pub = nullptr;
   ChainQueues chain{};         // queues of the per-env chained step (pipeline = 2)
   unsigned char* chain_cls = nullptr;
   ChainParams* chain_params = nullptr;     // device copy of k_chain's parameter block
@@ -337,7 +339,7 @@ int build_model(so101_sim* s, const BlobView& b) {
 // (pool resets are plain copies: nothing to prefetch)
 bool prefetch_on(const so101_sim* s) { return s->cfg.prefetch_resets && s->prep_stream && s->cfg.solver == SO101_SOLVER_NEWTON && s->prep.pool_size == 0; }
 
-void launch_prepare(so101_sim* s, hipStream_t stream) {
+void launch_prepare(so101_sim* s, hipStream_t stream, bool wide = false) {
   if (!prefetch_on(s)) return;
   if (s->prep_pending) {
     if (hipEventQuery(s->prep_done) != hipSuccess) { (void)hipGetLastError(); return; }
@@ -345,8 +347,12 @@ void launch_prepare(so101_sim* s, hipStream_t stream) {
   }
   if (hipEventRecord(s->main_ev, stream) != hipSuccess) return;
   if (hipStreamWaitEvent(s->prep_stream, s->main_ev, 0) != hipSuccess) return;
-  if (hipMemsetAsync(s->prep.cursor, 0, sizeof(int), s->prep_stream) != hipSuccess) return;
-  so101::launch_prepare(s->prep_waves, s->prep_stream, s->dm, make_params(s), s->buf, s->prep);
+  if (hipMemsetAsync(s->prep.cursor, 0, 2 * sizeof(int), s->prep_stream) != hipSuccess) return;
+  // `wide` (after an explicit so101_reset, when nothing is stepping yet): the first fill of the cache - two episodes for every
+  // env - at the width of the machine (0.8 s for 4096 envs) instead of 256 wavefronts beside the first ~600 control steps, during
+  // which every env whose physics diverged had to settle inside the step call (130 ms for the whole batch each time)
+  int waves = wide ? (s->n_envs < 2048 ? s->n_envs : 2048) : s->prep_waves;
+  so101::launch_prepare(waves, s->prep_stream, s->dm, make_params(s), s->buf, s->prep);
   if (hipEventRecord(s->prep_done, s->prep_stream) == hipSuccess) s->prep_pending = true;
 }
 
@@ -389,7 +395,7 @@ int so101_default_config(so101_config* cfg) {
   memset(cfg, 0, sizeof *cfg);
   cfg->last_step = 1 << 30; cfg->n_substeps = 10; cfg->solver_iterations = 0; cfg->solver_tolerance = -1.f;
   cfg->settle_max_substeps = 1000; cfg->terminate_on_success = 1; cfg->env_id_base = 0; cfg->solver = SO101_SOLVER_NEWTON;
-  cfg->prefetch_resets = 1; cfg->pipeline = 2; cfg->groups = 0; cfg->use_graph = 1; cfg->chain_waves = 0;
+  cfg->prefetch_resets = 1; cfg->pipeline = 1; cfg->groups = 0; cfg->use_graph = 1; cfg->chain_waves = 0;
   return SO101_OK;
 }
 
@@ -415,7 +421,7 @@ int so101_create(const void* blob, size_t bytes, int n_envs, int device, uint64_
     PrepBuffers& C = s->prep;
     bool ok = dev_alloc(s, &C.qpos, 2 * NQ * n, 0, "hipMalloc(prep)") && dev_alloc(s, &C.qvel, 2 * NV * n, 0, "hipMalloc(prep)") &&
               dev_alloc(s, &C.warm, 2 * NV * n, 0, "hipMalloc(prep)") && dev_alloc(s, &C.tag, 2 * n, 0xFF, "hipMalloc(prep)") &&
-              dev_alloc(s, &C.cursor, (size_t)1, 0, "hipMalloc(prep)") && dev_alloc(s, &C.flags, 2 * n, 0, "hipMalloc(prep)");
+              dev_alloc(s, &C.cursor, (size_t)2, 0, "hipMalloc(prep)") && dev_alloc(s, &C.flags, 2 * n, 0, "hipMalloc(prep)");
     int lo = 0, hi = 0;
     ok = ok && hip_ok(s, hipDeviceGetStreamPriorityRange(&lo, &hi), "hipDeviceGetStreamPriorityRange") &&
          hip_ok(s, hipStreamCreateWithPriority(&s->prep_stream, hipStreamNonBlocking, lo), "hipStreamCreateWithPriority") &&
@@ -437,6 +443,13 @@ int so101_create(const void* blob, size_t bytes, int n_envs, int device, uint64_
               dev_alloc(s, &s->chain.qctl, (size_t)4 * 64, 0, "hipMalloc(chain)") && dev_alloc(s, &s->chain.chain_ctl, (size_t)64, 0, "hipMalloc(chain)") &&
               dev_alloc(s, &s->chain_params, (size_t)1, 0, "hipMalloc(chain)") && dev_alloc(s, &s->chain.stats, (size_t)16, 0, "hipMalloc(chain)");
     s->chain.cls = s->chain_cls;
+    // merged launches (pipeline = 3): one chunk ring per chain (capacity: the next power of two above 64 chunks per env of the
+    // chain, so a ring can never wrap onto live granules), head / avail / tail words and per-launch counters per chain
+    {
+      size_t cap = 64; while (cap < 2 * n * (MAXCAND / NARROW_CHUNK)) cap <<= 1;
+      ok = ok && dev_alloc(s, &s->mq_slot, cap, 0, "hipMalloc(merged)") && dev_alloc(s, &s->mq_ctl, (size_t)64 * so101_sim::MAXGROUPS, 0, "hipMalloc(merged)") &&
+           dev_alloc(s, &s->mq_pub, (size_t)128 * so101_sim::MAXGROUPS, 0, "hipMalloc(merged)");
+    }
     s->chain.idle_sleeps = getenv("SO101_CHAIN_IDLE") ? atoi(getenv("SO101_CHAIN_IDLE")) : 8;
     s->chain.role_mode = getenv("SO101_CHAIN_ROLE") ? atoi(getenv("SO101_CHAIN_ROLE")) : 0;
     // work queues of the chained step: narrow chunks (at most MAXCAND / NARROW_CHUNK outstanding per env), solve items (one per env)
@@ -515,7 +528,7 @@ int so101_reset(so101_sim* s, const uint8_t* mask, void* stream) {
   GUARD_DEVICE(s);
   so101::launch_reset(s->cfg.solver, s->n_envs, (hipStream_t)stream, s->dm, make_params(s), s->buf, prep_view(s), s->ev, mask, s->need_reset, s->diag);
   LAUNCH_CHECK(s, "k_reset");
-  launch_prepare(s, (hipStream_t)stream);
+  launch_prepare(s, (hipStream_t)stream, mask == nullptr);
   return SO101_OK;
 }
 
@@ -616,10 +629,23 @@ static int enqueue_pipelined(so101_sim* s, hipStream_t st, const so101::StepIO& 
     int nw = ng * 2 < 4096 ? ng * 2 : 4096;
     if (G > 1 && !hip_ok(s, hipStreamWaitEvent(gs, s->step_begin, 0), "hipStreamWaitEvent")) return SO101_ERR_HIP;
     if (!hip_ok(s, hipMemsetAsync(W.counters, 0, sizeof(int) * 2 * MAXSUB, gs), "hipMemsetAsync(pipe)")) return SO101_ERR_HIP;
-    so101::launch_pipe_begin(ng, gs, s->dm, P, s->buf, C, s->ev, W, io, s->need_reset, s->diag, e0);
-    for (int k = 0; k < P.n_substeps; k++) {
-      so101::launch_narrow(nw, gs, s->dm, s->n_envs, W, k);
-      so101::launch_pipe_solve(ng, gs, s->dm, P, s->buf, s->ev, W, k, (int)(k == P.n_substeps - 1), io, s->need_reset, s->diag, e0);
+    if (s->cfg.pipeline == 3) {
+      // merged launches: the narrowphase of substep k + 1 rides in the solve launch of substep k (so101_chain.hpp)
+      size_t capg = 64; while (capg < (size_t)ng * (MAXCAND / NARROW_CHUNK)) capg <<= 1;
+      W.mq_ctl = s->mq_ctl + 64 * g; W.mq_pub = s->mq_pub + 128 * g;
+      W.mq_slot = s->mq_slot + (size_t)2 * e0 * (MAXCAND / NARROW_CHUNK); W.mq_mask = (unsigned int)(capg - 1);
+      if (!hip_ok(s, hipMemsetAsync(W.mq_pub, 0, sizeof(unsigned int) * 127, gs), "hipMemsetAsync(merged)")) return SO101_ERR_HIP;
+      so101::launch_pipe_begin(ng, gs, s->dm, P, s->buf, C, s->ev, W, io, s->need_reset, s->diag, e0);
+      so101::launch_pipe_merged(nw, gs, s->dm, P, s->buf, s->ev, W, -1, 0, 0, io, s->need_reset, s->diag, e0);
+      for (int k = 0; k < P.n_substeps; k++)
+        so101::launch_pipe_merged(ng, gs, s->dm, P, s->buf, s->ev, W, k, (int)(k == P.n_substeps - 1), k + 1, io, s->need_reset, s->diag, e0);
+    } else {
+      W.mq_ctl = nullptr;
+      so101::launch_pipe_begin(ng, gs, s->dm, P, s->buf, C, s->ev, W, io, s->need_reset, s->diag, e0);
+      for (int k = 0; k < P.n_substeps; k++) {
+        so101::launch_narrow(nw, gs, s->dm, s->n_envs, W, k);
+        so101::launch_pipe_solve(ng, gs, s->dm, P, s->buf, s->ev, W, k, (int)(k == P.n_substeps - 1), io, s->need_reset, s->diag, e0);
+      }
     }
     LAUNCH_CHECK(s, "k_pipe_solve");
     if (G > 1 && !(hip_ok(s, hipEventRecord(s->group_done[g], gs), "hipEventRecord") &&
@@ -678,7 +704,7 @@ int so101_step(so101_sim* s, const float* action, float* obs, float* reward, flo
   // the pipelined step is a Newton path; PGS (107 ms per control step at 4096 envs) runs the fused kernel
   if (s->cfg.pipeline && s->cfg.n_substeps <= MAXSUB && s->cfg.solver == SO101_SOLVER_NEWTON) {
     const bool chained = s->cfg.pipeline == 2;
-    s->last_path = chained ? 2 : 1;
+    s->last_path = s->cfg.pipeline;
     if (chained && !sync_chain_params(s, st, io)) return SO101_ERR_HIP;
     // The launch sequence of a control step (launch chains: ~90 kernels, memsets and event edges over 5 streams; chained: 3
     // kernels and a memset) depends only on the configuration and the caller's pointers: it is captured ONCE into a HIP

@@ -7,19 +7,21 @@
 // Fills the cache of settled initial states for every env whose next episode is not in it yet.  A few persistent
 // waves pull env indices from a queue so that the stepping kernels keep most of the machine.
 template <int SOLVER>
-__global__ void __launch_bounds__(64, 2) k_prepare(const DevModel* m, StepParams P, DevBuffers B, PrepBuffers C) {
+__global__ void __launch_bounds__(64, 2) k_prepare(const DevModel* m, StepParams P, DevBuffers B, PrepBuffers C, int ahead) {
   __shared__ EnvLDS L;
   int lane = wave_lane(), N = P.n_envs;
   for (;;) {
+    // one launch per look-ahead (so101_hip.hip launch_prepare): the NEXT episode of every env first, then the one after it - an
+    // env whose physics diverges needs its next entry at once, the second one only at the reset after that.  Within a launch
+    // an env belongs to one wavefront (two entries of an env share nothing but the env's episode counter).
     int e = 0;
-    if (lane == 0) e = atomicAdd(C.cursor, 1);
+    if (lane == 0) e = atomicAdd(C.cursor + ahead, 1);
     e = wave_uniform_i(e);
     if (e >= N) break;
-    // the next episode and the one after it; an entry is only overwritten when its episode lies behind the env's
-    // counter, i.e. after env_reset() has consumed it (the counter is bumped after the entry has been read)
+    // an entry is only overwritten when its episode lies behind the env's counter, i.e. after env_reset() has consumed it
+    // (the counter is bumped after the entry has been read)
     int next = __atomic_load_n(&B.episode[e], __ATOMIC_ACQUIRE);
-#pragma unroll 1
-    for (int ahead = 0; ahead < 2; ahead++) {
+    {
       int target = next + ahead;
       size_t slot = (unsigned int)target & 1u;
       if (__atomic_load_n(&C.tag[slot * N + e], __ATOMIC_ACQUIRE) == target) continue;

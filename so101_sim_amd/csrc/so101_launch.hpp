@@ -35,6 +35,10 @@ void launch_narrow(int waves, hipStream_t st, const DevModel* m, int n_envs, con
 void launch_pipe_solve(int n_group, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B, const EventBuffers& E,
                        const PipeBuffers& W, int substep, int last, const StepIO& io, unsigned char* need_reset, int* diag, int e0);
 
+// merged launches (pipeline = 3): solve of substep s + narrowphase chunks of substep s + 1 in one launch per chain
+void launch_pipe_merged(int n_group, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B, const EventBuffers& E,
+                        const PipeBuffers& W, int substep, int last, int launch, const StepIO& io, unsigned char* need_reset, int* diag, int e0);
+
 // per-env chained step (so101_chain.hpp): k_order + k_pipe_begin + ONE persistent launch
 void launch_chain(int waves, hipStream_t st, const ChainParams* params /* device memory */);
 

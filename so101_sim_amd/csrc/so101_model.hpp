@@ -188,6 +188,11 @@ struct PipeBuffers {
   int* order;             // [N] per group: env indices sorted by decreasing cost, see k_order
   unsigned int work_cap;  // capacity of one work list = envs of the group * MAXCAND
   unsigned int* ticks;    // [N][MAXCAND] narrowphase time of each candidate (10 ns ticks; SO101_DEBUG_CLOCKS builds)
+  // merged launches (pipeline = 3, so101_chain.hpp): the chain's chunk queue and per-launch counters
+  unsigned int* mq_ctl;   // [64] head, avail, tail (QC_*)
+  unsigned long long* mq_slot;
+  unsigned int mq_mask;
+  unsigned int* mq_pub;   // [128] per launch of the chain: [l] wavefronts past their publish point, [64 + l] lingering wavefronts; [127] abort
   float* state;           // [N][STATE_AOS] qpos | qvel | warm | ctrl of an env, contiguous: the substep round trips of the
                           // pipelined step (the caller's buffers are env-fastest struct-of-arrays: with one env per
                           // wavefront every scalar is its own 64-byte line; they are read once and written once per call)

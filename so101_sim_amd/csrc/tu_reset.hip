@@ -18,6 +18,6 @@ void launch_settle_table(int solver, int n_envs, int first, int count, hipStream
   hipLaunchKernelGGL(k_settle_table<1>, dim3((unsigned int)n_envs * (unsigned int)count), dim3(64), 0, st, m, P, B, first, qpos, qvel, warm, flags);
 }
 void launch_prepare(int waves, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B, const PrepBuffers& C) {
-  hipLaunchKernelGGL(k_prepare<1>, dim3(waves), dim3(64), 0, st, m, P, B, C);
+  for (int ahead = 0; ahead < 2; ahead++) hipLaunchKernelGGL(k_prepare<1>, dim3(waves), dim3(64), 0, st, m, P, B, C, ahead);
 }
 }  // namespace so101

@@ -99,6 +99,13 @@ def test_chained_step_matches_fused_at_4096_envs(make_sim, golden):
     pc.check_pipeline_identical(make_sim, golden, n=4096, steps=8, seed=11, all_reset_last=False, pipelines=(0, 2))
 
 
+def test_merged_launches_match_fused(make_sim, golden):
+    """pipeline = 3: the narrowphase of substep s + 1 rides in the solve launch of substep s (chunks through a per-chain
+    device-side queue); four chains at 4096 envs, bit for bit against the fused step."""
+    pc.check_pipeline_identical(make_sim, golden, n=4096, steps=8, seed=11, all_reset_last=False, pipelines=(0, 3))
+    pc.check_pipeline_identical(make_sim, golden, n=8, steps=6, pipelines=(0, 3))
+
+
 def test_chained_step_with_few_wavefronts(make_sim, golden):
     """Eight persistent wavefronts for 160 envs: every wavefront alternates between narrowphase chunks and solve items of many
     envs (queue wrap, the CAS paths, idle polling)."""

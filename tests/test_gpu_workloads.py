@@ -334,7 +334,8 @@ def test_env_on_a_non_current_device_guard():
     torch.cuda.synchronize()
     assert torch.cuda.current_device() == dev_before and bool(torch.isfinite(env.qpos).all())
     ev = env.events()
-    assert set(ev) == {"candidate_overflow", "contact_overflow", "arm_pool_overflow", "diverged", "placement_rejected", "settle_not_converged"}
+    assert set(ev) == {"candidate_overflow", "contact_overflow", "arm_pool_overflow", "diverged", "placement_rejected", "settle_not_converged",
+                       "scheduler_abort"} and ev["scheduler_abort"] == 0
     env.close()
 
 
