@@ -122,6 +122,15 @@ int so101_default_config(so101_config* cfg);
 int so101_configure(so101_sim* sim, const so101_config* cfg);
 int so101_bind_state(so101_sim* sim, const so101_buffers* buffers);
 
+/* Optional observables physics_state = concat(qpos, qvel) (shape (38,), so100_task.py:366-368; enabled by the reference iff
+ * image_observation_enabled, :203) and delayed_physics_state, the same delayed by 0.3 s = 15 control steps and padded with the
+ * episode's first value (:204-210, task_suite.py:154).  ring [15][38][N] is the delay line (caller-owned like obs_ring),
+ * physics_state / delayed [N][38] are rewritten by every so101_step / so101_reset / so101_begin_episode.  All NULL = off
+ * (default).  The pointers must stay valid like the bound state buffers. */
+#define SO101_PHYSICS_STATE_DIM 38
+#define SO101_PHYSICS_STATE_DELAY 15
+int so101_bind_physics_state(so101_sim* sim, float* ring, float* physics_state, float* delayed_physics_state);
+
 /* Replaces: env.reset() -> task.initialize_episode (so100_task.py:304-320, so100_hand_over.py:320-323):
  * arm qpos/qvel = 0, ctrl = home + offsets, object/container placement drawn from the counter RNG keyed
  * (seed, env_id, episode), container rejection-sampled against collisions, props settled with the arm
@@ -209,8 +218,9 @@ int so101_get_events(so101_sim* sim, uint64_t* out, int clear, void* hip_stream)
 int so101_debug_forward(so101_sim* sim, float* out, void* hip_stream);
 
 /* Diagnostics of the pipelined step's last narrowphase launch (device buffers, any may be NULL):
- * ncand[N] (count | overflow << 16), cand[N][256] (geom1 | geom2 << 16), ticks[N][256] (10 ns per candidate),
- * conres[N][256][24] (contact count, normal, 5 x (dist, position)). */
+ * ncand[N] (count | overflow << 16), cand[N][256] (geom1 | geom2 << 16), ticks[N][256] (10 ns per candidate; profiling builds
+ * only, SO101_ERR_STATE otherwise), conres[48 N][24] (contact count, normal, 5 x (dist, position) per candidate, at the
+ * candidates' work-list positions of the last substep - 48 records per env of a slice, mean use 12). */
 /* (profiling builds, -DSO101_DEBUG_CLOCKS; zeros otherwise) Stage clocks of k_pipe_solve's second-to-last substep: stage[N][8] = smooth dynamics, contact gather, constraint
  * rows, solver, integrate, next broadphase (10 ns ticks), ncon, solver iterations. */
 int so101_debug_stages(so101_sim* sim, uint32_t* stage, void* hip_stream);

@@ -16,7 +16,23 @@ __version__ = "0.2.0"
 # The pipelined step runs four launch chains + two service streams.  The HIP runtime maps streams onto
 # GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue serialise, so ask for 8 - effective
 # when this package is imported before HIP initialises (the library falls back to three chains otherwise).
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+def _hip_initialised() -> bool:
+    torch = _sys.modules.get("torch")
+    try:
+        return bool(torch is not None and torch.cuda.is_initialized())
+    except Exception:
+        return False
+
+
+if "GPU_MAX_HW_QUEUES" not in _os.environ:
+    if _hip_initialised():
+        # too late for the runtime to see it: tell the library to stay with three chains (it trusts the variable otherwise)
+        import warnings as _warnings
+        _warnings.warn("so101_sim_amd imported after HIP was initialised: GPU_MAX_HW_QUEUES cannot take effect any more, the "
+                       "pipelined step uses three launch chains instead of four (export GPU_MAX_HW_QUEUES=8 before the first GPU call)")
+        _os.environ["SO101_HW_QUEUES_EFFECTIVE"] = "4"
+    else:
+        _os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
 
 def install_as_so101_sim():

@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "libso101_hip.so")
+LIB_CLOCKS = os.path.join(CSRC, "libso101_hip_clocks.so")     # -DSO101_DEBUG_CLOCKS profiling build: its own file (SO101_HIP_LIB selects it)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-hip-fp32-correctly-rounded-divide-sqrt: v_rcp/v_sqrt based fp32 division and sqrt (<= ~2.5 ulp) instead of
 # the 10-15 instruction IEEE expansions; the solver is latency-bound and full of both (profiles/README.md).
@@ -36,25 +37,29 @@ def sources():
     return translation_units() + sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + [os.path.join(root, "include", "so101.h")]
 
 
-def source_hash() -> str:
-    """Hash of every source the library is built from (bench.py keys PMC traffic files by it)."""
+def source_hash(clocks: bool = False) -> str:
+    """Hash of every source AND the compiler flags the library is built from (bench.py keys PMC traffic files by it; the
+    settled-state cache and the bench line carry it)."""
     h = hashlib.sha256()
+    h.update(" ".join(FLAGS + (["-DSO101_DEBUG_CLOCKS"] if clocks else [])).encode())
     for p in sources():
         h.update(os.path.basename(p).encode())
         h.update(open(p, "rb").read())
     return h.hexdigest()[:16]
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB):
+def needs_build(clocks: bool = False) -> bool:
+    lib = LIB_CLOCKS if clocks else LIB
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(s) > t for s in sources())
 
 
 def build(force: bool = False, verbose: bool = False, clocks: bool = False) -> str:
-    if not (force or needs_build()):
-        return LIB
+    lib = LIB_CLOCKS if clocks else LIB
+    if not (force or needs_build(clocks)):
+        return lib
     os.makedirs(OBJ, exist_ok=True)
     flags = list(FLAGS)
     if clocks:
@@ -72,8 +77,8 @@ def build(force: bool = False, verbose: bool = False, clocks: bool = False) -> s
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
         objs = list(pool.map(compile_one, translation_units()))
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
-    return LIB
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])
+    return lib
 
 
 if __name__ == "__main__":

@@ -26,6 +26,27 @@ DEV void store_state(const EnvLDS& L, const DevBuffers& B, int e, int N) {
   if (lane < NU) B.ctrl[(size_t)lane * N + e] = L.ctrl[lane];
 }
 
+// physics_state observable (qpos | qvel) and its 15-control-step delay line, when the caller bound them.  `fill`: an episode
+// starts here - every slot of the line takes the current state (the observable's INITIAL_VALUE padding, task_suite.py:154) and
+// both outputs report it; otherwise `sc` = control steps since reset including this one: read the value of step sc - 15,
+// store this step's.
+DEV void physics_state_obs(const EnvLDS& L, const DevBuffers& B, int e, int N, bool fill, int sc) {
+  if (!B.ps_ring) return;
+  int lane = wave_lane();
+  if (lane < PS_DIM) {
+    float v = lane < NQ ? L.qpos[lane] : L.qvel[lane - NQ], delayed = v;
+    if (fill) {
+      for (int r = 0; r < PS_DELAY; r++) B.ps_ring[((size_t)r * PS_DIM + lane) * N + e] = v;
+    } else {
+      size_t ri = ((size_t)((sc - 1) % PS_DELAY) * PS_DIM + lane) * N + e;
+      delayed = B.ps_ring[ri];
+      B.ps_ring[ri] = v;
+    }
+    B.ps_out[(size_t)e * PS_DIM + lane] = v;
+    B.ps_delayed[(size_t)e * PS_DIM + lane] = delayed;
+  }
+}
+
 // diag words (include/so101.h): 0 ncon, 1 nefc, 2 solver iterations, 3 broadphase candidates, 4 flags of the LAST
 // substep; 5-7 stage clocks (debug builds); the sticky flag word lives in so101_sim::flags (see store_flags)
 DEV void store_diag(const EnvLDS& L, int* diag, int e) {
@@ -140,6 +161,7 @@ DEV void env_reset(const DevModel* m, EnvLDS& L, const StepParams& P, const DevB
   if (lane < NARM) {
     for (int r = 0; r < 5; r++) B.ring[((size_t)r * NARM + lane) * N + e] = L.qpos[lane];
   }
+  physics_state_obs(L, B, e, N, true, 0);
   // the cache entry has been read completely before the episode counter tells k_prepare() to refill it
   __threadfence();
   wave_sync();
@@ -178,6 +200,7 @@ DEV void finish_step(const DevModel* m, EnvLDS& L, const StepParams& P, const De
     obs[(size_t)e * 18 + 6 + lane] = L.qpos[lane];
     obs[(size_t)e * 18 + 12 + lane] = L.ctrl[lane];
   }
+  physics_state_obs(L, B, e, N, false, sc);
   float r = diverged ? 0.f : task_reward(m, L);
   // physics error (dm_control): reward 0, discount 0, episode terminates
   bool success = (P.terminate_on_success && r >= 1.f) || diverged, timeout = sc >= P.last_step;

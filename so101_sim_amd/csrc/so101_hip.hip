@@ -95,6 +95,7 @@ struct so101_sim {
   hipEvent_t prep_done = nullptr, main_ev = nullptr;
   bool prep_pending = false;
   int prep_waves = 0;
+  float* conres_full = nullptr;            // [N][MAXCAND][CONRES_DIM] contact records of pipelines 2 and 3 (allocated on first use)
   unsigned long long* mq_slot = nullptr;   // merged launches (pipeline = 3): chunk rings, queue words and launch counters of the chains
   unsigned int *mq_ctl = nullptr, *mq_pub = nullptr;
   ChainQueues chain{};         // queues of the per-env chained step (pipeline = 2)
@@ -435,30 +436,24 @@ int so101_create(const void* blob, size_t bytes, int n_envs, int device, uint64_
     bool ok = dev_alloc(s, &W.pose, NDYN * 12 * n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.cand, MAXCAND * n, 0, "hipMalloc(pipe)") &&
               dev_alloc(s, &W.ncand, n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.work, 2 * MAXCAND * n, 0, "hipMalloc(pipe)") &&
               dev_alloc(s, &W.counters, (size_t)2 * MAXSUB * so101_sim::MAXGROUPS, 0, "hipMalloc(pipe)") &&
-              dev_alloc(s, &W.conres, CONRES_DIM * MAXCAND * n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.active, n, 0, "hipMalloc(pipe)") &&
-              dev_alloc(s, &W.ticks, MAXCAND * n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.stage, 8 * n, 0, "hipMalloc(pipe)") &&
+              dev_alloc(s, &W.conres, CONRES_DIM * CONRES_PER_ENV * n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.cbase, n, 0, "hipMalloc(pipe)") &&
+              dev_alloc(s, &W.active, n, 0, "hipMalloc(pipe)") &&
+#ifdef SO101_DEBUG_CLOCKS
+              dev_alloc(s, &W.ticks, MAXCAND * n, 0, "hipMalloc(pipe)") &&
+#else
+              dev_alloc(s, &W.ticks, (size_t)1, 0, "hipMalloc(pipe)") &&
+#endif
+              dev_alloc(s, &W.stage, 8 * n, 0, "hipMalloc(pipe)") &&
               dev_alloc(s, &W.cost, n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.order, n, 0, "hipMalloc(pipe)") &&
               dev_alloc(s, &W.state, STATE_AOS * n, 0, "hipMalloc(pipe)") &&
               dev_alloc(s, &s->chain.pending, n, 0, "hipMalloc(chain)") && dev_alloc(s, &s->chain_cls, n, 0, "hipMalloc(chain)") &&
               dev_alloc(s, &s->chain.qctl, (size_t)4 * 64, 0, "hipMalloc(chain)") && dev_alloc(s, &s->chain.chain_ctl, (size_t)64, 0, "hipMalloc(chain)") &&
               dev_alloc(s, &s->chain_params, (size_t)1, 0, "hipMalloc(chain)") && dev_alloc(s, &s->chain.stats, (size_t)16, 0, "hipMalloc(chain)");
     s->chain.cls = s->chain_cls;
-    // merged launches (pipeline = 3): one chunk ring per chain (capacity: the next power of two above 64 chunks per env of the
-    // chain, so a ring can never wrap onto live granules), head / avail / tail words and per-launch counters per chain
-    {
-      size_t cap = 64; while (cap < 2 * n * (MAXCAND / NARROW_CHUNK)) cap <<= 1;
-      ok = ok && dev_alloc(s, &s->mq_slot, cap, 0, "hipMalloc(merged)") && dev_alloc(s, &s->mq_ctl, (size_t)64 * so101_sim::MAXGROUPS, 0, "hipMalloc(merged)") &&
-           dev_alloc(s, &s->mq_pub, (size_t)128 * so101_sim::MAXGROUPS, 0, "hipMalloc(merged)");
-    }
     s->chain.idle_sleeps = getenv("SO101_CHAIN_IDLE") ? atoi(getenv("SO101_CHAIN_IDLE")) : 8;
     s->chain.role_mode = getenv("SO101_CHAIN_ROLE") ? atoi(getenv("SO101_CHAIN_ROLE")) : 0;
-    // work queues of the chained step: narrow chunks (at most MAXCAND / NARROW_CHUNK outstanding per env), solve items (one per env)
-    for (int q = 0; q < 4 && ok; q++) {
-      size_t need = q < Q_SOLVE ? n * (MAXCAND / NARROW_CHUNK) : n, cap = 64;
-      while (cap < need) cap <<= 1;
-      ok = dev_alloc(s, &s->chain.qslot[q], cap, 0, "hipMalloc(chain)");
-      s->chain.qmask[q] = (unsigned int)(cap - 1);
-    }
+    // (the queues of pipelines 2 and 3 and their full-size contact-record array are allocated when such a step is first asked
+    // for: ensure_experimental_buffers())
     W.work_cap = 0u;
     for (int g = 0; g < so101_sim::MAXGROUPS && ok; g++)
       ok = hip_ok(s, hipStreamCreateWithFlags(&s->group_stream[g], hipStreamNonBlocking), "hipStreamCreate") &&
@@ -516,6 +511,17 @@ int so101_bind_state(so101_sim* s, const so101_buffers* b) {
   s->buf.ep_return = b->ep_return; s->buf.step_count = b->step_count; s->buf.episode = b->episode;
   s->buf.mass_scale = b->mass_scale;
   s->bound = true;
+  s->generation++;
+  return SO101_OK;
+}
+
+int so101_bind_physics_state(so101_sim* s, float* ring, float* out, float* delayed) {
+  if (!s) return SO101_ERR_ARG;
+  bool all = ring && out && delayed, none = !ring && !out && !delayed;
+  if (!all && !none) { s->err = "so101_bind_physics_state: give all three arrays or none"; return SO101_ERR_ARG; }
+  GUARD_DEVICE(s);
+  if (!drain_prepare(s)) return SO101_ERR_HIP;
+  s->buf.ps_ring = ring; s->buf.ps_out = out; s->buf.ps_delayed = delayed;
   s->generation++;
   return SO101_OK;
 }
@@ -590,8 +596,16 @@ static int enqueue_pipelined(so101_sim* s, hipStream_t st, const so101::StepIO& 
   // The runtime maps streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues; this step uses chains + 2 streams,
   // and streams that share a queue serialise: with the default, 4 chains run at 400 k env-steps/s against 650 k for
   // 3; with GPU_MAX_HW_QUEUES=8 (so101_sim_amd sets it when imported before HIP initialises) 4 chains reach 672 k.
-  static const int hwq = getenv("GPU_MAX_HW_QUEUES") ? atoi(getenv("GPU_MAX_HW_QUEUES")) : 4;
+  // SO101_HW_QUEUES_EFFECTIVE: set by a host that knows the variable came too late for the runtime (so101_sim_amd/__init__.py)
+  static const int hwq = getenv("SO101_HW_QUEUES_EFFECTIVE") ? atoi(getenv("SO101_HW_QUEUES_EFFECTIVE"))
+                         : (getenv("GPU_MAX_HW_QUEUES") ? atoi(getenv("GPU_MAX_HW_QUEUES")) : 4);
   int G = s->cfg.groups > 0 ? s->cfg.groups : (hwq >= 6 ? 4 : 3);
+  static bool warned = false;
+  if (!warned && hwq < 6 && s->cfg.groups == 0 && s->n_envs >= 64) {
+    warned = true;
+    fprintf(stderr, "libso101_hip: %d hardware queues (GPU_MAX_HW_QUEUES): the pipelined step runs three launch chains instead of four "
+                    "(about 3 %% slower at 4096 envs); export GPU_MAX_HW_QUEUES=8 before HIP initialises\n", hwq);
+  }
   if (G > so101_sim::MAXGROUPS) G = so101_sim::MAXGROUPS;
   int n = s->n_envs;
   if (n < 64) G = 1;
@@ -624,6 +638,8 @@ static int enqueue_pipelined(so101_sim* s, hipStream_t st, const so101::StepIO& 
     W.counters = s->pipe.counters + 2 * MAXSUB * g;
     W.work = s->pipe.work + (size_t)2 * MAXCAND * e0;
     W.work_cap = (unsigned int)ng * MAXCAND;
+    W.conres = s->pipe.conres + (size_t)e0 * CONRES_PER_ENV * CONRES_DIM;          // the slice's pool of contact records
+    W.conres_cap = (unsigned int)ng * CONRES_PER_ENV;
     // persistent narrowphase waves (they pull work items until the list is empty): two per env of the slice, at
     // most what fills 256 CUs - a smaller narrowphase grid leaves slots to the other chains' solve kernels
     int nw = ng * 2 < 4096 ? ng * 2 : 4096;
@@ -632,6 +648,7 @@ static int enqueue_pipelined(so101_sim* s, hipStream_t st, const so101::StepIO& 
     if (s->cfg.pipeline == 3) {
       // merged launches: the narrowphase of substep k + 1 rides in the solve launch of substep k (so101_chain.hpp)
       size_t capg = 64; while (capg < (size_t)ng * (MAXCAND / NARROW_CHUNK)) capg <<= 1;
+      W.conres = s->conres_full; W.conres_cap = 0u;
       W.mq_ctl = s->mq_ctl + 64 * g; W.mq_pub = s->mq_pub + 128 * g;
       W.mq_slot = s->mq_slot + (size_t)2 * e0 * (MAXCAND / NARROW_CHUNK); W.mq_mask = (unsigned int)(capg - 1);
       if (!hip_ok(s, hipMemsetAsync(W.mq_pub, 0, sizeof(unsigned int) * 127, gs), "hipMemsetAsync(merged)")) return SO101_ERR_HIP;
@@ -654,6 +671,28 @@ static int enqueue_pipelined(so101_sim* s, hipStream_t st, const so101::StepIO& 
   return SO101_OK;
 }
 
+// Buffers that only the experimental step paths need (pipeline 2: four work queues; pipeline 3: one chunk ring per chain; both: the
+// contact records indexed [env][candidate]): allocated the first time such a step is requested, outside any capture.
+static bool ensure_experimental_buffers(so101_sim* s) {
+  if (s->conres_full) return true;
+  size_t n = (size_t)s->n_envs;
+  bool ok = dev_alloc(s, &s->conres_full, CONRES_DIM * MAXCAND * n, 0, "hipMalloc(chain)");
+  // merged launches: one chunk ring per chain (capacity: the next power of two above 64 chunks per env of the chain, so a ring
+  // can never wrap onto live granules), head / avail / tail words and per-launch counters per chain
+  size_t cap = 64; while (cap < 2 * n * (MAXCAND / NARROW_CHUNK)) cap <<= 1;
+  ok = ok && dev_alloc(s, &s->mq_slot, cap, 0, "hipMalloc(merged)") && dev_alloc(s, &s->mq_ctl, (size_t)64 * so101_sim::MAXGROUPS, 0, "hipMalloc(merged)") &&
+       dev_alloc(s, &s->mq_pub, (size_t)128 * so101_sim::MAXGROUPS, 0, "hipMalloc(merged)");
+  // chained step: narrow chunks (at most MAXCAND / NARROW_CHUNK outstanding per env), solve items (one per env)
+  for (int q = 0; q < 4 && ok; q++) {
+    size_t need = q < Q_SOLVE ? n * (MAXCAND / NARROW_CHUNK) : n, c = 64;
+    while (c < need) c <<= 1;
+    ok = dev_alloc(s, &s->chain.qslot[q], c, 0, "hipMalloc(chain)");
+    s->chain.qmask[q] = (unsigned int)(c - 1);
+  }
+  if (!ok) s->conres_full = nullptr;
+  return ok;
+}
+
 // The per-env chained step (pipeline = 2, csrc/so101_chain.hpp): cost order + classes, prologue, ONE persistent launch.
 // k_chain reads its parameters from a device-memory block; sync_chain_params() brings it up to date on `st` BEFORE any
 // capture starts (an upload from host memory must not become a graph node).
@@ -661,6 +700,7 @@ static ChainParams chain_params_now(so101_sim* s, const so101::StepIO& io) {
   ChainParams cp;
   memset(&cp, 0, sizeof cp);
   cp.m = s->dm; cp.P = make_params(s); cp.B = s->buf; cp.E = s->ev; cp.W = s->pipe; cp.Q = s->chain;
+  cp.W.conres = s->conres_full; cp.W.conres_cap = 0u;
   cp.io = SolveIO{io.obs, io.reward, io.discount, io.step_type, s->need_reset, s->diag};
   return cp;
 }
@@ -681,7 +721,9 @@ static int enqueue_chained(so101_sim* s, hipStream_t st, const so101::StepIO& io
   so101::launch_order(st, s->pipe.cost, s->pipe.order, s->chain_cls, n);
   LAUNCH_CHECK(s, "k_order");
   if (!hip_ok(s, hipMemsetAsync(s->chain.chain_ctl, 0, sizeof(unsigned int), st), "hipMemsetAsync(chain)")) return SO101_ERR_HIP;
-  so101::launch_pipe_begin(n, st, s->dm, P, s->buf, C, s->ev, s->pipe, io, s->need_reset, s->diag, 0, s->chain_params);
+  PipeBuffers W = s->pipe;
+  W.conres = s->conres_full; W.conres_cap = 0u; W.mq_ctl = nullptr;
+  so101::launch_pipe_begin(n, st, s->dm, P, s->buf, C, s->ev, W, io, s->need_reset, s->diag, 0, s->chain_params);
   LAUNCH_CHECK(s, "k_pipe_begin");
   // persistent wavefronts: what fills the machine at 2 per SIMD (8 per CU x 256 CUs), fewer for small batches
   int waves = s->cfg.chain_waves > 0 ? s->cfg.chain_waves : 2048;
@@ -705,6 +747,7 @@ int so101_step(so101_sim* s, const float* action, float* obs, float* reward, flo
   if (s->cfg.pipeline && s->cfg.n_substeps <= MAXSUB && s->cfg.solver == SO101_SOLVER_NEWTON) {
     const bool chained = s->cfg.pipeline == 2;
     s->last_path = s->cfg.pipeline;
+    if (s->cfg.pipeline >= 2 && !ensure_experimental_buffers(s)) return SO101_ERR_HIP;
     if (chained && !sync_chain_params(s, st, io)) return SO101_ERR_HIP;
     // The launch sequence of a control step (launch chains: ~90 kernels, memsets and event edges over 5 streams; chained: 3
     // kernels and a memset) depends only on the configuration and the caller's pointers: it is captured ONCE into a HIP
@@ -755,7 +798,8 @@ long long so101_get_info(so101_sim* s, int what, void* stream) {
     case SO101_INFO_GRAPH_ACTIVE: return s->last_graph ? 1 : 0;
     case SO101_INFO_STEP_PATH: return s->last_path;
     case SO101_INFO_CHAINS: return s->last_chains;
-    case SO101_INFO_HW_QUEUES: return getenv("GPU_MAX_HW_QUEUES") ? atoi(getenv("GPU_MAX_HW_QUEUES")) : 4;
+    case SO101_INFO_HW_QUEUES: return getenv("SO101_HW_QUEUES_EFFECTIVE") ? atoi(getenv("SO101_HW_QUEUES_EFFECTIVE"))
+                                      : (getenv("GPU_MAX_HW_QUEUES") ? atoi(getenv("GPU_MAX_HW_QUEUES")) : 4);
     case SO101_INFO_SCRATCH_BYTES: return (long long)s->scratch_bytes;
     case SO101_INFO_SCHED_ABORTS: {
       DeviceGuard guard(s);
@@ -836,8 +880,13 @@ int so101_debug_candidates(so101_sim* s, int32_t* ncand, uint32_t* cand, uint32_
   bool ok = true;
   if (ncand) ok = ok && hip_ok(s, hipMemcpyAsync(ncand, s->pipe.ncand, sizeof(int) * n, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync(debug)");
   if (cand) ok = ok && hip_ok(s, hipMemcpyAsync(cand, s->pipe.cand, sizeof(int) * MAXCAND * n, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync(debug)");
+#ifdef SO101_DEBUG_CLOCKS
   if (ticks) ok = ok && hip_ok(s, hipMemcpyAsync(ticks, s->pipe.ticks, sizeof(int) * MAXCAND * n, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync(debug)");
-  if (conres) ok = ok && hip_ok(s, hipMemcpyAsync(conres, s->pipe.conres, sizeof(float) * CONRES_DIM * MAXCAND * n, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync(debug)");
+#else
+  if (ticks) { s->err = "so101_debug_candidates: per-candidate ticks exist in profiling builds only (python -m so101_sim_amd.build --clocks)"; return SO101_ERR_STATE; }
+#endif
+  // contact records: [conres_cap of the slices][24] at work-list positions (launch chains), see csrc/so101_model.hpp PipeBuffers
+  if (conres) ok = ok && hip_ok(s, hipMemcpyAsync(conres, s->pipe.conres, sizeof(float) * CONRES_DIM * CONRES_PER_ENV * n, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync(debug)");
   return ok ? SO101_OK : SO101_ERR_HIP;
 }
 

@@ -131,7 +131,11 @@ struct DevBuffers {
   float *qpos, *qvel, *ctrl, *warm, *ring, *ep_return;
   int *step_count, *episode;
   const float* mass_scale;     // [NFREE][n_envs] or NULL (= 1)
+  // optional (so101_bind_physics_state): the physics_state observable and its 15-step delayed copy (so100_task.py:203-210,366-368)
+  float *ps_ring, *ps_out, *ps_delayed;      // [PS_DELAY][NQ + NV][n_envs], [n_envs][NQ + NV], [n_envs][NQ + NV]
 };
+#define PS_DELAY 15            // delayed_physics_state: 0.3 s = 15 control steps
+#define PS_DIM (NQ + NV)
 
 // Library-owned cache of settled initial states.  The settled state of an episode is a pure function of
 // (seed, global env id, episode index, config), so it can be computed ahead of time: k_prepare() fills the
@@ -173,6 +177,7 @@ struct EventBuffers {
 
 #define MAXSUB 32
 #define CONRES_DIM (4 + 4 * NCPP)
+#define CONRES_PER_ENV 48       // compact contact-record pool: records per env of a slice (mean use 12); overflow drops candidates and is counted
 
 // Scratch of the pipelined step (so101_pipeline.hpp)
 struct PipeBuffers {
@@ -181,7 +186,11 @@ struct PipeBuffers {
   int* ncand;             // [N]           count | broadphase overflow flag << 16
   unsigned int* work;     // [2][work_cap] env * MAXCAND + k, double buffered over substeps (per env group)
   int* counters;          // [MAXSUB][2]   work items, cursor
-  float* conres;          // [N][MAXCAND][CONRES_DIM] narrowphase result: count, normal, NCPP x (dist, position)
+  float* conres;          // narrowphase results: count, normal, NCPP x (dist, position) per candidate.  Launch chains: one record
+                          // per work-list position of the current substep, [conres_cap][CONRES_DIM] per env slice (an env's
+                          // records start at cbase[e]); conres_cap = 0 (pipelines 2, 3): [N][MAXCAND][CONRES_DIM]
+  unsigned int conres_cap;
+  int* cbase;             // [N] work-list position of the env's first candidate in the current substep
   unsigned char* active;  // [N] 0 not stepping in this call (auto-reset), 1 stepping, 2 diverged
   unsigned int* stage;    // [N][8] k_pipe_solve stage clocks of the last substep (10 ns ticks; SO101_DEBUG_CLOCKS builds)
   unsigned int* cost;     // [N] solver time of the env in its last substep (ticks): scheduling hint only

@@ -63,7 +63,11 @@ DEV void publish_candidates(const EnvLDS& L, const PipeBuffers& W, int e, int N,
   int base = 0;
   if (lane == 0) {
     base = ncand ? atomicAdd(&W.counters[2 * s], ncand) : 0;
-    W.ncand[e] = ncand | ((L.overflow & 1) << 16);
+    // the contact records of this substep live at the candidates' work-list positions: what does not fit the slice's pool is
+    // dropped from the solve (k_narrow skips those positions) and counted as a candidate overflow
+    int room = (int)W.conres_cap - base, keep = ncand < room ? ncand : (room > 0 ? room : 0);
+    W.cbase[e] = base;
+    W.ncand[e] = keep | (((L.overflow & 1) | (keep < ncand ? 1 : 0)) << 16);
   }
   base = wave_bcast_i(base, 0);
   unsigned int* list = W.work + (size_t)(s & 1) * W.work_cap;
@@ -83,7 +87,7 @@ DEV void gather_contacts(const DevModel* m, EnvLDS& L, const PipeBuffers& W, int
   for (int k0 = 0; k0 < ncand; k0 += WAVE) {
     int k = k0 + lane;
     size_t w = (size_t)e * MAXCAND + k;
-    const float* r = W.conres + w * CONRES_DIM;
+    const float* r = W.conres + (W.conres_cap ? (size_t)(W.cbase[e] + k) : w) * CONRES_DIM;
     int cnt = k < ncand ? (int)pld<AG>(&r[0]) : 0;
     // exclusive prefix of the per-candidate contact counts (at most NCPP each): one ballot per possible count bit
     int idx = ncon, total = 0;

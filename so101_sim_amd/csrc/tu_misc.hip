@@ -10,6 +10,11 @@ __global__ void __launch_bounds__(64) k_begin(const DevModel* m, StepParams P, D
     B.ctrl[(size_t)lane * N + e] = m->home_ctrl[lane] + P.action_offset[lane];
   }
   if (lane == 0) { B.step_count[e] = 0; B.ep_return[e] = 0.f; need_reset[e] = 0; }
+  if (B.ps_ring && lane < PS_DIM) {           // physics_state delay line: padded with the state the episode starts from
+    float v = lane < NQ ? B.qpos[(size_t)lane * N + e] : B.qvel[(size_t)(lane - NQ) * N + e];
+    for (int r = 0; r < PS_DELAY; r++) B.ps_ring[((size_t)r * PS_DIM + lane) * N + e] = v;
+    B.ps_out[(size_t)e * PS_DIM + lane] = v; B.ps_delayed[(size_t)e * PS_DIM + lane] = v;
+  }
 }
 
 __global__ void __launch_bounds__(64) k_reward(const DevModel* m, StepParams P, DevBuffers B, float* reward) {

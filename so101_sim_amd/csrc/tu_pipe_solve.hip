@@ -29,6 +29,7 @@ __global__ void __launch_bounds__(64, 2) k_narrow(const DevModel* m, int N, Pipe
 #pragma unroll 1
     for (int j = 0; j < NARROW_CHUNK; j++) {
       if (i0 + j >= nwork) break;
+      if ((unsigned int)(i0 + j) >= W.conres_cap) continue;       // no room for this candidate's contact record (counted by its env)
       unsigned long long t0 = SO101_CLOCK();
       unsigned int w = (unsigned int)__builtin_amdgcn_readlane((int)wl, j), c = (unsigned int)__builtin_amdgcn_readlane((int)cl, j);
       int e = (int)(w / MAXCAND), g1 = (int)(c & 0xffffu), g2 = (int)(c >> 16);
@@ -48,7 +49,7 @@ __global__ void __launch_bounds__(64, 2) k_narrow(const DevModel* m, int N, Pipe
       narrow_pair<HullCache>(m, G1, G2, g1, g2, pc);
 #endif
       if (lane == 0) {
-        float* r = W.conres + (size_t)w * CONRES_DIM;
+        float* r = W.conres + (size_t)(i0 + j) * CONRES_DIM;
         r[0] = (float)__popc(pc.valid); r[1] = pc.nrm[0]; r[2] = pc.nrm[1]; r[3] = pc.nrm[2];
         int o = 4;                                     // valid slots are written compactly, in slot order
 #pragma unroll

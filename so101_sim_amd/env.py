@@ -102,7 +102,7 @@ class BatchedEnvironment:
     def __init__(self, task: SO100HandOverTask, n_envs: int = 1, time_limit: float = float("inf"),
                  random_state=None, device=None, env_id_base: int = 0, solver_iterations: int = 0,
                  solver_tolerance: float = -1.0, settle_max_substeps: int = 1000, solver: str = "newton",
-                 prefetch_resets: bool = True):
+                 prefetch_resets: bool = True, physics_state: bool = False):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("so101_sim_amd needs a ROCm GPU (MI355X): the step path has no CPU fallback")
@@ -135,6 +135,13 @@ class BatchedEnvironment:
         self._pool = None
         self.sim.bind(*(t.data_ptr() for t in (self.qpos, self.qvel, self.ctrl, self.warm, self.ring,
                                                  self.ep_return, self.step_count, self.episode, self.mass_scale)))
+        # physics_state / delayed_physics_state (so100_task.py:203-210,366-368; the reference enables them together with the
+        # cameras): device-side 15-step delay line, on request - the throughput configurations are proprioceptive only
+        self.physics_state = self.delayed_physics_state = self._ps_ring = None
+        if physics_state:
+            self._ps_ring = z(native.PS_DELAY, native.PS_DIM, N)
+            self.physics_state, self.delayed_physics_state = z(N, native.PS_DIM), z(N, native.PS_DIM)
+            self.sim.bind_physics_state(self._ps_ring.data_ptr(), self.physics_state.data_ptr(), self.delayed_physics_state.data_ptr())
         nsub = int(round(task.control_timestep / PHYSICS_TIMESTEP))
         last = scenes.time_limit_last_step(time_limit, task.control_timestep, PHYSICS_TIMESTEP) if np.isfinite(time_limit) else 1 << 30
         self.last_step = last
@@ -162,11 +169,12 @@ class BatchedEnvironment:
         spec["commanded_joints_pos"] = Array((6,), np.float64, "commanded_joints_pos")
         spec["joints_pos"] = Array((6,), np.float64, "joints_pos")
         spec["joints_vel"] = Array((0,), np.float64, "joints_vel")
-        if self.task.image_observation_enabled:
+        with_state = self.physics_state is not None or (self.n_envs == 1 and self.task.image_observation_enabled)
+        if with_state:
             spec["physics_state"] = Array((38,), np.float64, "physics_state")
         spec["undelayed_joints_pos"] = Array((6,), np.float64, "undelayed_joints_pos")
         spec["undelayed_joints_vel"] = Array((0,), np.float64, "undelayed_joints_vel")
-        if self.task.image_observation_enabled:
+        if with_state:
             spec["delayed_physics_state"] = Array((38,), np.float64, "delayed_physics_state")
         return spec
 
@@ -200,8 +208,12 @@ class BatchedEnvironment:
         o["commanded_joints_pos"] = self.obs[:, 12:18]
         o["joints_pos"] = self.obs[:, 0:6]
         o["joints_vel"] = self.obs[:, 0:0]
+        if self.physics_state is not None:
+            o["physics_state"] = self.physics_state
         o["undelayed_joints_pos"] = self.obs[:, 6:12]
         o["undelayed_joints_vel"] = self.obs[:, 0:0]
+        if self.physics_state is not None:
+            o["delayed_physics_state"] = self.delayed_physics_state
         return o
 
     def reset(self) -> TimeStep:
@@ -227,7 +239,10 @@ class BatchedEnvironment:
     def set_mass_scale(self, scale):
         """scale: [2, N] (object, container) multipliers of the props' mass and inertia.  Flushes the reset prefetch
         (cached initial states were settled with the old masses)."""
-        self.mass_scale.copy_(self.torch.as_tensor(scale, dtype=self.torch.float32, device=self.device).reshape(2, self.n_envs))
+        scale = self.torch.as_tensor(scale, dtype=self.torch.float32, device=self.device).reshape(2, self.n_envs)
+        if not bool((scale > 0).all()):
+            raise ValueError("mass scales must be positive")
+        self.mass_scale.copy_(scale)
         if self._store is not None:
             self.set_settled_store(None)       # a settled-state store belongs to the old masses as well
         self.sim.configure()
@@ -336,6 +351,9 @@ class SingleEnvironment(BatchedEnvironment):
             self._np_random = np.random.RandomState()
         else:
             self._np_random = np.random.RandomState(int(random_state))
+        if self._seed_compatible:
+            kw.setdefault("prefetch_resets", False)      # the host draws the placements: nothing the kernels could settle ahead of time
+        kw.pop("physics_state", None)                    # N = 1 keeps the reference's rule (image_observation_enabled) and a host-side line
         super().__init__(task, n_envs=1, random_state=(random_state if not isinstance(random_state, np.random.RandomState) else 0), **kw)
         self._state_ring = collections.deque(maxlen=_PHYSICS_DELAY_STEPS)
         self._pending_first = False
@@ -379,10 +397,14 @@ class SingleEnvironment(BatchedEnvironment):
         if not placed:
             raise RuntimeError("Failed to place the container without collisions in 20 attempts (dm_control PropPlacer raises here too)")
         self.placements = dict(object_position=opos.copy(), object_yaw=float(yaw), container_position=q[13:16].copy())
-        self.events(clear=True)
+        before = self.events()["settle_not_converged"]          # (cumulative counters stay what events() documents)
+        # settle with the controls the episode starts with (ctrl = home + offsets), like the kernels' own reset
+        home = np.asarray(scenes.SO100_HOME_CTRL, dtype=np.float64)
+        self.ctrl.copy_(torch.as_tensor(home + np.asarray(self.task.calibration.homing_offsets, dtype=np.float64),
+                                        dtype=torch.float32, device=self.device).unsqueeze(1))
         self.sim.settle(self._stream())
         self.begin_episode()
-        if self.events()["settle_not_converged"]:
+        if self.events()["settle_not_converged"] > before:
             import warnings
             warnings.warn("Failed to settle physics within the settle budget (dm_control warns likewise)")
 

@@ -16,6 +16,7 @@ OBS_DIM = 18
 ACT_DIM = 6
 RING_DEPTH = 5
 DIAG_DIM = 8
+PS_DIM, PS_DELAY = 38, 15
 NEVENTS = 8
 EVENT_NAMES = ("candidate_overflow", "contact_overflow", "arm_pool_overflow", "diverged", "placement_rejected",
                "settle_not_converged", "scheduler_abort")
@@ -29,7 +30,7 @@ DBG = dict(M=0, MINV=36, BIAS=72, SMOOTH=78, QACC=96, COUNTS=114, XPOS=120, CON=
 
 EXPORTS = (
     "so101_version", "so101_max_contacts", "so101_create", "so101_destroy", "so101_default_config",
-    "so101_configure", "so101_bind_state", "so101_set_reset_pool", "so101_compute_settled", "so101_set_settled_store", "so101_reset", "so101_settle", "so101_begin_episode", "so101_step", "so101_physics", "so101_reward",
+    "so101_configure", "so101_bind_state", "so101_bind_physics_state", "so101_set_reset_pool", "so101_compute_settled", "so101_set_settled_store", "so101_reset", "so101_settle", "so101_begin_episode", "so101_step", "so101_physics", "so101_reward",
     "so101_get_returns", "so101_get_diag", "so101_get_events", "so101_debug_forward", "so101_debug_candidates", "so101_debug_stages", "so101_get_info", "so101_debug_chain_stats", "so101_last_error",
 )
 
@@ -75,6 +76,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.so101_default_config.argtypes = [C.POINTER(Config)]
     L.so101_configure.argtypes = [vp, C.POINTER(Config)]
     L.so101_bind_state.argtypes = [vp, C.POINTER(Buffers)]
+    L.so101_bind_physics_state.argtypes = [vp, vp, vp, vp]
     L.so101_set_reset_pool.argtypes = [vp, vp, vp, vp, C.c_int]
     L.so101_compute_settled.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     L.so101_set_settled_store.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int]
@@ -161,6 +163,10 @@ class Sim:
     def bind(self, qpos, qvel, ctrl, warmstart, obs_ring, ep_return, step_count, episode, mass_scale=None):
         b = Buffers(qpos, qvel, ctrl, warmstart, obs_ring, ep_return, step_count, episode, mass_scale)
         self._check(self.L.so101_bind_state(self.h, C.byref(b)), "so101_bind_state")
+
+    def bind_physics_state(self, ring, physics_state, delayed):
+        self._check(self.L.so101_bind_physics_state(self.h, *(C.c_void_p(x) if x else None for x in (ring, physics_state, delayed))),
+                    "so101_bind_physics_state")
 
     def set_reset_pool(self, qpos, qvel, ctrl, pool_size: int):
         self._check(self.L.so101_set_reset_pool(self.h, qpos, qvel, ctrl, int(pool_size)), "so101_set_reset_pool")

@@ -85,8 +85,9 @@ def create_task_env(
     name explicitly are silently dropped (task_suite.py:134-144) — for `SO100HandOver`, whose signature
     is `(object_name, reward_based_on_overlap=True, **kwargs)`, that is everything except those two.
     Batched extension: `n_envs`, `device`, `solver` ("newton" | "pgs"), `solver_iterations`, `solver_tolerance`,
-    `settle_max_substeps`, `prefetch_resets`, `env_id_base` are
-    consumed here and never reach the task.
+    `settle_max_substeps`, `prefetch_resets`, `env_id_base`, `physics_state` (batched `physics_state` /
+    `delayed_physics_state` observables, off by default: 38 + 38 floats per env and step) are consumed here and never
+    reach the task.
     """
     if task_name not in TASK_FACTORIES:
         raise ValueError(
@@ -95,7 +96,7 @@ def create_task_env(
         )
     n_envs = int(kwargs.pop("n_envs", 1))
     env_kwargs = {k: kwargs.pop(k) for k in ("device", "solver_iterations", "solver_tolerance", "env_id_base", "settle_max_substeps", "solver",
-                                                 "prefetch_resets")
+                                                 "prefetch_resets", "physics_state")
                   if k in kwargs}
 
     task_class, task_kwargs = TASK_FACTORIES[task_name]

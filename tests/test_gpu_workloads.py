@@ -30,7 +30,7 @@ def _batched_env(name, n, **kw):
     cwd = os.getcwd()
     os.chdir("/tmp")                       # no calibration offsets
     try:
-        return task_suite.create_task_env(name, time_limit=10.0, random_state=0, n_envs=n, **kw)
+        return task_suite.create_task_env(name, time_limit=kw.pop("time_limit", 10.0), random_state=0, n_envs=n, **kw)
     finally:
         os.chdir(cwd)
 
@@ -336,6 +336,34 @@ def test_env_on_a_non_current_device_guard():
     ev = env.events()
     assert set(ev) == {"candidate_overflow", "contact_overflow", "arm_pool_overflow", "diverged", "placement_rejected", "settle_not_converged",
                        "scheduler_abort"} and ev["scheduler_abort"] == 0
+    env.close()
+
+
+def test_batched_physics_state_and_its_15_step_delay():
+    """physics_state = concat(qpos, qvel) and delayed_physics_state (15 control steps, padded with the episode's first value:
+    so100_task.py:203-210,366-368) for a batch, across a time-limit auto-reset, against a host-side replay of the same line."""
+    import collections
+    import torch
+    env = _batched_env("SO100HandOverBanana", 6, settle_max_substeps=40, time_limit=0.4, physics_state=True)    # 20-step episodes
+    ts = env.reset()
+    assert list(ts.observation)[:4] == ["commanded_joints_pos", "joints_pos", "joints_vel", "physics_state"] and list(ts.observation)[-1] == "delayed_physics_state"
+    assert ts.observation["physics_state"].shape == (6, 38)
+    state = lambda: torch.cat([env.qpos, env.qvel]).t().clone()
+    lines = [collections.deque([state()[e]] * 15, maxlen=15) for e in range(6)]
+    assert torch.equal(env.physics_state, state()) and torch.equal(env.delayed_physics_state, state())
+    g = torch.Generator(device=env.device); g.manual_seed(3)
+    firsts = 0
+    for t in range(47):
+        ts = env.step(0.3 * torch.randn(6, 6, device=env.device, generator=g))
+        cur = state()
+        assert torch.equal(env.physics_state, cur)
+        for e in range(6):
+            if int(env.step_type[e]) == 0:                       # auto-reset: the line restarts from the new episode's first state
+                lines[e] = collections.deque([cur[e]] * 15, maxlen=15); firsts += 1
+            expect = lines[e][0]
+            lines[e].append(cur[e])
+            assert torch.equal(env.delayed_physics_state[e], expect), (t, e)
+    assert firsts >= 6
     env.close()
 
 
