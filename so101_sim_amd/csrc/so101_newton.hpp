@@ -443,6 +443,69 @@ DEV void solve_newton_impl(const DevModel* m, EnvLDS& L, int max_iter, float tol
       actX[1] = wave_ballot(on && C.g0 == 0 && C.g1 == 2) != 0ull;
       actX[2] = wave_ballot(on && C.g0 == 1 && C.g1 == 2) != 0ull;
     }
+#ifndef SO101_DPP_HESSIAN
+    // Contact part on the matrix cores:  sum_k J_k' Hc_k J_k = Jt W  with the constraint rows as the K dimension, W = Hc J.
+    // Six contacts at a time stage their 36 rows of J and W (18 coordinates each) in LDS - in the storage of the geom
+    // boxes / arm-contact pool, which nobody reads during the solve -, 18 v_mfma_f32_32x32x2_f32 accumulate them, and the
+    // accumulator's column a (H is symmetric) goes to lane a.  With every group pair coupled the 171 cross-lane sums below cost
+    // 17.8 us per assembly and wavefront on a full machine, this path 3.1-5.4 us for 4-16 contacts
+    // (scripts/microbench/mfma_hessian.hip, profiles/README.md) - and coupled envs are the ones whose solves last longest.
+    if (actG[0] || actG[1] || actG[2]) {
+      constexpr int HB = 6;                                  // contacts per batch
+      float* Jl = &L.aabb[0][0];
+      float* Wl = Jl + 6 * HB * NVS;
+      static_assert(sizeof(float) * 2 * 6 * HB * NVS <= sizeof(ArmCon) * MAXARMCON, "Hessian staging must fit the collision scratch (union in EnvLDS)");
+      mfma_acc16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[r] = 0.f;
+      const int col = lane & 31, half = lane >> 5;
+      const bool live = col < NVS;
+      const int off = half * NVS + (live ? col : 0);
+      for (int k0 = 0; k0 < ncon; k0 += HB) {
+        int k1 = k0 + HB < ncon ? k0 + HB : ncon;
+        if (lane >= k0 && lane < k1) {
+          // rows 6 (lane - k0) ..: the group this contact does not touch is zero, the two slots go to their groups' columns
+          // (a contact with one group: slot 1 is all zeros and lands on a group of its own)
+          int ga = C.g0 < 0 ? 0 : C.g0, gb = C.g1 < 0 ? (ga == 0 ? 1 : 0) : C.g1, gz = 3 - ga - gb;
+          float* jd = Jl + 6 * (lane - k0) * NVS; float* wd = Wl + 6 * (lane - k0) * NVS;
+#pragma unroll
+          for (int q = 0; q < 6; q++) {
+            // column q of both slots: W0 = Hc J[:, q of slot 0], W1 = Hc J[:, q of slot 1]  (the products of the sums' path)
+            float W0[6], W1[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+              float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+              for (int j = 0; j < 6; j++) { float hc = Hc[i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i]; s0 += hc * C.J[q][j]; s1 += hc * C.J[6 + q][j]; }
+              W0[i] = s0; W1[i] = s1;
+            }
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+              jd[j * NVS + 6 * ga + q] = C.J[q][j]; jd[j * NVS + 6 * gb + q] = C.J[6 + q][j]; jd[j * NVS + 6 * gz + q] = 0.f;
+              wd[j * NVS + 6 * ga + q] = W0[j]; wd[j * NVS + 6 * gb + q] = W1[j]; wd[j * NVS + 6 * gz + q] = 0.f;
+            }
+            SCHED_FENCE();
+          }
+        }
+        wave_sync();
+        int steps = 3 * (k1 - k0);
+        for (int t = 0; t < steps; t++) {
+          float av = Jl[off + 2 * NVS * t], bv = Wl[off + 2 * NVS * t];
+          acc = mfma_32x32x2(live ? av : 0.f, live ? bv : 0.f, acc);
+        }
+        wave_sync();
+      }
+      // lane l: column l % 32, rows 8 blk + 4 (l / 32) + r % 4 in element 4 blk + r % 4 -> lane a gets column a = row a
+      float o[8];
+#pragma unroll
+      for (int r = 0; r < 8; r++) o[r] = wave_xor32_f(acc[r]);
+      if (lane < NVS) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) { h[r] += acc[r]; h[4 + r] += o[r]; h[8 + r] += acc[4 + r]; h[12 + r] += o[4 + r]; }
+        h[16] += acc[8]; h[17] += acc[9];
+      }
+    }
+#else
     if (actG[0] || actG[1] || actG[2]) {
 #pragma unroll
       for (int b = 0; b < 6; b++) {
@@ -490,6 +553,7 @@ DEV void solve_newton_impl(const DevModel* m, EnvLDS& L, int max_iter, float tol
         }
       }
     }
+#endif
     NPROF(2)
     // ---- symmetric diagonal scaling  H~ = S H S, S = diag(H)^-1/2 : translational (mass ~ 4e-2) and rotational
     // (inertia ~ 1e-5) coordinates differ by ~1e3 in scale, which puts cond(H) near 1/eps_fp32; after scaling the

@@ -180,6 +180,16 @@ __device__ __forceinline__ void row_argmax3(float& val, int& idx, float& x, floa
   row_argmax3_step<DPP_ROW_HALF_MIRROR>(val, idx, x, y, z);
   row_argmax3_step<DPP_ROW_MIRROR>(val, idx, x, y, z);
 }
+// ---- matrix cores: D (32 x 32, f32) += A (32 x 2) * B (2 x 32), v_mfma_f32_32x32x2_f32.  Lane l supplies A[l % 32][l / 32] and
+// B[l / 32][l % 32]; it holds D[8 (r / 4) + 4 (l / 32) + r % 4][l % 32] in element r of the accumulator.
+typedef float mfma_acc16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ mfma_acc16 mfma_32x32x2(float a, float b, mfma_acc16 acc) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0); }
+// nothing is scheduled across this point: keeps unrolled, mutually independent blocks from being interleaved into one
+// register-hungry stream
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// value of lane ^ 32 (the other half of the wavefront)
+__device__ __forceinline__ float wave_xor32_f(float v) { return __shfl_xor(v, 32); }
+
 // ---- agent-scope memory operations: hand-offs between wavefronts INSIDE one launch (so101_chain.hpp) ------------------
 // Per-XCD L2s are not coherent with each other and a CU's vector L1 is never refreshed by another CU's stores
 // (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility").  Bytes that one wavefront hands

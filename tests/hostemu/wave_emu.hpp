@@ -98,6 +98,20 @@ inline void row_argmax3(float& val, int& idx, float& x, float& y, float& z) {
   pthread_barrier_wait(&emu_row_barrier[row]);
   val = ov; idx = oi; x = ox; y = oy; z = oz;
 }
+// matrix cores (wave.hpp): D += A (32 x 2) * B (2 x 32) in the lane layout of v_mfma_f32_32x32x2_f32
+struct mfma_acc16 { float v[16]; float& operator[](int i) { return v[i]; } const float& operator[](int i) const { return v[i]; } };
+inline mfma_acc16 mfma_32x32x2(float a, float b, mfma_acc16 acc) {
+  int l = threadIdx.x;
+  emu_blk->px[l] = a; emu_blk->py[l] = b; __syncthreads();
+  for (int r = 0; r < 16; r++) {
+    int i = 8 * (r / 4) + 4 * (l / 32) + r % 4, j = l % 32;
+    acc.v[r] = std::fma(emu_blk->px[i + 32], emu_blk->py[j + 32], std::fma(emu_blk->px[i], emu_blk->py[j], acc.v[r]));
+  }
+  __syncthreads();
+  return acc;
+}
+#define SCHED_FENCE() (void)0
+inline float wave_xor32_f(float v) { emu_xchg_f[threadIdx.x] = v; __syncthreads(); float r = emu_xchg_f[threadIdx.x ^ 32]; __syncthreads(); return r; }
 // agent-scope memory operations (wave.hpp): sequentially consistent host atomics
 template <class T> inline T ld_agent(const T* p) { int v = __atomic_load_n((const int*)p, __ATOMIC_SEQ_CST); T o; std::memcpy(&o, &v, 4); return o; }
 template <class T> inline void st_agent(T* p, T v) { int x; std::memcpy(&x, &v, 4); __atomic_store_n((int*)p, x, __ATOMIC_SEQ_CST); }

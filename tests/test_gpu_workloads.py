@@ -126,18 +126,31 @@ def test_pickplace_pool_against_oracle(blobs):
     # (b) solver: with the KERNEL's contact list injected into the oracle, constraint rows + Newton solve must agree to
     #     1e-3 of max|qacc| on every entry - stiff pad contacts (solimp clamped to 0.9999) squeezing a 70 g banana are
     #     the case in which a cost-based fp32 termination stops early (so101_newton.hpp, decrement test).
+    #     The count is taken over ALL 32 grasp entries of the pool (round 2 looked at 8 of them and allowed 4): which entries sit
+    #     on such a corner changes with the last bit of the rollout that built the pool - seeds 3 / 4 / 5 give 12 / 3 / 6 of 32.
+    grasp = list(range(half))
+    simg = ArraySim(blobs["f32"], len(grasp), backend="gpu", last_step=500)
+    simg.set_state(PQ[:, grasp], PV[:, grasp], PC[:, grasp], np.zeros((18, len(grasp))))
+    dbgg = simg.debug_forward()
+    narrow_differs = 0
+    for j, k in enumerate(grasp):
+        o = Oracle(blobs["f64"])
+        o.set_state(PQ[:, k], PV[:, k], np.zeros(18))
+        o.set_ctrl(PC[:, k])
+        o.forward()
+        narrow_differs += bool(pc._compare_contact_lists(dbgg[j]["contacts"], o.contacts())[0])
+    assert narrow_differs <= len(grasp) // 2, narrow_differs
     idx = list(range(0, 8)) + list(range(half, half + 8))
     sim = ArraySim(blobs["f32"], len(idx), backend="gpu", last_step=500)
     sim.set_state(PQ[:, idx], PV[:, idx], PC[:, idx], np.zeros((18, len(idx))))
     dbg = sim.debug_forward()
-    ncon, narrow_differs = [], 0
+    ncon = []
     for j, k in enumerate(idx):
         o = Oracle(blobs["f64"])
         o.set_state(PQ[:, k], PV[:, k], np.zeros(18))
         o.set_ctrl(PC[:, k])
         o.forward()
         problems, _, _ = pc._compare_contact_lists(dbg[j]["contacts"], o.contacts())
-        narrow_differs += bool(problems)
         assert not (problems and j >= 8), (j, problems)               # drop entries: no pad contacts, must agree
         ncon.append(len(o.contacts()))
         o.inject_contacts(dbg[j]["contacts"])
@@ -145,7 +158,6 @@ def test_pickplace_pool_against_oracle(blobs):
         a = o.qacc()[0]
         err = np.abs(dbg[j]["qacc"] - a).max() / np.abs(a).max()
         assert err <= 1e-3, (j, err, dbg[j]["iters"])
-    assert narrow_differs <= 4, narrow_differs
     assert np.mean(ncon[:8]) >= 12, ncon                            # contact-heavy: banana + bowl on the table + the gripper
     # ---- one control step from the same entries: task outputs exact; states to the free-space bound on the drop
     # entries (arm parked).  On the grasp entries parity is what (a) and (b) establish per forward pass; ten substeps of
