@@ -162,6 +162,7 @@ def main():
     ap.add_argument("--fused", action="store_true", help="one fused k_step launch per control step instead of the pipeline")
     ap.add_argument("--pipeline", type=int, default=-1, help="step path: 3 merged launches, 2 per-env chained, 1 launch chains, 0 fused (-1 = library default)")
     ap.add_argument("--chain-waves", type=int, default=0, help="pipeline 2: persistent wavefronts (0 = library default)")
+    ap.add_argument("--no-graph", action="store_true", help="plain launches instead of HIP-graph replay")
     ap.add_argument("--groups", type=int, default=0, help="env slices of the pipelined step (0 = library default)")
     ap.add_argument("--solver-iterations", type=int, default=0, help="iteration cap; 0 = model default (100)")
     ap.add_argument("--solver-tolerance", type=float, default=-1.0, help="<0 = model default (1e-8)")
@@ -223,6 +224,8 @@ def main():
             env.sim.configure(pipeline=args.pipeline)
         if args.chain_waves:
             env.sim.configure(chain_waves=args.chain_waves)
+        if args.no_graph:
+            env.sim.configure(use_graph=0)
         if args.groups:
             env.sim.configure(groups=args.groups)
 
@@ -376,12 +379,12 @@ def main():
     n_local = sum(e.n_envs for e in envs)
     stats = stats_first
 
-    path = 0 if args.fused else (args.pipeline if args.pipeline >= 0 else 2)
+    path = 0 if args.fused else (args.pipeline if args.pipeline >= 0 else 1)
     if rank == 0:
         build_hash = sbuild.source_hash()
         value = world * n_local * args.steps / elapsed
         achieved = ALGO_BYTES_PER_ENV_STEP * n_local / (kernel_ms * 1e-3) / 1e9
-        pmc = load_pmc(build_hash) if args.workload == "handover" and N == 4096 and path == 2 else None
+        pmc = load_pmc(build_hash) if args.workload == "handover" and N == 4096 and path == 1 else None
         env_steps = n_local * args.steps
         names = {"handover": "SO100HandOverBanana, uniform random actions, 500-step episodes with the reference reset (placement + settle, prefetched)",
                  "pickplace": f"SO100HandOverBanana pick-and-place, episodes from a scripted pre-grasp pool of {args.pool_size} states, hold pose + N(0,0.05) actions with the jaw closing",
