@@ -434,10 +434,15 @@ def main():
                                   "one synchronize at the end"}
         if segments:
             seg_rates = [n_local * 100 / (ms * 1e-3) for ms in segments]
-            out["sustained"] = {"steps": args.steps, "env_steps_per_s": value, "per_100_steps_env_steps_per_s": seg_rates,
+            out["sustained"] = {"steps": args.steps, "env_steps_per_s": value,
+                                "device_env_steps_per_s": n_local * world * args.steps / (1e-3 * sum(segments)),
+                                "per_100_steps_env_steps_per_s": seg_rates,
                                 "min": min(seg_rates), "max": max(seg_rates),
                                 "note": "one window long enough for every env to pass its time limit (auto-reset inside); device time "
-                                        "of each 100-step slice on rank 0, the way the reference logs its step time (run_eval.py:103-124)"}
+                                        "of each 100-step slice on rank 0, the way the reference logs its step time (run_eval.py:103-124). "
+                                        "`env_steps_per_s` = `value` (host clock, device-wide synchronize: it also waits for the reset "
+                                        "prefetch of FUTURE episodes that the last mass reset started, up to 1.6 s of background work); "
+                                        "`device_env_steps_per_s` = the same steps over the device time of the launch streams"}
         if hasattr(envs[0], "sim") and hasattr(envs[0].sim, "info"):
             out["config"]["step_path"] = envs[0].sim.info()
             if path == 2:

@@ -3,7 +3,7 @@
 # of scripts/gpu_profile.sh (rocprofv3 kernel stats + separate PMC passes).  Everything lands in gpurun_out/<tag>_*; the
 # files to keep are copied into profiles/ by hand.
 #   usage: bash scripts/gpu_round_report.sh r02
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out; mkdir -p $O
 cd $R
@@ -19,6 +19,11 @@ timeout 900 python bench.py --envs-per-gpu 32768 --steps 30 --no-cpu-baseline 2>
 timeout 900 python bench.py --workload pickplace --steps 40 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_pickplace.json
 timeout 900 python bench.py --workload mixed --steps 30 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_mixed.json
 timeout 600 python bench.py --fused --no-cpu-baseline --steps 40 2>/dev/null | tail -1 > $O/${TAG}_bench_fused.json
+# the other step paths (same device functions, bit-identical): per-env chained persistent kernel, merged launches
+timeout 600 python bench.py --pipeline 2 --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/${TAG}_bench_chained.json
+timeout 600 python bench.py --pipeline 3 --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/${TAG}_bench_merged.json
+timeout 900 python bench.py --steps 1500 --warmup 10 --no-cpu-baseline --repeats 1 2>/dev/null | tail -1 > $O/${TAG}_bench_1500.json
+[ -x $R/ab/mfma_hessian ] && timeout 120 $R/ab/mfma_hessian > $O/${TAG}_mfma_hessian.txt 2>&1
 timeout 600 python scripts/gpu_reset_cost.py 2>&1 | tail -6 > $O/${TAG}_reset_cost.txt
 rocm-smi --showclocks 2>/dev/null | grep -E "sclk|mclk" | head -4 > $O/${TAG}_clocks_after.txt
 bash $R/scripts/gpu_profile.sh $TAG > $O/${TAG}_profile.log 2>&1
