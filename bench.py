@@ -27,12 +27,31 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # four launch chains need their own hardware queues (so101_sim_amd/__init__.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # four launch chains need their own hardware queues (so101_sim_amd/__init__.py)
 
 ALGO_BYTES_PER_ENV_STEP = 620      # fused 10-substep step, fp32, per env-step
 HBM_SPEC_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_TFLOPS = 157.3           # MI355X_MICROARCH.md: fp32 vector peak (256 CUs x 4 SIMD x 16 lanes x 2 x 2.4 GHz)
 DEFAULT_ENVS = {"handover": 4096, "pickplace": 16384, "mixed": 32768}
+
+
+def usable_cores() -> int:
+    """Cores this process may actually use: the affinity mask, cut by the cgroup CPU quota (a container on a 256-thread host
+    with a quota of 16 CPUs reports os.cpu_count() = 256, and 256 busy threads then share 16 CPUs)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                n = max(1, min(n, int(float(quota) / period)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
 
 
 def cpu_baseline(envs_per_worker: int = 64, steps: int = 6, reps: int = 5):
@@ -54,7 +73,7 @@ def cpu_baseline(envs_per_worker: int = 64, steps: int = 6, reps: int = 5):
     settings = [("newton_100it_tol1e-8", 100, 1e-8), ("newton_fixed_4it", 4, 0.0)]
     its = (C.c_int * 2)(*[x[1] for x in settings])
     tol = (C.c_double * 2)(*[x[2] for x in settings])
-    ncpu = os.cpu_count() or 1
+    ncpu = usable_cores()
 
     def leg(threads):
         rs = C.c_double(0.0)
@@ -77,6 +96,7 @@ def cpu_baseline(envs_per_worker: int = 64, steps: int = 6, reps: int = 5):
     key = settings[0][0]
     eff = many[key]["env_steps_per_s_mean"] / (ncpu * one[key]["env_steps_per_s_mean"])
     return {"value": many[key]["with_reset_amortised_over_500_steps"], "unit": "env-steps/s", "cores": ncpu, "kind": "port",
+            "host_logical_cpus": os.cpu_count(),
             "label": "CPU restatement baseline (MuJoCo unavailable)",
             "single_core_value": one[key]["with_reset_amortised_over_500_steps"], "parallel_efficiency": eff,
             "one_thread": one, "all_threads": many,

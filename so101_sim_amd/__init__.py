@@ -32,7 +32,7 @@ if "GPU_MAX_HW_QUEUES" not in _os.environ:
                        "pipelined step uses three launch chains instead of four (export GPU_MAX_HW_QUEUES=8 before the first GPU call)")
         _os.environ["SO101_HW_QUEUES_EFFECTIVE"] = "4"
     else:
-        _os.environ["GPU_MAX_HW_QUEUES"] = "8"
+        _os.environ["GPU_MAX_HW_QUEUES"] = "16"     # (two handles in one process - the mixed suite - need 12 streams: 1.00 M with 8 queues, 1.12 M with 16)
 
 
 def install_as_so101_sim():
