@@ -304,6 +304,75 @@ def test_mixed_suite_two_streams():
             assert torch.equal(a, b), nm
 
 
+def test_mixed_suite_at_full_size_with_oracle_slices(blobs, blobs_pen):
+    """configs[3] at its BASELINE.json size: 16384 x Banana + 16384 x Pen on two streams with per-env mass scales.  One control
+    step from the reset state of a slice of envs of EACH handle is repeated by the fp64 oracle with the same mass scale
+    (resting props, free arm: the free-space / resting-contact bound of check_control_step); properties on all 32768 envs."""
+    import torch
+    n, k = 16384, 6
+    names = {"SO100HandOverBanana": blobs, "SO100HandOverPen": blobs_pen}
+    envs = {nm: _batched_env(nm, n, settle_max_substeps=1000) for nm in names}
+    streams = {nm: torch.cuda.Stream() for nm in names}
+    gen = torch.Generator(device="cuda")
+    act, before = {}, {}
+    for nm, env in envs.items():
+        with torch.cuda.stream(streams[nm]):
+            gen.manual_seed(11 + len(nm))
+            env.set_mass_scale(0.5 + torch.rand(2, n, device=env.device, generator=gen))
+            act[nm] = 0.5 * (torch.rand(n, 6, device=env.device, generator=gen) * 2 - 1)
+            env.reset_all()
+            before[nm] = (env.qpos[:, :k].clone(), env.qvel[:, :k].clone(), env.warm[:, :k].clone(), env.ctrl[:, :k].clone())
+    for nm, env in envs.items():
+        with torch.cuda.stream(streams[nm]):
+            env.step_tensor(act[nm])
+    torch.cuda.synchronize()
+    for nm, env in envs.items():
+        assert bool(torch.isfinite(env.qpos).all()) and bool(torch.isfinite(env.qvel).all())
+        assert bool(((env.reward == 0) | (env.reward == 1)).all()) and bool((env.step_type == 1).all())
+        assert torch.allclose(env.qpos[9:13].norm(dim=0), torch.ones(n, device=env.device), atol=1e-5)
+        ev = env.events()
+        assert ev["diverged"] == 0 and ev["scheduler_abort"] == 0 and ev["candidate_overflow"] == 0, ev
+        q0, v0, w0, c0 = (t.cpu().numpy().astype(np.float64) for t in before[nm])
+        ms = env.mass_scale[:, :k].cpu().numpy().astype(np.float64)
+        for e in range(k):
+            o = Oracle(names[nm]["f64"])
+            o.set_mass_scale(ms[:, e])
+            o.set_state(q0[:, e], v0[:, e], w0[:, e])
+            o.set_ctrl(act[nm][e].cpu().numpy().astype(np.float64))
+            o.substeps(10)
+            qo, vo, _ = o.get_state()
+            dq = np.abs(env.qpos[:, e].cpu().numpy() - qo).max(); dv = np.abs(env.qvel[:, e].cpu().numpy() - vo).max()
+            assert dq <= 2e-5 and dv <= 2e-3, (nm, e, dq, dv)
+        env.close()
+
+
+def test_failure_rates_on_the_headline_workload():
+    """4096 envs x 500 control steps of uniform random actions over the action spec (seeded): how often the physics diverge
+    (the episode then ends like a dm_control PhysicsError), how often a contact or arm-contact pool overflows, and that
+    no candidate list overflows and the scheduler never aborts.  Bounds = about twice what was measured (7.2e-5 divergences per
+    env-step: 141-151 in 2.05 M; DESIGN.md section 4 on why uniform random actions do that)."""
+    import torch
+    n, steps = 4096, 500
+    env = _batched_env("SO100HandOverBanana", n)
+    spec = env.action_spec()
+    lo = torch.tensor(spec.minimum, device=env.device); hi = torch.tensor(spec.maximum, device=env.device)
+    gen = torch.Generator(device=env.device); gen.manual_seed(1)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        env.reset_all()
+        env.events(clear=True)
+        for t in range(steps):
+            env.step_tensor(lo + (hi - lo) * torch.rand(n, 6, device=env.device, generator=gen))
+    torch.cuda.synchronize()
+    ev = env.events()
+    per = {k: v / (n * steps) for k, v in ev.items()}
+    assert per["diverged"] <= 1.5e-4, ev
+    assert per["contact_overflow"] <= 5e-5 and per["arm_pool_overflow"] <= 5e-5, ev
+    assert ev["candidate_overflow"] == 0 and ev["scheduler_abort"] == 0 and ev["placement_rejected"] == 0, ev
+    assert bool(torch.isfinite(env.qpos).all())
+    env.close()
+
+
 def test_properties_at_32768_envs(make_sim):
     """Per-GPU share of configs[4] (262144 envs over 8 GPUs) with the benchmarked solver settings (100 iterations,
     tolerance 1e-8): reset + 5 random-action steps; finite state, unit quaternions, arm untouched by the reset,
