@@ -159,15 +159,22 @@ def test_pickplace_pool_against_oracle(blobs):
         err = np.abs(dbg[j]["qacc"] - a).max() / np.abs(a).max()
         assert err <= 1e-3, (j, err, dbg[j]["iters"])
     assert np.mean(ncon[:8]) >= 12, ncon                            # contact-heavy: banana + bowl on the table + the gripper
-    # ---- one control step from the same entries: task outputs exact; states to the free-space bound on the drop
-    # entries (arm parked).  On the grasp entries parity is what (a) and (b) establish per forward pass; ten substeps of
-    # stiff pad contacts amplify a narrowphase difference of the first substep, so the rollout only gets a sanity bound.
+    # ---- one control step (ten substeps, jaws closing) from ALL 32 grasp entries and 8 drop entries: task outputs exact.
+    # Drop entries: states to the free-space bound (arm parked), contact-phase bound when the banana already touches the rim.
+    # Grasp entries: ten substeps of stiff pad contacts amplify a narrowphase difference of the first substep, so the bound
+    # is a distribution - the typical entry agrees like any contact phase (measured median 1.6e-5 rad / 9e-4 rad/s), at least
+    # 60 % are inside 2e-3 rad / 0.1 rad/s (measured 69-75 %), and the worst, on the entries counted in (a), stay inside
+    # 5e-2 rad / 20 rad/s (measured 0.033 / 9.1).  Round 2 checked 8 entries against the last bound only.
+    idx2 = grasp + list(range(half, half + 8))
+    sim = ArraySim(blobs["f32"], len(idx2), backend="gpu", last_step=500)
+    sim.set_state(PQ[:, idx2], PV[:, idx2], PC[:, idx2], np.zeros((18, len(idx2))))
     sim.begin_episode()
-    act = PC[:, idx].T.astype(np.float32).copy()
+    act = PC[:, idx2].T.astype(np.float32).copy()
     act[:, 5] -= 0.3
     obs, rew, disc, st = sim.step(act)
     q1, v1, _ = sim.get_state()
-    for j, k in enumerate(idx):
+    gq, gv = [], []
+    for j, k in enumerate(idx2):
         o = Oracle(blobs["f64"])
         o.env_config(seed=0, env_id=j, last_step=500)
         o.set_state(PQ[:, k], PV[:, k], np.zeros(18))
@@ -175,11 +182,17 @@ def test_pickplace_pool_against_oracle(blobs):
         oo, orew, odisc, ost = o.env_step(act[j].astype(np.float64))
         qo, vo, _ = o.get_state()
         assert (rew[j], disc[j], st[j]) == (orew, odisc, ost), j
-        # drop entries: free fall + a resting bowl -> round-off level; a banana released low enough to touch the bowl's
-        # rim right away rolls on single hull-hull MPR contacts -> contact-phase bound
-        touching = ncon[j] > 13
-        tq, tv = (5e-2, 20.0) if j < 8 else ((2e-3, 0.1) if touching else (2e-5, 5e-3))
-        assert np.abs(q1[:, j] - qo).max() <= tq and np.abs(v1[:, j] - vo).max() <= tv, (j, np.abs(q1[:, j] - qo).max(), np.abs(v1[:, j] - vo).max())
+        dq, dv = np.abs(q1[:, j] - qo).max(), np.abs(v1[:, j] - vo).max()
+        if j < len(grasp):
+            gq.append(dq); gv.append(dv)
+            assert dq <= 5e-2 and dv <= 20.0, (j, dq, dv)
+        else:
+            touching = ncon[8 + j - len(grasp)] > 13
+            tq, tv = (2e-3, 0.1) if touching else (2e-5, 5e-3)
+            assert dq <= tq and dv <= tv, (j, dq, dv)
+    gq, gv = np.array(gq), np.array(gv)
+    assert np.median(gq) <= 2e-4 and np.median(gv) <= 1e-2, (np.median(gq), np.median(gv))
+    assert np.mean((gq <= 2e-3) & (gv <= 0.1)) >= 0.6, (np.sort(gq)[-12:], np.sort(gv)[-12:])
     # ---- jaws squeezing a banana of randomised mass: GPU vs oracle with the same scale, and the scale matters
     g8 = list(range(8))
     scale = np.random.RandomState(2).uniform(0.5, 1.5, size=(2, 8))
