@@ -363,7 +363,8 @@ def test_failure_rates_on_the_headline_workload():
     """4096 envs x 500 control steps of uniform random actions over the action spec (seeded): how often the physics diverge
     (the episode then ends like a dm_control PhysicsError), how often a contact or arm-contact pool overflows, and that
     no candidate list overflows and the scheduler never aborts.  Bounds = about twice what was measured (7.2e-5 divergences per
-    env-step: 141-151 in 2.05 M; DESIGN.md section 4 on why uniform random actions do that)."""
+    env-step: 141-151 in 2.05 M; DESIGN.md section 4 on why uniform random actions do that).  At five points of the rollout
+    one control step of 24 envs is repeated by the fp64 oracle from the same live state (one-step parity on rollout states)."""
     import torch
     n, steps = 4096, 500
     env = _batched_env("SO100HandOverBanana", n)
@@ -371,12 +372,41 @@ def test_failure_rates_on_the_headline_workload():
     lo = torch.tensor(spec.minimum, device=env.device); hi = torch.tensor(spec.maximum, device=env.device)
     gen = torch.Generator(device=env.device); gen.manual_seed(1)
     st = torch.cuda.Stream()
+    from so101_sim_amd.model import scenes
+    raw64, _ = scenes.load_blob("banana", "f64")
+    k, checks = 24, []
     with torch.cuda.stream(st):
         env.reset_all()
         env.events(clear=True)
         for t in range(steps):
-            env.step_tensor(lo + (hi - lo) * torch.rand(n, 6, device=env.device, generator=gen))
+            act = lo + (hi - lo) * torch.rand(n, 6, device=env.device, generator=gen)
+            probe = t in (60, 180, 300, 420, 480)
+            if probe:        # the state these envs start the step from, for the one-step comparison below
+                before = [x[:, :k].clone() for x in (env.qpos, env.qvel, env.warm)]
+            env.step_tensor(act)
+            if probe:
+                checks.append((before, act[:k].clone(), env.qpos[:, :k].clone(), env.qvel[:, :k].clone(), env.step_type[:k].clone()))
     torch.cuda.synchronize()
+    # one control step of 5 x 24 envs at five points of the rollout (live states: props pushed around, arm on the table)
+    # repeated by the fp64 oracle from the same state
+    err = []
+    for before, act, q1, v1, stp in checks:
+        b = [x.cpu().numpy().astype(np.float64) for x in before]
+        for e in range(k):
+            if int(stp[e]) != 1:
+                continue                                   # the env reset in this call
+            o = Oracle(raw64)
+            o.set_state(b[0][:, e], b[1][:, e], b[2][:, e])
+            o.set_ctrl(act[e].cpu().numpy().astype(np.float64))
+            o.substeps(10)
+            qo, vo, _ = o.get_state()
+            err.append((np.abs(q1[:, e].cpu().numpy() - qo).max(), np.abs(v1[:, e].cpu().numpy() - vo).max()))
+    err = np.array(err)
+    # measured: median 7e-7 rad / 4e-5 rad/s, 90 % inside 2e-3 rad / 0.1 rad/s, worst 0.012 rad / 1.8 rad/s (MPR portal differences)
+    assert len(err) >= 100
+    assert np.median(err[:, 0]) <= 2e-5 and np.median(err[:, 1]) <= 2e-3, (np.median(err[:, 0]), np.median(err[:, 1]))
+    assert np.mean((err[:, 0] <= 2e-3) & (err[:, 1] <= 0.1)) >= 0.8 and err[:, 0].max() <= 5e-2 and err[:, 1].max() <= 20.0, (
+        np.mean((err[:, 0] <= 2e-3) & (err[:, 1] <= 0.1)), err[:, 0].max(), err[:, 1].max())
     ev = env.events()
     per = {k: v / (n * steps) for k, v in ev.items()}
     assert per["diverged"] <= 1.5e-4, ev
@@ -564,7 +594,11 @@ def test_config0_single_env_500_random_steps(blobs):
     uniform random actions through the reference's own Python surface.  The oracle's env layer, started from the same
     reset state, runs beside it for the first steps (arm joints to 1e-4 until the arm touches something, 5e-3 for five more
     steps): exact task outputs and the observation delay line throughout; the episode must end with LAST on control step 500 (or earlier on a physics error /
-    success, discount 0) and auto-reset."""
+    success, discount 0) and auto-reset.
+    ALL 500 steps are also checked one by one: a second oracle is put on the state the step started from (qpos, qvel, warm start)
+    and makes the same ten substeps - free trajectories separate chaotically once the arm hits something, single steps do not.
+    Without arm contact: 2e-5 rad / 2e-2 rad/s (measured 4e-6 / 5e-3); with arm contact (480 of the 500 steps): median below
+    1e-5 rad (3e-7), at least 97 % inside 2e-3 rad / 0.1 rad/s (99.8 %), every step inside 5e-2 / 20 (1.3e-3 / 0.18)."""
     from so101_sim_amd import task_suite
     cwd = os.getcwd()
     os.chdir(os.path.dirname(os.path.abspath(__file__)))       # no calibration/red_arm.json here: offsets are zero
@@ -585,10 +619,20 @@ def test_config0_single_env_500_random_steps(blobs):
     o.env_begin()
     rng = np.random.RandomState(0)
     undelayed, compared, touched, budget, ended = [], 0, False, 5, None
+    o1 = Oracle(blobs["f64"])                 # the one-step checker
+    one_step = []
     for t in range(1, 501):
         a = rng.uniform(spec.minimum, spec.maximum).astype(np.float32)
+        before = [x[:, 0].cpu().numpy().astype(np.float64) for x in (env.qpos, env.qvel, env.warm)]
         ts = env.step(a)
         ob = ts.observation
+        if not ts.last():
+            o1.set_state(*before)
+            o1.set_ctrl(a.astype(np.float64))
+            o1.substeps(10)
+            q1, v1, _ = o1.get_state()
+            arm = any(pc._arm_geom(c["geom1"]) or pc._arm_geom(c["geom2"]) for c in o1.contacts())
+            one_step.append((np.abs(ob["physics_state"][:20] - q1).max(), np.abs(ob["physics_state"][20:] - v1).max(), arm))
         assert ob["joints_pos"].shape == (6,) and ob["joints_vel"].shape == (0,) and ob["physics_state"].shape == (38,)
         assert np.all(np.isfinite(ob["physics_state"])) and ts.reward in (0.0, 1.0)
         np.testing.assert_array_equal(ob["commanded_joints_pos"], a.astype(np.float64))        # unclamped ctrl, zero offsets
@@ -610,6 +654,12 @@ def test_config0_single_env_500_random_steps(blobs):
             break
         assert ts.mid() and ts.discount == 1.0
     assert compared >= 5, compared
+    r = np.array(one_step, dtype=np.float64)
+    free, arm = r[r[:, 2] == 0], r[r[:, 2] == 1]
+    assert len(r) >= 400 and len(arm) >= 100, (len(r), len(arm))
+    assert free[:, 0].max() <= 2e-5 and free[:, 1].max() <= 2e-2, (free[:, 0].max(), free[:, 1].max())
+    assert np.median(arm[:, 0]) <= 1e-5 and arm[:, 0].max() <= 5e-2 and arm[:, 1].max() <= 20.0, (np.median(arm[:, 0]), arm[:, 0].max(), arm[:, 1].max())
+    assert np.mean((arm[:, 0] <= 2e-3) & (arm[:, 1] <= 0.1)) >= 0.97, np.mean((arm[:, 0] <= 2e-3) & (arm[:, 1] <= 0.1))
     assert ended is not None and (ended == 500 or ts.discount == 0.0), (ended, ts.discount)
     if ended == 500:
         assert ts.discount == 1.0 and ts.reward == 0.0
