@@ -5,7 +5,7 @@
 // The arithmetic of that path lives in third-party packages that are NOT vendored in the reference
 // tree: mujoco>=3.3.3, dm-control>=1.0.31 (reference requirements.txt:2,7; no lock file).  This file
 // therefore restates MuJoCo's published computation pipeline (mj_step: kinematics, CRBA, RNE,
-// actuation, collision, constraint assembly, PGS, semi-implicit Euler) as driven by the reference
+// actuation, collision, constraint assembly, Newton / PGS, semi-implicit Euler) as driven by the reference
 // call sites:
 //   * 10 substeps per control step         so101_sim/task_suite.py:41 (+ scene_pbr.xml:4 default dt)
 //   * options multiccd / noslip=0          so101_sim/tasks/base/so100_task.py:151-152
@@ -17,14 +17,21 @@
 //   * discount / termination               so101_sim/tasks/base/so100_task.py:292-302
 //   * reset placement + settle             so101_sim/tasks/so100_hand_over.py:37-55,208-229,320-323
 //
-// PINNING STATUS: the reference holds no numeric test for this path.  The oracle is pinned by the
-// known-answer vectors captured in the reference's executed notebooks (tests/golden/kat*.json;
-// so101_rl.ipynb:219-240, examples/so101_rl_breakdown.ipynb:274-288,352-363): the free-space arm
-// step (KAT-1) to <=1e-8 relative.  Contact-phase behaviour (narrow phase, soft-contact solve) is
-// "parity unpinned" beyond the loose rest-height facts of KAT-2: MuJoCo cannot run in this image.
-// Documented deviations from mujoco 3.3.x defaults: convex pairs use the libccd-style MPR
-// penetration query (MuJoCo's narrow phase before the native GJK/EPA became default) with ONE
-// contact per convex pair; solver is PGS (BASELINE.json north_star) rather than Newton.
+// PINNING STATUS: the reference holds no numeric test for this path.  The oracle is pinned by
+//   (1) the known-answer vectors captured in the reference's executed notebooks (tests/golden/kat*.json;
+//       so101_rl.ipynb:219-240, examples/so101_rl_breakdown.ipynb:274-288,352-363): the free-space arm step (KAT-1) to
+//       <=1e-8 relative; the notebook's resting pose of banana and bowl is an equilibrium of this contact model (net
+//       vertical acceleration < 0.5 % of g, height after one control step within 1e-5 m: tests/test_oracle_golden.py);
+//   (2) an algorithm-independent definition of what mujoco's GJK / EPA returns for a penetrating pair - the minimum
+//       translation, brute-forced from support functions in oracle/geomcheck.py: on the twelve contact-rich fixture states
+//       89 % of the contacting pairs report a depth within 2 % of it, 95.5 % within 25 %, worst 1.59x (deep arm-on-arm and
+//       arm-on-hull penetrations; tests/test_contact_geometry.py holds the numbers for oracle and kernel alike).
+// Beyond that the contact phase is "parity unpinned": MuJoCo cannot run in this image, so no contact FORCE of the reference
+// is available to compare with.
+// Documented deviations from mujoco 3.3.x: non-flat convex pairs use the libccd-style MPR penetration query (MuJoCo's narrow
+// phase before the native GJK / EPA became default) - flat-face pairs are closed form with up to 5 patch contacts
+// (multiccd, so100_task.py:151).  Solver: Newton by default (mujoco's default; the reference scene sets no <option solver>),
+// PGS (the one BASELINE.json's north_star names) selectable - both restated here and parity-tested.
 #pragma once
 #include <cstdint>
 #include <cstddef>
@@ -47,7 +54,7 @@ void orc_set_mass_scale(orc_sim*, const double* scale /*[nfree]*/);
 /* solver-parity tests: forward() uses this contact list instead of its own narrowphase; rows [n][9] = pos3 normal3
  * dist geom1 geom2, n = 0 restores the narrowphase */
 void orc_inject_contacts(orc_sim*, int n, const double* rows);
-// 0 = PGS (default; BASELINE north_star), 1 = Newton (mujoco's default solver, mj_solNewton restated)
+// 1 = Newton (default: mujoco's default solver, mj_solNewton restated), 0 = PGS (BASELINE north_star)
 void orc_set_solver_type(orc_sim*, int type);
 int orc_ls_evals(const orc_sim*);
 

@@ -3,7 +3,7 @@ import sys
 
 import os
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before HIP initialises (see so101_sim_amd/__init__.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # before HIP initialises (see so101_sim_amd/__init__.py)
 
 import pytest
 
