@@ -680,8 +680,16 @@ DEV void solve_newton(const DevModel* m, EnvLDS& L, int max_iter, float toleranc
   bool coupled = false;
   if (lane < L.ncon) { int g0, g1; contact_groups(L.con[lane], &g0, &g1); coupled = g1 >= 0; }
   bool cross = wave_ballot(coupled) != 0ull;
+#if defined(SO101_PROBE_INSTANCE) && SO101_PROBE_INSTANCE == 1
+  (void)cross; solve_newton_impl<true, true>(m, L, max_iter, tolerance);
+#elif defined(SO101_PROBE_INSTANCE) && SO101_PROBE_INSTANCE == 2
+  (void)cross; solve_newton_impl<true, false>(m, L, max_iter, tolerance);
+#elif defined(SO101_PROBE_INSTANCE) && SO101_PROBE_INSTANCE == 3
+  (void)cross; solve_newton_impl<false, false>(m, L, max_iter, tolerance);
+#else
   if (wave_uniform_i((int)(L.ncon <= 16 && L.nrow <= 16))) {
     if (!cross) solve_newton_impl<true, true>(m, L, max_iter, tolerance);
     else solve_newton_impl<true, false>(m, L, max_iter, tolerance);
   } else solve_newton_impl<false, false>(m, L, max_iter, tolerance);
+#endif
 }
