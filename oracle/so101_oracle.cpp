@@ -21,8 +21,8 @@ typedef double real;
 const real MINVAL = 1e-15;   // mjMINVAL
 const real MINIMP = 1e-4, MAXIMP = 0.9999;
 enum { G_PLANE = 0, G_SPHERE = 1, G_CAPSULE = 2, G_CYLINDER = 3, G_BOX = 4, G_MESH = 5 };
-enum { J_NONE = 0, J_HINGE = 1, J_FREE = 2 };
-enum { C_FRICTION = 0, C_LIMIT = 1, C_CONTACT = 2 };
+enum { J_NONE = 0, J_HINGE = 1, J_FREE = 2, J_SLIDE = 3 };
+enum { C_FRICTION = 0, C_LIMIT = 1, C_CONTACT = 2, C_EQUALITY = 3 };
 
 // ---------------------------------------------------------------- small vector helpers
 inline real dot3(const real* a, const real* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
@@ -119,6 +119,7 @@ struct Blob {
     if (it == ent.end()) { std::fprintf(stderr, "oracle: blob entry %s missing\n", n); return v; }
     v.resize(it->second.second); std::memcpy(v.data(), it->second.first, 8 * v.size()); return v;
   }
+  bool has(const char* n) const { return ent.find(n) != ent.end(); }
   int i(const char* n) const { return I(n)[0]; }
   real r(const char* n) const { return R(n)[0]; }
 };
@@ -135,7 +136,12 @@ struct Model {
       dof_frictionloss, dof_damping, dof_invweight0, act_gain, act_bias, act_ctrlrange, act_forcerange,
       geom_pos, geom_quat, geom_size, geom_friction, geom_solref, geom_solimp, geom_solmix, geom_margin,
       geom_gap, geom_rbound, geom_center, geom_aabb, mesh_vert;
-  std::vector<int> body_hinge;   // body -> hinge index or -1
+  std::vector<int> body_hinge;   // body -> index of its one-dof joint (hinge / slide) or -1
+  // general-tree scenes (ALOHA; absent from the SO100 blobs): joint-level clamp of the actuator force
+  // (<joint actuatorfrcrange>), joint equalities q1 - q1_0 = poly(q2 - q2_0) (aloha_pbr.xml:296-299; qpos0 = 0)
+  int neq = 0; bool any_damping = false;
+  std::vector<int> jnt_actfrclimited, eq_dof, eq_qposadr;
+  std::vector<real> jnt_actfrcrange, eq_polycoef, eq_solref, eq_solimp, home_qpos;
   // task
   int obj_body, con_body, nbox;
   std::vector<real> box_pos, box_half, obj_lo, obj_hi, obj_yaw, con_lo, con_hi, home_ctrl;
@@ -205,6 +211,11 @@ void kinematics(orc_sim* s) {
         mulquat(xq, xq, jq);
       }
       normquat(xq);
+      if (m.body_jnttype[b] == J_SLIDE) {            // translation along the joint axis (body frame), qpos0 = 0
+        real a[3]; rotvecquat(a, &m.jnt_axis[3 * m.body_hinge[b]], xq);
+        real q = s->qpos[m.body_qposadr[b]];
+        for (int k = 0; k < 3; k++) xp[k] += a[k] * q;
+      }
     }
     quat2mat(&s->xmat[9 * b], xq);
     real t[3]; mulmatvec3(t, &s->xmat[9 * b], &m.body_ipos[3 * b]);
@@ -229,6 +240,10 @@ void kinematics(orc_sim* s) {
       real a[3]; mulmatvec3(a, &s->xmat[9 * b], &m.jnt_axis[3 * m.body_hinge[b]]);
       real* r = &s->S[6 * d];
       r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; cross3(r + 3, xp, a);
+    } else if (m.body_jnttype[b] == J_SLIDE) {
+      real a[3]; mulmatvec3(a, &s->xmat[9 * b], &m.jnt_axis[3 * m.body_hinge[b]]);
+      real* r = &s->S[6 * d];
+      r[3] = a[0]; r[4] = a[1]; r[5] = a[2];
     } else if (m.body_jnttype[b] == J_FREE) {
       for (int k = 0; k < 3; k++) {
         s->S[6 * (d + k) + 3 + k] = 1;
@@ -331,6 +346,11 @@ void rne_bias(orc_sim* s) {
         real qd = s->qvel[m.body_dofadr[b]];
         real t[3]; cross3(t, &w[3 * p], a);
         for (int k = 0; k < 3; k++) { wb[k] += a[k] * qd; ab[k] += t[k] * qd; }
+      } else if (m.body_jnttype[b] == J_SLIDE) {      // origin moving along a in the rotating parent frame: Coriolis 2 w x (a qd)
+        real a[3]; mulmatvec3(a, &s->xmat[9 * b], &m.jnt_axis[3 * m.body_hinge[b]]);
+        real qd = s->qvel[m.body_dofadr[b]];
+        real t[3]; cross3(t, &w[3 * p], a);
+        for (int k = 0; k < 3; k++) aob[k] += 2 * t[k] * qd;
       }
     }
     real mass = m.body_mass[b];
@@ -354,6 +374,9 @@ void rne_bias(orc_sim* s) {
     if (m.body_jnttype[b] == J_HINGE) {
       real a[3]; mulmatvec3(a, &s->xmat[9 * b], &m.jnt_axis[3 * m.body_hinge[b]]);
       s->bias[d] = dot3(a, &n[3 * b]);
+    } else if (m.body_jnttype[b] == J_SLIDE) {
+      real a[3]; mulmatvec3(a, &s->xmat[9 * b], &m.jnt_axis[3 * m.body_hinge[b]]);
+      s->bias[d] = dot3(a, &f[3 * b]);
     } else if (m.body_jnttype[b] == J_FREE) {
       for (int k = 0; k < 3; k++) s->bias[d + k] = f[3 * b + k];
       real t[3]; mulmatTvec3(t, &s->xmat[9 * b], &n[3 * b]);
@@ -380,6 +403,10 @@ void actuation(orc_sim* s) {
     if (m.act_forcelimited[a]) force = std::min(std::max(force, m.act_forcerange[2 * a]), m.act_forcerange[2 * a + 1]);
     s->act_force[a] = force;
     s->qfrc_act[d] += force;
+  }
+  for (size_t h = 0; h < m.jnt_actfrclimited.size(); h++) if (m.jnt_actfrclimited[h]) {      // mj_fwdActuation: jnt_actfrcrange
+    int d = m.body_dofadr[m.arm_body[h]];
+    s->qfrc_act[d] = std::min(std::max(s->qfrc_act[d], m.jnt_actfrcrange[2 * h]), m.jnt_actfrcrange[2 * h + 1]);
   }
 }
 
@@ -850,6 +877,7 @@ void make_constraints(orc_sim* s, bool freeze_arm) {
   // count rows
   struct Row { int type, id, dim; };
   std::vector<Row> rows;
+  for (int e = 0; e < m.neq; e++) rows.push_back({C_EQUALITY, e, 1});      // mj_makeConstraint order: equality, friction, limit, contact
   for (int d = 0; d < nv; d++) if (m.dof_frictionloss[d] > 0) rows.push_back({C_FRICTION, d, 1});
   std::vector<std::pair<int, int>> lim;   // (hinge, side)
   for (int h = 0; h < m.narm; h++) if (m.jnt_limited[h]) {
@@ -868,7 +896,17 @@ void make_constraints(orc_sim* s, bool freeze_arm) {
   int i = 0;
   for (auto& r : rows) {
     real solref[2], solimp[5], diag[6] = {0, 0, 0, 0, 0, 0}, pos = 0;
-    if (r.type == C_FRICTION) {
+    if (r.type == C_EQUALITY) {                         // mj_instantiateEquality, mjEQ_JOINT with two joints
+      int e = r.id, d1 = m.eq_dof[2 * e], d2 = m.eq_dof[2 * e + 1];
+      const real* pc = &m.eq_polycoef[5 * e];
+      real q1 = s->qpos[m.eq_qposadr[2 * e]], q2 = s->qpos[m.eq_qposadr[2 * e + 1]];      // qpos0 = 0 for both
+      real poly = pc[0] + q2 * (pc[1] + q2 * (pc[2] + q2 * (pc[3] + q2 * pc[4])));
+      real deriv = pc[1] + q2 * (2 * pc[2] + q2 * (3 * pc[3] + q2 * 4 * pc[4]));
+      pos = q1 - poly;
+      s->J[(size_t)i * nv + d1] = 1; s->J[(size_t)i * nv + d2] = -deriv;
+      std::memcpy(solref, &m.eq_solref[2 * e], sizeof solref); std::memcpy(solimp, &m.eq_solimp[5 * e], sizeof solimp);
+      diag[0] = m.dof_invweight0[d1] + m.dof_invweight0[d2];
+    } else if (r.type == C_FRICTION) {
       int d = r.id;
       s->J[(size_t)i * nv + d] = 1;
       s->efc_floss[i] = m.dof_frictionloss[d];
@@ -979,7 +1017,9 @@ void constraint_update(orc_sim* s, const real* jar) {
   int i = 0;
   while (i < s->nefc) {
     int tp = s->efc_type[i], dim = s->efc_dim[i];
-    if (tp == C_FRICTION) {
+    if (tp == C_EQUALITY) {
+      s->efc_force[i] = -s->efc_D[i] * jar[i];
+    } else if (tp == C_FRICTION) {
       real f = -s->efc_D[i] * jar[i], fl = s->efc_floss[i];
       s->efc_force[i] = std::min(std::max(f, -fl), fl);
     } else if (tp == C_LIMIT || dim == 1) {
@@ -1057,7 +1097,7 @@ void solve_pgs(orc_sim* s) {
       if (dim == 1) {
         f[i] -= res[0] / Athis[0];
         if (tp == C_FRICTION) { real fl = s->efc_floss[i]; f[i] = std::min(std::max(f[i], -fl), fl); }
-        else if (f[i] < 0) f[i] = 0;
+        else if (tp != C_EQUALITY && f[i] < 0) f[i] = 0;
       } else {
         const Contact& c = s->con[s->efc_id[i]];
         // normal / ray update
@@ -1128,6 +1168,10 @@ struct RowEval { real cost, g1, g2; };    // cost and its first/second derivativ
 real block_cost(const orc_sim* s, int i, const real* jar, real* force, real* Hc) {
   int tp = s->efc_type[i], dim = s->efc_dim[i];
   if (Hc) for (int k = 0; k < dim * dim; k++) Hc[k] = 0;
+  if (tp == C_EQUALITY) {                              // always active, either sign
+    real D = s->efc_D[i], r = jar[0];
+    force[0] = -D * r; if (Hc) Hc[0] = D; return 0.5 * D * r * r;
+  }
   if (tp == C_FRICTION) {
     real D = s->efc_D[i], R = s->efc_R[i], fl = s->efc_floss[i], rf = R * fl, r = jar[0];
     if (r <= -rf) { force[0] = fl; return fl * (-0.5 * rf - r); }
@@ -1277,7 +1321,8 @@ void forward(orc_sim* s, bool freeze_arm) {
   s->qacc_smooth.assign(nv, 0);
   for (int r = 0; r < nv; r++) {
     real v = 0;
-    for (int c = 0; c < nv; c++) v += s->Minv[r * nv + c] * (s->qfrc_act[c] - s->bias[c]);   // damping = 0 in this model
+    for (int c = 0; c < nv; c++)        // qfrc_passive = -damping * qvel (zero in the SO100 model)
+      v += s->Minv[r * nv + c] * (s->qfrc_act[c] - s->bias[c] - m.dof_damping[c] * s->qvel[c]);
     s->qacc_smooth[r] = v;
   }
   if (s->injected.empty()) collision(s);
@@ -1297,10 +1342,25 @@ void forward(orc_sim* s, bool freeze_arm) {
 void euler(orc_sim* s) {
   const Model& m = s->m;
   real dt = m.dt;
-  for (int d = 0; d < m.nv; d++) s->qvel[d] += dt * s->qacc[d];
+  std::vector<real> acc(s->qacc);
+  if (m.any_damping) {
+    // mj_Euler with joint damping (eulerdamp enabled by default): damping implicit in velocity,
+    // qacc' = (M + h diag(damping))^-1 (qfrc_smooth + qfrc_constraint) = (M + h D)^-1 M qacc
+    int nv = m.nv;
+    std::vector<real> A(s->M), rhs(nv, 0);
+    for (int r = 0; r < nv; r++) { for (int c = 0; c < nv; c++) rhs[r] += s->M[r * nv + c] * s->qacc[c]; A[r * nv + r] += dt * m.dof_damping[r]; }
+    for (int j = 0; j < nv; j++) {
+      for (int k = 0; k < j; k++) for (int i = j; i < nv; i++) A[i * nv + j] -= A[i * nv + k] * A[j * nv + k];
+      real d = std::sqrt(A[j * nv + j]);
+      for (int i = j; i < nv; i++) A[i * nv + j] /= d;
+    }
+    for (int i = 0; i < nv; i++) { real v = rhs[i]; for (int k = 0; k < i; k++) v -= A[i * nv + k] * rhs[k]; rhs[i] = v / A[i * nv + i]; }
+    for (int i = nv - 1; i >= 0; i--) { real v = rhs[i]; for (int k = i + 1; k < nv; k++) v -= A[k * nv + i] * acc[k]; acc[i] = v / A[i * nv + i]; }
+  }
+  for (int d = 0; d < m.nv; d++) s->qvel[d] += dt * acc[d];
   for (int b = 1; b < m.nbody; b++) {
     int qa = m.body_qposadr[b], d = m.body_dofadr[b];
-    if (m.body_jnttype[b] == J_HINGE) s->qpos[qa] += dt * s->qvel[d];
+    if (m.body_jnttype[b] == J_HINGE || m.body_jnttype[b] == J_SLIDE) s->qpos[qa] += dt * s->qvel[d];
     else if (m.body_jnttype[b] == J_FREE) {
       for (int k = 0; k < 3; k++) s->qpos[qa + k] += dt * s->qvel[d + k];
       real w[3] = {s->qvel[d + 3], s->qvel[d + 4], s->qvel[d + 5]};
@@ -1436,6 +1496,10 @@ void env_reset(orc_sim* s) {
   auto U = [&](real lo, real hi) { real u = rng_uniform(s->cfg.seed, s->cfg.env_id, s->episode, draw++); return lo + u * (hi - lo); };
   std::fill(s->qpos.begin(), s->qpos.end(), 0.0); std::fill(s->qvel.begin(), s->qvel.end(), 0.0);
   std::fill(s->warm.begin(), s->warm.end(), 0.0);
+  if (!m.home_qpos.empty()) {                       // ALOHA: arms at HOME_QPOS, ctrl = HOME_CTRL (aloha2_task.py:369-380)
+    for (int k = 0; k < m.narm; k++) s->qpos[k] = m.home_qpos[k];
+    for (int k = 0; k < m.nu; k++) s->ctrl[k] = m.home_ctrl[k];
+  } else
   for (int k = 0; k < 6; k++) { s->ctrl[k] = m.home_ctrl[k] + s->cfg.offsets[k]; s->cmd[k] = s->ctrl[k]; }
   int qo = m.body_qposadr[m.obj_body], qc = m.body_qposadr[m.con_body];
   // object: position then yaw (so100_hand_over.py:209-214), collisions ignored
@@ -1494,6 +1558,14 @@ orc_sim* orc_create(const void* blob, size_t bytes) {
 #undef LR
   m.body_hinge.assign(m.nbody, -1);
   for (int h = 0; h < m.narm; h++) m.body_hinge[m.arm_body[h]] = h;
+  if (b.has("neq")) {                               // general-tree scene (ALOHA)
+    m.neq = b.i("neq");
+    m.jnt_actfrclimited = b.I("jnt_actfrclimited"); m.jnt_actfrcrange = b.R("jnt_actfrcrange");
+    m.eq_dof = b.I("eq_dof"); m.eq_qposadr = b.I("eq_qposadr"); m.eq_polycoef = b.R("eq_polycoef");
+    m.eq_solref = b.R("eq_solref"); m.eq_solimp = b.R("eq_solimp");
+    if (b.has("task_home_qpos")) m.home_qpos = b.R("task_home_qpos");
+  }
+  for (real d : m.dof_damping) m.any_damping = m.any_damping || d > 0;
   m.obj_body = b.i("task_object_body"); m.con_body = b.i("task_container_body"); m.nbox = b.i("task_nbox");
   m.box_pos = b.R("task_box_pos"); m.box_half = b.R("task_box_half"); m.obj_lo = b.R("task_obj_pos_lo");
   m.obj_hi = b.R("task_obj_pos_hi"); m.obj_yaw = b.R("task_obj_yaw"); m.con_lo = b.R("task_con_pos_lo");

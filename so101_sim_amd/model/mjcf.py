@@ -22,7 +22,7 @@ from . import meshes as mm
 GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX, GEOM_MESH = 0, 1, 2, 3, 4, 5
 _GEOM_TYPES = {"plane": GEOM_PLANE, "sphere": GEOM_SPHERE, "capsule": GEOM_CAPSULE,
                "cylinder": GEOM_CYLINDER, "box": GEOM_BOX, "mesh": GEOM_MESH}
-JNT_NONE, JNT_HINGE, JNT_FREE = 0, 1, 2
+JNT_NONE, JNT_HINGE, JNT_FREE, JNT_SLIDE = 0, 1, 2, 3
 
 # MuJoCo built-in defaults for the attributes this subset reads
 _GEOM_DEFAULTS = dict(type="sphere", contype="1", conaffinity="1", condim="3",
@@ -33,6 +33,32 @@ _JOINT_DEFAULTS = dict(type="hinge", armature="0", damping="0", frictionloss="0"
                        axis="0 0 1", solreflimit="0.02 1", solimplimit="0.9 0.95 0.001 0.5 2",
                        solreffriction="0.02 1", solimpfriction="0.9 0.95 0.001 0.5 2")
 _GENERAL_DEFAULTS = dict(gaintype="fixed", gainprm="1 0 0", biastype="none", biasprm="0 0 0")
+_POSITION_DEFAULTS = dict(kp="1", kv="0")
+_EQUALITY_DEFAULTS = dict(solref="0.02 1", solimp="0.9 0.95 0.001 0.5 2", polycoef="0 1 0 0 0")
+
+
+def _expand_includes(root: ET.Element, base_dir: str) -> ET.Element:
+    """<include file=.../> = the children of the included file's root spliced in at the include's position (MuJoCo's
+    semantics; aloha/scene_pbr.xml:23 includes aloha_pbr.xml, which :302 includes joint_position_actuators.xml)."""
+    out = ET.Element(root.tag, root.attrib)
+    for child in root:
+        if child.tag == "include":
+            inc = _expand_includes(ET.parse(os.path.join(base_dir, child.attrib["file"])).getroot(), base_dir)
+            out.extend(list(inc))
+        else:
+            out.append(child)
+    return out
+
+
+def _euler2quat(e):
+    """intrinsic x-y-z (MuJoCo's default eulerseq "xyz"), radians"""
+    q = np.array([1.0, 0, 0, 0])
+    for k, ang in enumerate(e):
+        h = np.zeros(4); h[0] = np.cos(0.5 * ang); h[1 + k] = np.sin(0.5 * ang)
+        w1, x1, y1, z1 = q; w2, x2, y2, z2 = h
+        q = np.array([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                      w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2])
+    return q
 
 
 def _floats(s, n=None, fill=None):
@@ -47,8 +73,11 @@ class _Defaults:
 
     def __init__(self, root: ET.Element):
         self.classes: dict[str, dict[str, dict[str, str]]] = {}
-        top = root.find("default")
-        self._walk(top, "main", {}) if top is not None else self.classes.setdefault("main", {})
+        tops = root.findall("default")
+        if not tops:
+            self.classes.setdefault("main", {})
+        for top in tops:       # several top-level sections (one per included file) all extend the unnamed root class
+            self._walk(top, "main", self.classes.get("main", {}))
 
     def _walk(self, node, name, inherited):
         cur = {k: dict(v) for k, v in inherited.items()}
@@ -112,6 +141,7 @@ class _Body:
     solimplimit: np.ndarray = None
     solreffriction: np.ndarray = None
     solimpfriction: np.ndarray = None
+    actfrcrange: np.ndarray | None = None   # joint-level clamp of the total actuator force (<joint actuatorfrcrange>)
     inertial: tuple | None = None       # (ipos, iquat, mass, diaginertia)
 
 
@@ -127,6 +157,9 @@ class SceneCompiler:
                            cone="pyramidal", tolerance=1e-8, iterations=100,
                            mpr_tolerance=1e-6, mpr_iterations=50)
         self.prop_bodies: list[int] = []
+        self.equalities: list[dict] = []     # <equality><joint joint1 joint2 polycoef solref solimp/>
+        self.keyframes: dict[str, dict] = {}
+        self.general_tree = False            # scenes outside the one-hinge-chain SO100 subset (ALOHA)
 
     # ---------------------------------------------------------------- parsing
     def _mesh_table(self, root, base_dir, scale_override=None):
@@ -135,8 +168,7 @@ class SceneCompiler:
         if comp is not None:
             meshdir = comp.attrib.get("meshdir", comp.attrib.get("assetdir", ""))
         table = {}
-        asset = root.find("asset")
-        if asset is not None:
+        for asset in root.findall("asset"):
             for m in asset.findall("mesh"):
                 file = m.attrib["file"]
                 name = m.attrib.get("name", os.path.splitext(os.path.basename(file))[0])
@@ -147,8 +179,8 @@ class SceneCompiler:
         return table
 
     def add_scene(self, xml_path: str):
-        root = ET.parse(xml_path).getroot()
         base = os.path.dirname(xml_path)
+        root = _expand_includes(ET.parse(xml_path).getroot(), base)
         opt = root.find("option")
         if opt is not None:
             for k in ("timestep", "impratio", "tolerance"):
@@ -160,17 +192,32 @@ class SceneCompiler:
                 self.option["gravity"] = _floats(opt.attrib["gravity"])
         defaults = _Defaults(root)
         meshes = self._mesh_table(root, base)
-        self._walk_body(root.find("worldbody"), 0, None, defaults, meshes)
-        contact = root.find("contact")
-        if contact is not None:
+        for wb in root.findall("worldbody"):        # (one per included file, merged in document order)
+            self._walk_body(wb, 0, None, defaults, meshes)
+        for contact in root.findall("contact"):
             for ex in contact.findall("exclude"):
                 self.excludes.append((ex.attrib["body1"], ex.attrib["body2"]))
-        act = root.find("actuator")
-        if act is not None:
+        for act in root.findall("actuator"):
             for a in act:
-                if a.tag != "general":
-                    raise NotImplementedError(f"actuator <{a.tag}> is outside the SO100 subset")
-                self.actuators.append(defaults.resolve("general", a, None, _GENERAL_DEFAULTS))
+                if a.tag == "general":
+                    self.actuators.append(defaults.resolve("general", a, None, _GENERAL_DEFAULTS))
+                elif a.tag == "position":
+                    # <position kp kv> = general with gainprm (kp 0 0), biastype affine, biasprm (0 -kp -kv)  [MuJoCo XML reference]
+                    r = defaults.resolve("position", a, None, _POSITION_DEFAULTS)
+                    kp, kv = float(r["kp"]), float(r["kv"])
+                    r.update(gaintype="fixed", gainprm=f"{kp!r} 0 0", biastype="affine", biasprm=f"0 {-kp!r} {-kv!r}")
+                    self.actuators.append(r)
+                else:
+                    raise NotImplementedError(f"actuator <{a.tag}> is outside the supported subset")
+        for eq in root.findall("equality"):
+            for e in eq:
+                if e.tag != "joint" or "joint2" not in e.attrib:
+                    raise NotImplementedError(f"equality <{e.tag}> is outside the supported subset")
+                self.equalities.append(defaults.resolve("equality", e, None, _EQUALITY_DEFAULTS))
+        for kf in root.findall("keyframe"):
+            for k in kf.findall("key"):
+                self.keyframes[k.attrib.get("name", f"key{len(self.keyframes)}")] = {
+                    f: _floats(k.attrib[f]) for f in ("qpos", "ctrl") if f in k.attrib}
 
     def add_free_prop(self, xml_path: str, name: str, mesh_scale: float | None = None) -> int:
         """Attach the single root body of a prop model as a free body at the world origin
@@ -197,7 +244,8 @@ class SceneCompiler:
                 cc = el.attrib.get("childclass", childclass)
                 b = _Body(el.attrib.get("name", f"body{len(self.bodies)}"), parent,
                           _floats(el.attrib.get("pos", "0 0 0")),
-                          _floats(el.attrib.get("quat", "1 0 0 0")))
+                          _euler2quat(_floats(el.attrib["euler"])) if "euler" in el.attrib
+                          else _floats(el.attrib.get("quat", "1 0 0 0")))
                 b.quat = b.quat / np.linalg.norm(b.quat)
                 idx = len(self.bodies)
                 self.bodies.append(b)
@@ -206,9 +254,11 @@ class SceneCompiler:
                     raise NotImplementedError("scene bodies carry at most one hinge joint")
                 if joints:
                     j = defaults.resolve("joint", joints[0], cc, _JOINT_DEFAULTS)
-                    if j["type"] != "hinge" or np.any(_floats(j["pos"]) != 0):
-                        raise NotImplementedError("only hinge joints at the body origin")
-                    b.jnt_type = JNT_HINGE
+                    if j["type"] not in ("hinge", "slide") or np.any(_floats(j["pos"]) != 0):
+                        raise NotImplementedError("only hinge / slide joints at the body origin")
+                    b.jnt_type = JNT_HINGE if j["type"] == "hinge" else JNT_SLIDE
+                    if "actuatorfrcrange" in j:
+                        b.actfrcrange = _floats(j["actuatorfrcrange"])
                     b.jnt_name = j.get("name", "")
                     ax = _floats(j["axis"])
                     b.jnt_axis = ax / np.linalg.norm(ax)
@@ -313,7 +363,7 @@ def finalize(sc: SceneCompiler) -> dict:
     dofadr = -np.ones(nb, dtype=np.int32)
     nq = nv = 0
     for i, b in enumerate(B):
-        if b.jnt_type == JNT_HINGE:
+        if b.jnt_type in (JNT_HINGE, JNT_SLIDE):
             qposadr[i], dofadr[i] = nq, nv
             nq, nv = nq + 1, nv + 1
         elif b.jnt_type == JNT_FREE:
@@ -337,6 +387,9 @@ def finalize(sc: SceneCompiler) -> dict:
         if b.jnt_type == JNT_HINGE:
             a = xmat[i] @ b.jnt_axis
             S[dofadr[i]] = np.concatenate([a, np.cross(xpos[i], a)])
+            dof_body[dofadr[i]] = i
+        elif b.jnt_type == JNT_SLIDE:
+            S[dofadr[i]] = np.concatenate([np.zeros(3), xmat[i] @ b.jnt_axis])
             dof_body[dofadr[i]] = i
         elif b.jnt_type == JNT_FREE:
             for k in range(3):
@@ -371,13 +424,13 @@ def finalize(sc: SceneCompiler) -> dict:
     frictionloss = np.zeros(nv)
     damping = np.zeros(nv)
     for i, b in enumerate(B):
-        if b.jnt_type == JNT_HINGE:
+        if b.jnt_type in (JNT_HINGE, JNT_SLIDE):
             armature[dofadr[i]], frictionloss[dofadr[i]], damping[dofadr[i]] = b.armature, b.frictionloss, b.damping
     M += np.diag(armature)                      # armature sits on M's diagonal (KAT-1 pins this)
     Minv = np.linalg.inv(M)
     dof_invweight0 = np.zeros(nv)
     for i, b in enumerate(B):
-        if b.jnt_type == JNT_HINGE:
+        if b.jnt_type in (JNT_HINGE, JNT_SLIDE):
             dof_invweight0[dofadr[i]] = Minv[dofadr[i], dofadr[i]]
         elif b.jnt_type == JNT_FREE:
             d = dofadr[i]
@@ -399,6 +452,8 @@ def finalize(sc: SceneCompiler) -> dict:
 
     # ---- geoms -----------------------------------------------------------------------------
     coll = [g for g in sc.geoms if (g.contype or g.conaffinity)]
+    if sc.general_tree:
+        coll.sort(key=lambda g: g.body)        # MuJoCo numbers geoms body by body (stable: document order within a body)
     ng = len(coll)
     vert_chunks, mesh_vertadr, mesh_vertnum = [], [], []
     g_arr = dict(type=np.zeros(ng, np.int32), body=np.zeros(ng, np.int32), pos=np.zeros((ng, 3)),
@@ -410,6 +465,7 @@ def finalize(sc: SceneCompiler) -> dict:
                  vertnum=np.zeros(ng, np.int32), rbound=np.zeros(ng), center=np.zeros((ng, 3)),
                  aabb=np.zeros((ng, 6)))
     nvert = 0
+    shared: dict[bytes, int] = {}
     for k, g in enumerate(coll):
         for f in ("type", "body", "pos", "quat", "size", "contype", "conaffinity", "condim", "friction",
                   "solref", "solimp", "solmix", "margin", "gap", "priority"):
@@ -417,9 +473,14 @@ def finalize(sc: SceneCompiler) -> dict:
         if g.type == GEOM_MESH:
             hv = g.hull
             lo, hi = hv.min(0), hv.max(0)
-            g_arr["vertadr"][k], g_arr["vertnum"][k] = nvert, len(hv)
-            vert_chunks.append(hv)
-            nvert += len(hv)
+            key = hv.tobytes()
+            if sc.general_tree and key in shared:          # the same mesh on several geoms (left / right arm, camera bodies): one copy
+                g_arr["vertadr"][k], g_arr["vertnum"][k] = shared[key], len(hv)
+            else:
+                shared[key] = nvert
+                g_arr["vertadr"][k], g_arr["vertnum"][k] = nvert, len(hv)
+                vert_chunks.append(hv)
+                nvert += len(hv)
             ctr = 0.5 * (lo + hi)
             g_arr["center"][k] = ctr
             g_arr["rbound"][k] = np.linalg.norm(hv - ctr, axis=1).max()
@@ -489,7 +550,7 @@ def finalize(sc: SceneCompiler) -> dict:
     act = dict(gain=np.zeros(nu), bias=np.zeros((nu, 3)), ctrlrange=np.zeros((nu, 2)),
                forcerange=np.zeros((nu, 2)), ctrllimited=np.zeros(nu, np.int32),
                forcelimited=np.zeros(nu, np.int32), dof=np.zeros(nu, np.int32))
-    jname2dof = {b.jnt_name: dofadr[i] for i, b in enumerate(B) if b.jnt_type == JNT_HINGE}
+    jname2dof = {b.jnt_name: dofadr[i] for i, b in enumerate(B) if b.jnt_type in (JNT_HINGE, JNT_SLIDE)}
     for k, a in enumerate(sc.actuators):
         act["gain"][k] = _floats(a["gainprm"], 3)[0]
         act["bias"][k] = _floats(a["biasprm"], 3) if a["biastype"] == "affine" else 0
@@ -499,7 +560,7 @@ def finalize(sc: SceneCompiler) -> dict:
             act["forcerange"][k], act["forcelimited"][k] = _floats(a["forcerange"]), 1
         act["dof"][k] = jname2dof[a["joint"]]
 
-    hinge = [i for i, b in enumerate(B) if b.jnt_type == JNT_HINGE]
+    hinge = [i for i, b in enumerate(B) if b.jnt_type in (JNT_HINGE, JNT_SLIDE)]     # bodies with a one-dof joint
     free = [i for i, b in enumerate(B) if b.jnt_type == JNT_FREE]
     model = dict(
         nq=nq, nv=nv, nu=nu, nbody=nb, ngeom=ng, nvert=len(verts), npair=len(pairs),
@@ -536,6 +597,22 @@ def finalize(sc: SceneCompiler) -> dict:
         geom_center=g_arr["center"], geom_aabb=g_arr["aabb"],
         mesh_vert=verts, pair_geom=pairs,
     )
+    if sc.general_tree:
+        # fields only the general-tree scenes (ALOHA) carry; the SO100 blobs stay as they were
+        neq = len(sc.equalities)
+        jname2q = {b.jnt_name: qposadr[i] for i, b in enumerate(B) if b.jnt_type in (JNT_HINGE, JNT_SLIDE)}
+        frc = np.array([B[i].actfrcrange if B[i].actfrcrange is not None else [0.0, 0.0] for i in hinge]).reshape(-1, 2)
+        model.update(
+            jnt_type=np.array([B[i].jnt_type for i in hinge], np.int32),
+            jnt_actfrclimited=np.array([int(B[i].actfrcrange is not None) for i in hinge], np.int32),
+            jnt_actfrcrange=frc,
+            neq=neq,
+            eq_dof=np.array([[jname2dof[e["joint1"]], jname2dof[e["joint2"]]] for e in sc.equalities], np.int32).reshape(-1, 2),
+            eq_qposadr=np.array([[jname2q[e["joint1"]], jname2q[e["joint2"]]] for e in sc.equalities], np.int32).reshape(-1, 2),
+            eq_polycoef=np.array([_floats(e["polycoef"], 5) for e in sc.equalities]).reshape(-1, 5),
+            eq_solref=np.array([_floats(e["solref"], 2, [0.02, 1]) for e in sc.equalities]).reshape(-1, 2),
+            eq_solimp=np.array([_floats(e["solimp"], 5, [0.9, 0.95, 0.001, 0.5, 2]) for e in sc.equalities]).reshape(-1, 5),
+        )
     meta = dict(body_names=[b.name for b in B], geom_names=[g.name for g in coll],
                 joint_names=[B[i].jnt_name for i in hinge], proxy_inertia=proxy_inertia,
                 M0_diag=np.diag(M).tolist())

@@ -135,3 +135,90 @@ if __name__ == "__main__":
         m = o["model"]
         print(name, {k: m[k] for k in ("nq", "nv", "nu", "nbody", "ngeom", "nvert", "npair")},
               "proxy:", o["meta"]["proxy_inertia"])
+
+
+# ------------------------------------------------------------------------------------------------ ALOHA
+# tasks/hand_over.py:33-56 (reset distributions), :80-118 (HANDOVER_CONFIGS: same boxes and scales as the SO100 task,
+# other instructions), tasks/base/aloha2_task.py:38-45 (home pose), :57-70 (gripper ranges), :107 (table height offset)
+ALOHA_TABLE_HEIGHT = 0.0
+ALOHA_RESET_HEIGHT = 0.1
+ALOHA_TABLE_HEIGHT_OFFSET = 0.011
+ALOHA_HOME_CTRL = np.array([0.0, -0.96, 1.16, 0.0, -0.3, 0.0, 0.002])
+ALOHA_HOME_QPOS = np.array([0.0, -0.959, 1.182, 0.0, -0.274, 0.0, 0.0082, 0.0082])
+ALOHA_GRIPPER_LIMITS = dict(sim_qpos=(0.037, 0.0078), sim_ctrl=(0.037, 0.002), follower=(1.5155, -0.06135),
+                            leader=(0.78, -0.04))      # (open, close)
+ALOHA_INSTRUCTIONS = dict(banana="hand over the banana and put it in the bowl",
+                          pen="hand over the pen and put it in the container")
+
+
+def compile_aloha_scene(object_name: str | None, assets: str | None = None,
+                        table_height_offset: float = ALOHA_TABLE_HEIGHT_OFFSET) -> dict:
+    """aloha/scene_pbr.xml (+ the two props of a hand-over task when `object_name` is given; None = the bare AlohaTask
+    of tasks/test/aloha2_task_test.py) as a general-tree model: two 8-dof arms (6 hinges + 2 slide fingers coupled by a
+    joint equality), position actuators, joint damping, nq = 16 (+ 14), nv = 16 (+ 12), nu = 14."""
+    assets = assets or find_assets()
+    if assets is None:
+        raise FileNotFoundError("MJCF assets not found: set SO101_ASSETS to .../so101_sim/assets")
+    sc = mjcf.SceneCompiler()
+    sc.general_tree = True
+    sc.add_scene(os.path.join(assets, "aloha", "scene_pbr.xml"))
+    if table_height_offset:            # aloha2_task.py:493-496 (the camera and the visual extrusions move too; no physics)
+        for b in sc.bodies:
+            if b.name == "table":
+                b.pos = b.pos + np.array([0.0, 0.0, table_height_offset])
+    obj = con = -1
+    cfg = None
+    if object_name is not None:
+        cfg = HANDOVER_CONFIGS[object_name]
+        obj = sc.add_free_prop(os.path.join(assets, cfg["object_model"]), "object")
+        con = sc.add_free_prop(os.path.join(assets, cfg["container_model"]), "container",
+                               mesh_scale=cfg["container_mesh_scale"])
+    out = mjcf.finalize(sc)
+    m = out["model"]
+    boxes = cfg["overlap_boxes"] if cfg else []
+    z = ALOHA_TABLE_HEIGHT + ALOHA_RESET_HEIGHT
+    m.update(
+        task_object_body=obj, task_container_body=con, task_nbox=len(boxes),
+        task_box_pos=np.array([b["position"] for b in boxes]).reshape(-1, 3),
+        task_box_half=np.array([b["half_extents"] for b in boxes]).reshape(-1, 3),
+        task_dist_threshold=cfg["success_threshold"] if cfg else 0.0,
+        task_obj_pos_lo=np.array([0.12, -0.1, z]), task_obj_pos_hi=np.array([0.18, 0.1, z]),
+        task_obj_yaw=np.array([-np.pi * 0.1 - np.pi * 0.5, np.pi * 0.1 - np.pi * 0.5]),
+        task_con_pos_lo=np.array([-0.18, -0.1, z]), task_con_pos_hi=np.array([-0.12, 0.1, z]),
+        task_home_ctrl=np.concatenate([ALOHA_HOME_CTRL, ALOHA_HOME_CTRL]),
+        task_home_qpos=np.concatenate([ALOHA_HOME_QPOS, ALOHA_HOME_QPOS]),
+    )
+    out["meta"]["instruction"] = ALOHA_INSTRUCTIONS.get(object_name, "")
+    out["meta"]["object_name"] = object_name
+    out["meta"]["keyframes"] = {k: {f: v.tolist() for f, v in d.items()} for k, d in sc.keyframes.items()}
+    return out
+
+
+def aloha_blob_paths(object_name: str | None) -> tuple[str, str, str]:
+    stem = os.path.join(BLOB_DIR, f"aloha_handover_{object_name}" if object_name else "aloha_bare")
+    return stem + ".f32.bin", stem + ".f64.bin", stem + ".json"
+
+
+def write_aloha_blobs(object_name: str | None, assets: str | None = None):
+    out = compile_aloha_scene(object_name, assets)
+    p32, p64, pj = aloha_blob_paths(object_name)
+    os.makedirs(BLOB_DIR, exist_ok=True)
+    with open(p32, "wb") as f:
+        f.write(blobfmt.pack(out["model"], np.float32))
+    with open(p64, "wb") as f:
+        f.write(blobfmt.pack(out["model"], np.float64))
+    with open(pj, "w") as f:
+        json.dump(out["meta"], f, indent=1)
+    return out
+
+
+def load_aloha_blob(object_name: str | None, real: str = "f64") -> tuple[bytes, dict]:
+    p32, p64, pj = aloha_blob_paths(object_name)
+    path = p32 if real == "f32" else p64
+    if not os.path.exists(path):
+        write_aloha_blobs(object_name)
+    with open(path, "rb") as f:
+        raw = f.read()
+    with open(pj) as f:
+        meta = json.load(f)
+    return raw, meta
