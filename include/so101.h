@@ -250,6 +250,32 @@ int so101_debug_chain_stats(so101_sim* sim, uint64_t* out, int clear, void* hip_
 
 const char* so101_last_error(const so101_sim* sim);
 
+/* ---- general-tree engine (csrc/so101_tree.hpp): models outside the SO100 topology - the ALOHA hand-over scenes of
+ * so101_sim/tasks/hand_over.py (two 8-dof arms with slide fingers coupled by joint equalities, position actuators, joint
+ * damping; reference model so101_sim/assets/aloha/aloha_pbr.xml).  The blob is the f32 blob of
+ * so101_sim_amd.model.scenes.compile_aloha_scene; limits: 32 bodies, 32 dofs, 16 actuators, 128 geoms, 64 contacts.
+ * Physics entry points only so far (what dm_control's physics.step() does for these scenes); same conventions as above:
+ * device pointers, env-fastest struct-of-arrays state [dim][n_envs], asynchronous on `hip_stream`. */
+typedef struct so101_tree so101_tree;
+int so101_tree_create(const void* model_blob, size_t blob_bytes, int n_envs, int hip_device, so101_tree** out);
+void so101_tree_destroy(so101_tree* sim);
+/* dims[7] = nq, nv, nu, nbody, ngeom, floats per env of so101_tree_debug_forward, contact capacity */
+int so101_tree_dims(const so101_tree* sim, int* dims);
+int so101_tree_bind_state(so101_tree* sim, float* qpos, float* qvel, float* ctrl, float* warmstart);
+/* solver_iterations <= 0 / solver_tolerance < 0 keep the model's (100, 1e-8) */
+int so101_tree_configure(so101_tree* sim, int solver_iterations, float solver_tolerance);
+/* n_substeps of mj_step (forward dynamics with contacts and the Newton solver, Euler with implicit joint damping) on the
+ * bound state, ctrl as bound */
+int so101_tree_physics(so101_tree* sim, int n_substeps, void* hip_stream);
+/* forward dynamics at the bound state without integrating; out[n_envs][dims[5]] floats: counts (contacts, rows, solver
+ * iterations, candidates, flags, scalar rows) at 0, bias at 8, qacc_smooth at 40, qacc at 72, body positions at 104,
+ * mass matrix [32][32] at 200, contacts [64][10] (position, normal, distance, geom1, geom2, condim) at 1224, normal forces at 1864 */
+int so101_tree_debug_forward(so101_tree* sim, float* out, void* hip_stream);
+/* out[n_envs][8] int32 of the last so101_tree_physics: contacts, rows, solver iterations, candidates, flags (1 candidate
+ * overflow, 2 contact overflow, 8 physics diverged) */
+int so101_tree_get_diag(so101_tree* sim, int32_t* out, void* hip_stream);
+const char* so101_tree_last_error(const so101_tree* sim);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,880 @@
+// General-tree engine (the ALOHA hand-over scenes): a substep for models outside the SO100 topology -
+// any tree of bodies with one hinge / slide joint each, free bodies, position actuators, joint damping, joint
+// equalities - with every dimension read from the model at run time.
+//
+// One env = one wavefront, as everywhere in this library, but nothing here is specialised: lanes take bodies, dofs,
+// constraint rows or contacts in turn, matrices live in LDS, the constraint Jacobian in a per-env global scratch.  It is the
+// FIRST GPU path for these scenes, written for parity with the fp64 oracle (oracle/so101_oracle.cpp, the same stages in the
+// same order); the SO100 kernels of so101_device.hpp / so101_newton.hpp stay the fast path for the headline workload.
+// The narrowphase (support functions, flat-face scan, MPR, patch contacts) is shared with them.
+#pragma once
+#include "so101_device.hpp"
+
+#define TB 32          // bodies (world included)
+#define TV 32          // dofs
+#define TQ 40          // generalized positions
+#define TU 16          // actuators
+#define TJ 24          // one-dof joints
+#define TE 4           // joint equalities
+#define TFR 16         // dofs with frictionloss
+#define TCON 64        // contacts per env
+#define TROW 384       // constraint rows per env (6 per contact at most)
+#define TCAND 256      // broadphase candidates per env
+#define TGEOM 128      // collision geoms
+#define TJS 32         // row stride of the constraint Jacobian scratch
+
+enum { TJ_NONE = 0, TJ_HINGE = 1, TJ_FREE = 2, TJ_SLIDE = 3 };
+enum { TR_FRICTION = 0, TR_LIMIT = 1, TR_CONTACT = 2, TR_EQUALITY = 3 };
+
+struct TreeModel {
+  int nq, nv, nu, nbody, ngeom, npair, njnt, nfree, neq, nfric, maxdepth, elliptic, iterations, any_damping, pad0, pad1;
+  float dt, grav[3], impratio, tolerance, meaninertia, pad2;
+  int body_parent[TB], body_jnttype[TB], body_qposadr[TB], body_dofadr[TB], body_depth[TB], body_jnt[TB];
+  unsigned int body_anc[TB];       // bit a: body a is this body or one of its ancestors
+  unsigned int body_dofs[TB];      // bit d: dof d moves this body
+  float body_pos[TB][3], body_quat[TB][4], body_ipos[TB][3], body_iquat[TB][4], body_mass[TB], body_inertia[TB][3], body_invweight0[TB][2];
+  int dof_body[TV], dof_jnt[TV];   // joint index of a one-dof joint, -1 for the dofs of a free body
+  float dof_armature[TV], dof_damping[TV], dof_frictionloss[TV], dof_invweight0[TV], dof_solref[TV][2], dof_solimp[TV][5];
+  int jnt_body[TJ], jnt_limited[TJ], jnt_actfrclimited[TJ];
+  float jnt_axis[TJ][3], jnt_range[TJ][2], jnt_solref[TJ][2], jnt_solimp[TJ][5], jnt_actfrcrange[TJ][2];
+  int act_dof[TU], act_qposadr[TU], act_ctrllimited[TU], act_forcelimited[TU];
+  float act_gain[TU], act_bias[TU][3], act_ctrlrange[TU][2], act_forcerange[TU][2];
+  int eq_dof[TE][2], eq_qposadr[TE][2];
+  float eq_polycoef[TE][5], eq_solref[TE][2], eq_solimp[TE][5];
+  int fric_dof[TFR];
+  const int* geom_body;            // [ngeom]
+  const float* geom_solmix;        // [ngeom]
+  const int* geom_priority;        // [ngeom]
+};
+
+struct TreeBuffers { float *qpos, *qvel, *ctrl, *warm; float* J; int* diag; };   // [nq|nv|nu|nv][N] env-fastest; J [N][TROW][TJS]; diag [N][8]
+
+struct TCon {                      // 32 words
+  float pos[3], frame[9], dist, mu, fric[5], solref[2], solimp[5];
+  int g1, g2, b1, b2, dim, row;
+};
+
+struct TreeLDS {
+  float qpos[TQ], qvel[TV], ctrl[TU], warm[TV], qacc[TV], qsm[TV], bias[TV], qfrc[TV], qact[TV];
+  float xpos[TB][3], xquat[TB][4], xmat[TB][9], xipos[TB][3], ximat[TB][9];
+  float S[TV][6];
+  union {
+    struct { float own[TB][36], comp[TB][36]; } Ic;     // spatial inertias about the world origin: each body's own, composite
+    float Hc[TCON][36];                                  // Newton: Hessian block of each contact
+  };
+  float M[TV][TV + 1], L[TV][TV + 1], H[TV][TV + 1];
+  float rw[TB][3], ral[TB][3], rao[TB][3], rf[TB][3], rn[TB][3];
+  float aabb[6][TGEOM];
+  unsigned int cand[TCAND];
+  TCon con[TCON];
+  float eD[TROW], eR[TROW], earef[TROW], eB[TROW], eKp[TROW], efl[TROW], ejar[TROW], ef[TROW], ejv[TROW];
+  unsigned char etype[TROW];
+  float Jc[6][TJS];
+  float x[TV], grad[TV], search[TV], Ma[TV], Mv[TV], tmp[TV], xs[TV];
+  int cdim[TCON + 1];
+  int ncand, ncon, nrow, nscalar, iters, flags;
+};
+
+namespace tree {
+
+DEV float ld(const float* p) { return *p; }
+
+// ------------------------------------------------------------------ state in / out (env-fastest struct-of-arrays)
+DEV void load_state(const TreeModel* tm, TreeLDS& L, const TreeBuffers& B, int e, int N) {
+  int lane = wave_lane();
+  if (lane < tm->nq) L.qpos[lane] = B.qpos[(size_t)lane * N + e];
+  if (lane < tm->nv) { L.qvel[lane] = B.qvel[(size_t)lane * N + e]; L.warm[lane] = B.warm[(size_t)lane * N + e]; }
+  if (lane < tm->nu) L.ctrl[lane] = B.ctrl[(size_t)lane * N + e];
+  wave_sync();
+}
+DEV void store_state(const TreeModel* tm, TreeLDS& L, const TreeBuffers& B, int e, int N) {
+  int lane = wave_lane();
+  wave_sync();
+  if (lane < tm->nq) B.qpos[(size_t)lane * N + e] = L.qpos[lane];
+  if (lane < tm->nv) { B.qvel[(size_t)lane * N + e] = L.qvel[lane]; B.warm[(size_t)lane * N + e] = L.warm[lane]; }
+}
+
+// ------------------------------------------------------------------ kinematics: lane = body, one tree level at a time
+DEV void kinematics(const TreeModel* tm, TreeLDS& L) {
+  int lane = wave_lane(), nb = tm->nbody;
+  if (lane == 0) {
+    L.xpos[0][0] = L.xpos[0][1] = L.xpos[0][2] = 0.f;
+    L.xquat[0][0] = 1.f; L.xquat[0][1] = L.xquat[0][2] = L.xquat[0][3] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { L.xmat[0][i] = (i % 4 == 0) ? 1.f : 0.f; L.ximat[0][i] = (i % 4 == 0) ? 1.f : 0.f; }
+    L.xipos[0][0] = L.xipos[0][1] = L.xipos[0][2] = 0.f;
+  }
+  wave_sync();
+  for (int level = 1; level <= tm->maxdepth; level++) {
+    if (lane > 0 && lane < nb && tm->body_depth[lane] == level) {
+      int b = lane, p = tm->body_parent[b], jt = tm->body_jnttype[b], qa = tm->body_qposadr[b];
+      float xp[3], xq[4];
+      if (jt == TJ_FREE) {
+        xp[0] = L.qpos[qa]; xp[1] = L.qpos[qa + 1]; xp[2] = L.qpos[qa + 2];
+        xq[0] = L.qpos[qa + 3]; xq[1] = L.qpos[qa + 4]; xq[2] = L.qpos[qa + 5]; xq[3] = L.qpos[qa + 6];
+        normquat(xq);
+      } else {
+        float t[3]; matvec3(t, L.xmat[p], tm->body_pos[b]);
+        xp[0] = L.xpos[p][0] + t[0]; xp[1] = L.xpos[p][1] + t[1]; xp[2] = L.xpos[p][2] + t[2];
+        mulquat(xq, L.xquat[p], tm->body_quat[b]);
+        if (jt == TJ_HINGE) {
+          const float* ax = tm->jnt_axis[tm->body_jnt[b]];
+          float sn, cs; sincos_f(0.5f * L.qpos[qa], &sn, &cs);
+          float jq[4] = {cs, ax[0] * sn, ax[1] * sn, ax[2] * sn}, o[4];
+          mulquat(o, xq, jq);
+          xq[0] = o[0]; xq[1] = o[1]; xq[2] = o[2]; xq[3] = o[3];
+        }
+        normquat(xq);
+        if (jt == TJ_SLIDE) {
+          float a[3]; rotvecquat(a, tm->jnt_axis[tm->body_jnt[b]], xq);
+          float q = L.qpos[qa];
+          xp[0] += a[0] * q; xp[1] += a[1] * q; xp[2] += a[2] * q;
+        }
+      }
+      float xm[9]; quat2mat(xm, xq);
+      float t[3]; matvec3(t, xm, tm->body_ipos[b]);
+      float im[9], xim[9]; quat2mat(im, tm->body_iquat[b]); matmul3(xim, xm, im);
+#pragma unroll
+      for (int i = 0; i < 3; i++) { L.xpos[b][i] = xp[i]; L.xipos[b][i] = xp[i] + t[i]; }
+#pragma unroll
+      for (int i = 0; i < 4; i++) L.xquat[b][i] = xq[i];
+#pragma unroll
+      for (int i = 0; i < 9; i++) { L.xmat[b][i] = xm[i]; L.ximat[b][i] = xim[i]; }
+    }
+    wave_sync();
+  }
+  // motion axes: S[d] = (omega ; velocity of the point at the world origin), lane = dof
+  if (lane < tm->nv) {
+    int d = lane, b = tm->dof_body[d], jt = tm->body_jnttype[b];
+    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (jt == TJ_HINGE || jt == TJ_SLIDE) {
+      float a[3]; matvec3(a, L.xmat[b], tm->jnt_axis[tm->dof_jnt[d]]);
+      if (jt == TJ_HINGE) { s[0] = a[0]; s[1] = a[1]; s[2] = a[2]; cross3(s + 3, L.xpos[b], a); }
+      else { s[3] = a[0]; s[4] = a[1]; s[5] = a[2]; }
+    } else {
+      int k = d - tm->body_dofadr[b];
+      if (k < 3) s[3 + k] = 1.f;
+      else {
+        float a[3] = {L.xmat[b][k - 3], L.xmat[b][3 + k - 3], L.xmat[b][6 + k - 3]};
+        s[0] = a[0]; s[1] = a[1]; s[2] = a[2]; cross3(s + 3, L.xpos[b], a);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) L.S[d][i] = s[i];
+  }
+  wave_sync();
+}
+
+// ------------------------------------------------------------------ Cholesky in LDS: lane = row; A = L L^T, lower part in place
+DEV void chol_factor(float (*A)[TV + 1], int n) {
+  int lane = wave_lane();
+  for (int j = 0; j < n; j++) {
+    wave_sync();
+    float d = sqrtf(fmaxf(A[j][j], MINVAL_F));
+    wave_sync();
+    if (lane == j) A[j][j] = d;
+    if (lane > j && lane < n) A[lane][j] /= d;
+    wave_sync();
+    if (lane > j && lane < n) {
+      float lij = A[lane][j];
+      for (int k = j + 1; k <= lane; k++) A[lane][k] -= lij * A[k][j];
+    }
+  }
+  wave_sync();
+}
+// x := A^-1 x for the factor above (x in LDS, n entries)
+DEV void chol_solve(float (*A)[TV + 1], int n, float* x) {
+  int lane = wave_lane();
+  for (int j = 0; j < n; j++) {
+    wave_sync();
+    float xj = x[j] / A[j][j];
+    wave_sync();
+    if (lane == j) x[j] = xj;
+    if (lane > j && lane < n) x[lane] -= A[lane][j] * xj;
+  }
+  for (int j = n - 1; j >= 0; j--) {
+    wave_sync();
+    float xj = x[j] / A[j][j];
+    wave_sync();
+    if (lane == j) x[j] = xj;
+    if (lane < j) x[lane] -= A[j][lane] * xj;
+  }
+  wave_sync();
+}
+
+// ------------------------------------------------------------------ CRBA: composite spatial inertias about the world origin
+DEV void crba(const TreeModel* tm, TreeLDS& L) {
+  int lane = wave_lane(), nb = tm->nbody, nv = tm->nv;
+  if (lane < nb) {
+    int b = lane;
+    float o[36];
+#pragma unroll
+    for (int i = 0; i < 36; i++) o[i] = 0.f;
+    float mass = tm->body_mass[b];
+    if (b > 0 && mass > 0.f) {
+      const float* c = L.xipos[b]; const float* R = L.ximat[b];
+      float I[9];
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          float v = 0.f;
+#pragma unroll
+          for (int k = 0; k < 3; k++) v += R[3 * i + k] * tm->body_inertia[b][k] * R[3 * j + k];
+          I[3 * i + j] = v;
+        }
+      float cx[9] = {0.f, -c[2], c[1], c[2], 0.f, -c[0], -c[1], c[0], 0.f}, cx2[9];
+      matmul3(cx2, cx, cx);
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          o[6 * i + j] = I[3 * i + j] - mass * cx2[3 * i + j];
+          o[6 * i + 3 + j] = mass * cx[3 * i + j];
+          o[6 * (3 + i) + j] = -mass * cx[3 * i + j];
+          o[6 * (3 + i) + 3 + j] = (i == j) ? mass : 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 36; i++) L.Ic.own[b][i] = o[i];
+  }
+  wave_sync();
+  if (lane < nb) {                       // composite of body b: its own plus every descendant's, in body order
+    int b = lane;
+    float o[36];
+#pragma unroll
+    for (int i = 0; i < 36; i++) o[i] = L.Ic.own[b][i];
+    for (int d = b + 1; d < nb; d++)
+      if ((tm->body_anc[d] >> b) & 1u) {
+#pragma unroll
+        for (int i = 0; i < 36; i++) o[i] += L.Ic.own[d][i];
+      }
+#pragma unroll
+    for (int i = 0; i < 36; i++) L.Ic.comp[b][i] = o[i];
+  }
+  wave_sync();
+  // M[r][c] = S_r' Ic[deeper body] S_c when one of the two bodies is an ancestor of the other; lane = column
+  if (lane < nv) {
+    int c = lane, bc = tm->dof_body[c];
+    float sc[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) sc[i] = L.S[c][i];
+    for (int r = 0; r < nv; r++) {
+      int br = tm->dof_body[r], bb = -1;
+      if ((tm->body_anc[br] >> bc) & 1u) bb = br; else if ((tm->body_anc[bc] >> br) & 1u) bb = bc;
+      float v = 0.f;
+      if (bb >= 0) {
+        const float* I = L.Ic.comp[bb];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+          float t = 0.f;
+#pragma unroll
+          for (int j = 0; j < 6; j++) t += I[6 * i + j] * sc[j];
+          v += L.S[r][i] * t;
+        }
+      }
+      if (r == c) v += tm->dof_armature[c];
+      L.M[r][c] = v; L.L[r][c] = v;
+    }
+  }
+  wave_sync();
+  chol_factor(L.L, nv);
+}
+
+// ------------------------------------------------------------------ RNE bias (Coriolis / centrifugal + gravity at qacc = 0)
+DEV void rne_bias(const TreeModel* tm, TreeLDS& L) {
+  int lane = wave_lane(), nb = tm->nbody;
+  if (lane < nb) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { L.rw[lane][k] = 0.f; L.ral[lane][k] = 0.f; L.rao[lane][k] = -tm->grav[k]; L.rf[lane][k] = 0.f; L.rn[lane][k] = 0.f; }
+  }
+  wave_sync();
+  for (int level = 1; level <= tm->maxdepth; level++) {
+    if (lane > 0 && lane < nb && tm->body_depth[lane] == level) {
+      int b = lane, p = tm->body_parent[b], jt = tm->body_jnttype[b], da = tm->body_dofadr[b];
+      float wb[3], ab[3], aob[3];
+      if (jt == TJ_FREE) {
+        float v3[3] = {L.qvel[da + 3], L.qvel[da + 4], L.qvel[da + 5]};
+        matvec3(wb, L.xmat[b], v3);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { ab[k] = 0.f; aob[k] = -tm->grav[k]; }
+      } else {
+        float d[3] = {L.xpos[b][0] - L.xpos[p][0], L.xpos[b][1] - L.xpos[p][1], L.xpos[b][2] - L.xpos[p][2]};
+        float t1[3], t2[3], t3[3];
+        cross3(t1, L.ral[p], d); cross3(t2, L.rw[p], d); cross3(t3, L.rw[p], t2);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { aob[k] = L.rao[p][k] + t1[k] + t3[k]; wb[k] = L.rw[p][k]; ab[k] = L.ral[p][k]; }
+        if (jt == TJ_HINGE || jt == TJ_SLIDE) {
+          float a[3]; matvec3(a, L.xmat[b], tm->jnt_axis[tm->body_jnt[b]]);
+          float qd = L.qvel[da], t[3]; cross3(t, L.rw[p], a);
+          if (jt == TJ_HINGE) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { wb[k] += a[k] * qd; ab[k] += t[k] * qd; }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 3; k++) aob[k] += 2.f * t[k] * qd;
+          }
+        }
+      }
+      float mass = tm->body_mass[b];
+      float F[3] = {0.f, 0.f, 0.f}, Nn[3] = {0.f, 0.f, 0.f};
+      if (mass > 0.f) {
+        float r[3] = {L.xipos[b][0] - L.xpos[b][0], L.xipos[b][1] - L.xpos[b][1], L.xipos[b][2] - L.xpos[b][2]};
+        float t1[3], t2[3], t3[3]; cross3(t1, ab, r); cross3(t2, wb, r); cross3(t3, wb, t2);
+#pragma unroll
+        for (int k = 0; k < 3; k++) F[k] = mass * (aob[k] + t1[k] + t3[k]);
+        const float* R = L.ximat[b];
+        float lw[3], la[3], Iw[3], Ia[3];
+        matTvec3(lw, R, wb); matTvec3(la, R, ab);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { lw[k] *= tm->body_inertia[b][k]; la[k] *= tm->body_inertia[b][k]; }
+        matvec3(Iw, R, lw); matvec3(Ia, R, la);
+        float N3[3], rF[3]; cross3(N3, wb, Iw); cross3(rF, r, F);
+#pragma unroll
+        for (int k = 0; k < 3; k++) Nn[k] = Ia[k] + N3[k] + rF[k];
+      }
+#pragma unroll
+      for (int k = 0; k < 3; k++) { L.rw[b][k] = wb[k]; L.ral[b][k] = ab[k]; L.rao[b][k] = aob[k]; L.rf[b][k] = F[k]; L.rn[b][k] = Nn[k]; }
+    }
+    wave_sync();
+  }
+  // force and moment (about the body's own origin) of the subtree of each dof's body; lane = dof
+  if (lane < tm->nv) {
+    int d = lane, b = tm->dof_body[d], jt = tm->body_jnttype[b];
+    float F[3] = {0.f, 0.f, 0.f}, Nn[3] = {0.f, 0.f, 0.f};
+    for (int c = b; c < nb; c++)
+      if ((tm->body_anc[c] >> b) & 1u) {
+        float dd[3] = {L.xpos[c][0] - L.xpos[b][0], L.xpos[c][1] - L.xpos[b][1], L.xpos[c][2] - L.xpos[b][2]}, t[3];
+        cross3(t, dd, L.rf[c]);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { F[k] += L.rf[c][k]; Nn[k] += L.rn[c][k] + t[k]; }
+      }
+    float v;
+    if (jt == TJ_HINGE || jt == TJ_SLIDE) {
+      float a[3]; matvec3(a, L.xmat[b], tm->jnt_axis[tm->dof_jnt[d]]);
+      v = jt == TJ_HINGE ? dot3(a, Nn) : dot3(a, F);
+    } else {
+      int k = d - tm->body_dofadr[b];
+      if (k < 3) v = F[k];
+      else { float t[3]; matTvec3(t, L.xmat[b], Nn); v = t[k - 3]; }
+    }
+    L.bias[d] = v;
+  }
+  wave_sync();
+}
+
+// ------------------------------------------------------------------ actuation, passive forces, unconstrained acceleration
+DEV void smooth(const TreeModel* tm, TreeLDS& L) {
+  int lane = wave_lane(), nv = tm->nv;
+  if (lane < nv) L.qact[lane] = 0.f;
+  wave_sync();
+  if (lane < tm->nu) {                              // (every actuator of these scenes drives its own dof)
+    int a = lane, d = tm->act_dof[a];
+    float c = L.ctrl[a];
+    if (tm->act_ctrllimited[a]) c = fminf(fmaxf(c, tm->act_ctrlrange[a][0]), tm->act_ctrlrange[a][1]);
+    float force = tm->act_gain[a] * c + tm->act_bias[a][0] + tm->act_bias[a][1] * L.qpos[tm->act_qposadr[a]] + tm->act_bias[a][2] * L.qvel[d];
+    if (tm->act_forcelimited[a]) force = fminf(fmaxf(force, tm->act_forcerange[a][0]), tm->act_forcerange[a][1]);
+    L.qact[d] = force;
+  }
+  wave_sync();
+  if (lane < nv) {
+    int d = lane, j = tm->dof_jnt[d];
+    float f = L.qact[d];
+    if (j >= 0 && tm->jnt_actfrclimited[j]) f = fminf(fmaxf(f, tm->jnt_actfrcrange[j][0]), tm->jnt_actfrcrange[j][1]);
+    float rhs = f - L.bias[d] - tm->dof_damping[d] * L.qvel[d];
+    L.qfrc[d] = rhs; L.qsm[d] = rhs;
+  }
+  wave_sync();
+  chol_solve(L.L, nv, L.qsm);
+}
+
+// ------------------------------------------------------------------ collision
+DEV void geom_pose(const TreeModel* tm, const DevModel* gm, const TreeLDS& L, int g, float* p, float* R) {
+  int b = tm->geom_body[g];
+  const float* gp = gm->geom_pos + 3 * g; const float* gmat = gm->geom_mat + 9 * g;
+  float lp[3] = {gp[0], gp[1], gp[2]}, lm[9], t[3];
+#pragma unroll
+  for (int i = 0; i < 9; i++) lm[i] = gmat[i];
+  matvec3(t, L.xmat[b], lp);
+  p[0] = L.xpos[b][0] + t[0]; p[1] = L.xpos[b][1] + t[1]; p[2] = L.xpos[b][2] + t[2];
+  matmul3(R, L.xmat[b], lm);
+}
+
+DEV void contact_params(const TreeModel* tm, const DevModel* gm, TCon& c, int g1, int g2) {      // mj_contactParam
+  int cd1 = gm->geom_condim[g1], cd2 = gm->geom_condim[g2];
+  c.dim = cd1 > cd2 ? cd1 : cd2;
+  float f[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) f[k] = fmaxf(gm->geom_friction[3 * g1 + k], gm->geom_friction[3 * g2 + k]);
+  c.fric[0] = c.fric[1] = f[0]; c.fric[2] = f[1]; c.fric[3] = c.fric[4] = f[2];
+  float s1 = tm->geom_solmix[g1], s2 = tm->geom_solmix[g2];
+  float mix = (s1 >= MINVAL_F && s2 >= MINVAL_F) ? s1 / (s1 + s2) : (s1 < MINVAL_F && s2 < MINVAL_F ? 0.5f : (s1 < MINVAL_F ? 0.f : 1.f));
+  int p1 = tm->geom_priority[g1], p2 = tm->geom_priority[g2];
+  if (p1 > p2) mix = 1.f; else if (p1 < p2) mix = 0.f;
+#pragma unroll
+  for (int k = 0; k < 2; k++) c.solref[k] = mix * gm->geom_solref[2 * g1 + k] + (1.f - mix) * gm->geom_solref[2 * g2 + k];
+#pragma unroll
+  for (int k = 0; k < 5; k++) c.solimp[k] = mix * gm->geom_solimp[5 * g1 + k] + (1.f - mix) * gm->geom_solimp[5 * g2 + k];
+}
+
+DEV void collision(const TreeModel* tm, const DevModel* gm, TreeLDS& L) {
+  int lane = wave_lane(), ng = tm->ngeom;
+  // world boxes of the geoms
+  for (int g = lane; g < ng; g += WAVE) {
+    float p[3], R[9]; geom_pose(tm, gm, L, g, p, R);
+    const float* c = gm->geom_aabb + 6 * g;
+    float cl[3] = {c[0], c[1], c[2]}, h[3] = {c[3], c[4], c[5]}, cw[3];
+    matvec3(cw, R, cl);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      float e = fabsf(R[3 * i]) * h[0] + fabsf(R[3 * i + 1]) * h[1] + fabsf(R[3 * i + 2]) * h[2];
+      L.aabb[i][g] = p[i] + cw[i] - e; L.aabb[3 + i][g] = p[i] + cw[i] + e;
+    }
+  }
+  if (lane == 0) { L.ncand = 0; L.ncon = 0; }
+  wave_sync();
+  // candidate pairs in pair-list order
+  int base = 0;
+  for (int p0 = 0; p0 < tm->npair; p0 += WAVE) {
+    int p = p0 + lane;
+    bool hit = false;
+    int g1 = 0, g2 = 0;
+    if (p < tm->npair) {
+      g1 = gm->pair[2 * p]; g2 = gm->pair[2 * p + 1];
+      if (gm->geom_type[g1] > gm->geom_type[g2]) { int t = g1; g1 = g2; g2 = t; }
+      if (gm->geom_type[g1] == G_PLANE) {
+        float pp[3], R[9]; geom_pose(tm, gm, L, g1, pp, R);
+        float nrm[3] = {R[2], R[5], R[8]}, lowest = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) lowest += nrm[k] * ((nrm[k] >= 0.f ? L.aabb[k][g2] : L.aabb[3 + k][g2]) - pp[k]);
+        hit = !(lowest > 0.f);
+      } else {
+        hit = true;
+#pragma unroll
+        for (int k = 0; k < 3; k++) if (L.aabb[k][g1] > L.aabb[3 + k][g2] || L.aabb[k][g2] > L.aabb[3 + k][g1]) hit = false;
+      }
+    }
+    unsigned long long mask = wave_ballot(hit);
+    int idx = base + wave_prefix(mask);
+    if (hit && idx < TCAND) L.cand[idx] = (unsigned int)g1 | ((unsigned int)g2 << 16);
+    base += __popcll(mask);
+  }
+  wave_sync();
+  int ncand = base;
+  if (ncand > TCAND) { ncand = TCAND; if (lane == 0) L.flags |= 1; }
+  int ncon = 0;
+  for (int k = 0; k < ncand; k++) {
+    unsigned int cg = L.cand[k];
+    int g1 = wave_uniform_i((int)(cg & 0xffffu)), g2 = wave_uniform_i((int)(cg >> 16));
+    int b1 = wave_uniform_i(tm->geom_body[g1]), b2 = wave_uniform_i(tm->geom_body[g2]);
+    GeomW G1, G2;
+    load_geom_at(gm, g1, L.xpos[b1], L.xmat[b1], G1); load_geom_at(gm, g2, L.xpos[b2], L.xmat[b2], G2);
+    PairContacts pc;
+    narrow_pair<NoCache, G64>(gm, G1, G2, g1, g2, pc);
+    unsigned int valid = pc.valid;
+    int n = __popc(valid);
+    if (n == 0) continue;
+    if (ncon + n > TCON) { if (lane == 0) L.flags |= 2; break; }
+    if (lane < NCPP && ((valid >> lane) & 1u)) {
+      int slot = ncon + __popc(valid & ((1u << lane) - 1u));
+      TCon& c = L.con[slot];
+      float dist = 0.f, pos[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < NCPP; j++) if (j == lane) { dist = pc.dist[j]; pos[0] = pc.pos[j][0]; pos[1] = pc.pos[j][1]; pos[2] = pc.pos[j][2]; }
+      float fr[9] = {pc.nrm[0], pc.nrm[1], pc.nrm[2], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      make_frame(fr);
+#pragma unroll
+      for (int i = 0; i < 9; i++) c.frame[i] = fr[i];
+      c.pos[0] = pos[0]; c.pos[1] = pos[1]; c.pos[2] = pos[2]; c.dist = dist;
+      c.g1 = g1; c.g2 = g2; c.b1 = b1; c.b2 = b2;
+      contact_params(tm, gm, c, g1, g2);
+      if (!tm->elliptic) c.dim = 1;
+    }
+    ncon += n;
+    wave_sync();
+  }
+  if (lane == 0) { L.ncon = ncon; L.ncand = ncand; }
+  wave_sync();
+}
+
+// ------------------------------------------------------------------ constraint rows (mj_makeConstraint order: equality, dof friction, limits, contacts)
+// impedance, regulariser and reference-acceleration coefficients of one row group
+DEV void row_params(const TreeModel* tm, const float* solref_in, const float* solimp, float pos, float* imp, float* K, float* Bc) {
+  float s0 = solref_in[0], s1 = solref_in[1];
+  float dmax = fminf(fmaxf(solimp[1], MINIMP_F), MAXIMP_F);
+  if (s0 > 0.f) {
+    s0 = fmaxf(s0, 2.f * tm->dt);
+    *K = 1.f / fmaxf(MINVAL_F, dmax * dmax * s0 * s0 * s1 * s1); *Bc = 2.f / fmaxf(MINVAL_F, dmax * s0);
+  } else { *K = -s0 / fmaxf(MINVAL_F, dmax * dmax); *Bc = -s1 / fmaxf(MINVAL_F, dmax); }
+  *imp = impedance(solimp, pos);
+}
+
+DEV void make_constraints(const TreeModel* tm, TreeLDS& L, float* Jg) {
+  int lane = wave_lane(), nv = tm->nv, neq = tm->neq, nfric = tm->nfric, njnt = tm->njnt;
+  // joint limits that are violated: (joint, side) pairs in joint order
+  bool lo_on = false, hi_on = false;
+  float q_j = 0.f;
+  if (lane < njnt && tm->jnt_limited[lane]) {
+    q_j = L.qpos[tm->body_qposadr[tm->jnt_body[lane]]];
+    lo_on = q_j - tm->jnt_range[lane][0] < 0.f; hi_on = tm->jnt_range[lane][1] - q_j < 0.f;
+  }
+  unsigned long long mlo = wave_ballot(lo_on), mhi = wave_ballot(hi_on);
+  int nlim = __popcll(mlo) + __popcll(mhi);
+  int nscalar = neq + nfric + nlim;
+  int ncon = L.ncon;
+  // first row of every contact
+  if (lane < ncon) L.cdim[lane] = L.con[lane].dim;
+  wave_sync();
+  int crow = nscalar;
+  if (lane < ncon) { for (int k = 0; k < lane; k++) crow += L.cdim[k]; L.con[lane].row = crow; }
+  int nrow = nscalar;
+  for (int k = 0; k < ncon; k++) nrow += L.cdim[k];
+  if (nrow > TROW) { if (lane == 0) L.flags |= 4; }      // (cannot happen: TCON * 6 = TROW)
+  if (lane == 0) { L.nrow = nrow; L.nscalar = nscalar; }
+  // zero the Jacobian rows of the scalar constraints
+  for (int r = 0; r < nscalar; r++) if (lane < TJS) Jg[r * TJS + lane] = 0.f;
+  wave_sync();
+  // ---- scalar rows: one lane each
+  {
+    int r = -1, type = 0, d1 = -1, d2 = -1;
+    float j1 = 0.f, j2 = 0.f, pos = 0.f, diag = 0.f, floss = 0.f;
+    float solref[2] = {0.02f, 1.f}, solimp[5] = {0.9f, 0.95f, 0.001f, 0.5f, 2.f};
+    if (lane < neq) {
+      int e = lane; r = e; type = TR_EQUALITY;
+      d1 = tm->eq_dof[e][0]; d2 = tm->eq_dof[e][1];
+      const float* pc = tm->eq_polycoef[e];
+      float q1 = L.qpos[tm->eq_qposadr[e][0]], q2 = L.qpos[tm->eq_qposadr[e][1]];
+      float poly = pc[0] + q2 * (pc[1] + q2 * (pc[2] + q2 * (pc[3] + q2 * pc[4])));
+      float deriv = pc[1] + q2 * (2.f * pc[2] + q2 * (3.f * pc[3] + q2 * 4.f * pc[4]));
+      pos = q1 - poly; j1 = 1.f; j2 = -deriv;
+      solref[0] = tm->eq_solref[e][0]; solref[1] = tm->eq_solref[e][1];
+#pragma unroll
+      for (int k = 0; k < 5; k++) solimp[k] = tm->eq_solimp[e][k];
+      diag = tm->dof_invweight0[d1] + tm->dof_invweight0[d2];
+    } else if (lane < neq + nfric) {
+      int d = tm->fric_dof[lane - neq]; r = lane; type = TR_FRICTION;
+      d1 = d; j1 = 1.f; floss = tm->dof_frictionloss[d];
+      solref[0] = tm->dof_solref[d][0]; solref[1] = tm->dof_solref[d][1];
+#pragma unroll
+      for (int k = 0; k < 5; k++) solimp[k] = tm->dof_solimp[d][k];
+      diag = tm->dof_invweight0[d];
+    }
+    // limit rows are taken by the joint's own lane (after the rows above, which belong to lanes < neq + nfric <= 20 < 32; the
+    // two groups of lanes overlap, so the limits go through a second pass below)
+    if (r >= 0) {
+      float imp, K, Bc; row_params(tm, solref, solimp, pos, &imp, &K, &Bc);
+      float R = fmaxf(MINVAL_F, (1.f - imp) * diag / imp);
+      float vel = j1 * L.qvel[d1] + (d2 >= 0 ? j2 * L.qvel[d2] : 0.f);
+      Jg[r * TJS + d1] = j1; if (d2 >= 0) Jg[r * TJS + d2] = j2;
+      L.etype[r] = (unsigned char)type; L.eR[r] = R; L.eD[r] = 1.f / R; L.efl[r] = floss;
+      L.earef[r] = -Bc * vel - (type == TR_FRICTION ? 0.f : K * imp * pos);
+    }
+  }
+  if (lo_on || hi_on) {
+    int j = lane, b = tm->jnt_body[j], d = tm->body_dofadr[b];
+    int r0 = neq + nfric + wave_prefix(mlo) + wave_prefix(mhi);
+    float solref[2] = {tm->jnt_solref[j][0], tm->jnt_solref[j][1]}, solimp[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) solimp[k] = tm->jnt_solimp[j][k];
+    for (int side = 0; side < 2; side++) {
+      if (!(side == 0 ? lo_on : hi_on)) continue;
+      int r = r0 + (side == 1 && lo_on ? 1 : 0);
+      float pos = side == 0 ? q_j - tm->jnt_range[j][0] : tm->jnt_range[j][1] - q_j, sg = side == 0 ? 1.f : -1.f;
+      float imp, K, Bc; row_params(tm, solref, solimp, pos, &imp, &K, &Bc);
+      float R = fmaxf(MINVAL_F, (1.f - imp) * tm->dof_invweight0[d] / imp);
+      Jg[r * TJS + d] = sg;
+      L.etype[r] = TR_LIMIT; L.eR[r] = R; L.eD[r] = 1.f / R; L.efl[r] = 0.f;
+      L.earef[r] = -Bc * sg * L.qvel[d] - K * imp * pos;
+    }
+  }
+  // ---- contact rows: Jacobian by lane = dof (coalesced rows), parameters by lane = contact
+  for (int c = 0; c < ncon; c++) {
+    const TCon& C = L.con[c];
+    int row = C.row, dim = C.dim, b1 = C.b1, b2 = C.b2;
+    if (lane < TJS) {
+      int d = lane;
+      float jp[3] = {0.f, 0.f, 0.f}, jr[3] = {0.f, 0.f, 0.f};
+      if (d < nv) {
+        bool in1 = (tm->body_dofs[b1] >> d) & 1u, in2 = (tm->body_dofs[b2] >> d) & 1u;
+        float sgn = (in2 ? 1.f : 0.f) - (in1 ? 1.f : 0.f);
+        if (sgn != 0.f) {
+          float t[3]; cross3(t, L.S[d], C.pos);
+#pragma unroll
+          for (int k = 0; k < 3; k++) { jp[k] = sgn * (L.S[d][3 + k] + t[k]); jr[k] = sgn * L.S[d][k]; }
+        }
+      }
+      for (int j = 0; j < dim; j++) {
+        const float* ax = &C.frame[3 * (j < 3 ? j : j - 3)];
+        Jg[(row + j) * TJS + d] = j < 3 ? dot3(ax, jp) : dot3(ax, jr);
+      }
+    }
+  }
+  if (lane < ncon) {
+    TCon& C = L.con[lane];
+    int row = C.row, dim = C.dim;
+    float imp, K, Bc; row_params(tm, C.solref, C.solimp, C.dist, &imp, &K, &Bc);
+    float tran = tm->body_invweight0[C.b1][0] + tm->body_invweight0[C.b2][0], rot = tm->body_invweight0[C.b1][1] + tm->body_invweight0[C.b2][1];
+    float R0 = fmaxf(MINVAL_F, (1.f - imp) * tran / imp);
+    float R[6];
+    R[0] = R0;
+    for (int j = 1; j < 6; j++) R[j] = fmaxf(MINVAL_F, (1.f - imp) * (j < 3 ? tran : rot) / imp);
+    if (dim > 1) {
+      R[1] = R[0] / fmaxf(MINVAL_F, tm->impratio);
+      C.mu = C.fric[0] * sqrtf(R[1] / R[0]);
+      for (int j = 2; j < dim; j++) R[j] = fmaxf(MINVAL_F, R[1] * C.fric[0] * C.fric[0] / (C.fric[j - 1] * C.fric[j - 1]));
+    } else C.mu = 0.f;
+    for (int j = 0; j < dim; j++) {
+      L.etype[row + j] = TR_CONTACT; L.eR[row + j] = R[j]; L.eD[row + j] = 1.f / R[j]; L.efl[row + j] = 0.f;
+      L.eB[row + j] = Bc; L.eKp[row + j] = j == 0 ? K * imp * C.dist : 0.f;
+    }
+  }
+  wave_sync();
+  // reference acceleration of the contact rows: aref = -B (J qvel) - K imp pos; lane = row
+  for (int r = nscalar + lane; r < nrow; r += WAVE) {
+    float vel = 0.f;
+    for (int d = 0; d < nv; d++) vel += Jg[r * TJS + d] * L.qvel[d];
+    L.earef[r] = -L.eB[r] * vel - L.eKp[r];
+  }
+  wave_sync();
+}
+
+// ------------------------------------------------------------------ Newton (mj_solNewton restated; oracle solve_newton)
+// cost, force (= -ds/dr) and Hessian of one elliptic contact block at r (dim rows); returns the cost
+DEV float contact_block(const TCon& C, const float* D, int dim, const float* r, float* force, float* Hc, bool want_h) {
+  if (want_h) for (int k = 0; k < 36; k++) Hc[k] = 0.f;
+  if (dim == 1) {
+    if (r[0] < 0.f) { force[0] = -D[0] * r[0]; if (want_h) Hc[0] = D[0]; return 0.5f * D[0] * r[0] * r[0]; }
+    force[0] = 0.f; return 0.f;
+  }
+  float mu = C.mu, U[6];
+  U[0] = r[0] * mu;
+  float T = 0.f;
+  for (int j = 1; j < dim; j++) { U[j] = r[j] * C.fric[j - 1]; T += U[j] * U[j]; }
+  T = sqrtf(T);
+  float N = U[0];
+  if ((N >= mu * T) || (T <= 0.f && N >= 0.f)) { for (int j = 0; j < dim; j++) force[j] = 0.f; return 0.f; }
+  if ((mu * N + T <= 0.f) || (T <= 0.f && N < 0.f)) {
+    float cost = 0.f;
+    for (int j = 0; j < dim; j++) { force[j] = -D[j] * r[j]; cost += 0.5f * D[j] * r[j] * r[j]; if (want_h) Hc[j * dim + j] = D[j]; }
+    return cost;
+  }
+  float Dm = D[0] / fmaxf(mu * mu * (1.f + mu * mu), MINVAL_F), sN = N - mu * T;
+  force[0] = -Dm * sN * mu;
+  for (int j = 1; j < dim; j++) force[j] = -force[0] / T * U[j] * C.fric[j - 1];
+  if (want_h) {
+    Hc[0] = Dm * mu * mu;
+    for (int k = 1; k < dim; k++) {
+      float mk = C.fric[k - 1];
+      Hc[k] = Hc[k * dim] = -Dm * mu * mu * U[k] * mk / T;
+      for (int l = 1; l < dim; l++) {
+        float ml = C.fric[l - 1];
+        Hc[k * dim + l] = Dm * mu * mu * mk * ml * U[k] * U[l] / (T * T) - Dm * sN * mu * mk * ml * ((k == l ? 1.f : 0.f) / T - U[k] * U[l] / (T * T * T));
+      }
+    }
+  }
+  return 0.5f * Dm * sN * sN;
+}
+// scalar rows: cost, force, second derivative
+DEV float scalar_block(int type, float D, float R, float fl, float r, float* force, float* h) {
+  *h = 0.f;
+  if (type == TR_EQUALITY) { *force = -D * r; *h = D; return 0.5f * D * r * r; }
+  if (type == TR_FRICTION) {
+    float rf = R * fl;
+    if (r <= -rf) { *force = fl; return fl * (-0.5f * rf - r); }
+    if (r >= rf) { *force = -fl; return fl * (-0.5f * rf + r); }
+    *force = -D * r; *h = D; return 0.5f * D * r * r;
+  }
+  if (r < 0.f) { *force = -D * r; *h = D; return 0.5f * D * r * r; }
+  *force = 0.f; return 0.f;
+}
+
+// total cost at the point L.x; with want: gradient in L.grad and Hessian in L.H (not yet factored); forces in L.ef, jar in L.ejar
+DEV float total_cost(const TreeModel* tm, TreeLDS& L, const float* Jg, bool want) {
+  int lane = wave_lane(), nv = tm->nv, nrow = L.nrow, nscalar = L.nscalar, ncon = L.ncon;
+  float part = 0.f;
+  if (lane < nv) {
+    float v = 0.f;
+    for (int c = 0; c < nv; c++) v += L.M[lane][c] * L.x[c];
+    L.Ma[lane] = v;
+    part = 0.5f * (v - L.qfrc[lane]) * (L.x[lane] - L.qsm[lane]);
+  }
+  for (int r = lane; r < nrow; r += WAVE) {
+    float v = -L.earef[r];
+    for (int d = 0; d < nv; d++) v += Jg[r * TJS + d] * L.x[d];
+    L.ejar[r] = v;
+  }
+  wave_sync();
+  for (int r = lane; r < nscalar; r += WAVE) {
+    float f, h;
+    part += scalar_block(L.etype[r], L.eD[r], L.eR[r], L.efl[r], L.ejar[r], &f, &h);
+    L.ef[r] = f; L.ejv[r] = h;        // (ejv doubles as the scalar rows' second derivative until the line search fills it)
+  }
+  if (lane < ncon) {
+    const TCon& C = L.con[lane];
+    float r6[6], f6[6], D6[6], Hc[36];
+    for (int j = 0; j < C.dim; j++) { r6[j] = L.ejar[C.row + j]; D6[j] = L.eD[C.row + j]; }
+    part += contact_block(C, D6, C.dim, r6, f6, Hc, want);
+    for (int j = 0; j < C.dim; j++) L.ef[C.row + j] = f6[j];
+    if (want) for (int k = 0; k < C.dim * C.dim; k++) L.Hc[lane][k] = Hc[k];
+  }
+  float cost = wave_sum_f(part);
+  wave_sync();
+  if (!want) return cost;
+  // gradient: Ma - qfrc_smooth - J' force; lane = dof
+  if (lane < nv) {
+    float g = L.Ma[lane] - L.qfrc[lane];
+    for (int r = 0; r < nrow; r++) g -= Jg[r * TJS + lane] * L.ef[r];
+    L.grad[lane] = g;
+  }
+  // Hessian: M + sum J' Hc J; lane = column
+  float hcol[TV];
+  if (lane < nv) for (int a = 0; a < nv; a++) hcol[a] = L.M[a][lane];
+  for (int r = 0; r < nscalar; r++) {
+    float h = L.ejv[r];
+    if (h == 0.f) continue;
+    float jc = lane < nv ? Jg[r * TJS + lane] : 0.f;
+    if (lane < TJS) L.Jc[0][lane] = lane < nv ? jc : 0.f;
+    wave_sync();
+    if (lane < nv && jc != 0.f) for (int a = 0; a < nv; a++) hcol[a] += L.Jc[0][a] * h * jc;
+    wave_sync();
+  }
+  for (int c = 0; c < ncon; c++) {
+    int row = L.con[c].row, dim = L.con[c].dim;
+    if (lane < TJS) for (int j = 0; j < dim; j++) L.Jc[j][lane] = lane < nv ? Jg[(row + j) * TJS + lane] : 0.f;
+    wave_sync();
+    if (lane < nv) {
+      float t[6];
+      for (int j = 0; j < dim; j++) { float v = 0.f; for (int k = 0; k < dim; k++) v += L.Hc[c][j * dim + k] * L.Jc[k][lane]; t[j] = v; }
+      for (int a = 0; a < nv; a++) { float v = 0.f; for (int j = 0; j < dim; j++) v += L.Jc[j][a] * t[j]; hcol[a] += v; }
+    }
+    wave_sync();
+  }
+  if (lane < nv) for (int a = 0; a < nv; a++) L.H[a][lane] = hcol[a];
+  wave_sync();
+  return cost;
+}
+
+DEV void solve_newton(const TreeModel* tm, TreeLDS& L, const float* Jg, int max_iter, float tolerance) {
+  int lane = wave_lane(), nv = tm->nv, nrow = L.nrow, nscalar = L.nscalar, ncon = L.ncon;
+  if (lane == 0) L.iters = 0;
+  if (nrow == 0) { if (lane < nv) L.qacc[lane] = L.qsm[lane]; wave_sync(); return; }
+  // warm start: the better of the previous acceleration and the unconstrained one
+  if (lane < nv) L.x[lane] = L.warm[lane];
+  wave_sync();
+  float cw = total_cost(tm, L, Jg, false);
+  if (lane < nv) L.x[lane] = L.qsm[lane];
+  wave_sync();
+  float cs = total_cost(tm, L, Jg, false);
+  if (cw < cs) { if (lane < nv) L.x[lane] = L.warm[lane]; }
+  wave_sync();
+  float scale = 1.f / (tm->meaninertia * (float)(nv > 1 ? nv : 1));
+  float cost = total_cost(tm, L, Jg, true);
+  int it = 0;
+  for (; it < max_iter; ) {
+    chol_factor(L.H, nv);
+    if (lane < nv) L.search[lane] = -L.grad[lane];
+    wave_sync();
+    chol_solve(L.H, nv, L.search);
+    // line search on phi(alpha) = cost(x + alpha search): safeguarded Newton on phi'
+    for (int r = lane; r < nrow; r += WAVE) {
+      float v = 0.f;
+      for (int d = 0; d < nv; d++) v += Jg[r * TJS + d] * L.search[d];
+      L.ejv[r] = v;
+    }
+    float p1 = 0.f, p2 = 0.f;
+    if (lane < nv) {
+      float mv = 0.f;
+      for (int c = 0; c < nv; c++) mv += L.M[lane][c] * L.search[c];
+      p1 = L.search[lane] * (L.Ma[lane] - L.qfrc[lane]); p2 = L.search[lane] * mv;
+    }
+    float q1 = wave_sum_f(p1), q2 = wave_sum_f(p2);
+    wave_sync();
+    float alpha = 0.f, lo = 0.f, hi = -1.f, d10 = 0.f;
+    for (int ls = 0; ls < 24; ls++) {
+      float a1 = 0.f, a2 = 0.f;
+      for (int r = lane; r < nscalar; r += WAVE) {
+        float f, h, jv = L.ejv[r];
+        scalar_block(L.etype[r], L.eD[r], L.eR[r], L.efl[r], L.ejar[r] + alpha * jv, &f, &h);
+        a1 -= f * jv; a2 += jv * h * jv;
+      }
+      if (lane < ncon) {
+        const TCon& C = L.con[lane];
+        float r6[6], f6[6], D6[6], Hc[36], jv6[6];
+        for (int j = 0; j < C.dim; j++) { jv6[j] = L.ejv[C.row + j]; r6[j] = L.ejar[C.row + j] + alpha * jv6[j]; D6[j] = L.eD[C.row + j]; }
+        contact_block(C, D6, C.dim, r6, f6, Hc, true);
+        for (int j = 0; j < C.dim; j++) { a1 -= f6[j] * jv6[j]; for (int k = 0; k < C.dim; k++) a2 += jv6[j] * Hc[j * C.dim + k] * jv6[k]; }
+      }
+      float d1 = q1 + q2 * alpha + wave_sum_f(a1), d2 = q2 + wave_sum_f(a2);
+      if (ls == 0) { d10 = fabsf(d1); if (!(d1 < 0.f)) break; }
+      else {
+        if (fabsf(d1) <= 1e-5f * d10) break;
+        if (d1 < 0.f) lo = alpha; else hi = alpha;
+      }
+      float cand = alpha - d1 / fmaxf(d2, 1e-30f);
+      if (hi > 0.f && (cand <= lo || cand >= hi)) cand = 0.5f * (lo + hi);
+      alpha = cand;
+    }
+    if (lane < nv) L.x[lane] += alpha * L.search[lane];
+    wave_sync();
+    float newcost = total_cost(tm, L, Jg, true);
+    float improvement = scale * (cost - newcost);
+    float gn = wave_sum_f(lane < nv ? L.grad[lane] * L.grad[lane] : 0.f);
+    float gnorm = scale * sqrtf(gn);
+    cost = newcost;
+    it++;
+    if (improvement < tolerance || gnorm < tolerance) break;
+  }
+  if (lane < nv) L.qacc[lane] = L.x[lane];
+  if (lane == 0) L.iters = it;
+  wave_sync();
+}
+
+// ------------------------------------------------------------------ forward dynamics and integration
+DEV void forward(const TreeModel* tm, const DevModel* gm, TreeLDS& L, float* Jg, int max_iter, float tolerance) {
+  kinematics(tm, L);
+  crba(tm, L);
+  rne_bias(tm, L);
+  smooth(tm, L);
+  collision(tm, gm, L);
+  make_constraints(tm, L, Jg);
+  solve_newton(tm, L, Jg, max_iter, tolerance);
+}
+
+DEV void euler(const TreeModel* tm, TreeLDS& L) {
+  int lane = wave_lane(), nv = tm->nv, nb = tm->nbody;
+  float dt = tm->dt;
+  if (lane < nv) L.warm[lane] = L.qacc[lane];
+  if (tm->any_damping) {
+    // joint damping implicit in the velocity (mj_Euler): qacc' = (M + h D)^-1 M qacc
+    if (lane < nv) {
+      float v = 0.f;
+      for (int c = 0; c < nv; c++) { v += L.M[lane][c] * L.qacc[c]; L.H[lane][c] = L.M[lane][c] + (c == lane ? dt * tm->dof_damping[lane] : 0.f); }
+      L.tmp[lane] = v;
+    }
+    wave_sync();
+    chol_factor(L.H, nv);
+    chol_solve(L.H, nv, L.tmp);
+  } else {
+    if (lane < nv) L.tmp[lane] = L.qacc[lane];
+    wave_sync();
+  }
+  if (lane < nv) L.qvel[lane] += dt * L.tmp[lane];
+  wave_sync();
+  if (lane > 0 && lane < nb) {
+    int b = lane, jt = tm->body_jnttype[b], qa = tm->body_qposadr[b], d = tm->body_dofadr[b];
+    if (jt == TJ_HINGE || jt == TJ_SLIDE) L.qpos[qa] += dt * L.qvel[d];
+    else if (jt == TJ_FREE) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) L.qpos[qa + k] += dt * L.qvel[d + k];
+      float w[3] = {L.qvel[d + 3], L.qvel[d + 4], L.qvel[d + 5]};
+      float ang = dt * normalize3(w), sn, cs; sincos_f(0.5f * ang, &sn, &cs);
+      float dq[4] = {cs, w[0] * sn, w[1] * sn, w[2] * sn}, q0[4] = {L.qpos[qa + 3], L.qpos[qa + 4], L.qpos[qa + 5], L.qpos[qa + 6]}, o[4];
+      mulquat(o, q0, dq); normquat(o);
+#pragma unroll
+      for (int k = 0; k < 4; k++) L.qpos[qa + 3 + k] = o[k];
+    }
+  }
+  wave_sync();
+}
+
+}  // namespace tree

@@ -1,0 +1,318 @@
+// General-tree engine (so101_tree.hpp): kernels and the so101_tree_* entry points of include/so101.h.
+// Kernels and their launches live in one translation unit (no relocatable device code).
+#include <hip/hip_runtime.h>
+#include "so101_blob.hpp"
+#include "../../include/so101.h"
+#include "so101_tree.hpp"
+
+#include <cmath>
+#include <string>
+#include <vector>
+
+#define TDBG_COUNTS 0        // ncon, nrow, iters, ncand, flags, nscalar
+#define TDBG_BIAS 8
+#define TDBG_QSM 40
+#define TDBG_QACC 72
+#define TDBG_XPOS 104        // [TB][3]
+#define TDBG_M 200           // [TV][TV]
+#define TDBG_CON 1224        // [TCON][10] pos3 normal3 dist geom1 geom2 dim
+#define TDBG_FORCE 1864      // [TCON] normal force of each contact
+#define TDBG_DIM 2048
+
+__global__ void __launch_bounds__(64) k_tree_physics(const TreeModel* tm, const DevModel* gm, TreeBuffers B, int N, int nsub, int iterations, float tolerance) {
+  BLOCK_SHARED(TreeLDS, L);
+  int e = blockIdx.x, lane = wave_lane();
+  if (lane == 0) L.flags = 0;
+  tree::load_state(tm, L, B, e, N);
+  float* Jg = B.J + (size_t)e * TROW * TJS;
+  int bad = 0;
+  for (int s = 0; s < nsub; s++) {
+    tree::forward(tm, gm, L, Jg, iterations, tolerance);
+    tree::euler(tm, L);
+    // mj_checkPos / Vel / Acc: NaN or beyond 1e10 ends the episode (the caller sees flag 8 and resets the env)
+    bool ok = true;
+    if (lane < tm->nq) ok = ok && fabsf(L.qpos[lane]) <= 1e10f;
+    if (lane < tm->nv) ok = ok && fabsf(L.qvel[lane]) <= 1e10f && fabsf(L.qacc[lane]) <= 1e10f;
+    if (wave_ballot(!ok) != 0ull) { bad = 1; break; }
+  }
+  if (lane == 0 && bad) L.flags |= 8;
+  tree::store_state(tm, L, B, e, N);
+  if (lane == 0 && B.diag) { int* d = B.diag + 8 * e; d[0] = L.ncon; d[1] = L.nrow; d[2] = L.iters; d[3] = L.ncand; d[4] = L.flags; }
+}
+
+__global__ void __launch_bounds__(64) k_tree_forward(const TreeModel* tm, const DevModel* gm, TreeBuffers B, int N, int iterations, float tolerance, float* out) {
+  BLOCK_SHARED(TreeLDS, L);
+  int e = blockIdx.x, lane = wave_lane();
+  if (lane == 0) L.flags = 0;
+  tree::load_state(tm, L, B, e, N);
+  float* Jg = B.J + (size_t)e * TROW * TJS;
+  tree::forward(tm, gm, L, Jg, iterations, tolerance);
+  float* o = out + (size_t)e * TDBG_DIM;
+  int nv = tm->nv, nb = tm->nbody;
+  if (lane == 0) { o[0] = (float)L.ncon; o[1] = (float)L.nrow; o[2] = (float)L.iters; o[3] = (float)L.ncand; o[4] = (float)L.flags; o[5] = (float)L.nscalar; }
+  if (lane < nv) {
+    o[TDBG_BIAS + lane] = L.bias[lane]; o[TDBG_QSM + lane] = L.qsm[lane]; o[TDBG_QACC + lane] = L.qacc[lane];
+    for (int r = 0; r < nv; r++) o[TDBG_M + r * TV + lane] = L.M[r][lane];
+  }
+  if (lane < nb) for (int k = 0; k < 3; k++) o[TDBG_XPOS + 3 * lane + k] = L.xpos[lane][k];
+  if (lane < L.ncon) {
+    const TCon& c = L.con[lane];
+    float* q = o + TDBG_CON + 10 * lane;
+    for (int k = 0; k < 3; k++) { q[k] = c.pos[k]; q[3 + k] = c.frame[k]; }
+    q[6] = c.dist; q[7] = (float)c.g1; q[8] = (float)c.g2; q[9] = (float)c.dim;
+    o[TDBG_FORCE + lane] = L.nrow > 0 ? L.ef[c.row] : 0.f;
+  }
+}
+
+// ==================================================================================================== host side
+struct so101_tree {
+  int n_envs = 0, device = 0;
+  TreeModel hm{};
+  DevModel hg{};
+  TreeModel* dm = nullptr;
+  DevModel* dg = nullptr;
+  TreeBuffers buf{};
+  bool bound = false;
+  int iterations = 0; float tolerance = 0.f;
+  std::vector<void*> owned;
+  std::string err;
+};
+
+namespace {
+thread_local std::string g_tree_error;
+
+void tq2m(float* m, const float* q) {
+  float w = q[0], x = q[1], y = q[2], z = q[3];
+  m[0] = 1 - 2 * (y * y + z * z); m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+  m[3] = 2 * (x * y + w * z); m[4] = 1 - 2 * (x * x + z * z); m[5] = 2 * (y * z - w * x);
+  m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = 1 - 2 * (x * x + y * y);
+}
+bool t_ok(so101_tree* s, hipError_t e, const char* what) {
+  if (e == hipSuccess) return true;
+  s->err = std::string(what) + ": " + hipGetErrorString(e);
+  return false;
+}
+template <class T>
+bool t_upload(so101_tree* s, const std::vector<T>& v, const T** out) {
+  void* p = nullptr;
+  if (!t_ok(s, hipMalloc(&p, (v.size() ? v.size() : 1) * sizeof(T)), "hipMalloc(tree model)")) return false;
+  s->owned.push_back(p);
+  if (!v.empty() && !t_ok(s, hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice), "hipMemcpy(tree model)")) return false;
+  *out = (const T*)p;
+  return true;
+}
+
+int tree_build(so101_tree* s, const BlobView& b) {
+  auto fail = [&](const std::string& msg) { s->err = msg; return (int)SO101_ERR_MODEL; };
+  for (const char* n : {"nq", "nv", "nu", "nbody", "ngeom", "narm", "nfree", "npair", "nvert", "neq", "opt_iterations", "opt_mpr_iterations", "opt_cone_elliptic",
+                        "opt_timestep", "opt_impratio", "opt_tolerance", "opt_mpr_tolerance", "stat_meaninertia"})
+    if (b.count(n) < 1) return fail(std::string("blob entry missing (not a general-tree model?): ") + n);
+  TreeModel& M = s->hm;
+  M.nq = b.I("nq")[0]; M.nv = b.I("nv")[0]; M.nu = b.I("nu")[0]; M.nbody = b.I("nbody")[0]; M.ngeom = b.I("ngeom")[0];
+  M.npair = b.I("npair")[0]; M.njnt = b.I("narm")[0]; M.nfree = b.I("nfree")[0]; M.neq = b.I("neq")[0];
+  int nvert = b.I("nvert")[0];
+  if (M.nq > TQ || M.nv > TV || M.nu > TU || M.nbody > TB || M.ngeom > TGEOM || M.njnt > TJ || M.neq > TE || M.nq < 0 || M.nv < 0 || M.nbody < 1)
+    return fail("model dimensions outside the general-tree build (32 bodies, 32 dofs, 16 actuators, 128 geoms)");
+  size_t nb = M.nbody, ng = M.ngeom, nv = M.nv, nj = M.njnt, nu = M.nu, ne = M.neq, np = M.npair;
+  struct Need { const char* name; size_t count; };
+  const Need arrays[] = {
+    {"body_parent", nb}, {"body_jnttype", nb}, {"body_qposadr", nb}, {"body_dofadr", nb}, {"body_pos", 3 * nb}, {"body_quat", 4 * nb}, {"body_ipos", 3 * nb},
+    {"body_iquat", 4 * nb}, {"body_mass", nb}, {"body_inertia", 3 * nb}, {"body_invweight0", 2 * nb}, {"arm_body", nj}, {"dof_body", nv}, {"dof_armature", nv},
+    {"dof_damping", nv}, {"dof_frictionloss", nv}, {"dof_invweight0", nv}, {"dof_solref", 2 * nj}, {"dof_solimp", 5 * nj}, {"jnt_axis", 3 * nj}, {"jnt_range", 2 * nj},
+    {"jnt_limited", nj}, {"jnt_solref", 2 * nj}, {"jnt_solimp", 5 * nj}, {"jnt_actfrclimited", nj}, {"jnt_actfrcrange", 2 * nj}, {"act_dof", nu}, {"act_gain", nu},
+    {"act_bias", 3 * nu}, {"act_ctrlrange", 2 * nu}, {"act_forcerange", 2 * nu}, {"act_ctrllimited", nu}, {"act_forcelimited", nu}, {"eq_dof", 2 * ne},
+    {"eq_qposadr", 2 * ne}, {"eq_polycoef", 5 * ne}, {"eq_solref", 2 * ne}, {"eq_solimp", 5 * ne}, {"opt_gravity", 3}, {"geom_type", ng}, {"geom_body", ng},
+    {"geom_condim", ng}, {"geom_vertadr", ng}, {"geom_vertnum", ng}, {"geom_pos", 3 * ng}, {"geom_quat", 4 * ng}, {"geom_size", 3 * ng}, {"geom_friction", 3 * ng},
+    {"geom_solref", 2 * ng}, {"geom_solimp", 5 * ng}, {"geom_center", 3 * ng}, {"geom_aabb", 6 * ng}, {"geom_solmix", ng}, {"geom_priority", ng}, {"geom_rbound", ng},
+    {"geom_margin", ng}, {"geom_gap", ng}, {"mesh_vert", 3 * (size_t)nvert}, {"pair_geom", 2 * np}};
+  for (const Need& a : arrays) if (b.count(a.name) < a.count) return fail(std::string("blob entry missing or too short: ") + a.name);
+  auto in_range = [&](const char* name, size_t limit) { for (int v : b.I(name)) if (v < 0 || (size_t)v >= limit) return false; return true; };
+  if (!in_range("body_parent", nb) || !in_range("geom_body", nb) || !in_range("pair_geom", ng) || !in_range("arm_body", nb) || !in_range("dof_body", nb) ||
+      !in_range("act_dof", nv) || !in_range("eq_dof", nv) || !in_range("eq_qposadr", M.nq)) return fail("blob index array out of range");
+  auto gva = b.I("geom_vertadr"), gvn = b.I("geom_vertnum");
+  for (size_t g = 0; g < ng; g++) if (gvn[g] > 0 && (gva[g] < 0 || (size_t)gva[g] + (size_t)gvn[g] > (size_t)nvert)) return fail("geom vertex range outside mesh_vert");
+  for (float v : b.F("geom_margin")) if (v != 0.f) return fail("geom margin must be 0");
+  for (float v : b.F("geom_gap")) if (v != 0.f) return fail("geom gap must be 0");
+
+  M.elliptic = b.I("opt_cone_elliptic")[0]; M.iterations = b.I("opt_iterations")[0];
+  M.dt = b.F("opt_timestep")[0]; M.impratio = b.F("opt_impratio")[0]; M.tolerance = b.F("opt_tolerance")[0]; M.meaninertia = b.F("stat_meaninertia")[0];
+  auto grav = b.F("opt_gravity"); for (int k = 0; k < 3; k++) M.grav[k] = grav[k];
+  auto parent = b.I("body_parent"), jt = b.I("body_jnttype"), qadr = b.I("body_qposadr"), dadr = b.I("body_dofadr"), armb = b.I("arm_body");
+  auto bpos = b.F("body_pos"), bquat = b.F("body_quat"), ipos = b.F("body_ipos"), iquat = b.F("body_iquat"), mass = b.F("body_mass"), inertia = b.F("body_inertia"),
+       invw = b.F("body_invweight0");
+  M.maxdepth = 0;
+  for (int i = 0; i < M.nbody; i++) {
+    if (i > 0 && parent[i] >= i) return fail("bodies must be numbered parents first");
+    M.body_parent[i] = parent[i]; M.body_jnttype[i] = jt[i]; M.body_qposadr[i] = qadr[i]; M.body_dofadr[i] = dadr[i]; M.body_jnt[i] = -1;
+    M.body_depth[i] = i == 0 ? 0 : M.body_depth[parent[i]] + 1;
+    M.body_anc[i] = (i == 0 ? 0u : M.body_anc[parent[i]]) | (1u << i);
+    M.body_dofs[i] = i == 0 ? 0u : M.body_dofs[parent[i]];
+    if (M.body_depth[i] > M.maxdepth) M.maxdepth = M.body_depth[i];
+    for (int k = 0; k < 3; k++) { M.body_pos[i][k] = bpos[3 * i + k]; M.body_ipos[i][k] = ipos[3 * i + k]; M.body_inertia[i][k] = inertia[3 * i + k]; }
+    for (int k = 0; k < 4; k++) { M.body_quat[i][k] = bquat[4 * i + k]; M.body_iquat[i][k] = iquat[4 * i + k]; }
+    M.body_mass[i] = mass[i]; M.body_invweight0[i][0] = invw[2 * i]; M.body_invweight0[i][1] = invw[2 * i + 1];
+    int ndof = jt[i] == TJ_FREE ? 6 : (jt[i] == TJ_HINGE || jt[i] == TJ_SLIDE ? 1 : 0);
+    if (ndof && (dadr[i] < 0 || dadr[i] + ndof > M.nv)) return fail("body dof address out of range");
+    if (ndof && (qadr[i] < 0 || qadr[i] + (ndof == 6 ? 7 : 1) > M.nq)) return fail("body qpos address out of range");
+    for (int k = 0; k < ndof; k++) M.body_dofs[i] |= 1u << (dadr[i] + k);
+  }
+  auto dbody = b.I("dof_body");
+  auto arma = b.F("dof_armature"), damp = b.F("dof_damping"), floss = b.F("dof_frictionloss"), dinv = b.F("dof_invweight0"), dsr = b.F("dof_solref"), dsi = b.F("dof_solimp");
+  auto jaxis = b.F("jnt_axis"), jrange = b.F("jnt_range"), jsr = b.F("jnt_solref"), jsi = b.F("jnt_solimp"), jfr = b.F("jnt_actfrcrange");
+  auto jlim = b.I("jnt_limited"), jfl = b.I("jnt_actfrclimited");
+  for (int j = 0; j < M.njnt; j++) {
+    int body = armb[j];
+    if (jt[body] != TJ_HINGE && jt[body] != TJ_SLIDE) return fail("arm_body entry without a one-dof joint");
+    M.jnt_body[j] = body; M.body_jnt[body] = j; M.jnt_limited[j] = jlim[j]; M.jnt_actfrclimited[j] = jfl[j];
+    for (int k = 0; k < 3; k++) M.jnt_axis[j][k] = jaxis[3 * j + k];
+    for (int k = 0; k < 2; k++) { M.jnt_range[j][k] = jrange[2 * j + k]; M.jnt_solref[j][k] = jsr[2 * j + k]; M.jnt_actfrcrange[j][k] = jfr[2 * j + k]; }
+    for (int k = 0; k < 5; k++) M.jnt_solimp[j][k] = jsi[5 * j + k];
+  }
+  M.nfric = 0; M.any_damping = 0;
+  for (int d = 0; d < M.nv; d++) {
+    int body = dbody[d];
+    M.dof_body[d] = body; M.dof_jnt[d] = M.body_jnt[body];
+    M.dof_armature[d] = arma[d]; M.dof_damping[d] = damp[d]; M.dof_frictionloss[d] = floss[d]; M.dof_invweight0[d] = dinv[d];
+    if (damp[d] > 0.f) M.any_damping = 1;
+    int j = M.dof_jnt[d];
+    M.dof_solref[d][0] = j >= 0 ? dsr[2 * j] : 0.02f; M.dof_solref[d][1] = j >= 0 ? dsr[2 * j + 1] : 1.f;
+    const float defimp[5] = {0.9f, 0.95f, 0.001f, 0.5f, 2.f};
+    for (int k = 0; k < 5; k++) M.dof_solimp[d][k] = j >= 0 ? dsi[5 * j + k] : defimp[k];
+    if (floss[d] > 0.f) { if (M.nfric >= TFR) return fail("too many dofs with frictionloss"); M.fric_dof[M.nfric++] = d; }
+  }
+  auto adof = b.I("act_dof"), acl = b.I("act_ctrllimited"), afl = b.I("act_forcelimited");
+  auto again = b.F("act_gain"), abias = b.F("act_bias"), acr = b.F("act_ctrlrange"), afr = b.F("act_forcerange");
+  for (int a = 0; a < M.nu; a++) {
+    M.act_dof[a] = adof[a]; M.act_ctrllimited[a] = acl[a]; M.act_forcelimited[a] = afl[a]; M.act_gain[a] = again[a];
+    int body = dbody[adof[a]];
+    if (jt[body] == TJ_FREE) return fail("actuator on a free body");
+    M.act_qposadr[a] = qadr[body];
+    for (int k = 0; k < 3; k++) M.act_bias[a][k] = abias[3 * a + k];
+    for (int k = 0; k < 2; k++) { M.act_ctrlrange[a][k] = acr[2 * a + k]; M.act_forcerange[a][k] = afr[2 * a + k]; }
+    for (int a2 = 0; a2 < a; a2++) if (adof[a2] == adof[a]) return fail("two actuators on one dof");
+  }
+  auto edof = b.I("eq_dof"), eqa = b.I("eq_qposadr");
+  auto epc = b.F("eq_polycoef"), esr = b.F("eq_solref"), esi = b.F("eq_solimp");
+  for (int e = 0; e < M.neq; e++) {
+    for (int k = 0; k < 2; k++) { M.eq_dof[e][k] = edof[2 * e + k]; M.eq_qposadr[e][k] = eqa[2 * e + k]; M.eq_solref[e][k] = esr[2 * e + k]; }
+    for (int k = 0; k < 5; k++) { M.eq_polycoef[e][k] = epc[5 * e + k]; M.eq_solimp[e][k] = esi[5 * e + k]; }
+  }
+  if (M.neq + M.nfric > 32) return fail("too many scalar constraint rows");
+
+  // geometry: the tables the shared narrowphase reads (DevModel), every geom relative to its body
+  DevModel& G = s->hg;
+  G.ngeom = M.ngeom; G.npair = M.npair; G.nvert = nvert; G.iterations = M.iterations; G.mpr_iter = b.I("opt_mpr_iterations")[0];
+  G.dt = M.dt; G.mpr_tol = b.F("opt_mpr_tolerance")[0]; G.impratio = M.impratio; G.tolerance = M.tolerance; G.meaninertia = M.meaninertia;
+  auto gquat = b.F("geom_quat");
+  std::vector<float> gmat(9 * ng);
+  for (size_t g = 0; g < ng; g++) tq2m(&gmat[9 * g], &gquat[4 * g]);
+  auto mv = b.F("mesh_vert");
+  std::vector<float> vx(nvert), vy(nvert), vz(nvert);
+  for (int i = 0; i < nvert; i++) { vx[i] = mv[3 * i]; vy[i] = mv[3 * i + 1]; vz[i] = mv[3 * i + 2]; }
+  auto gtype = b.I("geom_type"), pairs = b.I("pair_geom");
+  std::vector<unsigned int> packed(np);
+  for (size_t p = 0; p < np; p++) {
+    int g1 = pairs[2 * p], g2 = pairs[2 * p + 1];
+    if (gtype[g1] > gtype[g2]) std::swap(g1, g2);
+    packed[p] = (unsigned)g1 | ((unsigned)g2 << 8) | (gtype[g1] == G_PLANE ? 1u << 16 : 0u);
+  }
+  bool ok = t_upload(s, gtype, &G.geom_type) && t_upload(s, b.I("geom_body"), &G.geom_dyn) && t_upload(s, b.I("geom_condim"), &G.geom_condim) &&
+            t_upload(s, gva, &G.geom_vertadr) && t_upload(s, gvn, &G.geom_vertnum) && t_upload(s, b.F("geom_pos"), &G.geom_pos) && t_upload(s, gmat, &G.geom_mat) &&
+            t_upload(s, b.F("geom_size"), &G.geom_size) && t_upload(s, b.F("geom_friction"), &G.geom_friction) && t_upload(s, b.F("geom_solref"), &G.geom_solref) &&
+            t_upload(s, b.F("geom_solimp"), &G.geom_solimp) && t_upload(s, b.F("geom_center"), &G.geom_center) && t_upload(s, b.F("geom_aabb"), &G.geom_aabb) &&
+            t_upload(s, b.F("geom_rbound"), &G.geom_rbound) && t_upload(s, vx, &G.vx) && t_upload(s, vy, &G.vy) && t_upload(s, vz, &G.vz) &&
+            t_upload(s, pairs, &G.pair) && t_upload(s, packed, &G.pair_packed) && t_upload(s, b.I("geom_body"), &M.geom_body) &&
+            t_upload(s, b.F("geom_solmix"), &M.geom_solmix) && t_upload(s, b.I("geom_priority"), &M.geom_priority);
+  if (!ok) return SO101_ERR_HIP;
+  void* p = nullptr;
+  if (!t_ok(s, hipMalloc(&p, sizeof(TreeModel)), "hipMalloc(TreeModel)")) return SO101_ERR_HIP;
+  s->owned.push_back(p); s->dm = (TreeModel*)p;
+  if (!t_ok(s, hipMemcpy(p, &M, sizeof(TreeModel), hipMemcpyHostToDevice), "hipMemcpy(TreeModel)")) return SO101_ERR_HIP;
+  if (!t_ok(s, hipMalloc(&p, sizeof(DevModel)), "hipMalloc(DevModel)")) return SO101_ERR_HIP;
+  s->owned.push_back(p); s->dg = (DevModel*)p;
+  if (!t_ok(s, hipMemcpy(p, &G, sizeof(DevModel), hipMemcpyHostToDevice), "hipMemcpy(DevModel)")) return SO101_ERR_HIP;
+  return SO101_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int so101_tree_create(const void* blob, size_t bytes, int n_envs, int hip_device, so101_tree** out) {
+  if (!out) return SO101_ERR_ARG;
+  *out = nullptr;
+  if (!blob || n_envs <= 0) { g_tree_error = "so101_tree_create: bad argument"; return SO101_ERR_ARG; }
+  BlobView b;
+  if (!b.parse(blob, bytes, g_tree_error)) return SO101_ERR_MODEL;
+  so101_tree* s = new so101_tree();
+  s->n_envs = n_envs; s->device = hip_device;
+  int rc = SO101_OK;
+  if (!t_ok(s, hipSetDevice(hip_device), "hipSetDevice")) rc = SO101_ERR_HIP;
+  if (rc == SO101_OK) rc = tree_build(s, b);
+  if (rc == SO101_OK) {
+    void* p = nullptr;
+    if (!t_ok(s, hipMalloc(&p, (size_t)n_envs * TROW * TJS * sizeof(float)), "hipMalloc(J)")) rc = SO101_ERR_HIP;
+    else { s->owned.push_back(p); s->buf.J = (float*)p; }
+  }
+  if (rc == SO101_OK) {
+    void* p = nullptr;
+    if (!t_ok(s, hipMalloc(&p, (size_t)n_envs * 8 * sizeof(int)), "hipMalloc(diag)")) rc = SO101_ERR_HIP;
+    else { s->owned.push_back(p); s->buf.diag = (int*)p; (void)hipMemset(p, 0, (size_t)n_envs * 8 * sizeof(int)); }
+  }
+  if (rc != SO101_OK) { g_tree_error = s->err; for (void* p : s->owned) (void)hipFree(p); delete s; return rc; }
+  s->iterations = s->hm.iterations; s->tolerance = s->hm.tolerance;
+  *out = s;
+  return SO101_OK;
+}
+
+void so101_tree_destroy(so101_tree* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  for (void* p : s->owned) (void)hipFree(p);
+  delete s;
+}
+
+const char* so101_tree_last_error(const so101_tree* s) { return s ? s->err.c_str() : g_tree_error.c_str(); }
+
+int so101_tree_dims(const so101_tree* s, int* dims /* nq nv nu nbody ngeom debug_dim max_contacts */) {
+  if (!s || !dims) return SO101_ERR_ARG;
+  dims[0] = s->hm.nq; dims[1] = s->hm.nv; dims[2] = s->hm.nu; dims[3] = s->hm.nbody; dims[4] = s->hm.ngeom; dims[5] = TDBG_DIM; dims[6] = TCON;
+  return SO101_OK;
+}
+
+int so101_tree_bind_state(so101_tree* s, float* qpos, float* qvel, float* ctrl, float* warmstart) {
+  if (!s || !qpos || !qvel || !ctrl || !warmstart) { if (s) s->err = "so101_tree_bind_state: NULL buffer"; return SO101_ERR_ARG; }
+  s->buf.qpos = qpos; s->buf.qvel = qvel; s->buf.ctrl = ctrl; s->buf.warm = warmstart;
+  s->bound = true;
+  return SO101_OK;
+}
+
+int so101_tree_configure(so101_tree* s, int solver_iterations, float solver_tolerance) {
+  if (!s) return SO101_ERR_ARG;
+  s->iterations = solver_iterations > 0 ? solver_iterations : s->hm.iterations;
+  s->tolerance = solver_tolerance >= 0.f ? solver_tolerance : s->hm.tolerance;
+  return SO101_OK;
+}
+
+int so101_tree_physics(so101_tree* s, int n_substeps, void* stream) {
+  if (!s || n_substeps < 0) return SO101_ERR_ARG;
+  if (!s->bound) { s->err = "so101_tree_physics before so101_tree_bind_state"; return SO101_ERR_STATE; }
+  (void)hipSetDevice(s->device);
+  hipLaunchKernelGGL(k_tree_physics, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, s->dg, s->buf, s->n_envs, n_substeps, s->iterations, s->tolerance);
+  return t_ok(s, hipGetLastError(), "k_tree_physics") ? SO101_OK : SO101_ERR_HIP;
+}
+
+int so101_tree_debug_forward(so101_tree* s, float* out, void* stream) {
+  if (!s || !out) return SO101_ERR_ARG;
+  if (!s->bound) { s->err = "so101_tree_debug_forward before so101_tree_bind_state"; return SO101_ERR_STATE; }
+  (void)hipSetDevice(s->device);
+  hipLaunchKernelGGL(k_tree_forward, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, s->dg, s->buf, s->n_envs, s->iterations, s->tolerance, out);
+  return t_ok(s, hipGetLastError(), "k_tree_forward") ? SO101_OK : SO101_ERR_HIP;
+}
+
+int so101_tree_get_diag(so101_tree* s, int* out /* [n_envs][8] device or host-visible memory */, void* stream) {
+  if (!s || !out) return SO101_ERR_ARG;
+  (void)hipSetDevice(s->device);
+  return t_ok(s, hipMemcpyAsync(out, s->buf.diag, (size_t)s->n_envs * 8 * sizeof(int), hipMemcpyDefault, (hipStream_t)stream), "hipMemcpyAsync(diag)") ? SO101_OK : SO101_ERR_HIP;
+}
+
+}  // extern "C"

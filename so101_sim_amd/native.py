@@ -32,6 +32,8 @@ EXPORTS = (
     "so101_version", "so101_max_contacts", "so101_create", "so101_destroy", "so101_default_config",
     "so101_configure", "so101_bind_state", "so101_bind_physics_state", "so101_set_reset_pool", "so101_compute_settled", "so101_set_settled_store", "so101_reset", "so101_settle", "so101_begin_episode", "so101_step", "so101_physics", "so101_reward",
     "so101_get_returns", "so101_get_diag", "so101_get_events", "so101_debug_forward", "so101_debug_candidates", "so101_debug_stages", "so101_get_info", "so101_debug_chain_stats", "so101_last_error",
+    "so101_tree_create", "so101_tree_destroy", "so101_tree_dims", "so101_tree_bind_state", "so101_tree_configure", "so101_tree_physics",
+    "so101_tree_debug_forward", "so101_tree_get_diag", "so101_tree_last_error",
 )
 
 
@@ -214,3 +216,67 @@ class Sim:
 
     def debug_forward(self, out, stream=0):
         self._check(self.L.so101_debug_forward(self.h, out, stream), "so101_debug_forward")
+
+
+TREE_DBG = dict(COUNTS=0, BIAS=8, QSM=40, QACC=72, XPOS=104, M=200, CON=1224, FORCE=1864)
+
+
+class TreeSim:
+    """Handle of the general-tree engine (include/so101.h, so101_tree_*): the ALOHA scenes.  Array arguments are raw device
+    addresses (ints), state arrays are [dim][n_envs] float32."""
+
+    def __init__(self, blob_f32: bytes, n_envs: int, device: int = 0, lib_path: str | None = None):
+        self.L = load_library(lib_path)
+        L = self.L
+        L.so101_tree_create.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.so101_tree_destroy.argtypes = [C.c_void_p]
+        L.so101_tree_destroy.restype = None
+        L.so101_tree_dims.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.so101_tree_bind_state.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.so101_tree_configure.argtypes = [C.c_void_p, C.c_int, C.c_float]
+        L.so101_tree_physics.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.so101_tree_debug_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.so101_tree_get_diag.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.so101_tree_last_error.argtypes = [C.c_void_p]
+        L.so101_tree_last_error.restype = C.c_char_p
+        self.n_envs = int(n_envs)
+        h = C.c_void_p()
+        rc = L.so101_tree_create(blob_f32, len(blob_f32), self.n_envs, int(device), C.byref(h))
+        if rc != 0:
+            msg = L.so101_tree_last_error(None)
+            raise RuntimeError(f"so101_tree_create failed ({rc}): {msg.decode() if msg else '?'}")
+        self.h = h
+        d = (C.c_int * 7)()
+        self._check(L.so101_tree_dims(h, d), "so101_tree_dims")
+        self.nq, self.nv, self.nu, self.nbody, self.ngeom, self.debug_dim, self.max_contacts = list(d)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.so101_tree_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.L.so101_tree_last_error(self.h)
+            raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+
+    def bind(self, qpos, qvel, ctrl, warm):
+        self._check(self.L.so101_tree_bind_state(self.h, qpos, qvel, ctrl, warm), "so101_tree_bind_state")
+
+    def configure(self, solver_iterations: int = 0, solver_tolerance: float = -1.0):
+        self._check(self.L.so101_tree_configure(self.h, int(solver_iterations), float(solver_tolerance)), "so101_tree_configure")
+
+    def physics(self, n_substeps: int, stream: int = 0):
+        self._check(self.L.so101_tree_physics(self.h, int(n_substeps), stream), "so101_tree_physics")
+
+    def debug_forward(self, out, stream: int = 0):
+        self._check(self.L.so101_tree_debug_forward(self.h, out, stream), "so101_tree_debug_forward")
+
+    def get_diag(self, out, stream: int = 0):
+        self._check(self.L.so101_tree_get_diag(self.h, out, stream), "so101_tree_get_diag")

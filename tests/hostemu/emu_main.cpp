@@ -13,3 +13,4 @@ thread_local EmuBlock* emu_blk;
 #include "../../so101_sim_amd/csrc/tu_pipe_merged.hip"
 #include "../../so101_sim_amd/csrc/tu_pgs_a.hip"
 #include "../../so101_sim_amd/csrc/tu_pgs_b.hip"
+#include "../../so101_sim_amd/csrc/tu_tree.hip"

@@ -52,7 +52,7 @@ using std::min;
 typedef int hipError_t;
 typedef void* hipStream_t;
 enum { hipSuccess = 0 };
-enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
+enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? 0 : 1; }
 inline hipError_t hipFree(void* p) { free(p); return 0; }

@@ -197,3 +197,76 @@ class ArraySim:
                             xpos=r[D["XPOS"]:D["XPOS"] + 24].reshape(8, 3), contacts=cons,
                             rowf=r[D["ROWF"]:D["ROWF"] + 12], reward=r[D["REWARD"]]))
         return out
+
+
+class TreeArraySim:
+    """The general-tree engine (so101_tree_*, the ALOHA scenes) behind the same two backends."""
+
+    def __init__(self, blob_f32: bytes, n_envs: int, backend: str = "gpu"):
+        self.N, self.backend = n_envs, backend
+        if backend == "gpu":
+            import torch
+            self.torch = torch
+            self.dev = torch.device("cuda:0")
+            self.sim = native.TreeSim(blob_f32, n_envs, device=0)
+            z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=self.dev)
+            i32 = torch.int32
+        else:
+            self.sim = native.TreeSim(blob_f32, n_envs, device=0, lib_path=build_emu())
+            z = lambda *s, dt=np.float32: np.zeros(s, dtype=dt)
+            i32 = np.int32
+        s = self.sim
+        self.qpos, self.qvel, self.ctrl, self.warm = z(s.nq, n_envs), z(s.nv, n_envs), z(s.nu, n_envs), z(s.nv, n_envs)
+        self.dbg = z(n_envs, s.debug_dim)
+        self.diag = z(n_envs, 8, dt=i32)
+        s.bind(self.ptr(self.qpos), self.ptr(self.qvel), self.ptr(self.ctrl), self.ptr(self.warm))
+
+    def ptr(self, a):
+        return a.data_ptr() if self.backend == "gpu" else a.ctypes.data
+
+    def stream(self):
+        return self.torch.cuda.current_stream().cuda_stream if self.backend == "gpu" else 0
+
+    def _put(self, dst, src):
+        src = np.asarray(src, dtype=np.float32).reshape(dst.shape)
+        if self.backend == "gpu":
+            dst.copy_(self.torch.from_numpy(src))
+        else:
+            dst[...] = src
+
+    def _get(self, a):
+        if self.backend == "gpu":
+            self.torch.cuda.synchronize()
+            return a.cpu().numpy()
+        return a.copy()
+
+    def set_state(self, qpos=None, qvel=None, ctrl=None, warm=None):
+        for dst, src in ((self.qpos, qpos), (self.qvel, qvel), (self.ctrl, ctrl), (self.warm, warm)):
+            if src is not None:
+                self._put(dst, src)
+
+    def get_state(self):
+        return self._get(self.qpos).astype(np.float64), self._get(self.qvel).astype(np.float64), self._get(self.warm).astype(np.float64)
+
+    def physics(self, nsub=10):
+        self.sim.physics(nsub, self.stream())
+
+    def get_diag(self):
+        self.sim.get_diag(self.ptr(self.diag), self.stream())
+        return self._get(self.diag)
+
+    def debug_forward(self):
+        self.sim.debug_forward(self.ptr(self.dbg), self.stream())
+        d = self._get(self.dbg).astype(np.float64)
+        D, nv, nb = native.TREE_DBG, self.sim.nv, self.sim.nbody
+        out = []
+        for e in range(self.N):
+            r = d[e]
+            ncon = int(r[0])
+            cons = [dict(pos=r[D["CON"] + 10 * k: D["CON"] + 10 * k + 3], normal=r[D["CON"] + 10 * k + 3: D["CON"] + 10 * k + 6],
+                         dist=r[D["CON"] + 10 * k + 6], geom1=int(r[D["CON"] + 10 * k + 7]), geom2=int(r[D["CON"] + 10 * k + 8]),
+                         dim=int(r[D["CON"] + 10 * k + 9]), fn=r[D["FORCE"] + k]) for k in range(ncon)]
+            out.append(dict(ncon=ncon, nrow=int(r[1]), iters=int(r[2]), ncand=int(r[3]), flags=int(r[4]), nscalar=int(r[5]),
+                            bias=r[D["BIAS"]:D["BIAS"] + nv], qacc_smooth=r[D["QSM"]:D["QSM"] + nv], qacc=r[D["QACC"]:D["QACC"] + nv],
+                            xpos=r[D["XPOS"]:D["XPOS"] + 3 * nb].reshape(nb, 3), M=r[D["M"]:D["M"] + 32 * 32].reshape(32, 32)[:nv, :nv], contacts=cons))
+        return out
