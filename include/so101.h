@@ -274,6 +274,30 @@ int so101_tree_debug_forward(so101_tree* sim, float* out, void* hip_stream);
 /* out[n_envs][8] int32 of the last so101_tree_physics: contacts, rows, solver iterations, candidates, flags (1 candidate
  * overflow, 2 contact overflow, 8 physics diverged) */
 int so101_tree_get_diag(so101_tree* sim, int32_t* out, void* hip_stream);
+/* ---- env layer of the hand-over scenes on this engine (HandOverBanana / HandOverPen of the reference's task_suite.py:60-61):
+ * before_step with the gripper unit conversion (aloha2_task.py:316-349), n_substeps of physics, the observables of
+ * aloha2_task.py:386-444 with their 0.1 s delay, the overlap reward and termination of hand_over.py:246-284 / aloha2_task.py:355-367,
+ * reset = home pose + prop placement + settle (aloha2_task.py:369-383, hand_over.py:208-236).  Caller-owned per-env arrays
+ * (device, env-fastest): ring_pos [5][npos][n_envs], ring_vel [5][nvel][n_envs] (npos = nu = 14, nvel = 16 for ALOHA), ep_return,
+ * step_count, episode.  Observation row of so101_tree_step, so101_tree_obs_dim() = 3 npos + 2 nvel floats per env:
+ *   joints_pos (delayed 5 control steps) | joints_vel (delayed) | undelayed_joints_pos | undelayed_joints_vel | commanded_joints_pos
+ * step_type 0 FIRST (the call after a LAST resets the env and ignores the action), 1 MID, 2 LAST; a physics error ends the
+ * episode with reward 0 and discount 0.  Reset happens inside the step call (no prefetch yet). */
+typedef struct {
+  int n_substeps;            /* physics steps per control step (10) */
+  int last_step;             /* control step on which the time limit ends the episode */
+  int settle_max_substeps;   /* settle budget of a reset (1000) */
+  int terminate_on_success;
+  int solver_iterations;     /* <= 0: the model's */
+  float solver_tolerance;    /* < 0: the model's */
+  uint64_t seed, env_id_base;
+} so101_tree_config;
+int so101_tree_obs_dim(const so101_tree* sim);
+int so101_tree_bind_env(so101_tree* sim, float* ring_pos, float* ring_vel, float* ep_return, int32_t* step_count, int32_t* episode);
+int so101_tree_configure_env(so101_tree* sim, const so101_tree_config* cfg);
+int so101_tree_reset(so101_tree* sim, const uint8_t* mask, void* hip_stream);
+int so101_tree_step(so101_tree* sim, const float* action /*[n_envs][nu]*/, float* obs, float* reward, float* discount, uint8_t* step_type,
+                    void* hip_stream);
 const char* so101_tree_last_error(const so101_tree* sim);
 
 #ifdef __cplusplus

@@ -135,7 +135,7 @@ class Oracle:
 
     # -- physics
     def substeps(self, n=10, freeze_arm=False):
-        self.L.orc_substeps(self.h, int(n), int(freeze_arm))
+        return bool(self.L.orc_substeps(self.h, int(n), int(freeze_arm)))
 
     def forward(self, freeze_arm=False):
         self.L.orc_forward(self.h, int(freeze_arm))

@@ -1618,7 +1618,7 @@ void orc_get_state(const orc_sim* s, double* q, double* v, double* w) {
   if (w) std::copy(s->warm.begin(), s->warm.end(), w);
 }
 void orc_set_ctrl(orc_sim* s, const double* c) { std::copy(c, c + s->m.nu, s->ctrl.begin()); }
-void orc_substeps(orc_sim* s, int n, int fz) { substeps(s, n, fz != 0); }
+int orc_substeps(orc_sim* s, int n, int fz) { return substeps(s, n, fz != 0) ? 1 : 0; }
 void orc_forward(orc_sim* s, int fz) { forward(s, fz != 0); }
 int orc_ncon(const orc_sim* s) { return (int)s->con.size(); }
 int orc_nefc(const orc_sim* s) { return s->nefc; }

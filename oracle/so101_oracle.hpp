@@ -63,8 +63,9 @@ void orc_set_state(orc_sim*, const double* qpos, const double* qvel, const doubl
 void orc_get_state(const orc_sim*, double* qpos, double* qvel, double* warm);
 void orc_set_ctrl(orc_sim*, const double* ctrl);
 
-// physics: nsub x { forward ; Euler }.  freeze_arm != 0 holds the hinge dofs static (settle phase)
-void orc_substeps(orc_sim*, int nsub, int freeze_arm);
+// physics: nsub x { forward ; Euler }.  freeze_arm != 0 holds the hinge dofs static (settle phase).  Returns 1 when the
+// physics diverged (mj_check*: the state has been reset to qpos0)
+int orc_substeps(orc_sim*, int nsub, int freeze_arm);
 // forward only (fills derived quantities below)
 void orc_forward(orc_sim*, int freeze_arm);
 

@@ -877,4 +877,135 @@ DEV void euler(const TreeModel* tm, TreeLDS& L) {
   wave_sync();
 }
 
+
+// ================================================================== env layer of the ALOHA hand-over tasks
+// (so101_sim/tasks/base/aloha2_task.py:279-444 action / observables / reset, so101_sim/tasks/hand_over.py:36-56,246-349
+// placement and the overlap reward; the SO100 counterpart is so101_env.hpp)
+}  // namespace tree
+
+#define T_RING 5               // joints_pos / joints_vel delay: 0.1 s = 5 control steps
+struct TreeTask {
+  int npos, nvel, obj_body, con_body, nbox, n_substeps, last_step, settle_max, terminate_on_success, n_envs, iterations, pad;
+  float tolerance, grip[6];    // gripper limits: sim_qpos open, close, sim_ctrl open, close, follower open, close
+  int obs_qposadr[TU], obs_is_gripper[TU], act_is_gripper[TU];
+  float box_pos[2][3], box_half[2][3], obj_bvh[6];
+  float obj_lo[3], obj_hi[3], obj_yaw[2], con_lo[3], con_hi[3], home_qpos[TQ], home_ctrl[TU];
+  unsigned long long seed, env_id_base;
+};
+struct TreeEnvBuffers { float *ring_pos, *ring_vel, *ep_return; int *step_count, *episode; unsigned char* need_reset; };
+
+namespace tree {
+
+DEV float convert_gripper(float v, float from_open, float from_close, float to_open, float to_close) {
+  return (v - from_close) / (from_open - from_close) * (to_open - to_close) + to_close;
+}
+
+// requires the kinematics of the current state in LDS
+DEV float task_reward(const TreeModel* tm, const TreeTask& T, const TreeLDS& L) {
+  int ob = T.obj_body, cb = T.con_body;
+  const float* vo = &L.qvel[tm->body_dofadr[ob]]; const float* vc = &L.qvel[tm->body_dofadr[cb]];
+  if (fmaxf(fabsf(vo[0]), fmaxf(fabsf(vo[1]), fabsf(vo[2]))) >= 1e-3f) return 0.f;        // any_props_moving: linear part only
+  if (fmaxf(fabsf(vc[0]), fmaxf(fabsf(vc[1]), fabsf(vc[2]))) >= 1e-3f) return 0.f;
+  BoxW o;
+  mat2quat(o.quat, L.ximat[ob]);
+  float ctr[3]; rotvecquat(ctr, T.obj_bvh, o.quat);
+#pragma unroll
+  for (int i = 0; i < 3; i++) { o.pos[i] = ctr[i] + L.xipos[ob][i]; o.half[i] = T.obj_bvh[3 + i]; }
+  float cq[4] = {L.xquat[cb][0], L.xquat[cb][1], L.xquat[cb][2], L.xquat[cb][3]};
+  for (int k = 0; k < T.nbox; k++) {
+    BoxW cw;
+    float r[3]; rotvecquat(r, T.box_pos[k], cq);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { cw.pos[i] = L.xpos[cb][i] + r[i]; cw.half[i] = T.box_half[k][i]; }
+    float ident[4] = {1.f, 0.f, 0.f, 0.f};
+    mulquat(cw.quat, cq, ident);
+    if (!overlap_oobb_oobb(o, cw)) return 0.f;
+  }
+  return 1.f;
+}
+
+// env.reset(): arms at the home pose, object and container placed (container by rejection, <= 20 tries), settled with the arms held
+// (aloha2_task.py:369-383, hand_over.py:208-236,340-346).  Same counter-RNG draws as the SO100 reset and the oracle.
+DEV void env_reset(const TreeModel* tm, const DevModel* gm, const TreeTask& T, TreeLDS& L, float* Jg, const TreeBuffers& B, const TreeEnvBuffers& E, int e) {
+  int lane = wave_lane(), N = T.n_envs;
+  unsigned int episode = (unsigned int)E.episode[e];
+  unsigned long long env_id = T.env_id_base + (unsigned long long)e;
+  if (lane < tm->nq) L.qpos[lane] = lane < tm->njnt ? T.home_qpos[lane] : 0.f;
+  if (lane < tm->nv) { L.qvel[lane] = 0.f; L.warm[lane] = 0.f; L.qacc[lane] = 0.f; }
+  if (lane < tm->nu) L.ctrl[lane] = T.home_ctrl[lane];
+  wave_sync();
+  int qo = tm->body_qposadr[T.obj_body], qc = tm->body_qposadr[T.con_body];
+  if (lane == 0) {
+    for (int k = 0; k < 3; k++) L.qpos[qo + k] = T.obj_lo[k] + rng_uniform(T.seed, env_id, episode, k) * (T.obj_hi[k] - T.obj_lo[k]);
+    float yaw = T.obj_yaw[0] + rng_uniform(T.seed, env_id, episode, 3) * (T.obj_yaw[1] - T.obj_yaw[0]);
+    float sn, cs; sincos_f(0.5f * yaw, &sn, &cs);
+    L.qpos[qo + 3] = cs; L.qpos[qo + 4] = 0.f; L.qpos[qo + 5] = 0.f; L.qpos[qo + 6] = sn;
+    L.qpos[qc + 3] = 1.f; L.qpos[qc + 4] = 0.f; L.qpos[qc + 5] = 0.f; L.qpos[qc + 6] = 0.f;
+  }
+  wave_sync();
+  bool placed = false;
+  for (int attempt = 0; attempt < 20 && !placed; attempt++) {
+    if (lane < 3) L.qpos[qc + lane] = T.con_lo[lane] + rng_uniform(T.seed, env_id, episode, 4 + 3 * attempt + lane) * (T.con_hi[lane] - T.con_lo[lane]);
+    wave_sync();
+    kinematics(tm, L);
+    collision(tm, gm, L);
+    bool hit = false;
+    for (int k = 0; k < L.ncon; k++) if (L.con[k].b1 == T.con_body || L.con[k].b2 == T.con_body) hit = true;
+    wave_sync();
+    placed = !hit;
+  }
+  if (!placed && lane == 0) L.flags |= 16;
+  float q0 = lane < tm->njnt ? L.qpos[lane] : 0.f;
+  // settle until |qvel| < 1e-3 and |qacc| < 1e-2 over the props' dofs
+  bool settled = T.settle_max == 0;
+  for (int k = 0; k < T.settle_max && !settled; k++) {
+    forward(tm, gm, L, Jg, T.iterations, T.tolerance);
+    euler(tm, L);
+    bool ok = true;
+    if (lane < tm->nq) ok = ok && fabsf(L.qpos[lane]) <= 1e10f;
+    if (lane < tm->nv) ok = ok && fabsf(L.qvel[lane]) <= 1e10f && fabsf(L.qacc[lane]) <= 1e10f;
+    if (wave_ballot(!ok) != 0ull) { if (lane == 0) L.flags |= 8; break; }
+    if (lane < tm->njnt) { L.qpos[lane] = q0; L.qvel[lane] = 0.f; }     // (one-dof joints come first in qpos / qvel; dm_control holds them)
+    wave_sync();
+    float mv = 0.f, ma = 0.f;
+    if (lane >= tm->njnt && lane < tm->nv) { mv = fabsf(L.qvel[lane]); ma = fabsf(L.qacc[lane]); }
+    mv = wave_max_f(mv); ma = wave_max_f(ma);
+    settled = mv < 1e-3f && ma < 1e-2f;
+  }
+  if (!settled && lane == 0) L.flags |= 32;
+  wave_sync();
+  // delay lines padded with the reset-time value (task_suite.py:154 INITIAL_VALUE)
+  if (lane < T.npos) {
+    float v = L.qpos[T.obs_qposadr[lane]];
+    if (T.obs_is_gripper[lane]) v = convert_gripper(v, T.grip[0], T.grip[1], T.grip[4], T.grip[5]);
+    for (int r = 0; r < T_RING; r++) E.ring_pos[((size_t)r * T.npos + lane) * N + e] = v;
+  }
+  if (lane < T.nvel) for (int r = 0; r < T_RING; r++) E.ring_vel[((size_t)r * T.nvel + lane) * N + e] = L.qvel[lane];
+  if (lane == 0) { E.step_count[e] = 0; E.ep_return[e] = 0.f; E.episode[e] = (int)(episode + 1u); }
+}
+
+// observation row: joints_pos (delayed) | joints_vel (delayed) | undelayed_joints_pos | undelayed_joints_vel | commanded_joints_pos
+DEV int obs_dim(const TreeTask& T) { return 3 * T.npos + 2 * T.nvel; }
+
+DEV void write_obs(const TreeTask& T, const TreeLDS& L, const TreeEnvBuffers& E, int e, int sc, bool first, float* obs) {
+  int lane = wave_lane(), N = T.n_envs, D = obs_dim(T);
+  float* o = obs + (size_t)e * D;
+  int slot = first ? 0 : (sc - 1) % T_RING;
+  if (lane < T.npos) {
+    float v = L.qpos[T.obs_qposadr[lane]], c = L.ctrl[lane];
+    if (T.obs_is_gripper[lane]) { v = convert_gripper(v, T.grip[0], T.grip[1], T.grip[4], T.grip[5]); c = convert_gripper(c, T.grip[2], T.grip[3], T.grip[4], T.grip[5]); }
+    size_t ri = ((size_t)slot * T.npos + lane) * N + e;
+    float delayed = E.ring_pos[ri];
+    if (!first) E.ring_pos[ri] = v;
+    o[lane] = delayed; o[T.npos + T.nvel + lane] = v; o[2 * T.npos + 2 * T.nvel + lane] = c;
+  }
+  if (lane < T.nvel) {
+    float v = L.qvel[lane];
+    size_t ri = ((size_t)slot * T.nvel + lane) * N + e;
+    float delayed = E.ring_vel[ri];
+    if (!first) E.ring_vel[ri] = v;
+    o[T.npos + lane] = delayed; o[2 * T.npos + T.nvel + lane] = v;
+  }
+}
+
 }  // namespace tree

@@ -64,6 +64,80 @@ __global__ void __launch_bounds__(64) k_tree_forward(const TreeModel* tm, const 
   }
 }
 
+// env.reset() of the envs whose mask byte is set (NULL: all), then the FIRST observation is what the next step call reports
+__global__ void __launch_bounds__(64) k_tree_reset(const TreeModel* tm, const DevModel* gm, TreeTask T, TreeBuffers B, TreeEnvBuffers E, const unsigned char* mask) {
+  BLOCK_SHARED(TreeLDS, L);
+  int e = blockIdx.x, lane = wave_lane(), N = T.n_envs;
+  if (mask && !mask[e]) return;
+  if (lane == 0) L.flags = 0;
+  wave_sync();
+  float* Jg = B.J + (size_t)e * TROW * TJS;
+  tree::env_reset(tm, gm, T, L, Jg, B, E, e);
+  tree::store_state(tm, L, B, e, N);
+  if (lane < tm->nu) B.ctrl[(size_t)lane * N + e] = L.ctrl[lane];
+  if (lane == 0) { E.need_reset[e] = 0; if (B.diag) { int* d = B.diag + 8 * e; d[0] = L.ncon; d[1] = L.nrow; d[2] = L.iters; d[3] = L.ncand; d[4] = L.flags; } }
+}
+
+// one control step of every env: dm_control's Environment.step - an env whose last step was LAST resets and reports FIRST
+// (the action is ignored), the others apply the action, run n_substeps and report observation, reward, discount, step type
+__global__ void __launch_bounds__(64) k_tree_step(const TreeModel* tm, const DevModel* gm, TreeTask T, TreeBuffers B, TreeEnvBuffers E, const float* action,
+                                                  float* obs, float* reward, float* discount, unsigned char* step_type) {
+  BLOCK_SHARED(TreeLDS, L);
+  int e = blockIdx.x, lane = wave_lane(), N = T.n_envs;
+  if (lane == 0) L.flags = 0;
+  wave_sync();
+  float* Jg = B.J + (size_t)e * TROW * TJS;
+  if (E.need_reset[e]) {
+    tree::env_reset(tm, gm, T, L, Jg, B, E, e);
+    tree::kinematics(tm, L);
+    tree::write_obs(T, L, E, e, 0, true, obs);
+    tree::store_state(tm, L, B, e, N);
+    if (lane < tm->nu) B.ctrl[(size_t)lane * N + e] = L.ctrl[lane];
+    if (lane == 0) { reward[e] = 0.f; discount[e] = 1.f; step_type[e] = 0; E.need_reset[e] = 0; }
+    if (lane == 0 && B.diag) { int* d = B.diag + 8 * e; d[0] = L.ncon; d[1] = L.nrow; d[2] = L.iters; d[3] = L.ncand; d[4] = L.flags; }
+    return;
+  }
+  tree::load_state(tm, L, B, e, N);
+  // before_step (aloha2_task.py:316-349): joint targets as given, grippers from follower units to the sim's ctrl range; no clipping
+  if (lane < tm->nu) {
+    float a = action[(size_t)e * tm->nu + lane];
+    if (T.act_is_gripper[lane]) a = tree::convert_gripper(a, T.grip[4], T.grip[5], T.grip[2], T.grip[3]);
+    L.ctrl[lane] = a;
+  }
+  wave_sync();
+  bool diverged = false;
+  for (int s = 0; s < T.n_substeps && !diverged; s++) {
+    tree::forward(tm, gm, L, Jg, T.iterations, T.tolerance);
+    tree::euler(tm, L);
+    bool ok = true;
+    if (lane < tm->nq) ok = ok && fabsf(L.qpos[lane]) <= 1e10f;
+    if (lane < tm->nv) ok = ok && fabsf(L.qvel[lane]) <= 1e10f && fabsf(L.qacc[lane]) <= 1e10f;
+    diverged = wave_ballot(!ok) != 0ull;
+  }
+  if (diverged) {         // mj_check*: the data is reset, dm_control ends the episode with reward 0 and discount 0
+    if (lane < tm->nq) L.qpos[lane] = 0.f;
+    if (lane < tm->nv) { L.qvel[lane] = 0.f; L.warm[lane] = 0.f; }
+    wave_sync();
+    if (lane > 0 && lane < tm->nbody && tm->body_jnttype[lane] == TJ_FREE) L.qpos[tm->body_qposadr[lane] + 3] = 1.f;
+    if (lane == 0) L.flags |= 8;
+    wave_sync();
+  }
+  int sc = E.step_count[e] + 1;
+  tree::kinematics(tm, L);
+  tree::write_obs(T, L, E, e, sc, false, obs);
+  float r = diverged ? 0.f : tree::task_reward(tm, T, L);
+  bool success = (T.terminate_on_success && r >= 1.f) || diverged, timeout = sc >= T.last_step;
+  tree::store_state(tm, L, B, e, N);
+  if (lane < tm->nu) B.ctrl[(size_t)lane * N + e] = L.ctrl[lane];
+  if (lane == 0) {
+    reward[e] = r; discount[e] = success ? 0.f : 1.f;
+    unsigned char st = (success || timeout) ? 2 : 1;
+    step_type[e] = st; E.need_reset[e] = st == 2;
+    E.step_count[e] = sc; E.ep_return[e] += r;
+    if (B.diag) { int* d = B.diag + 8 * e; d[0] = L.ncon; d[1] = L.nrow; d[2] = L.iters; d[3] = L.ncand; d[4] = L.flags; }
+  }
+}
+
 // ==================================================================================================== host side
 struct so101_tree {
   int n_envs = 0, device = 0;
@@ -72,7 +146,9 @@ struct so101_tree {
   TreeModel* dm = nullptr;
   DevModel* dg = nullptr;
   TreeBuffers buf{};
-  bool bound = false;
+  bool bound = false, env_bound = false, has_task = false;
+  TreeTask task{};
+  TreeEnvBuffers env{};
   int iterations = 0; float tolerance = 0.f;
   std::vector<void*> owned;
   std::string err;
@@ -224,6 +300,37 @@ int tree_build(so101_tree* s, const BlobView& b) {
             t_upload(s, pairs, &G.pair) && t_upload(s, packed, &G.pair_packed) && t_upload(s, b.I("geom_body"), &M.geom_body) &&
             t_upload(s, b.F("geom_solmix"), &M.geom_solmix) && t_upload(s, b.I("geom_priority"), &M.geom_priority);
   if (!ok) return SO101_ERR_HIP;
+  // task layer (hand-over scenes): absent from the bare-arm blob
+  TreeTask& T = s->task;
+  T.n_substeps = 10; T.last_step = 1 << 30; T.settle_max = 1000; T.terminate_on_success = 1;
+  s->has_task = b.count("task_object_body") >= 1 && b.I("task_object_body")[0] > 0 && b.count("task_obs_qposadr") >= 1;
+  if (s->has_task) {
+    size_t nbox = b.count("task_nbox") ? (size_t)b.I("task_nbox")[0] : 99;
+    size_t npos = b.count("task_obs_qposadr");
+    const Need tneed[] = {{"task_container_body", 1}, {"task_box_pos", 3 * nbox}, {"task_box_half", 3 * nbox}, {"task_obj_pos_lo", 3}, {"task_obj_pos_hi", 3},
+                          {"task_obj_yaw", 2}, {"task_con_pos_lo", 3}, {"task_con_pos_hi", 3}, {"task_home_ctrl", nu}, {"task_home_qpos", nj},
+                          {"task_obs_is_gripper", npos}, {"task_act_is_gripper", nu}, {"task_gripper_limits", 6}, {"body_bvh_aabb", 6 * nb}};
+    if (nbox > 2 || npos > TU || npos > 64) return fail("task dimensions out of range");
+    for (const Need& a : tneed) if (b.count(a.name) < a.count) return fail(std::string("blob entry missing or too short: ") + a.name);
+    T.obj_body = b.I("task_object_body")[0]; T.con_body = b.I("task_container_body")[0]; T.nbox = (int)nbox;
+    if (T.obj_body <= 0 || T.obj_body >= M.nbody || T.con_body <= 0 || T.con_body >= M.nbody || jt[T.obj_body] != TJ_FREE || jt[T.con_body] != TJ_FREE)
+      return fail("task bodies must be free bodies");
+    T.npos = (int)npos; T.nvel = M.njnt;
+    auto oq = b.I("task_obs_qposadr"), og = b.I("task_obs_is_gripper"), ag = b.I("task_act_is_gripper");
+    for (int k = 0; k < T.npos; k++) { if (oq[k] < 0 || oq[k] >= M.njnt) return fail("task_obs_qposadr out of range"); T.obs_qposadr[k] = oq[k]; T.obs_is_gripper[k] = og[k]; }
+    if (T.npos != M.nu) return fail("one commanded position per actuator expected");
+    for (int k = 0; k < M.nu; k++) T.act_is_gripper[k] = ag[k];
+    auto gl = b.F("task_gripper_limits"); for (int k = 0; k < 6; k++) T.grip[k] = gl[k];
+    auto bp = b.F("task_box_pos"), bh = b.F("task_box_half"), bvh = b.F("body_bvh_aabb");
+    for (int k = 0; k < T.nbox; k++) for (int i = 0; i < 3; i++) { T.box_pos[k][i] = bp[3 * k + i]; T.box_half[k][i] = bh[3 * k + i]; }
+    for (int i = 0; i < 6; i++) T.obj_bvh[i] = bvh[6 * T.obj_body + i];
+    auto lo = b.F("task_obj_pos_lo"), hi = b.F("task_obj_pos_hi"), yaw = b.F("task_obj_yaw"), clo = b.F("task_con_pos_lo"), chi = b.F("task_con_pos_hi");
+    for (int i = 0; i < 3; i++) { T.obj_lo[i] = lo[i]; T.obj_hi[i] = hi[i]; T.con_lo[i] = clo[i]; T.con_hi[i] = chi[i]; }
+    T.obj_yaw[0] = yaw[0]; T.obj_yaw[1] = yaw[1];
+    auto hq = b.F("task_home_qpos"), hc = b.F("task_home_ctrl");
+    for (int k = 0; k < M.njnt; k++) T.home_qpos[k] = hq[k];
+    for (int k = 0; k < M.nu; k++) T.home_ctrl[k] = hc[k];
+  }
   void* p = nullptr;
   if (!t_ok(s, hipMalloc(&p, sizeof(TreeModel)), "hipMalloc(TreeModel)")) return SO101_ERR_HIP;
   s->owned.push_back(p); s->dm = (TreeModel*)p;
@@ -257,6 +364,11 @@ int so101_tree_create(const void* blob, size_t bytes, int n_envs, int hip_device
     void* p = nullptr;
     if (!t_ok(s, hipMalloc(&p, (size_t)n_envs * 8 * sizeof(int)), "hipMalloc(diag)")) rc = SO101_ERR_HIP;
     else { s->owned.push_back(p); s->buf.diag = (int*)p; (void)hipMemset(p, 0, (size_t)n_envs * 8 * sizeof(int)); }
+  }
+  if (rc == SO101_OK) {
+    void* p = nullptr;
+    if (!t_ok(s, hipMalloc(&p, (size_t)n_envs), "hipMalloc(need_reset)")) rc = SO101_ERR_HIP;
+    else { s->owned.push_back(p); s->env.need_reset = (unsigned char*)p; (void)hipMemset(p, 1, (size_t)n_envs); }
   }
   if (rc != SO101_OK) { g_tree_error = s->err; for (void* p : s->owned) (void)hipFree(p); delete s; return rc; }
   s->iterations = s->hm.iterations; s->tolerance = s->hm.tolerance;
@@ -307,6 +419,44 @@ int so101_tree_debug_forward(so101_tree* s, float* out, void* stream) {
   (void)hipSetDevice(s->device);
   hipLaunchKernelGGL(k_tree_forward, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, s->dg, s->buf, s->n_envs, s->iterations, s->tolerance, out);
   return t_ok(s, hipGetLastError(), "k_tree_forward") ? SO101_OK : SO101_ERR_HIP;
+}
+
+// ---- env layer (hand-over scenes)
+int so101_tree_obs_dim(const so101_tree* s) { return s && s->has_task ? 3 * s->task.npos + 2 * s->task.nvel : 0; }
+
+int so101_tree_bind_env(so101_tree* s, float* ring_pos, float* ring_vel, float* ep_return, int32_t* step_count, int32_t* episode) {
+  if (!s || !ring_pos || !ring_vel || !ep_return || !step_count || !episode) { if (s) s->err = "so101_tree_bind_env: NULL buffer"; return SO101_ERR_ARG; }
+  if (!s->has_task) { s->err = "so101_tree_bind_env: the model carries no task (bare-arm blob)"; return SO101_ERR_STATE; }
+  s->env.ring_pos = ring_pos; s->env.ring_vel = ring_vel; s->env.ep_return = ep_return; s->env.step_count = step_count; s->env.episode = episode;
+  s->env_bound = true;
+  return SO101_OK;
+}
+
+int so101_tree_configure_env(so101_tree* s, const so101_tree_config* c) {
+  if (!s || !c) return SO101_ERR_ARG;
+  if (c->n_substeps < 1 || c->n_substeps > 1000 || c->last_step < 1 || c->settle_max_substeps < 0) { s->err = "so101_tree_configure_env: value out of range"; return SO101_ERR_ARG; }
+  TreeTask& T = s->task;
+  T.n_substeps = c->n_substeps; T.last_step = c->last_step; T.settle_max = c->settle_max_substeps; T.terminate_on_success = c->terminate_on_success;
+  T.seed = c->seed; T.env_id_base = c->env_id_base;
+  return so101_tree_configure(s, c->solver_iterations, c->solver_tolerance);
+}
+
+static TreeTask task_now(so101_tree* s) { TreeTask T = s->task; T.n_envs = s->n_envs; T.iterations = s->iterations; T.tolerance = s->tolerance; return T; }
+
+int so101_tree_reset(so101_tree* s, const uint8_t* mask, void* stream) {
+  if (!s) return SO101_ERR_ARG;
+  if (!s->bound || !s->env_bound) { s->err = "so101_tree_reset before so101_tree_bind_state / so101_tree_bind_env"; return SO101_ERR_STATE; }
+  (void)hipSetDevice(s->device);
+  hipLaunchKernelGGL(k_tree_reset, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, s->dg, task_now(s), s->buf, s->env, mask);
+  return t_ok(s, hipGetLastError(), "k_tree_reset") ? SO101_OK : SO101_ERR_HIP;
+}
+
+int so101_tree_step(so101_tree* s, const float* action, float* obs, float* reward, float* discount, uint8_t* step_type, void* stream) {
+  if (!s || !action || !obs || !reward || !discount || !step_type) { if (s) s->err = "so101_tree_step: NULL argument"; return SO101_ERR_ARG; }
+  if (!s->bound || !s->env_bound) { s->err = "so101_tree_step before so101_tree_bind_state / so101_tree_bind_env"; return SO101_ERR_STATE; }
+  (void)hipSetDevice(s->device);
+  hipLaunchKernelGGL(k_tree_step, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, s->dg, task_now(s), s->buf, s->env, action, obs, reward, discount, step_type);
+  return t_ok(s, hipGetLastError(), "k_tree_step") ? SO101_OK : SO101_ERR_HIP;
 }
 
 int so101_tree_get_diag(so101_tree* s, int* out /* [n_envs][8] device or host-visible memory */, void* stream) {

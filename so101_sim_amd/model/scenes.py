@@ -187,6 +187,14 @@ def compile_aloha_scene(object_name: str | None, assets: str | None = None,
         task_con_pos_lo=np.array([-0.18, -0.1, z]), task_con_pos_hi=np.array([-0.12, 0.1, z]),
         task_home_ctrl=np.concatenate([ALOHA_HOME_CTRL, ALOHA_HOME_CTRL]),
         task_home_qpos=np.concatenate([ALOHA_HOME_QPOS, ALOHA_HOME_QPOS]),
+        # observables and actions (aloha2_task.py:279-359,386-444): joints_pos = six arm joints and the LEFT finger of each arm,
+        # the finger in follower units; joints_vel = all sixteen joint velocities; action = ctrl with the grippers in follower units
+        task_obs_qposadr=np.array([0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13, 14], np.int32),
+        task_obs_is_gripper=np.array([0] * 6 + [1] + [0] * 6 + [1], np.int32),
+        task_act_is_gripper=np.array([0] * 6 + [1] + [0] * 6 + [1], np.int32),
+        task_gripper_limits=np.array([ALOHA_GRIPPER_LIMITS["sim_qpos"][0], ALOHA_GRIPPER_LIMITS["sim_qpos"][1],
+                                      ALOHA_GRIPPER_LIMITS["sim_ctrl"][0], ALOHA_GRIPPER_LIMITS["sim_ctrl"][1],
+                                      ALOHA_GRIPPER_LIMITS["follower"][0], ALOHA_GRIPPER_LIMITS["follower"][1]]),
     )
     out["meta"]["instruction"] = ALOHA_INSTRUCTIONS.get(object_name, "")
     out["meta"]["object_name"] = object_name

@@ -33,7 +33,8 @@ EXPORTS = (
     "so101_configure", "so101_bind_state", "so101_bind_physics_state", "so101_set_reset_pool", "so101_compute_settled", "so101_set_settled_store", "so101_reset", "so101_settle", "so101_begin_episode", "so101_step", "so101_physics", "so101_reward",
     "so101_get_returns", "so101_get_diag", "so101_get_events", "so101_debug_forward", "so101_debug_candidates", "so101_debug_stages", "so101_get_info", "so101_debug_chain_stats", "so101_last_error",
     "so101_tree_create", "so101_tree_destroy", "so101_tree_dims", "so101_tree_bind_state", "so101_tree_configure", "so101_tree_physics",
-    "so101_tree_debug_forward", "so101_tree_get_diag", "so101_tree_last_error",
+    "so101_tree_debug_forward", "so101_tree_get_diag", "so101_tree_last_error", "so101_tree_obs_dim", "so101_tree_bind_env",
+    "so101_tree_configure_env", "so101_tree_reset", "so101_tree_step",
 )
 
 
@@ -218,6 +219,11 @@ class Sim:
         self._check(self.L.so101_debug_forward(self.h, out, stream), "so101_debug_forward")
 
 
+class TreeConfig(C.Structure):
+    _fields_ = [("n_substeps", C.c_int), ("last_step", C.c_int), ("settle_max_substeps", C.c_int), ("terminate_on_success", C.c_int),
+                ("solver_iterations", C.c_int), ("solver_tolerance", C.c_float), ("seed", C.c_uint64), ("env_id_base", C.c_uint64)]
+
+
 TREE_DBG = dict(COUNTS=0, BIAS=8, QSM=40, QACC=72, XPOS=104, M=200, CON=1224, FORCE=1864)
 
 
@@ -239,6 +245,11 @@ class TreeSim:
         L.so101_tree_get_diag.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.so101_tree_last_error.argtypes = [C.c_void_p]
         L.so101_tree_last_error.restype = C.c_char_p
+        L.so101_tree_obs_dim.argtypes = [C.c_void_p]
+        L.so101_tree_bind_env.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+        L.so101_tree_configure_env.argtypes = [C.c_void_p, C.POINTER(TreeConfig)]
+        L.so101_tree_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.so101_tree_step.argtypes = [C.c_void_p] + [C.c_void_p] * 6
         self.n_envs = int(n_envs)
         h = C.c_void_p()
         rc = L.so101_tree_create(blob_f32, len(blob_f32), self.n_envs, int(device), C.byref(h))
@@ -249,6 +260,9 @@ class TreeSim:
         d = (C.c_int * 7)()
         self._check(L.so101_tree_dims(h, d), "so101_tree_dims")
         self.nq, self.nv, self.nu, self.nbody, self.ngeom, self.debug_dim, self.max_contacts = list(d)
+        self.obs_dim = int(L.so101_tree_obs_dim(h))
+        self.cfg = TreeConfig(n_substeps=10, last_step=1 << 30, settle_max_substeps=1000, terminate_on_success=1, solver_iterations=0,
+                              solver_tolerance=-1.0, seed=0, env_id_base=0)
 
     def close(self):
         if getattr(self, "h", None):
@@ -280,3 +294,19 @@ class TreeSim:
 
     def get_diag(self, out, stream: int = 0):
         self._check(self.L.so101_tree_get_diag(self.h, out, stream), "so101_tree_get_diag")
+
+    def bind_env(self, ring_pos, ring_vel, ep_return, step_count, episode):
+        self._check(self.L.so101_tree_bind_env(self.h, ring_pos, ring_vel, ep_return, step_count, episode), "so101_tree_bind_env")
+
+    def configure_env(self, **kw):
+        for k, v in kw.items():
+            if not hasattr(self.cfg, k):
+                raise TypeError(f"unknown config field {k}")
+            setattr(self.cfg, k, v)
+        self._check(self.L.so101_tree_configure_env(self.h, C.byref(self.cfg)), "so101_tree_configure_env")
+
+    def reset(self, mask=None, stream: int = 0):
+        self._check(self.L.so101_tree_reset(self.h, mask, stream), "so101_tree_reset")
+
+    def step(self, action, obs, reward, discount, step_type, stream: int = 0):
+        self._check(self.L.so101_tree_step(self.h, action, obs, reward, discount, step_type, stream), "so101_tree_step")

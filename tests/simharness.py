@@ -270,3 +270,30 @@ class TreeArraySim:
                             bias=r[D["BIAS"]:D["BIAS"] + nv], qacc_smooth=r[D["QSM"]:D["QSM"] + nv], qacc=r[D["QACC"]:D["QACC"] + nv],
                             xpos=r[D["XPOS"]:D["XPOS"] + 3 * nb].reshape(nb, 3), M=r[D["M"]:D["M"] + 32 * 32].reshape(32, 32)[:nv, :nv], contacts=cons))
         return out
+
+    # -- env layer (hand-over scenes)
+    def enable_env(self, **cfg):
+        s, N = self.sim, self.N
+        if self.backend == "gpu":
+            t = self.torch
+            z = lambda *sh, dt=t.float32: t.zeros(*sh, dtype=dt, device=self.dev)
+            i32, u8 = t.int32, t.uint8
+        else:
+            z = lambda *sh, dt=np.float32: np.zeros(sh, dtype=dt)
+            i32, u8 = np.int32, np.uint8
+        self.ring_pos, self.ring_vel = z(5, s.nu, N), z(5, 16, N)
+        self.ep_return, self.step_count, self.episode = z(N), z(N, dt=i32), z(N, dt=i32)
+        self.action, self.obs = z(N, s.nu), z(N, s.obs_dim)
+        self.reward_, self.discount, self.step_type = z(N), z(N), z(N, dt=u8)
+        p = self.ptr
+        s.bind_env(p(self.ring_pos), p(self.ring_vel), p(self.ep_return), p(self.step_count), p(self.episode))
+        s.configure_env(**cfg)
+
+    def reset(self):
+        self.sim.reset(None, self.stream())
+
+    def step(self, action):
+        self._put(self.action, action)
+        p = self.ptr
+        self.sim.step(p(self.action), p(self.obs), p(self.reward_), p(self.discount), p(self.step_type), self.stream())
+        return self._get(self.obs).astype(np.float64), self._get(self.reward_).astype(np.float64), self._get(self.discount).astype(np.float64), self._get(self.step_type)

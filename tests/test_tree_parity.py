@@ -121,3 +121,58 @@ def test_forward_against_the_oracle(name):
 @pytest.mark.parametrize("name", ["banana", "pen"])
 def test_rollout_against_the_oracle(name):
     check_rollout(name, "gpu", 16, 5)
+
+
+# ---------------------------------------------------------------------------------------------- env layer (hand-over tasks)
+def check_env(name, backend, n, steps, settle, seed=7):
+    """so101_tree_step against oracle/aloha_env.py: FIRST after the in-call reset, observations (delay lines included), reward,
+    discount and step type step by step, the time limit's LAST, then the auto-reset's FIRST."""
+    from oracle.aloha_env import AlohaOracleEnv
+    raw64, raw32 = _blobs(name)
+    sim = TreeArraySim(raw32, n, backend=backend)
+    sim.enable_env(seed=seed, env_id_base=3, last_step=steps, settle_max_substeps=settle)
+    obs, r, d, st = sim.step(np.zeros((n, 14)))
+    assert np.all(st == 0) and np.all(r == 0) and np.all(d == 1)
+    q, v, w = sim.get_state()
+    flags = sim.get_diag()[:, 4]
+    assert np.all((flags & ~32) == 0)                      # (32: settle budget used up - expected with the short budgets of the CPU runs)
+    envs = []
+    for e in range(n):
+        oe = AlohaOracleEnv(raw64, seed=seed, env_id=3 + e, last_step=steps, settle_max_substeps=settle)
+        o0 = oe.reset()
+        qo, vo, _ = oe.o.get_state()
+        # placement draws are the same counter-RNG values; the settle is `settle` substeps of contact dynamics in fp32 / fp64
+        assert np.abs(q[:16, e] - qo[:16]).max() < 1e-6 and np.abs(q[16:, e] - qo[16:]).max() < (1e-4 if settle <= 300 else 2e-3)
+        assert np.abs(obs[e] - o0).max() < 1e-5
+        assert np.all(obs[e][:14] == obs[e][30:44]) and np.all(obs[e][14:30] == obs[e][44:60])     # delay lines padded with the reset value
+        oe.begin(q[:, e], v[:, e], w[:, e], np.concatenate([scenes.ALOHA_HOME_CTRL] * 2))
+        envs.append(oe)
+    rng = np.random.RandomState(seed)
+    first_pos = obs[:, 30:44].copy()
+    for k in range(steps):
+        a = np.tile(np.concatenate([scenes.ALOHA_HOME_CTRL] * 2), (n, 1)) + 0.3 * rng.normal(size=(n, 14))
+        a[:, 6], a[:, 13] = rng.uniform(-0.06, 1.5, size=n), rng.uniform(-0.06, 1.5, size=n)
+        obs, r, d, st = sim.step(a)
+        for e in range(n):
+            o1, r1, d1, s1 = envs[e].step(a[e])
+            assert np.abs(obs[e] - o1).max() < 2e-4 * max(1.0, np.abs(o1).max()), (k, e, np.abs(obs[e] - o1).max())
+            assert (r[e], d[e], st[e]) == (r1, d1, s1)
+        if k < 5:
+            assert np.abs(obs[:, :14] - first_pos).max() < 1e-6          # joints_pos lags five control steps behind
+        np.testing.assert_allclose(obs[:, 60:66], a[:, :6], rtol=1e-6)   # commanded_joints_pos: the joint targets as given ...
+        np.testing.assert_allclose(obs[:, 66], a[:, 6], rtol=1e-4, atol=1e-5)   # ... and the gripper back in follower units
+    assert np.all(st == 2) and np.all(d == 1)               # time limit: LAST with discount 1
+    obs, r, d, st = sim.step(np.zeros((n, 14)))
+    assert np.all(st == 0)                                   # the call after LAST resets and reports FIRST
+    ep = sim._get(sim.episode)
+    assert np.all(ep == 2)
+
+
+def test_emulated_env_step():
+    check_env("banana", "emu", 1, 1, 5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["banana", "pen"])
+def test_env_against_the_oracle(name):
+    check_env(name, "gpu", 16, 8, 1000)
