@@ -1,0 +1,238 @@
+"""ALOHA hand-over tasks (`HandOverBanana`, `HandOverPen`) on the general-tree engine.
+
+Host-side mirror of the reference's `HandOver` task (so101_sim/tasks/hand_over.py:122-349) on `AlohaTask`
+(so101_sim/tasks/base/aloha2_task.py:145-444) behind the same dm_env-style surface as the SO100 environments of env.py:
+    env.reset() -> TimeStep    env.step(action[14]) -> TimeStep    env.action_spec()    env.observation_spec()
+    env.task.get_instruction()    env.close()
+Every number comes from the kernels behind the `so101_tree_*` entry points of include/so101.h (csrc/so101_tree.hpp); torch is the
+array container.  n_envs == 1 yields numpy observations without the env dimension (what a caller of the reference sees), n_envs > 1
+torch tensors on the GPU with a leading env dimension.
+
+Not built: cameras (no renderer in this library), the contact-FSM reward mode (`reward_based_on_overlap=False`,
+hand_over.py:286-338), non-default observation delays and table height offset (the committed model blob is compiled for the
+reference's defaults).
+"""
+from __future__ import annotations
+
+import collections
+import os
+
+import numpy as np
+
+from . import native
+from ._dmenv import Array, BoundedArray, TimeStep
+from .model import blob as blobfmt
+from .model import scenes
+
+DEFAULT_CONTROL_TIMESTEP = 0.02
+PHYSICS_TIMESTEP = 0.002
+_PHYSICS_DELAY_STEPS = 15          # 0.3 s / 0.02 s (aloha2_task.py:103,244-251)
+NPOS, NVEL = 14, 16
+
+# obs row of so101_tree_step (include/so101.h): joints_pos | joints_vel | undelayed_joints_pos | undelayed_joints_vel | commanded_joints_pos
+_SLICES = dict(joints_pos=(0, 14), joints_vel=(14, 30), undelayed_joints_pos=(30, 44), undelayed_joints_vel=(44, 60),
+               commanded_joints_pos=(60, 74))
+
+
+class HandOverTask:
+    """Host-side description of `HandOver` (hand_over.py:128-236)."""
+
+    def __init__(self, object_name, reward_based_on_overlap=True, reward_requires_handover=False, **kwargs):
+        if object_name not in scenes.HANDOVER_CONFIGS:
+            raise ValueError(f"Invalid object name: {object_name}, must be one of {scenes.HANDOVER_CONFIGS.keys()}")
+        if not reward_based_on_overlap:
+            raise NotImplementedError("the contact-sequence reward (hand_over.py:286-338) is not built; the default overlap reward is")
+        self.object_name = object_name
+        self.reward_requires_handover = bool(reward_requires_handover)      # only read by the reward mode that is not built
+        self.control_timestep = float(kwargs.pop("control_timestep", DEFAULT_CONTROL_TIMESTEP))
+        self.cameras = tuple(kwargs.pop("cameras", ()))
+        self.image_observation_enabled = bool(kwargs.pop("image_observation_enabled", True))
+        self.terminate_episode = bool(kwargs.pop("terminate_episode", True))
+        self.waist_joint_limit = float(kwargs.pop("waist_joint_limit", np.pi / 2))
+        if float(kwargs.pop("table_height_offset", scenes.ALOHA_TABLE_HEIGHT_OFFSET)) != scenes.ALOHA_TABLE_HEIGHT_OFFSET:
+            raise NotImplementedError("the model blob is compiled for table_height_offset = 0.011 (aloha2_task.py:107)")
+        if float(kwargs.pop("joints_observation_delay_secs", 0.1)) != 0.1 or float(kwargs.pop("image_observation_delay_secs", 0.3)) != 0.3:
+            raise NotImplementedError("observation delays other than the reference's defaults (0.1 s joints, 0.3 s physics state)")
+        self._instruction = scenes.ALOHA_INSTRUCTIONS[object_name]
+
+    def get_instruction(self):
+        return self._instruction
+
+
+def aloha_action_spec(ctrlrange: np.ndarray, waist_joint_limit: float = np.pi / 2) -> BoundedArray:
+    """AlohaTask.action_spec (aloha2_task.py:279-301): the actuators' ctrlrange, waists cut to +-waist_joint_limit, grippers in
+    follower units; shape (14,), float32."""
+    lo, hi = ctrlrange[:, 0].astype(np.float32), ctrlrange[:, 1].astype(np.float32)
+    lo[0] = lo[7] = -waist_joint_limit
+    hi[0] = hi[7] = waist_joint_limit
+    lo[6] = lo[13] = scenes.ALOHA_GRIPPER_LIMITS["follower"][1]
+    hi[6] = hi[13] = scenes.ALOHA_GRIPPER_LIMITS["follower"][0]
+    return BoundedArray((14,), np.float32, lo, hi)
+
+
+class AlohaEnvironment:
+    def __init__(self, task: HandOverTask, n_envs: int = 1, time_limit: float = float("inf"), random_state=None, device=None,
+                 env_id_base: int = 0, solver_iterations: int = 0, solver_tolerance: float = -1.0, settle_max_substeps: int = 1000,
+                 physics_state: bool | None = None):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("so101_sim_amd needs a ROCm GPU (MI355X): the step path has no CPU fallback")
+        self.torch = torch
+        self.task = task
+        self.n_envs = N = int(n_envs)
+        self.device = torch.device(device if device is not None else "cuda:0")
+        if isinstance(random_state, np.random.RandomState):
+            seed = int(random_state.randint(0, 2**31 - 1))
+        elif random_state is None:
+            seed = int.from_bytes(os.urandom(4), "little")
+        else:
+            seed = int(random_state)
+        self.seed = seed
+        blob, self.meta = scenes.load_aloha_blob(task.object_name, "f32")
+        self._ctrlrange = np.asarray(blobfmt.unpack(blob)["act_ctrlrange"], dtype=np.float64).reshape(-1, 2)
+        with torch.cuda.device(self.device):
+            self.sim = native.TreeSim(blob, N, device=self.device.index or 0)
+        s = self.sim
+        if (s.nu, s.obs_dim) != (NPOS, 3 * NPOS + 2 * NVEL):
+            raise RuntimeError("unexpected model dimensions for an ALOHA hand-over scene")
+        z = lambda *sh, dt=torch.float32: torch.zeros(*sh, dtype=dt, device=self.device)
+        self.qpos, self.qvel, self.ctrl, self.warm = z(s.nq, N), z(s.nv, N), z(s.nu, N), z(s.nv, N)
+        self._ring_pos, self._ring_vel = z(5, NPOS, N), z(5, NVEL, N)
+        self.ep_return, self.step_count, self.episode = z(N), z(N, dt=torch.int32), z(N, dt=torch.int32)
+        self.obs, self.reward, self.discount = z(N, s.obs_dim), z(N), z(N)
+        self.step_type = z(N, dt=torch.uint8)
+        self._action = z(N, s.nu)
+        self._diag = z(N, 8, dt=torch.int32)
+        s.bind(*(t.data_ptr() for t in (self.qpos, self.qvel, self.ctrl, self.warm)))
+        s.bind_env(*(t.data_ptr() for t in (self._ring_pos, self._ring_vel, self.ep_return, self.step_count, self.episode)))
+        nsub = int(round(task.control_timestep / PHYSICS_TIMESTEP))
+        self.last_step = scenes.time_limit_last_step(time_limit, task.control_timestep, PHYSICS_TIMESTEP) if np.isfinite(time_limit) else 1 << 30
+        s.configure_env(n_substeps=nsub, last_step=self.last_step, settle_max_substeps=int(settle_max_substeps),
+                        terminate_on_success=int(task.terminate_episode), solver_iterations=int(solver_iterations),
+                        solver_tolerance=float(solver_tolerance), seed=seed, env_id_base=int(env_id_base))
+        # physics_state / delayed_physics_state (aloha2_task.py:244-251,441-444): qpos | qvel and its copy of 15 control steps ago.
+        # The reference ties them to image_observation_enabled; for batches they are opt-in (58 + 58 floats per env and step).
+        self._with_state = bool(task.image_observation_enabled if physics_state is None and N == 1 else physics_state)
+        self._ps_ring = None
+        self._ps_dim = s.nq + s.nv
+
+    # ------------------------------------------------------------------ specs
+    def action_spec(self) -> BoundedArray:
+        return aloha_action_spec(self._ctrlrange, self.task.waist_joint_limit)
+
+    def observation_spec(self):
+        spec = collections.OrderedDict()
+        spec["commanded_joints_pos"] = Array((NPOS,), np.float64, "commanded_joints_pos")
+        spec["joints_pos"] = Array((NPOS,), np.float64, "joints_pos")
+        spec["joints_vel"] = Array((NVEL,), np.float64, "joints_vel")
+        if self._with_state:
+            spec["physics_state"] = Array((self._ps_dim,), np.float64, "physics_state")
+        spec["undelayed_joints_pos"] = Array((NPOS,), np.float64, "undelayed_joints_pos")
+        spec["undelayed_joints_vel"] = Array((NVEL,), np.float64, "undelayed_joints_vel")
+        spec["delayed_joints_pos"] = Array((NPOS,), np.float64, "delayed_joints_pos")
+        spec["delayed_joints_vel"] = Array((NVEL,), np.float64, "delayed_joints_vel")
+        if self._with_state:
+            spec["delayed_physics_state"] = Array((self._ps_dim,), np.float64, "delayed_physics_state")
+        return spec
+
+    # ------------------------------------------------------------------ stepping
+    def _stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def _physics_state(self):
+        return self.torch.cat([self.qpos.t(), self.qvel.t()], dim=1)
+
+    def _update_state_ring(self):
+        """host-side (torch) delay line of the physics state: envs that report FIRST refill their line with the reset state"""
+        if not self._with_state:
+            return None, None
+        torch = self.torch
+        ps = self._physics_state()
+        if self._ps_ring is None:
+            self._ps_ring = ps.unsqueeze(0).repeat(_PHYSICS_DELAY_STEPS, 1, 1)
+            self._ps_head = 0
+        first = (self.step_type == 0)
+        if bool(first.any()):
+            self._ps_ring[:, first] = ps[first]
+        delayed = self._ps_ring[self._ps_head].clone()
+        delayed[first] = ps[first]
+        self._ps_ring[self._ps_head] = torch.where(first.unsqueeze(1), self._ps_ring[self._ps_head], ps)
+        self._ps_head = (self._ps_head + 1) % _PHYSICS_DELAY_STEPS
+        return ps, delayed
+
+    def _obs_dict(self):
+        ps, delayed = self._update_state_ring()
+        o = collections.OrderedDict()
+        cut = lambda k: self.obs[:, _SLICES[k][0]:_SLICES[k][1]]
+        o["commanded_joints_pos"] = cut("commanded_joints_pos")
+        o["joints_pos"] = cut("joints_pos")
+        o["joints_vel"] = cut("joints_vel")
+        if ps is not None:
+            o["physics_state"] = ps
+        o["undelayed_joints_pos"] = cut("undelayed_joints_pos")
+        o["undelayed_joints_vel"] = cut("undelayed_joints_vel")
+        o["delayed_joints_pos"] = cut("joints_pos")
+        o["delayed_joints_vel"] = cut("joints_vel")
+        if delayed is not None:
+            o["delayed_physics_state"] = delayed
+        if self.n_envs == 1:
+            return collections.OrderedDict((k, v[0].double().cpu().numpy()) for k, v in o.items())
+        return o
+
+    def step_tensor(self, action):
+        """action: float tensor [N, 14] on the device.  Fills and returns (obs, reward, discount, step_type)."""
+        if tuple(action.shape) != (self.n_envs, NPOS):
+            raise ValueError(f"Expected 14 joint positions per env, got {tuple(action.shape)}")
+        self._action.copy_(action)
+        self.sim.step(self._action.data_ptr(), self.obs.data_ptr(), self.reward.data_ptr(), self.discount.data_ptr(),
+                      self.step_type.data_ptr(), self._stream())
+        return self.obs, self.reward, self.discount, self.step_type
+
+    def _timestep(self):
+        obs = self._obs_dict()
+        if self.n_envs == 1:
+            st = int(self.step_type[0])
+            if st == 0:
+                return TimeStep(st, None, None, obs)
+            return TimeStep(st, float(self.reward[0]), float(self.discount[0]), obs)
+        return TimeStep(self.step_type, self.reward, self.discount, obs)
+
+    def reset(self) -> TimeStep:
+        """every env starts a new episode; returns FIRST"""
+        self.sim.reset(None, self._stream())
+        self.torch.cuda.current_stream(self.device).synchronize()
+        # the FIRST observation is written by the step kernel for an env that resets inside a step call; for an explicit reset it
+        # is assembled here from the state the reset left
+        q = self.qpos.t()
+        pos = q[:, [0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12, 13, 14]].clone()
+        (qo, qc), (_, _), (fo, fc) = scenes.ALOHA_GRIPPER_LIMITS["sim_qpos"], scenes.ALOHA_GRIPPER_LIMITS["sim_ctrl"], scenes.ALOHA_GRIPPER_LIMITS["follower"]
+        for k in (6, 13):
+            pos[:, k] = (pos[:, k] - qc) / (qo - qc) * (fo - fc) + fc
+        cmd = self.ctrl.t().clone()
+        (co, cc) = scenes.ALOHA_GRIPPER_LIMITS["sim_ctrl"]
+        for k in (6, 13):
+            cmd[:, k] = (cmd[:, k] - cc) / (co - cc) * (fo - fc) + fc
+        vel = self.qvel.t()[:, :NVEL]
+        self.obs[:, 0:14], self.obs[:, 14:30], self.obs[:, 30:44], self.obs[:, 44:60], self.obs[:, 60:74] = pos, vel, pos, vel, cmd
+        self.step_type.zero_(); self.reward.zero_(); self.discount.fill_(1.0)
+        ts = self._timestep()
+        return TimeStep(ts.step_type, None, None, ts.observation)       # FIRST carries no reward / discount
+
+    def step(self, action) -> TimeStep:
+        torch = self.torch
+        a = torch.as_tensor(np.asarray(action) if not torch.is_tensor(action) else action, dtype=torch.float32, device=self.device)
+        if a.dim() == 1:
+            a = a.unsqueeze(0)
+        self.step_tensor(a)
+        return self._timestep()
+
+    def episode_returns(self):
+        return self.ep_return
+
+    def diagnostics(self):
+        """per env: contacts, constraint rows, solver iterations, broadphase candidates, flags of the last substep"""
+        self.sim.get_diag(self._diag.data_ptr(), self._stream())
+        return self._diag
+
+    def close(self):
+        self.sim.close()

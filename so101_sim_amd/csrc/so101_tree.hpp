@@ -4,7 +4,7 @@
 //
 // One env = one wavefront, as everywhere in this library, but nothing here is specialised: lanes take bodies, dofs,
 // constraint rows or contacts in turn, matrices live in LDS, the constraint Jacobian in a per-env global scratch.  It is the
-// FIRST GPU path for these scenes, written for parity with the fp64 oracle (oracle/so101_oracle.cpp, the same stages in the
+// FIRST GPU path for these scenes, written for parity with the fp64 CPU restatement used by the tests (the same stages in the
 // same order); the SO100 kernels of so101_device.hpp / so101_newton.hpp stay the fast path for the headline workload.
 // The narrowphase (support functions, flat-face scan, MPR, patch contacts) is shared with them.
 #pragma once
@@ -638,7 +638,7 @@ DEV void make_constraints(const TreeModel* tm, TreeLDS& L, float* Jg) {
   wave_sync();
 }
 
-// ------------------------------------------------------------------ Newton (mj_solNewton restated; oracle solve_newton)
+// ------------------------------------------------------------------ Newton (mj_solNewton restated)
 // cost, force (= -ds/dr) and Hessian of one elliptic contact block at r (dim rows); returns the cost
 DEV float contact_block(const TCon& C, const float* D, int dim, const float* r, float* force, float* Hc, bool want_h) {
   if (want_h) for (int k = 0; k < 36; k++) Hc[k] = 0.f;

@@ -1,8 +1,9 @@
 """Task registry and `create_task_env` with the reference's names, signature and error behaviour
 (so101_sim/task_suite.py:43-100 registry, :103-155 factory), backed by the MI355X batched simulator.
 
-All 22 registry keys are present; only the SO100 hand-over tasks are built (SURVEY.md section 8 scope);
-the ALOHA tasks raise NotImplementedError when constructed, not on import.
+All 22 registry keys are present.  Built: the SO100 hand-over tasks (SURVEY.md section 8 scope) and, on the general-tree
+engine, the ALOHA hand-over tasks `HandOverBanana` / `HandOverPen` (section 8f-1, aloha.py); the other ALOHA tasks raise
+NotImplementedError when constructed, not on import.
 Extension over the reference: `n_envs` (default 1) and `device` select the batched GPU environment.
 """
 from __future__ import annotations
@@ -12,6 +13,7 @@ import types
 
 import numpy as np
 
+from . import aloha as _aloha
 from . import env as _env
 
 DEFAULT_CAMERAS = (
@@ -30,7 +32,7 @@ def _unbuilt(name):
 
         def __init__(self, **kwargs):
             raise NotImplementedError(
-                f"{name} is an ALOHA bimanual task; this build covers the SO100 hand-over tasks only")
+                f"{name} is an ALOHA bimanual task that is not built; this build covers the hand-over tasks (SO100 and ALOHA)")
     _Unbuilt.__name__ = name
     return _Unbuilt
 
@@ -40,7 +42,7 @@ BowlOnRack = _unbuilt("BowlOnRack")
 DesktopWrapHeadphone = _unbuilt("DesktopWrapHeadphone")
 DiningPlaceInContainer = _unbuilt("DiningPlaceInContainer")
 DrawerOpen = _unbuilt("DrawerOpen")
-HandOver = _unbuilt("HandOver")
+HandOver = _aloha.HandOverTask
 LaptopClose = _unbuilt("LaptopClose")
 MarkerRemoveLid = _unbuilt("MarkerRemoveLid")
 ToolsInCaddy = _unbuilt("ToolsInCaddy")
@@ -109,6 +111,10 @@ def create_task_env(
     kwargs.update(constructor_kwargs)
 
     task_instance = task_class(**kwargs)
+    if isinstance(task_instance, _aloha.HandOverTask):
+        for k in ("solver", "prefetch_resets"):          # knobs of the SO100 kernels only
+            env_kwargs.pop(k, None)
+        return _aloha.AlohaEnvironment(task_instance, n_envs=n_envs, time_limit=time_limit, random_state=random_state, **env_kwargs)
     if n_envs == 1:
         return _env.SingleEnvironment(task_instance, time_limit=time_limit, random_state=random_state, **env_kwargs)
     return _env.BatchedEnvironment(task_instance, n_envs=n_envs, time_limit=time_limit, random_state=random_state, **env_kwargs)

@@ -65,7 +65,13 @@ def test_factory_errors_like_reference():
     with pytest.raises(ValueError, match="Unknown task_name: Nope. Available tasks:"):
         task_suite.create_task_env("Nope", time_limit=1.0)
     with pytest.raises(NotImplementedError):
-        task_suite.create_task_env("HandOverBanana", time_limit=1.0)          # ALOHA: registry key exists, not built
+        task_suite.create_task_env("BowlOnRack", time_limit=1.0)              # ALOHA tasks other than the hand-over: registry key exists, not built
+    with pytest.raises(NotImplementedError):
+        task_suite.HandOver(object_name="banana", reward_based_on_overlap=False)
+    with pytest.raises(ValueError, match="Invalid object name"):
+        task_suite.HandOver(object_name="mug")
+    t = task_suite.HandOver(object_name="pen", control_timestep=0.02, cameras=())
+    assert t.get_instruction() == "hand over the pen and put it in the container"       # hand_over.py:117
     with pytest.raises(ValueError, match="Invalid object name"):
         task_suite.SO100HandOver(object_name="mug")
 
@@ -170,3 +176,16 @@ def test_settled_cache_file_format(tmp_path):
         sc.read(path)
     with pytest.raises(sc.SettledCacheError, match="shape"):
         sc.write(path, key, 0, dict(arrays, qpos=arrays["qpos"][:, :19]))
+
+
+def test_aloha_action_spec():
+    """AlohaTask.action_spec (aloha2_task.py:279-301) from the compiled model's ctrlrange."""
+    from so101_sim_amd import aloha
+    from so101_sim_amd.model import blob as blobfmt, scenes
+    m = blobfmt.unpack(scenes.load_aloha_blob("banana", "f32")[0])
+    spec = aloha.aloha_action_spec(np.asarray(m["act_ctrlrange"], dtype=np.float64).reshape(-1, 2))
+    assert spec.shape == (14,) and spec.dtype == np.float32
+    assert spec.minimum[0] == spec.minimum[7] == np.float32(-np.pi / 2) and spec.maximum[0] == np.float32(np.pi / 2)
+    assert spec.minimum[6] == spec.minimum[13] == np.float32(-0.06135) and spec.maximum[6] == spec.maximum[13] == np.float32(1.5155)
+    np.testing.assert_allclose(spec.minimum[1:6], [-1.85005, -1.76278, -3.14158, -1.8675, -3.14158], rtol=1e-6)
+    np.testing.assert_allclose(spec.maximum[8:13], [1.25664, 1.6057, 3.14158, 2.23402, 3.14158], rtol=1e-6)

@@ -176,3 +176,43 @@ def test_emulated_env_step():
 @pytest.mark.parametrize("name", ["banana", "pen"])
 def test_env_against_the_oracle(name):
     check_env(name, "gpu", 16, 8, 1000)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_envs", [1, 8])
+def test_python_dropin_api_of_the_aloha_hand_over(n_envs):
+    """create_task_env('HandOverBanana') as a caller of the reference uses it (run_eval.py:70-124): FIRST without reward, the
+    observation keys and shapes of AlohaTask, the action spec, the instruction, the time limit's LAST and the auto-reset."""
+    from so101_sim_amd import task_suite
+    env = task_suite.create_task_env("HandOverBanana", time_limit=0.1, random_state=3, n_envs=n_envs, physics_state=True)
+    assert env.task.get_instruction() == "hand over the banana and put it in the bowl"
+    spec = env.action_spec()
+    assert spec.shape == (14,) and spec.dtype == np.float32
+    ospec = env.observation_spec()
+    assert list(ospec.keys()) == ["commanded_joints_pos", "joints_pos", "joints_vel", "physics_state", "undelayed_joints_pos", "undelayed_joints_vel",
+                                  "delayed_joints_pos", "delayed_joints_vel", "delayed_physics_state"]
+    ts = env.reset()
+    assert ts.reward is None and ts.discount is None
+    lead = () if n_envs == 1 else (n_envs,)
+    get = (lambda v: np.asarray(v)) if n_envs == 1 else (lambda v: v.double().cpu().numpy())
+    for k, sp in ospec.items():
+        assert get(ts.observation[k]).shape == lead + sp.shape, k
+    home = np.concatenate([scenes.ALOHA_HOME_QPOS[:6], [0.0], scenes.ALOHA_HOME_QPOS[:6], [0.0]])
+    jp = get(ts.observation["joints_pos"]).reshape(-1, 14)
+    assert np.abs(np.delete(jp, [6, 13], axis=1) - np.delete(home, [6, 13])).max() < 1e-6      # arms at HOME_QPOS; the fingers in follower units
+    assert np.abs(jp[:, 6] - 0.0216).max() < 1e-3                                               # 0.0082 m on the rail -> follower units
+    state0 = get(ts.observation["physics_state"]).reshape(-1, 58)
+    assert np.abs(state0[:, 18] - 0.0316).max() < 2e-3                                          # the banana rests on the table top
+    a = np.tile(np.concatenate([scenes.ALOHA_HOME_CTRL] * 2), (n_envs, 1)).astype(np.float32)
+    a[:, 6] = a[:, 13] = 1.0
+    act = a[0] if n_envs == 1 else a
+    types = []
+    for k in range(7):
+        ts = env.step(act)
+        types.append(int(np.asarray(get(ts.step_type)).reshape(-1)[0]) if n_envs > 1 else int(ts.step_type))
+        if k == 0:
+            np.testing.assert_allclose(get(ts.observation["delayed_physics_state"]).reshape(-1, 58), state0, atol=1e-6)
+            assert np.abs(get(ts.observation["commanded_joints_pos"]).reshape(-1, 14)[:, 6] - 1.0).max() < 1e-4
+    # time_limit 0.1 s: control step 6 is the first with physics.time() >= 0.1 (fp64 accumulation of 0.002), then FIRST again
+    assert types == [1, 1, 1, 1, 1, 2, 0], types
+    env.close()
