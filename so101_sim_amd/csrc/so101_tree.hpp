@@ -58,20 +58,21 @@ struct TreeLDS {
   float qpos[TQ], qvel[TV], ctrl[TU], warm[TV], qacc[TV], qsm[TV], bias[TV], qfrc[TV], qact[TV];
   float xpos[TB][3], xquat[TB][4], xmat[TB][9], xipos[TB][3], ximat[TB][9];
   float S[TV][6];
-  union {
-    struct { float own[TB][36], comp[TB][36]; } Ic;     // spatial inertias about the world origin: each body's own, composite
+  union {                                                // three phases of a substep share this storage
+    struct { float own[TB][36], comp[TB][36]; } Ic;     // CRBA: spatial inertias about the world origin, each body's own and composite
+    struct { float aabb[6][TGEOM]; unsigned int cand[TCAND]; };   // collision: world boxes of the geoms, candidate pairs
     float Hc[TCON][36];                                  // Newton: Hessian block of each contact
   };
-  float M[TV][TV + 1], L[TV][TV + 1], H[TV][TV + 1];
+  float M[TV][TV + 1];
+  union { float L[TV][TV + 1]; float H[TV][TV + 1]; };  // factor of M (until qacc_smooth is known), then the Newton Hessian / M + h D
   float rw[TB][3], ral[TB][3], rao[TB][3], rf[TB][3], rn[TB][3];
-  float aabb[6][TGEOM];
-  unsigned int cand[TCAND];
   TCon con[TCON];
-  float eD[TROW], eR[TROW], earef[TROW], eB[TROW], eKp[TROW], efl[TROW], ejar[TROW], ef[TROW], ejv[TROW];
+  float eD[TROW], eR[TROW], earef[TROW], efl[TROW], ejar[TROW], ef[TROW], ejv[TROW];
   unsigned char etype[TROW];
   float Jc[6][TJS];
   float x[TV], grad[TV], search[TV], Ma[TV], Mv[TV], tmp[TV], xs[TV];
   int cdim[TCON + 1];
+  int hdim[TCON];                  // Newton: rows of the contact's Hessian block, 0 when the block is inactive
   int ncand, ncon, nrow, nscalar, iters, flags;
 };
 
@@ -470,7 +471,7 @@ DEV void collision(const TreeModel* tm, const DevModel* gm, TreeLDS& L) {
     GeomW G1, G2;
     load_geom_at(gm, g1, L.xpos[b1], L.xmat[b1], G1); load_geom_at(gm, g2, L.xpos[b2], L.xmat[b2], G2);
     PairContacts pc;
-    narrow_pair<NoCache, G64>(gm, G1, G2, g1, g2, pc);
+    narrow_pair<HullCache, G64>(gm, G1, G2, g1, g2, pc);       // (registers are free here: the LDS footprint, not VGPRs, bounds occupancy)
     unsigned int valid = pc.valid;
     int n = __popc(valid);
     if (n == 0) continue;
@@ -625,7 +626,7 @@ DEV void make_constraints(const TreeModel* tm, TreeLDS& L, float* Jg) {
     } else C.mu = 0.f;
     for (int j = 0; j < dim; j++) {
       L.etype[row + j] = TR_CONTACT; L.eR[row + j] = R[j]; L.eD[row + j] = 1.f / R[j]; L.efl[row + j] = 0.f;
-      L.eB[row + j] = Bc; L.eKp[row + j] = j == 0 ? K * imp * C.dist : 0.f;
+      L.ejar[row + j] = Bc; L.ejv[row + j] = j == 0 ? K * imp * C.dist : 0.f;      // (parked until the pass below)
     }
   }
   wave_sync();
@@ -633,42 +634,52 @@ DEV void make_constraints(const TreeModel* tm, TreeLDS& L, float* Jg) {
   for (int r = nscalar + lane; r < nrow; r += WAVE) {
     float vel = 0.f;
     for (int d = 0; d < nv; d++) vel += Jg[r * TJS + d] * L.qvel[d];
-    L.earef[r] = -L.eB[r] * vel - L.eKp[r];
+    L.earef[r] = -L.ejar[r] * vel - L.ejv[r];
   }
   wave_sync();
 }
 
 // ------------------------------------------------------------------ Newton (mj_solNewton restated)
-// cost, force (= -ds/dr) and Hessian of one elliptic contact block at r (dim rows); returns the cost
+// cost, force (= -ds/dr) and Hessian (6 x 6 storage, the leading dim x dim part is used) of one elliptic contact block at r (dim rows);
+// returns the cost.  Every loop runs over the six possible rows with a guard, so that the small arrays stay in registers.
 DEV float contact_block(const TCon& C, const float* D, int dim, const float* r, float* force, float* Hc, bool want_h) {
-  if (want_h) for (int k = 0; k < 36; k++) Hc[k] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 36; k++) Hc[k] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 6; j++) force[j] = 0.f;
   if (dim == 1) {
-    if (r[0] < 0.f) { force[0] = -D[0] * r[0]; if (want_h) Hc[0] = D[0]; return 0.5f * D[0] * r[0] * r[0]; }
-    force[0] = 0.f; return 0.f;
+    if (r[0] < 0.f) { force[0] = -D[0] * r[0]; Hc[0] = D[0]; return 0.5f * D[0] * r[0] * r[0]; }
+    return 0.f;
   }
-  float mu = C.mu, U[6];
-  U[0] = r[0] * mu;
+  float mu = C.mu, U[6], fr[6];
+  U[0] = r[0] * mu; fr[0] = 0.f;
   float T = 0.f;
-  for (int j = 1; j < dim; j++) { U[j] = r[j] * C.fric[j - 1]; T += U[j] * U[j]; }
+#pragma unroll
+  for (int j = 1; j < 6; j++) { fr[j] = j < dim ? C.fric[j - 1] : 0.f; U[j] = j < dim ? r[j] * fr[j] : 0.f; T += U[j] * U[j]; }
   T = sqrtf(T);
   float N = U[0];
-  if ((N >= mu * T) || (T <= 0.f && N >= 0.f)) { for (int j = 0; j < dim; j++) force[j] = 0.f; return 0.f; }
+  if ((N >= mu * T) || (T <= 0.f && N >= 0.f)) return 0.f;
   if ((mu * N + T <= 0.f) || (T <= 0.f && N < 0.f)) {
     float cost = 0.f;
-    for (int j = 0; j < dim; j++) { force[j] = -D[j] * r[j]; cost += 0.5f * D[j] * r[j] * r[j]; if (want_h) Hc[j * dim + j] = D[j]; }
+#pragma unroll
+    for (int j = 0; j < 6; j++) if (j < dim) { force[j] = -D[j] * r[j]; cost += 0.5f * D[j] * r[j] * r[j]; Hc[j * 6 + j] = D[j]; }
     return cost;
   }
   float Dm = D[0] / fmaxf(mu * mu * (1.f + mu * mu), MINVAL_F), sN = N - mu * T;
   force[0] = -Dm * sN * mu;
-  for (int j = 1; j < dim; j++) force[j] = -force[0] / T * U[j] * C.fric[j - 1];
+#pragma unroll
+  for (int j = 1; j < 6; j++) if (j < dim) force[j] = -force[0] / T * U[j] * fr[j];
   if (want_h) {
     Hc[0] = Dm * mu * mu;
-    for (int k = 1; k < dim; k++) {
-      float mk = C.fric[k - 1];
-      Hc[k] = Hc[k * dim] = -Dm * mu * mu * U[k] * mk / T;
-      for (int l = 1; l < dim; l++) {
-        float ml = C.fric[l - 1];
-        Hc[k * dim + l] = Dm * mu * mu * mk * ml * U[k] * U[l] / (T * T) - Dm * sN * mu * mk * ml * ((k == l ? 1.f : 0.f) / T - U[k] * U[l] / (T * T * T));
+#pragma unroll
+    for (int k = 1; k < 6; k++) if (k < dim) {
+      float mk = fr[k];
+      float hk = -Dm * mu * mu * U[k] * mk / T;
+      Hc[k] = hk; Hc[k * 6] = hk;
+#pragma unroll
+      for (int l = 1; l < 6; l++) if (l < dim) {
+        float ml = fr[l];
+        Hc[k * 6 + l] = Dm * mu * mu * mk * ml * U[k] * U[l] / (T * T) - Dm * sN * mu * mk * ml * ((k == l ? 1.f : 0.f) / T - U[k] * U[l] / (T * T * T));
       }
     }
   }
@@ -711,11 +722,19 @@ DEV float total_cost(const TreeModel* tm, TreeLDS& L, const float* Jg, bool want
   }
   if (lane < ncon) {
     const TCon& C = L.con[lane];
+    int dim = C.dim, row = C.row;
     float r6[6], f6[6], D6[6], Hc[36];
-    for (int j = 0; j < C.dim; j++) { r6[j] = L.ejar[C.row + j]; D6[j] = L.eD[C.row + j]; }
-    part += contact_block(C, D6, C.dim, r6, f6, Hc, want);
-    for (int j = 0; j < C.dim; j++) L.ef[C.row + j] = f6[j];
-    if (want) for (int k = 0; k < C.dim * C.dim; k++) L.Hc[lane][k] = Hc[k];
+#pragma unroll
+    for (int j = 0; j < 6; j++) { r6[j] = j < dim ? L.ejar[row + j] : 0.f; D6[j] = j < dim ? L.eD[row + j] : 0.f; }
+    part += contact_block(C, D6, dim, r6, f6, Hc, want);
+#pragma unroll
+    for (int j = 0; j < 6; j++) if (j < dim) L.ef[row + j] = f6[j];
+    if (want) {
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < 36; k++) { L.Hc[lane][k] = Hc[k]; any = any || Hc[k] != 0.f; }
+      L.hdim[lane] = any ? dim : 0;          // (0: the block is inactive, nothing to add to the Hessian)
+    }
   }
   float cost = wave_sum_f(part);
   wave_sync();
@@ -728,28 +747,54 @@ DEV float total_cost(const TreeModel* tm, TreeLDS& L, const float* Jg, bool want
   }
   // Hessian: M + sum J' Hc J; lane = column
   float hcol[TV];
-  if (lane < nv) for (int a = 0; a < nv; a++) hcol[a] = L.M[a][lane];
+  int col = lane < TV ? lane : 0;
+#pragma unroll
+  for (int a = 0; a < TV; a++) hcol[a] = L.M[a][col];       // (rows / columns beyond nv are never read back)
   for (int r = 0; r < nscalar; r++) {
     float h = L.ejv[r];
     if (h == 0.f) continue;
     float jc = lane < nv ? Jg[r * TJS + lane] : 0.f;
-    if (lane < TJS) L.Jc[0][lane] = lane < nv ? jc : 0.f;
     wave_sync();
-    if (lane < nv && jc != 0.f) for (int a = 0; a < nv; a++) hcol[a] += L.Jc[0][a] * h * jc;
+    if (lane < TJS) L.Jc[0][lane] = jc;
     wave_sync();
+    float hj = h * jc;
+#pragma unroll
+    for (int a = 0; a < TV; a++) hcol[a] += L.Jc[0][a] * hj;
   }
   for (int c = 0; c < ncon; c++) {
-    int row = L.con[c].row, dim = L.con[c].dim;
-    if (lane < TJS) for (int j = 0; j < dim; j++) L.Jc[j][lane] = lane < nv ? Jg[(row + j) * TJS + lane] : 0.f;
+    int dim = L.hdim[c];
+    if (dim == 0) continue;
+    int row = L.con[c].row;
+    float jl[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) jl[j] = (j < dim && lane < nv) ? Jg[(row + j) * TJS + lane] : 0.f;
     wave_sync();
-    if (lane < nv) {
-      float t[6];
-      for (int j = 0; j < dim; j++) { float v = 0.f; for (int k = 0; k < dim; k++) v += L.Hc[c][j * dim + k] * L.Jc[k][lane]; t[j] = v; }
-      for (int a = 0; a < nv; a++) { float v = 0.f; for (int j = 0; j < dim; j++) v += L.Jc[j][a] * t[j]; hcol[a] += v; }
+    if (lane < TJS) {
+#pragma unroll
+      for (int j = 0; j < 6; j++) L.Jc[j][lane] = jl[j];
     }
     wave_sync();
+    float t[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < 6; k++) v += L.Hc[c][j * 6 + k] * jl[k];
+      t[j] = v;
+    }
+#pragma unroll
+    for (int a = 0; a < TV; a++) {
+      float v = 0.f;
+#pragma unroll
+      for (int j = 0; j < 6; j++) v += L.Jc[j][a] * t[j];
+      hcol[a] += v;
+    }
   }
-  if (lane < nv) for (int a = 0; a < nv; a++) L.H[a][lane] = hcol[a];
+  wave_sync();
+  if (lane < nv) {
+#pragma unroll
+    for (int a = 0; a < TV; a++) L.H[a][lane] = hcol[a];
+  }
   wave_sync();
   return cost;
 }
@@ -799,10 +844,17 @@ DEV void solve_newton(const TreeModel* tm, TreeLDS& L, const float* Jg, int max_
       }
       if (lane < ncon) {
         const TCon& C = L.con[lane];
+        int dim = C.dim, row = C.row;
         float r6[6], f6[6], D6[6], Hc[36], jv6[6];
-        for (int j = 0; j < C.dim; j++) { jv6[j] = L.ejv[C.row + j]; r6[j] = L.ejar[C.row + j] + alpha * jv6[j]; D6[j] = L.eD[C.row + j]; }
-        contact_block(C, D6, C.dim, r6, f6, Hc, true);
-        for (int j = 0; j < C.dim; j++) { a1 -= f6[j] * jv6[j]; for (int k = 0; k < C.dim; k++) a2 += jv6[j] * Hc[j * C.dim + k] * jv6[k]; }
+#pragma unroll
+        for (int j = 0; j < 6; j++) { jv6[j] = j < dim ? L.ejv[row + j] : 0.f; r6[j] = j < dim ? L.ejar[row + j] + alpha * jv6[j] : 0.f; D6[j] = j < dim ? L.eD[row + j] : 0.f; }
+        contact_block(C, D6, dim, r6, f6, Hc, true);
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+          a1 -= f6[j] * jv6[j];
+#pragma unroll
+          for (int k = 0; k < 6; k++) a2 += jv6[j] * Hc[j * 6 + k] * jv6[k];
+        }
       }
       float d1 = q1 + q2 * alpha + wave_sum_f(a1), d2 = q2 + wave_sum_f(a2);
       if (ls == 0) { d10 = fabsf(d1); if (!(d1 < 0.f)) break; }
@@ -830,14 +882,15 @@ DEV void solve_newton(const TreeModel* tm, TreeLDS& L, const float* Jg, int max_
 }
 
 // ------------------------------------------------------------------ forward dynamics and integration
-DEV void forward(const TreeModel* tm, const DevModel* gm, TreeLDS& L, float* Jg, int max_iter, float tolerance) {
+// `phases`: stage mask for timing runs (so101_tree_debug_forward with SO101_TREE_PHASES set); every caller on the step path passes all
+DEV void forward(const TreeModel* tm, const DevModel* gm, TreeLDS& L, float* Jg, int max_iter, float tolerance, int phases = 0x7f) {
   kinematics(tm, L);
-  crba(tm, L);
-  rne_bias(tm, L);
-  smooth(tm, L);
-  collision(tm, gm, L);
-  make_constraints(tm, L, Jg);
-  solve_newton(tm, L, Jg, max_iter, tolerance);
+  if (phases & 2) crba(tm, L);
+  if (phases & 4) rne_bias(tm, L);
+  if (phases & 8) smooth(tm, L);
+  if (phases & 16) collision(tm, gm, L); else { if (wave_lane() == 0) { L.ncon = 0; L.ncand = 0; } wave_sync(); }
+  if (phases & 32) make_constraints(tm, L, Jg); else { if (wave_lane() == 0) { L.nrow = 0; L.nscalar = 0; } wave_sync(); }
+  if (phases & 64) solve_newton(tm, L, Jg, max_iter, tolerance);
 }
 
 DEV void euler(const TreeModel* tm, TreeLDS& L) {

@@ -6,6 +6,7 @@
 #include "so101_tree.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -40,13 +41,13 @@ __global__ void __launch_bounds__(64) k_tree_physics(const TreeModel* tm, const 
   if (lane == 0 && B.diag) { int* d = B.diag + 8 * e; d[0] = L.ncon; d[1] = L.nrow; d[2] = L.iters; d[3] = L.ncand; d[4] = L.flags; }
 }
 
-__global__ void __launch_bounds__(64) k_tree_forward(const TreeModel* tm, const DevModel* gm, TreeBuffers B, int N, int iterations, float tolerance, float* out) {
+__global__ void __launch_bounds__(64) k_tree_forward(const TreeModel* tm, const DevModel* gm, TreeBuffers B, int N, int iterations, float tolerance, float* out, int phases) {
   BLOCK_SHARED(TreeLDS, L);
   int e = blockIdx.x, lane = wave_lane();
   if (lane == 0) L.flags = 0;
   tree::load_state(tm, L, B, e, N);
   float* Jg = B.J + (size_t)e * TROW * TJS;
-  tree::forward(tm, gm, L, Jg, iterations, tolerance);
+  tree::forward(tm, gm, L, Jg, iterations, tolerance, phases);
   float* o = out + (size_t)e * TDBG_DIM;
   int nv = tm->nv, nb = tm->nbody;
   if (lane == 0) { o[0] = (float)L.ncon; o[1] = (float)L.nrow; o[2] = (float)L.iters; o[3] = (float)L.ncand; o[4] = (float)L.flags; o[5] = (float)L.nscalar; }
@@ -417,7 +418,8 @@ int so101_tree_debug_forward(so101_tree* s, float* out, void* stream) {
   if (!s || !out) return SO101_ERR_ARG;
   if (!s->bound) { s->err = "so101_tree_debug_forward before so101_tree_bind_state"; return SO101_ERR_STATE; }
   (void)hipSetDevice(s->device);
-  hipLaunchKernelGGL(k_tree_forward, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, s->dg, s->buf, s->n_envs, s->iterations, s->tolerance, out);
+  static const int phases = getenv("SO101_TREE_PHASES") ? atoi(getenv("SO101_TREE_PHASES")) : 0x7f;      // timing runs only
+  hipLaunchKernelGGL(k_tree_forward, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, s->dg, s->buf, s->n_envs, s->iterations, s->tolerance, out, phases);
   return t_ok(s, hipGetLastError(), "k_tree_forward") ? SO101_OK : SO101_ERR_HIP;
 }
 

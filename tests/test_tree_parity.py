@@ -200,7 +200,7 @@ def test_python_dropin_api_of_the_aloha_hand_over(n_envs):
     home = np.concatenate([scenes.ALOHA_HOME_QPOS[:6], [0.0], scenes.ALOHA_HOME_QPOS[:6], [0.0]])
     jp = get(ts.observation["joints_pos"]).reshape(-1, 14)
     assert np.abs(np.delete(jp, [6, 13], axis=1) - np.delete(home, [6, 13])).max() < 1e-6      # arms at HOME_QPOS; the fingers in follower units
-    assert np.abs(jp[:, 6] - 0.0216).max() < 1e-3                                               # 0.0082 m on the rail -> follower units
+    assert np.abs(jp[:, 6] + 0.03975).max() < 1e-3                                              # 0.0082 m on the rail -> follower units (aloha2_task.py:304-314)
     state0 = get(ts.observation["physics_state"]).reshape(-1, 58)
     assert np.abs(state0[:, 18] - 0.0316).max() < 2e-3                                          # the banana rests on the table top
     a = np.tile(np.concatenate([scenes.ALOHA_HOME_CTRL] * 2), (n_envs, 1)).astype(np.float32)
