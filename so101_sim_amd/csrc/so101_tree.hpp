@@ -166,20 +166,32 @@ DEV void kinematics(const TreeModel* tm, TreeLDS& L) {
   wave_sync();
 }
 
-// ------------------------------------------------------------------ Cholesky in LDS: lane = row; A = L L^T, lower part in place
+// ------------------------------------------------------------------ Cholesky: A = L L^T, lower part in place in LDS.  Lane i takes row i into
+// registers; column j of the factor travels between lanes with v_readlane (right-looking: a[i][k] -= L[i][j] L[k][j], j ascending).
+// Entries beyond n are never read back.
 DEV void chol_factor(float (*A)[TV + 1], int n) {
-  int lane = wave_lane();
-  for (int j = 0; j < n; j++) {
-    wave_sync();
-    float d = sqrtf(fmaxf(A[j][j], MINVAL_F));
-    wave_sync();
-    if (lane == j) A[j][j] = d;
-    if (lane > j && lane < n) A[lane][j] /= d;
-    wave_sync();
-    if (lane > j && lane < n) {
-      float lij = A[lane][j];
-      for (int k = j + 1; k <= lane; k++) A[lane][k] -= lij * A[k][j];
+  int lane = wave_lane(), row = lane < TV ? lane : 0;
+  wave_sync();
+  float a[TV];
+#pragma unroll
+  for (int k = 0; k < TV; k++) a[k] = A[row][k];
+#pragma unroll
+  for (int j = 0; j < TV; j++) {
+    if (j < n) {
+      float ajj = wave_get_f(a[j], j);
+      float d = sqrtf(fmaxf(ajj, MINVAL_F));
+      float lij = lane == j ? d : a[j] / d;
+      a[j] = lij;
+#pragma unroll
+      for (int k = j + 1; k < TV; k++) {
+        float lkj = wave_get_f(lij, k);
+        a[k] -= lij * lkj;
+      }
     }
+  }
+  if (lane < n) {
+#pragma unroll
+    for (int k = 0; k < TV; k++) if (k <= lane) A[lane][k] = a[k];
   }
   wave_sync();
 }
@@ -441,9 +453,9 @@ DEV void collision(const TreeModel* tm, const DevModel* gm, TreeLDS& L) {
     bool hit = false;
     int g1 = 0, g2 = 0;
     if (p < tm->npair) {
-      g1 = gm->pair[2 * p]; g2 = gm->pair[2 * p + 1];
-      if (gm->geom_type[g1] > gm->geom_type[g2]) { int t = g1; g1 = g2; g2 = t; }
-      if (gm->geom_type[g1] == G_PLANE) {
+      unsigned int pk = gm->pair_packed[p];          // geom1 | geom2 << 8 | plane flag << 16, types ordered
+      g1 = (int)(pk & 0xffu); g2 = (int)((pk >> 8) & 0xffu);
+      if ((pk >> 16) & 1u) {
         float pp[3], R[9]; geom_pose(tm, gm, L, g1, pp, R);
         float nrm[3] = {R[2], R[5], R[8]}, lowest = 0.f;
 #pragma unroll
