@@ -47,7 +47,17 @@ struct TreeModel {
   const int* geom_priority;        // [ngeom]
 };
 
-struct TreeBuffers { float *qpos, *qvel, *ctrl, *warm; float* J; int* diag; };   // [nq|nv|nu|nv][N] env-fastest; J [N][TROW][TJS]; diag [N][8]
+struct TreeBuffers { float *qpos, *qvel, *ctrl, *warm; float* scratch; int* diag; };   // [nq|nv|nu|nv][N] env-fastest; scratch [N][T_SCRATCH]; diag [N][8]
+
+// Per-env working set that does not fit the LDS budget (occupancy is bounded by LDS here): the constraint Jacobian, the per-row
+// vectors of the solver and the contacts' Hessian blocks.  Written and read by the env's own wavefront only (through the CU's L1).
+#define T_SCRATCH (TROW * TJS + 8 * TROW + TCON * 36)       // floats per env
+struct TreeScratch {
+  float* J;                        // [TROW][TJS]
+  float *eD, *eR, *earef, *efl, *ejar, *ef, *ejv;   // [TROW] each
+  unsigned int* etype;             // [TROW]
+  float (*Hc)[36];                 // [TCON]
+};
 
 struct TCon {                      // 32 words
   float pos[3], frame[9], dist, mu, fric[5], solref[2], solimp[5];
@@ -58,17 +68,14 @@ struct TreeLDS {
   float qpos[TQ], qvel[TV], ctrl[TU], warm[TV], qacc[TV], qsm[TV], bias[TV], qfrc[TV], qact[TV];
   float xpos[TB][3], xquat[TB][4], xmat[TB][9], xipos[TB][3], ximat[TB][9];
   float S[TV][6];
-  union {                                                // three phases of a substep share this storage
-    struct { float own[TB][36], comp[TB][36]; } Ic;     // CRBA: spatial inertias about the world origin, each body's own and composite
+  union {                                                // two phases of a substep share this storage
+    float Ic[TB][36];                                    // CRBA: spatial inertia about the world origin, each body's own, then composite (in place)
     struct { float aabb[6][TGEOM]; unsigned int cand[TCAND]; };   // collision: world boxes of the geoms, candidate pairs
-    float Hc[TCON][36];                                  // Newton: Hessian block of each contact
   };
   float M[TV][TV + 1];
   union { float L[TV][TV + 1]; float H[TV][TV + 1]; };  // factor of M (until qacc_smooth is known), then the Newton Hessian / M + h D
   float rw[TB][3], ral[TB][3], rao[TB][3], rf[TB][3], rn[TB][3];
   TCon con[TCON];
-  float eD[TROW], eR[TROW], earef[TROW], efl[TROW], ejar[TROW], ef[TROW], ejv[TROW];
-  unsigned char etype[TROW];
   float Jc[6][TJS];
   float x[TV], grad[TV], search[TV], Ma[TV], Mv[TV], tmp[TV], xs[TV];
   int cdim[TCON + 1];
@@ -78,7 +85,15 @@ struct TreeLDS {
 
 namespace tree {
 
-DEV float ld(const float* p) { return *p; }
+DEV TreeScratch scratch_of(const TreeBuffers& B, int e) {
+  float* base = B.scratch + (size_t)e * T_SCRATCH;
+  TreeScratch G;
+  G.J = base; base += TROW * TJS;
+  G.eD = base; G.eR = base + TROW; G.earef = base + 2 * TROW; G.efl = base + 3 * TROW; G.ejar = base + 4 * TROW; G.ef = base + 5 * TROW; G.ejv = base + 6 * TROW;
+  G.etype = (unsigned int*)(base + 7 * TROW); base += 8 * TROW;
+  G.Hc = (float (*)[36])base;
+  return G;
+}
 
 // ------------------------------------------------------------------ state in / out (env-fastest struct-of-arrays)
 DEV void load_state(const TreeModel* tm, TreeLDS& L, const TreeBuffers& B, int e, int N) {
@@ -249,21 +264,24 @@ DEV void crba(const TreeModel* tm, TreeLDS& L) {
         }
     }
 #pragma unroll
-    for (int i = 0; i < 36; i++) L.Ic.own[b][i] = o[i];
+    for (int i = 0; i < 36; i++) L.Ic[b][i] = o[i];
   }
   wave_sync();
-  if (lane < nb) {                       // composite of body b: its own plus every descendant's, in body order
-    int b = lane;
+  {                                      // composite of body b: its own plus every descendant's, in body order; in place
+    int b = lane < nb ? lane : 0;
     float o[36];
 #pragma unroll
-    for (int i = 0; i < 36; i++) o[i] = L.Ic.own[b][i];
+    for (int i = 0; i < 36; i++) o[i] = L.Ic[b][i];
     for (int d = b + 1; d < nb; d++)
       if ((tm->body_anc[d] >> b) & 1u) {
 #pragma unroll
-        for (int i = 0; i < 36; i++) o[i] += L.Ic.own[d][i];
+        for (int i = 0; i < 36; i++) o[i] += L.Ic[d][i];
       }
+    wave_sync();                         // (every lane has read the bodies' own inertias before any composite replaces one)
+    if (lane < nb) {
 #pragma unroll
-    for (int i = 0; i < 36; i++) L.Ic.comp[b][i] = o[i];
+      for (int i = 0; i < 36; i++) L.Ic[b][i] = o[i];
+    }
   }
   wave_sync();
   // M[r][c] = S_r' Ic[deeper body] S_c when one of the two bodies is an ancestor of the other; lane = column
@@ -277,7 +295,7 @@ DEV void crba(const TreeModel* tm, TreeLDS& L) {
       if ((tm->body_anc[br] >> bc) & 1u) bb = br; else if ((tm->body_anc[bc] >> br) & 1u) bb = bc;
       float v = 0.f;
       if (bb >= 0) {
-        const float* I = L.Ic.comp[bb];
+        const float* I = L.Ic[bb];
 #pragma unroll
         for (int i = 0; i < 6; i++) {
           float t = 0.f;
@@ -522,7 +540,7 @@ DEV void row_params(const TreeModel* tm, const float* solref_in, const float* so
   *imp = impedance(solimp, pos);
 }
 
-DEV void make_constraints(const TreeModel* tm, TreeLDS& L, float* Jg) {
+DEV void make_constraints(const TreeModel* tm, TreeLDS& L, const TreeScratch& G) {
   int lane = wave_lane(), nv = tm->nv, neq = tm->neq, nfric = tm->nfric, njnt = tm->njnt;
   // joint limits that are violated: (joint, side) pairs in joint order
   bool lo_on = false, hi_on = false;
@@ -545,7 +563,7 @@ DEV void make_constraints(const TreeModel* tm, TreeLDS& L, float* Jg) {
   if (nrow > TROW) { if (lane == 0) L.flags |= 4; }      // (cannot happen: TCON * 6 = TROW)
   if (lane == 0) { L.nrow = nrow; L.nscalar = nscalar; }
   // zero the Jacobian rows of the scalar constraints
-  for (int r = 0; r < nscalar; r++) if (lane < TJS) Jg[r * TJS + lane] = 0.f;
+  for (int r = 0; r < nscalar; r++) if (lane < TJS) G.J[r * TJS + lane] = 0.f;
   wave_sync();
   // ---- scalar rows: one lane each
   {
@@ -578,9 +596,9 @@ DEV void make_constraints(const TreeModel* tm, TreeLDS& L, float* Jg) {
       float imp, K, Bc; row_params(tm, solref, solimp, pos, &imp, &K, &Bc);
       float R = fmaxf(MINVAL_F, (1.f - imp) * diag / imp);
       float vel = j1 * L.qvel[d1] + (d2 >= 0 ? j2 * L.qvel[d2] : 0.f);
-      Jg[r * TJS + d1] = j1; if (d2 >= 0) Jg[r * TJS + d2] = j2;
-      L.etype[r] = (unsigned char)type; L.eR[r] = R; L.eD[r] = 1.f / R; L.efl[r] = floss;
-      L.earef[r] = -Bc * vel - (type == TR_FRICTION ? 0.f : K * imp * pos);
+      G.J[r * TJS + d1] = j1; if (d2 >= 0) G.J[r * TJS + d2] = j2;
+      G.etype[r] = (unsigned int)type; G.eR[r] = R; G.eD[r] = 1.f / R; G.efl[r] = floss;
+      G.earef[r] = -Bc * vel - (type == TR_FRICTION ? 0.f : K * imp * pos);
     }
   }
   if (lo_on || hi_on) {
@@ -595,9 +613,9 @@ DEV void make_constraints(const TreeModel* tm, TreeLDS& L, float* Jg) {
       float pos = side == 0 ? q_j - tm->jnt_range[j][0] : tm->jnt_range[j][1] - q_j, sg = side == 0 ? 1.f : -1.f;
       float imp, K, Bc; row_params(tm, solref, solimp, pos, &imp, &K, &Bc);
       float R = fmaxf(MINVAL_F, (1.f - imp) * tm->dof_invweight0[d] / imp);
-      Jg[r * TJS + d] = sg;
-      L.etype[r] = TR_LIMIT; L.eR[r] = R; L.eD[r] = 1.f / R; L.efl[r] = 0.f;
-      L.earef[r] = -Bc * sg * L.qvel[d] - K * imp * pos;
+      G.J[r * TJS + d] = sg;
+      G.etype[r] = TR_LIMIT; G.eR[r] = R; G.eD[r] = 1.f / R; G.efl[r] = 0.f;
+      G.earef[r] = -Bc * sg * L.qvel[d] - K * imp * pos;
     }
   }
   // ---- contact rows: Jacobian by lane = dof (coalesced rows), parameters by lane = contact
@@ -618,7 +636,7 @@ DEV void make_constraints(const TreeModel* tm, TreeLDS& L, float* Jg) {
       }
       for (int j = 0; j < dim; j++) {
         const float* ax = &C.frame[3 * (j < 3 ? j : j - 3)];
-        Jg[(row + j) * TJS + d] = j < 3 ? dot3(ax, jp) : dot3(ax, jr);
+        G.J[(row + j) * TJS + d] = j < 3 ? dot3(ax, jp) : dot3(ax, jr);
       }
     }
   }
@@ -637,16 +655,16 @@ DEV void make_constraints(const TreeModel* tm, TreeLDS& L, float* Jg) {
       for (int j = 2; j < dim; j++) R[j] = fmaxf(MINVAL_F, R[1] * C.fric[0] * C.fric[0] / (C.fric[j - 1] * C.fric[j - 1]));
     } else C.mu = 0.f;
     for (int j = 0; j < dim; j++) {
-      L.etype[row + j] = TR_CONTACT; L.eR[row + j] = R[j]; L.eD[row + j] = 1.f / R[j]; L.efl[row + j] = 0.f;
-      L.ejar[row + j] = Bc; L.ejv[row + j] = j == 0 ? K * imp * C.dist : 0.f;      // (parked until the pass below)
+      G.etype[row + j] = TR_CONTACT; G.eR[row + j] = R[j]; G.eD[row + j] = 1.f / R[j]; G.efl[row + j] = 0.f;
+      G.ejar[row + j] = Bc; G.ejv[row + j] = j == 0 ? K * imp * C.dist : 0.f;      // (parked until the pass below)
     }
   }
   wave_sync();
   // reference acceleration of the contact rows: aref = -B (J qvel) - K imp pos; lane = row
   for (int r = nscalar + lane; r < nrow; r += WAVE) {
     float vel = 0.f;
-    for (int d = 0; d < nv; d++) vel += Jg[r * TJS + d] * L.qvel[d];
-    L.earef[r] = -L.ejar[r] * vel - L.ejv[r];
+    for (int d = 0; d < nv; d++) vel += G.J[r * TJS + d] * L.qvel[d];
+    G.earef[r] = -G.ejar[r] * vel - G.ejv[r];
   }
   wave_sync();
 }
@@ -712,7 +730,7 @@ DEV float scalar_block(int type, float D, float R, float fl, float r, float* for
 }
 
 // total cost at the point L.x; with want: gradient in L.grad and Hessian in L.H (not yet factored); forces in L.ef, jar in L.ejar
-DEV float total_cost(const TreeModel* tm, TreeLDS& L, const float* Jg, bool want) {
+DEV float total_cost(const TreeModel* tm, TreeLDS& L, const TreeScratch& G, bool want) {
   int lane = wave_lane(), nv = tm->nv, nrow = L.nrow, nscalar = L.nscalar, ncon = L.ncon;
   float part = 0.f;
   if (lane < nv) {
@@ -722,29 +740,29 @@ DEV float total_cost(const TreeModel* tm, TreeLDS& L, const float* Jg, bool want
     part = 0.5f * (v - L.qfrc[lane]) * (L.x[lane] - L.qsm[lane]);
   }
   for (int r = lane; r < nrow; r += WAVE) {
-    float v = -L.earef[r];
-    for (int d = 0; d < nv; d++) v += Jg[r * TJS + d] * L.x[d];
-    L.ejar[r] = v;
+    float v = -G.earef[r];
+    for (int d = 0; d < nv; d++) v += G.J[r * TJS + d] * L.x[d];
+    G.ejar[r] = v;
   }
   wave_sync();
   for (int r = lane; r < nscalar; r += WAVE) {
     float f, h;
-    part += scalar_block(L.etype[r], L.eD[r], L.eR[r], L.efl[r], L.ejar[r], &f, &h);
-    L.ef[r] = f; L.ejv[r] = h;        // (ejv doubles as the scalar rows' second derivative until the line search fills it)
+    part += scalar_block(G.etype[r], G.eD[r], G.eR[r], G.efl[r], G.ejar[r], &f, &h);
+    G.ef[r] = f; G.ejv[r] = h;        // (ejv doubles as the scalar rows' second derivative until the line search fills it)
   }
   if (lane < ncon) {
     const TCon& C = L.con[lane];
     int dim = C.dim, row = C.row;
     float r6[6], f6[6], D6[6], Hc[36];
 #pragma unroll
-    for (int j = 0; j < 6; j++) { r6[j] = j < dim ? L.ejar[row + j] : 0.f; D6[j] = j < dim ? L.eD[row + j] : 0.f; }
+    for (int j = 0; j < 6; j++) { r6[j] = j < dim ? G.ejar[row + j] : 0.f; D6[j] = j < dim ? G.eD[row + j] : 0.f; }
     part += contact_block(C, D6, dim, r6, f6, Hc, want);
 #pragma unroll
-    for (int j = 0; j < 6; j++) if (j < dim) L.ef[row + j] = f6[j];
+    for (int j = 0; j < 6; j++) if (j < dim) G.ef[row + j] = f6[j];
     if (want) {
       bool any = false;
 #pragma unroll
-      for (int k = 0; k < 36; k++) { L.Hc[lane][k] = Hc[k]; any = any || Hc[k] != 0.f; }
+      for (int k = 0; k < 36; k++) { G.Hc[lane][k] = Hc[k]; any = any || Hc[k] != 0.f; }
       L.hdim[lane] = any ? dim : 0;          // (0: the block is inactive, nothing to add to the Hessian)
     }
   }
@@ -754,7 +772,7 @@ DEV float total_cost(const TreeModel* tm, TreeLDS& L, const float* Jg, bool want
   // gradient: Ma - qfrc_smooth - J' force; lane = dof
   if (lane < nv) {
     float g = L.Ma[lane] - L.qfrc[lane];
-    for (int r = 0; r < nrow; r++) g -= Jg[r * TJS + lane] * L.ef[r];
+    for (int r = 0; r < nrow; r++) g -= G.J[r * TJS + lane] * G.ef[r];
     L.grad[lane] = g;
   }
   // Hessian: M + sum J' Hc J; lane = column
@@ -763,9 +781,9 @@ DEV float total_cost(const TreeModel* tm, TreeLDS& L, const float* Jg, bool want
 #pragma unroll
   for (int a = 0; a < TV; a++) hcol[a] = L.M[a][col];       // (rows / columns beyond nv are never read back)
   for (int r = 0; r < nscalar; r++) {
-    float h = L.ejv[r];
+    float h = G.ejv[r];
     if (h == 0.f) continue;
-    float jc = lane < nv ? Jg[r * TJS + lane] : 0.f;
+    float jc = lane < nv ? G.J[r * TJS + lane] : 0.f;
     wave_sync();
     if (lane < TJS) L.Jc[0][lane] = jc;
     wave_sync();
@@ -779,7 +797,7 @@ DEV float total_cost(const TreeModel* tm, TreeLDS& L, const float* Jg, bool want
     int row = L.con[c].row;
     float jl[6];
 #pragma unroll
-    for (int j = 0; j < 6; j++) jl[j] = (j < dim && lane < nv) ? Jg[(row + j) * TJS + lane] : 0.f;
+    for (int j = 0; j < 6; j++) jl[j] = (j < dim && lane < nv) ? G.J[(row + j) * TJS + lane] : 0.f;
     wave_sync();
     if (lane < TJS) {
 #pragma unroll
@@ -791,7 +809,7 @@ DEV float total_cost(const TreeModel* tm, TreeLDS& L, const float* Jg, bool want
     for (int j = 0; j < 6; j++) {
       float v = 0.f;
 #pragma unroll
-      for (int k = 0; k < 6; k++) v += L.Hc[c][j * 6 + k] * jl[k];
+      for (int k = 0; k < 6; k++) v += G.Hc[c][j * 6 + k] * jl[k];
       t[j] = v;
     }
 #pragma unroll
@@ -811,21 +829,21 @@ DEV float total_cost(const TreeModel* tm, TreeLDS& L, const float* Jg, bool want
   return cost;
 }
 
-DEV void solve_newton(const TreeModel* tm, TreeLDS& L, const float* Jg, int max_iter, float tolerance) {
+DEV void solve_newton(const TreeModel* tm, TreeLDS& L, const TreeScratch& G, int max_iter, float tolerance) {
   int lane = wave_lane(), nv = tm->nv, nrow = L.nrow, nscalar = L.nscalar, ncon = L.ncon;
   if (lane == 0) L.iters = 0;
   if (nrow == 0) { if (lane < nv) L.qacc[lane] = L.qsm[lane]; wave_sync(); return; }
   // warm start: the better of the previous acceleration and the unconstrained one
   if (lane < nv) L.x[lane] = L.warm[lane];
   wave_sync();
-  float cw = total_cost(tm, L, Jg, false);
+  float cw = total_cost(tm, L, G, false);
   if (lane < nv) L.x[lane] = L.qsm[lane];
   wave_sync();
-  float cs = total_cost(tm, L, Jg, false);
+  float cs = total_cost(tm, L, G, false);
   if (cw < cs) { if (lane < nv) L.x[lane] = L.warm[lane]; }
   wave_sync();
   float scale = 1.f / (tm->meaninertia * (float)(nv > 1 ? nv : 1));
-  float cost = total_cost(tm, L, Jg, true);
+  float cost = total_cost(tm, L, G, true);
   int it = 0;
   for (; it < max_iter; ) {
     chol_factor(L.H, nv);
@@ -835,8 +853,8 @@ DEV void solve_newton(const TreeModel* tm, TreeLDS& L, const float* Jg, int max_
     // line search on phi(alpha) = cost(x + alpha search): safeguarded Newton on phi'
     for (int r = lane; r < nrow; r += WAVE) {
       float v = 0.f;
-      for (int d = 0; d < nv; d++) v += Jg[r * TJS + d] * L.search[d];
-      L.ejv[r] = v;
+      for (int d = 0; d < nv; d++) v += G.J[r * TJS + d] * L.search[d];
+      G.ejv[r] = v;
     }
     float p1 = 0.f, p2 = 0.f;
     if (lane < nv) {
@@ -850,8 +868,8 @@ DEV void solve_newton(const TreeModel* tm, TreeLDS& L, const float* Jg, int max_
     for (int ls = 0; ls < 24; ls++) {
       float a1 = 0.f, a2 = 0.f;
       for (int r = lane; r < nscalar; r += WAVE) {
-        float f, h, jv = L.ejv[r];
-        scalar_block(L.etype[r], L.eD[r], L.eR[r], L.efl[r], L.ejar[r] + alpha * jv, &f, &h);
+        float f, h, jv = G.ejv[r];
+        scalar_block(G.etype[r], G.eD[r], G.eR[r], G.efl[r], G.ejar[r] + alpha * jv, &f, &h);
         a1 -= f * jv; a2 += jv * h * jv;
       }
       if (lane < ncon) {
@@ -859,7 +877,7 @@ DEV void solve_newton(const TreeModel* tm, TreeLDS& L, const float* Jg, int max_
         int dim = C.dim, row = C.row;
         float r6[6], f6[6], D6[6], Hc[36], jv6[6];
 #pragma unroll
-        for (int j = 0; j < 6; j++) { jv6[j] = j < dim ? L.ejv[row + j] : 0.f; r6[j] = j < dim ? L.ejar[row + j] + alpha * jv6[j] : 0.f; D6[j] = j < dim ? L.eD[row + j] : 0.f; }
+        for (int j = 0; j < 6; j++) { jv6[j] = j < dim ? G.ejv[row + j] : 0.f; r6[j] = j < dim ? G.ejar[row + j] + alpha * jv6[j] : 0.f; D6[j] = j < dim ? G.eD[row + j] : 0.f; }
         contact_block(C, D6, dim, r6, f6, Hc, true);
 #pragma unroll
         for (int j = 0; j < 6; j++) {
@@ -880,7 +898,7 @@ DEV void solve_newton(const TreeModel* tm, TreeLDS& L, const float* Jg, int max_
     }
     if (lane < nv) L.x[lane] += alpha * L.search[lane];
     wave_sync();
-    float newcost = total_cost(tm, L, Jg, true);
+    float newcost = total_cost(tm, L, G, true);
     float improvement = scale * (cost - newcost);
     float gn = wave_sum_f(lane < nv ? L.grad[lane] * L.grad[lane] : 0.f);
     float gnorm = scale * sqrtf(gn);
@@ -895,14 +913,14 @@ DEV void solve_newton(const TreeModel* tm, TreeLDS& L, const float* Jg, int max_
 
 // ------------------------------------------------------------------ forward dynamics and integration
 // `phases`: stage mask for timing runs (so101_tree_debug_forward with SO101_TREE_PHASES set); every caller on the step path passes all
-DEV void forward(const TreeModel* tm, const DevModel* gm, TreeLDS& L, float* Jg, int max_iter, float tolerance, int phases = 0x7f) {
+DEV void forward(const TreeModel* tm, const DevModel* gm, TreeLDS& L, const TreeScratch& G, int max_iter, float tolerance, int phases = 0x7f) {
   kinematics(tm, L);
   if (phases & 2) crba(tm, L);
   if (phases & 4) rne_bias(tm, L);
   if (phases & 8) smooth(tm, L);
   if (phases & 16) collision(tm, gm, L); else { if (wave_lane() == 0) { L.ncon = 0; L.ncand = 0; } wave_sync(); }
-  if (phases & 32) make_constraints(tm, L, Jg); else { if (wave_lane() == 0) { L.nrow = 0; L.nscalar = 0; } wave_sync(); }
-  if (phases & 64) solve_newton(tm, L, Jg, max_iter, tolerance);
+  if (phases & 32) make_constraints(tm, L, G); else { if (wave_lane() == 0) { L.nrow = 0; L.nscalar = 0; } wave_sync(); }
+  if (phases & 64) solve_newton(tm, L, G, max_iter, tolerance);
 }
 
 DEV void euler(const TreeModel* tm, TreeLDS& L) {
@@ -991,7 +1009,7 @@ DEV float task_reward(const TreeModel* tm, const TreeTask& T, const TreeLDS& L) 
 
 // env.reset(): arms at the home pose, object and container placed (container by rejection, <= 20 tries), settled with the arms held
 // (aloha2_task.py:369-383, hand_over.py:208-236,340-346).  Same counter-RNG draws as the SO100 reset and the oracle.
-DEV void env_reset(const TreeModel* tm, const DevModel* gm, const TreeTask& T, TreeLDS& L, float* Jg, const TreeBuffers& B, const TreeEnvBuffers& E, int e) {
+DEV void env_reset(const TreeModel* tm, const DevModel* gm, const TreeTask& T, TreeLDS& L, const TreeScratch& G, const TreeBuffers& B, const TreeEnvBuffers& E, int e) {
   int lane = wave_lane(), N = T.n_envs;
   unsigned int episode = (unsigned int)E.episode[e];
   unsigned long long env_id = T.env_id_base + (unsigned long long)e;
@@ -1024,7 +1042,7 @@ DEV void env_reset(const TreeModel* tm, const DevModel* gm, const TreeTask& T, T
   // settle until |qvel| < 1e-3 and |qacc| < 1e-2 over the props' dofs
   bool settled = T.settle_max == 0;
   for (int k = 0; k < T.settle_max && !settled; k++) {
-    forward(tm, gm, L, Jg, T.iterations, T.tolerance);
+    forward(tm, gm, L, G, T.iterations, T.tolerance);
     euler(tm, L);
     bool ok = true;
     if (lane < tm->nq) ok = ok && fabsf(L.qpos[lane]) <= 1e10f;

@@ -25,10 +25,10 @@ __global__ void __launch_bounds__(64) k_tree_physics(const TreeModel* tm, const 
   int e = blockIdx.x, lane = wave_lane();
   if (lane == 0) L.flags = 0;
   tree::load_state(tm, L, B, e, N);
-  float* Jg = B.J + (size_t)e * TROW * TJS;
+  TreeScratch G = tree::scratch_of(B, e);
   int bad = 0;
   for (int s = 0; s < nsub; s++) {
-    tree::forward(tm, gm, L, Jg, iterations, tolerance);
+    tree::forward(tm, gm, L, G, iterations, tolerance);
     tree::euler(tm, L);
     // mj_checkPos / Vel / Acc: NaN or beyond 1e10 ends the episode (the caller sees flag 8 and resets the env)
     bool ok = true;
@@ -46,8 +46,8 @@ __global__ void __launch_bounds__(64) k_tree_forward(const TreeModel* tm, const 
   int e = blockIdx.x, lane = wave_lane();
   if (lane == 0) L.flags = 0;
   tree::load_state(tm, L, B, e, N);
-  float* Jg = B.J + (size_t)e * TROW * TJS;
-  tree::forward(tm, gm, L, Jg, iterations, tolerance, phases);
+  TreeScratch G = tree::scratch_of(B, e);
+  tree::forward(tm, gm, L, G, iterations, tolerance, phases);
   float* o = out + (size_t)e * TDBG_DIM;
   int nv = tm->nv, nb = tm->nbody;
   if (lane == 0) { o[0] = (float)L.ncon; o[1] = (float)L.nrow; o[2] = (float)L.iters; o[3] = (float)L.ncand; o[4] = (float)L.flags; o[5] = (float)L.nscalar; }
@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(64) k_tree_forward(const TreeModel* tm, const 
     float* q = o + TDBG_CON + 10 * lane;
     for (int k = 0; k < 3; k++) { q[k] = c.pos[k]; q[3 + k] = c.frame[k]; }
     q[6] = c.dist; q[7] = (float)c.g1; q[8] = (float)c.g2; q[9] = (float)c.dim;
-    o[TDBG_FORCE + lane] = L.nrow > 0 ? L.ef[c.row] : 0.f;
+    o[TDBG_FORCE + lane] = L.nrow > 0 ? G.ef[c.row] : 0.f;
   }
 }
 
@@ -72,8 +72,8 @@ __global__ void __launch_bounds__(64) k_tree_reset(const TreeModel* tm, const De
   if (mask && !mask[e]) return;
   if (lane == 0) L.flags = 0;
   wave_sync();
-  float* Jg = B.J + (size_t)e * TROW * TJS;
-  tree::env_reset(tm, gm, T, L, Jg, B, E, e);
+  TreeScratch G = tree::scratch_of(B, e);
+  tree::env_reset(tm, gm, T, L, G, B, E, e);
   tree::store_state(tm, L, B, e, N);
   if (lane < tm->nu) B.ctrl[(size_t)lane * N + e] = L.ctrl[lane];
   if (lane == 0) { E.need_reset[e] = 0; if (B.diag) { int* d = B.diag + 8 * e; d[0] = L.ncon; d[1] = L.nrow; d[2] = L.iters; d[3] = L.ncand; d[4] = L.flags; } }
@@ -87,9 +87,9 @@ __global__ void __launch_bounds__(64) k_tree_step(const TreeModel* tm, const Dev
   int e = blockIdx.x, lane = wave_lane(), N = T.n_envs;
   if (lane == 0) L.flags = 0;
   wave_sync();
-  float* Jg = B.J + (size_t)e * TROW * TJS;
+  TreeScratch G = tree::scratch_of(B, e);
   if (E.need_reset[e]) {
-    tree::env_reset(tm, gm, T, L, Jg, B, E, e);
+    tree::env_reset(tm, gm, T, L, G, B, E, e);
     tree::kinematics(tm, L);
     tree::write_obs(T, L, E, e, 0, true, obs);
     tree::store_state(tm, L, B, e, N);
@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(64) k_tree_step(const TreeModel* tm, const Dev
   wave_sync();
   bool diverged = false;
   for (int s = 0; s < T.n_substeps && !diverged; s++) {
-    tree::forward(tm, gm, L, Jg, T.iterations, T.tolerance);
+    tree::forward(tm, gm, L, G, T.iterations, T.tolerance);
     tree::euler(tm, L);
     bool ok = true;
     if (lane < tm->nq) ok = ok && fabsf(L.qpos[lane]) <= 1e10f;
@@ -358,8 +358,8 @@ int so101_tree_create(const void* blob, size_t bytes, int n_envs, int hip_device
   if (rc == SO101_OK) rc = tree_build(s, b);
   if (rc == SO101_OK) {
     void* p = nullptr;
-    if (!t_ok(s, hipMalloc(&p, (size_t)n_envs * TROW * TJS * sizeof(float)), "hipMalloc(J)")) rc = SO101_ERR_HIP;
-    else { s->owned.push_back(p); s->buf.J = (float*)p; }
+    if (!t_ok(s, hipMalloc(&p, (size_t)n_envs * T_SCRATCH * sizeof(float)), "hipMalloc(scratch)")) rc = SO101_ERR_HIP;
+    else { s->owned.push_back(p); s->buf.scratch = (float*)p; }
   }
   if (rc == SO101_OK) {
     void* p = nullptr;
