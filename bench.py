@@ -293,7 +293,8 @@ def main():
                 env.set_mass_scale(0.5 + torch.rand(2, env.n_envs, device=dev, generator=gen))
             if args.workload == "pickplace":
                 from so101_sim_amd import pregrasp
-                env.set_reset_pool(*pregrasp.build_pickplace_pool(env, pool_size=args.pool_size, seed=rank))
+                # (built once, on rank 0, and broadcast: the pool is the same on every rank, only the draws from it differ per env)
+                env.set_reset_pool(*sdist.build_on_rank0(lambda: pregrasp.build_pickplace_pool(env, pool_size=args.pool_size, seed=0)))
                 noise[k] = 0.05 * torch.randn(total, env.n_envs, 6, device=dev, generator=gen)
             else:
                 tapes[k] = lo + (hi - lo) * torch.rand(total, env.n_envs, 6, device=dev, generator=gen)   # actions resident in HBM

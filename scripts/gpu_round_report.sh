@@ -25,6 +25,11 @@ timeout 600 python bench.py --pipeline 3 --no-cpu-baseline --steps 20 --warmup 5
 timeout 900 python bench.py --steps 1500 --warmup 10 --no-cpu-baseline --repeats 1 2>/dev/null | tail -1 > $O/${TAG}_bench_1500.json
 [ -x $R/ab/mfma_hessian ] && timeout 120 $R/ab/mfma_hessian > $O/${TAG}_mfma_hessian.txt 2>&1
 timeout 600 python scripts/gpu_reset_cost.py 2>&1 | tail -6 > $O/${TAG}_reset_cost.txt
+# ALOHA hand-over on the general-tree engine: throughput at three batch sizes, stage times, kernel stats
+timeout 600 python scripts/gpu_aloha_bench.py banana 2>/dev/null | grep workload > $O/${TAG}_aloha_bench.json
+timeout 600 python scripts/gpu_aloha_bench.py pen 2>/dev/null | grep workload > $O/${TAG}_aloha_bench_pen.json
+timeout 600 python scripts/gpu_tree_phases.py 2>/dev/null | grep mask > $O/${TAG}_aloha_phases.txt
+( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_aloha && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_aloha -- python3 $R/scripts/gpu_aloha_bench.py banana > /dev/null 2>&1; find /tmp/prof_aloha -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_aloha_kernel_stats.csv \; )
 rocm-smi --showclocks 2>/dev/null | grep -E "sclk|mclk" | head -4 > $O/${TAG}_clocks_after.txt
 bash $R/scripts/gpu_profile.sh $TAG > $O/${TAG}_profile.log 2>&1
 for f in $O/${TAG}_pytest_gpu.txt $O/${TAG}_smoke.txt $O/${TAG}_reset_cost.txt; do echo "== $f"; cat $f; done

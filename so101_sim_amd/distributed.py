@@ -60,6 +60,26 @@ def shard_range(n_global: int, world_size: int, rank: int) -> tuple[int, int]:
     return start, start + base + (1 if rank < rem else 0)
 
 
+def build_on_rank0(build, src: int = 0):
+    """`build()` -> tuple of tensors, run on rank `src` only; the other ranks receive the result (shapes and dtypes first, then
+    the data: RCCL broadcast on GPUs).  For set-up work that is the same on every rank - the pre-grasp pool of bench.py's
+    pick-and-place workload - so that eight ranks do not each repeat it."""
+    import torch
+    import torch.distributed as dist
+    rank, _, _ = rank_info()
+    if not _active():
+        return build()
+    out = build() if rank == src else None
+    meta = [[(tuple(t.shape), str(t.dtype).replace("torch.", ""), str(t.device.type)) for t in out]] if rank == src else [None]
+    dist.broadcast_object_list(meta, src=src)
+    if rank != src:
+        dev = "cuda" if meta[0][0][2] == "cuda" else "cpu"
+        out = tuple(torch.empty(shape, dtype=getattr(torch, dt), device=dev) for shape, dt, _ in meta[0])
+    for t in out:
+        dist.broadcast(t, src=src)
+    return tuple(out)
+
+
 def max_over_ranks(value: float, device=None) -> float:
     """Slowest rank's time: what the whole-job throughput is computed from."""
     if not _active():

@@ -47,6 +47,10 @@ def _worker(rank, world, port, n_global, out):
     delay = 0.02 * (1 + 2 * rank)
     value, elapsed, rets = sd.run_sharded(lambda base: _StubEnv(base, per_rank), lambda env, i: env.step(i, delay), per_rank, steps)
     tmax = sd.max_over_ranks(float(rank + 1))
+    # set-up work done on rank 0 only and broadcast (bench.py's pre-grasp pool): every rank ends with rank 0's tensors
+    calls = []
+    pool = sd.build_on_rank0(lambda: (calls.append(rank), (torch.arange(6, dtype=torch.float32).reshape(2, 3) + 100 * rank, torch.tensor([7 + rank], dtype=torch.int32)))[1])
+    assert calls == ([0] if rank == 0 else []) and pool[0].tolist() == [[0.0, 1.0, 2.0], [3.0, 4.0, 5.0]] and pool[1].tolist() == [7] and pool[1].dtype == torch.int32
     if rank == 0:
         out.put((g.numpy(), value, elapsed, rets.numpy(), tmax))
     sd.finalize()
