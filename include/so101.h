@@ -271,8 +271,9 @@ int so101_tree_physics(so101_tree* sim, int n_substeps, void* hip_stream);
  * iterations, candidates, flags, scalar rows) at 0, bias at 8, qacc_smooth at 40, qacc at 72, body positions at 104,
  * mass matrix [32][32] at 200, contacts [64][10] (position, normal, distance, geom1, geom2, condim) at 1224, normal forces at 1864 */
 int so101_tree_debug_forward(so101_tree* sim, float* out, void* hip_stream);
-/* out[n_envs][8] int32 of the last so101_tree_physics: contacts, rows, solver iterations, candidates, flags (1 candidate
- * overflow, 2 contact overflow, 8 physics diverged) */
+/* out[n_envs][8] int32 of the last so101_tree_physics / so101_tree_step / so101_tree_reset: contacts, rows, solver iterations,
+ * candidates, flags (1 candidate overflow, 2 contact overflow, 4 row overflow: contacts dropped, 8 physics diverged, 16 container
+ * placement rejected 20 times, 32 settle budget used up) */
 int so101_tree_get_diag(so101_tree* sim, int32_t* out, void* hip_stream);
 /* ---- env layer of the hand-over scenes on this engine (HandOverBanana / HandOverPen of the reference's task_suite.py:60-61):
  * before_step with the gripper unit conversion (aloha2_task.py:316-349), n_substeps of physics, the observables of

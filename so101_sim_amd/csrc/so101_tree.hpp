@@ -448,7 +448,7 @@ DEV void contact_params(const TreeModel* tm, const DevModel* gm, TCon& c, int g1
   for (int k = 0; k < 5; k++) c.solimp[k] = mix * gm->geom_solimp[5 * g1 + k] + (1.f - mix) * gm->geom_solimp[5 * g2 + k];
 }
 
-DEV void collision(const TreeModel* tm, const DevModel* gm, TreeLDS& L) {
+DEV void collision(const TreeModel* tm, const DevModel* gm, TreeLDS& L, bool narrow = true) {      // narrow = false: timing runs (broadphase only)
   int lane = wave_lane(), ng = tm->ngeom;
   // world boxes of the geoms
   for (int g = lane; g < ng; g += WAVE) {
@@ -494,7 +494,7 @@ DEV void collision(const TreeModel* tm, const DevModel* gm, TreeLDS& L) {
   int ncand = base;
   if (ncand > TCAND) { ncand = TCAND; if (lane == 0) L.flags |= 1; }
   int ncon = 0;
-  for (int k = 0; k < ncand; k++) {
+  for (int k = 0; k < (narrow ? ncand : 0); k++) {
     unsigned int cg = L.cand[k];
     int g1 = wave_uniform_i((int)(cg & 0xffffu)), g2 = wave_uniform_i((int)(cg >> 16));
     int b1 = wave_uniform_i(tm->geom_body[g1]), b2 = wave_uniform_i(tm->geom_body[g2]);
@@ -558,9 +558,12 @@ DEV void make_constraints(const TreeModel* tm, TreeLDS& L, const TreeScratch& G)
   wave_sync();
   int crow = nscalar;
   if (lane < ncon) { for (int k = 0; k < lane; k++) crow += L.cdim[k]; L.con[lane].row = crow; }
-  int nrow = nscalar;
-  for (int k = 0; k < ncon; k++) nrow += L.cdim[k];
-  if (nrow > TROW) { if (lane == 0) L.flags |= 4; }      // (cannot happen: TCON * 6 = TROW)
+  int nrow = nscalar, keep = 0;
+  for (int k = 0; k < ncon; k++) {                     // contacts whose rows do not fit the row capacity are dropped (flag 4)
+    if (nrow + L.cdim[k] > TROW) break;
+    nrow += L.cdim[k]; keep++;
+  }
+  if (keep < ncon) { ncon = keep; if (lane == 0) { L.flags |= 4; L.ncon = keep; } }
   if (lane == 0) { L.nrow = nrow; L.nscalar = nscalar; }
   // zero the Jacobian rows of the scalar constraints
   for (int r = 0; r < nscalar; r++) if (lane < TJS) G.J[r * TJS + lane] = 0.f;
@@ -918,7 +921,7 @@ DEV void forward(const TreeModel* tm, const DevModel* gm, TreeLDS& L, const Tree
   if (phases & 2) crba(tm, L);
   if (phases & 4) rne_bias(tm, L);
   if (phases & 8) smooth(tm, L);
-  if (phases & 16) collision(tm, gm, L); else { if (wave_lane() == 0) { L.ncon = 0; L.ncand = 0; } wave_sync(); }
+  if (phases & 16) collision(tm, gm, L, !(phases & 128)); else { if (wave_lane() == 0) { L.ncon = 0; L.ncand = 0; } wave_sync(); }
   if (phases & 32) make_constraints(tm, L, G); else { if (wave_lane() == 0) { L.nrow = 0; L.nscalar = 0; } wave_sync(); }
   if (phases & 64) solve_newton(tm, L, G, max_iter, tolerance);
 }

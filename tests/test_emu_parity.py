@@ -55,9 +55,10 @@ def test_pipelined_step_matches_fused(make_sim, golden):
 
 
 def test_chained_and_merged_steps_match_fused(make_sim, golden):
-    # two envs on concurrently alive emulated wavefronts: every queue hand-off of so101_chain.hpp (pipeline 2: persistent k_chain;
-    # pipeline 3: narrowphase chunks inside the solve launches) against the fused step, bit for bit
-    pc.check_pipeline_identical(make_sim, golden, n=2, steps=1, settle=2, pipelines=(0, 2, 3))
+    # two envs on concurrently alive emulated wavefronts: every queue hand-off of so101_chain.hpp (pipeline 2: persistent k_chain)
+    # against the fused step, bit for bit.  (Pipeline 3 - narrowphase chunks inside the solve launches, the same queue code - is
+    # compared on the GPU only, tests/test_gpu_parity.py: the emulated run costs a minute of the CPU suite per pipeline.)
+    pc.check_pipeline_identical(make_sim, golden, n=2, steps=1, settle=2, pipelines=(0, 2))
 
 
 def test_pgs_forward_matches_oracle_pgs(make_sim, blobs):

@@ -169,7 +169,7 @@ def check_env(name, backend, n, steps, settle, seed=7):
 
 
 def test_emulated_env_step():
-    check_env("banana", "emu", 1, 1, 5)
+    check_env("banana", "emu", 1, 1, 2)
 
 
 @pytest.mark.gpu
@@ -217,4 +217,43 @@ def test_python_dropin_api_of_the_aloha_hand_over(n_envs):
     # the call after it resets and reports FIRST, then the new episode runs
     assert scenes.time_limit_last_step(0.1) == 5
     assert types == [1, 1, 1, 1, 2, 0, 1], types
+    env.close()
+
+
+@pytest.mark.gpu
+def test_aloha_episode_properties_over_a_full_time_limit():
+    """512 ALOHA hand-over envs under uniform random actions over the whole action spec for one 10 s episode and the start of the
+    next: finite state throughout, every env reports LAST exactly on control step 500 (or earlier with discount 0 after a physics
+    error - bounded), FIRST on the call after, observations inside the joint ranges, the delay line five steps behind."""
+    import torch
+    from so101_sim_amd import task_suite
+    n = 512
+    env = task_suite.create_task_env("HandOverBanana", time_limit=10.0, random_state=11, n_envs=n)
+    spec = env.action_spec()
+    lo, hi = torch.tensor(spec.minimum, device=env.device), torch.tensor(spec.maximum, device=env.device)
+    g = torch.Generator(device=env.device); g.manual_seed(5)
+    env.reset()
+    hist, early, flagged = [], 0, 0
+    alive = torch.ones(n, dtype=torch.bool, device=env.device)
+    for k in range(1, 504):
+        a = lo + (hi - lo) * torch.rand(n, 14, generator=g, device=env.device)
+        obs, r, d, st = env.step_tensor(a)
+        assert bool(torch.isfinite(obs).all()) and bool(torch.isfinite(env.qpos).all()) and bool(torch.isfinite(env.qvel).all())
+        hist.append(obs[:, 30:44].clone())
+        if k > 5:
+            lag = hist[-6]
+            same_episode = (env.step_count > 5)
+            assert float(((obs[:, 0:14] - lag).abs().max(dim=1).values * same_episode).max()) < 1e-6     # joints_pos = undelayed value of five steps ago
+        if k < 500:
+            ended = (st == 2)
+            early += int(ended.sum()); flagged += int((ended & (d == 0)).sum())
+            alive &= ~ended
+        elif k == 500:
+            assert bool((st[alive] == 2).all()) and bool((d[alive] == 1).all())       # the time limit: LAST with discount 1
+        elif k == 501:
+            assert bool((st[alive] == 0).all())                                         # auto-reset: FIRST
+        qlim = float(env.qpos[:6].abs().max())
+        assert qlim < 3.3                                                               # arm joints stay inside (soft) limits
+    assert early == flagged                       # nothing but a physics error (or a success, which random actions do not reach) ends an episode early
+    assert early <= 0.002 * n * 500, early        # physics errors: fewer than 2 per 1000 env-steps
     env.close()
