@@ -9,7 +9,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from so101_sim_amd import task_suite          # noqa: E402
 from so101_sim_amd.model import scenes        # noqa: E402
 

@@ -8,7 +8,7 @@ import time
 if len(sys.argv) > 1:
     import numpy as np
     import torch
-    sys.path.insert(0, ".")
+    sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
     from so101_sim_amd import task_suite
     n = 2048
     env = task_suite.create_task_env("HandOverBanana", time_limit=10.0, random_state=0, n_envs=n, settle_max_substeps=200)
