@@ -273,7 +273,7 @@ int so101_tree_physics(so101_tree* sim, int n_substeps, void* hip_stream);
 int so101_tree_debug_forward(so101_tree* sim, float* out, void* hip_stream);
 /* out[n_envs][8] int32 of the last so101_tree_physics / so101_tree_step / so101_tree_reset: contacts, rows, solver iterations,
  * candidates, flags (1 candidate overflow, 2 contact overflow, 4 row overflow: contacts dropped, 8 physics diverged, 16 container
- * placement rejected 20 times, 32 settle budget used up) */
+ * placement rejected 20 times, 32 settle budget used up); after so101_tree_step word 5 holds the state of the contact-sequence reward */
 int so101_tree_get_diag(so101_tree* sim, int32_t* out, void* hip_stream);
 /* ---- env layer of the hand-over scenes on this engine (HandOverBanana / HandOverPen of the reference's task_suite.py:60-61):
  * before_step with the gripper unit conversion (aloha2_task.py:316-349), n_substeps of physics, the observables of
@@ -292,11 +292,15 @@ typedef struct {
   int solver_iterations;     /* <= 0: the model's */
   float solver_tolerance;    /* < 0: the model's */
   uint64_t seed, env_id_base;
+  int reward_mode;           /* 0 overlap boxes (HandOver's default), 1 contact sequence (reward_based_on_overlap = False, hand_over.py:286-338) */
+  int reward_requires_handover;   /* mode 1: start the sequence at "right gripper touches the object" instead of at its last state */
 } so101_tree_config;
 int so101_tree_obs_dim(const so101_tree* sim);
 int so101_tree_bind_env(so101_tree* sim, float* ring_pos, float* ring_vel, float* ep_return, int32_t* step_count, int32_t* episode);
 int so101_tree_configure_env(so101_tree* sim, const so101_tree_config* cfg);
 int so101_tree_reset(so101_tree* sim, const uint8_t* mask, void* hip_stream);
+/* adopt the bound state (qpos, qvel, ctrl) as the post-reset state of a new episode: delay lines filled with it, counters cleared */
+int so101_tree_begin_episode(so101_tree* sim, void* hip_stream);
 int so101_tree_step(so101_tree* sim, const float* action /*[n_envs][nu]*/, float* obs, float* reward, float* discount, uint8_t* step_type,
                     void* hip_stream);
 const char* so101_tree_last_error(const so101_tree* sim);

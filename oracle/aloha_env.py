@@ -29,8 +29,15 @@ def convert_gripper(v, a, b):
 
 
 class AlohaOracleEnv:
-    def __init__(self, blob_f64: bytes, seed=0, env_id=0, last_step=1 << 30, settle_max_substeps=1000):
+    def __init__(self, blob_f64: bytes, seed=0, env_id=0, last_step=1 << 30, settle_max_substeps=1000, reward_based_on_overlap=True,
+                 reward_requires_handover=False, geom_class=None, bodies=None, dist_threshold=0.0, n_substeps=10):
+        """geom_class / bodies = (object body, container body) / dist_threshold: the model's task_geom_class, task bodies and
+        task_dist_threshold, needed by the contact-sequence reward only"""
         self.o = Oracle(blob_f64)
+        self.overlap, self.requires_handover = reward_based_on_overlap, reward_requires_handover
+        self.geom_class, self.bodies, self.dist_threshold = geom_class, bodies, dist_threshold
+        self.success_state = 2
+        self.n_substeps = n_substeps      # physics steps per control step (10 in the reference; the emulated CPU tests shorten it)
         self.o.env_config(seed=seed, env_id=env_id, settle_max_substeps=settle_max_substeps)
         self.last_step = last_step
         self.need_reset = True
@@ -62,12 +69,33 @@ class AlohaOracleEnv:
         self.ring_pos = collections.deque([self._pos()] * 5, maxlen=5)
         self.ring_vel = collections.deque([self._vel()] * 5, maxlen=5)
         self.step_count, self.need_reset = 0, False
+        self.success_state = 0 if self.requires_handover else 2
 
     def reset(self):
         self.o.env_reset()
         q, v, w = self.o.get_state()
         self.begin(q, v, w, np.concatenate([[0.0, -0.96, 1.16, 0.0, -0.3, 0.0, 0.002]] * 2))
         return self._obs(self.ring_pos[0], self.ring_vel[0])
+
+    def _contact_reward(self):
+        """hand_over.py:286-338: the three-state sequence over the contacts of the last physics step"""
+        cls = self.geom_class
+        pairs = [(int(cls[c["geom1"]]), int(cls[c["geom2"]])) for c in self.o.contacts()]
+        touching = lambda a, b: any(((c1 & a) and (c2 & b)) or ((c2 & a) and (c1 & b)) for c1, c2 in pairs)
+        q, v, _ = self.o.get_state()
+        moving = max(np.abs(v[16:19]).max(), np.abs(v[22:25]).max()) >= 1e-3
+        if self.success_state == 0:
+            if touching(8, 1):
+                self.success_state = 1
+        elif self.success_state == 1:
+            if touching(4, 1):
+                self.success_state = 2
+        else:
+            po, pc = self.o.body_pose(self.bodies[0])[0], self.o.body_pose(self.bodies[1])[0]
+            inside = np.hypot(pc[0] - po[0], pc[1] - po[1]) < self.dist_threshold
+            if not moving and touching(1, 2) and inside:
+                return 1.0
+        return 0.0
 
     def step(self, action):
         """-> obs, reward, discount, step_type"""
@@ -77,11 +105,11 @@ class AlohaOracleEnv:
         self.ctrl = a.copy()
         self.ctrl[6], self.ctrl[13] = convert_gripper(a[6], "follower", "sim_ctrl"), convert_gripper(a[13], "follower", "sim_ctrl")
         self.o.set_ctrl(self.ctrl)
-        diverged = self.o.substeps(10, False)
+        diverged = self.o.substeps(self.n_substeps, False)
         self.step_count += 1
         dp, dv = self.ring_pos[0], self.ring_vel[0]          # the value of control step k - 5
         self.ring_pos.append(self._pos()); self.ring_vel.append(self._vel())
-        r = 0.0 if diverged else float(self.o.reward())
+        r = 0.0 if diverged else (float(self.o.reward()) if self.overlap else self._contact_reward())
         success, timeout = r >= 1.0 or bool(diverged), self.step_count >= self.last_step
         st = 2 if (success or timeout) else 1
         self.need_reset = st == 2

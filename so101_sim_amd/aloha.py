@@ -8,9 +8,9 @@ Every number comes from the kernels behind the `so101_tree_*` entry points of in
 array container.  n_envs == 1 yields numpy observations without the env dimension (what a caller of the reference sees), n_envs > 1
 torch tensors on the GPU with a leading env dimension.
 
-Not built: cameras (no renderer in this library), the contact-FSM reward mode (`reward_based_on_overlap=False`,
-hand_over.py:286-338), non-default observation delays and table height offset (the committed model blob is compiled for the
-reference's defaults).
+Not built: cameras (no renderer in this library), non-default observation delays and table height offset (the committed model
+blob is compiled for the reference's defaults).  Both reward modes are: the overlap boxes (default) and the contact sequence
+(`reward_based_on_overlap=False`, hand_over.py:286-338, with `reward_requires_handover`).
 """
 from __future__ import annotations
 
@@ -40,10 +40,9 @@ class HandOverTask:
     def __init__(self, object_name, reward_based_on_overlap=True, reward_requires_handover=False, **kwargs):
         if object_name not in scenes.HANDOVER_CONFIGS:
             raise ValueError(f"Invalid object name: {object_name}, must be one of {scenes.HANDOVER_CONFIGS.keys()}")
-        if not reward_based_on_overlap:
-            raise NotImplementedError("the contact-sequence reward (hand_over.py:286-338) is not built; the default overlap reward is")
         self.object_name = object_name
-        self.reward_requires_handover = bool(reward_requires_handover)      # only read by the reward mode that is not built
+        self.reward_based_on_overlap = bool(reward_based_on_overlap)         # False: the contact sequence of hand_over.py:286-338
+        self.reward_requires_handover = bool(reward_requires_handover)       # (read by the contact-sequence mode only, as in the reference)
         self.control_timestep = float(kwargs.pop("control_timestep", DEFAULT_CONTROL_TIMESTEP))
         self.cameras = tuple(kwargs.pop("cameras", ()))
         self.image_observation_enabled = bool(kwargs.pop("image_observation_enabled", True))
@@ -109,7 +108,8 @@ class AlohaEnvironment:
         self.last_step = scenes.time_limit_last_step(time_limit, task.control_timestep, PHYSICS_TIMESTEP) if np.isfinite(time_limit) else 1 << 30
         s.configure_env(n_substeps=nsub, last_step=self.last_step, settle_max_substeps=int(settle_max_substeps),
                         terminate_on_success=int(task.terminate_episode), solver_iterations=int(solver_iterations),
-                        solver_tolerance=float(solver_tolerance), seed=seed, env_id_base=int(env_id_base))
+                        solver_tolerance=float(solver_tolerance), seed=seed, env_id_base=int(env_id_base),
+                        reward_mode=0 if task.reward_based_on_overlap else 1, reward_requires_handover=int(task.reward_requires_handover))
         # physics_state / delayed_physics_state (aloha2_task.py:244-251,441-444): qpos | qvel and its copy of 15 control steps ago.
         # The reference ties them to image_observation_enabled; for batches they are opt-in (58 + 58 floats per env and step).
         self._with_state = bool(task.image_observation_enabled if physics_state is None and N == 1 else physics_state)

@@ -45,6 +45,7 @@ struct TreeModel {
   const int* geom_body;            // [ngeom]
   const float* geom_solmix;        // [ngeom]
   const int* geom_priority;        // [ngeom]
+  const int* geom_class;           // [ngeom] task classes: 1 object, 2 container, 4 below the left gripper_link, 8 below the right one (or NULL)
 };
 
 struct TreeBuffers { float *qpos, *qvel, *ctrl, *warm; float* scratch; int* diag; };   // [nq|nv|nu|nv][N] env-fastest; scratch [N][T_SCRATCH]; diag [N][8]
@@ -971,14 +972,15 @@ DEV void euler(const TreeModel* tm, TreeLDS& L) {
 
 #define T_RING 5               // joints_pos / joints_vel delay: 0.1 s = 5 control steps
 struct TreeTask {
-  int npos, nvel, obj_body, con_body, nbox, n_substeps, last_step, settle_max, terminate_on_success, n_envs, iterations, pad;
-  float tolerance, grip[6];    // gripper limits: sim_qpos open, close, sim_ctrl open, close, follower open, close
+  int npos, nvel, obj_body, con_body, nbox, n_substeps, last_step, settle_max, terminate_on_success, n_envs, iterations;
+  int reward_mode, requires_handover;      // 0 overlap boxes (the default), 1 contact sequence (hand_over.py:286-338)
+  float dist_threshold, tolerance, grip[6];    // gripper limits: sim_qpos open, close, sim_ctrl open, close, follower open, close
   int obs_qposadr[TU], obs_is_gripper[TU], act_is_gripper[TU];
   float box_pos[2][3], box_half[2][3], obj_bvh[6];
   float obj_lo[3], obj_hi[3], obj_yaw[2], con_lo[3], con_hi[3], home_qpos[TQ], home_ctrl[TU];
   unsigned long long seed, env_id_base;
 };
-struct TreeEnvBuffers { float *ring_pos, *ring_vel, *ep_return; int *step_count, *episode; unsigned char* need_reset; };
+struct TreeEnvBuffers { float *ring_pos, *ring_vel, *ep_return; int *step_count, *episode; unsigned char* need_reset; int* success_state; };
 
 namespace tree {
 
@@ -1008,6 +1010,31 @@ DEV float task_reward(const TreeModel* tm, const TreeTask& T, const TreeLDS& L) 
     if (!overlap_oobb_oobb(o, cw)) return 0.f;
   }
   return 1.f;
+}
+
+// reward_based_on_overlap = False (hand_over.py:286-338): a three-state sequence over the contacts of the last physics step - the right
+// gripper touched the object (0 -> 1), then the left one did (1 -> 2), then the object rests touching the container within the
+// distance threshold (reward 1).  Without reward_requires_handover an episode starts in state 2.  Needs the kinematics of the
+// current state and the contact list of the last substep in LDS.
+DEV float task_reward_contacts(const TreeModel* tm, const TreeTask& T, const TreeLDS& L, const TreeScratch& G, int* state_io) {
+  int lane = wave_lane(), ob = T.obj_body, cb = T.con_body;
+  const float* vo = &L.qvel[tm->body_dofadr[ob]]; const float* vc = &L.qvel[tm->body_dofadr[cb]];
+  bool moving = fmaxf(fabsf(vo[0]), fmaxf(fabsf(vo[1]), fabsf(vo[2]))) >= 1e-3f || fmaxf(fabsf(vc[0]), fmaxf(fabsf(vc[1]), fabsf(vc[2]))) >= 1e-3f;
+  int c1 = 0, c2 = 0;
+  if (lane < L.ncon) { c1 = tm->geom_class[L.con[lane].g1]; c2 = tm->geom_class[L.con[lane].g2]; }
+  auto touching = [&](int a, int b) { return wave_ballot(((c1 & a) && (c2 & b)) || ((c2 & a) && (c1 & b))) != 0ull; };
+  bool right_obj = touching(8, 1), left_obj = touching(4, 1), obj_con = touching(1, 2);
+  int st = *state_io;
+  float r = 0.f;
+  if (st == 0) { if (right_obj) st = 1; }
+  else if (st == 1) { if (left_obj) st = 2; }
+  else {
+    float dx = L.xpos[cb][0] - L.xpos[ob][0], dy = L.xpos[cb][1] - L.xpos[ob][1];
+    bool inside = sqrtf(dx * dx + dy * dy) < T.dist_threshold;
+    if (!moving && obj_con && inside) r = 1.f;
+  }
+  *state_io = st;
+  return r;
 }
 
 // env.reset(): arms at the home pose, object and container placed (container by rejection, <= 20 tries), settled with the arms held
@@ -1067,7 +1094,7 @@ DEV void env_reset(const TreeModel* tm, const DevModel* gm, const TreeTask& T, T
     for (int r = 0; r < T_RING; r++) E.ring_pos[((size_t)r * T.npos + lane) * N + e] = v;
   }
   if (lane < T.nvel) for (int r = 0; r < T_RING; r++) E.ring_vel[((size_t)r * T.nvel + lane) * N + e] = L.qvel[lane];
-  if (lane == 0) { E.step_count[e] = 0; E.ep_return[e] = 0.f; E.episode[e] = (int)(episode + 1u); }
+  if (lane == 0) { E.step_count[e] = 0; E.ep_return[e] = 0.f; E.episode[e] = (int)(episode + 1u); E.success_state[e] = T.requires_handover ? 0 : 2; }
 }
 
 // observation row: joints_pos (delayed) | joints_vel (delayed) | undelayed_joints_pos | undelayed_joints_vel | commanded_joints_pos

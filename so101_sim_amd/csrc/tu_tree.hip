@@ -79,6 +79,21 @@ __global__ void __launch_bounds__(64) k_tree_reset(const TreeModel* tm, const De
   if (lane == 0) { E.need_reset[e] = 0; if (B.diag) { int* d = B.diag + 8 * e; d[0] = L.ncon; d[1] = L.nrow; d[2] = L.iters; d[3] = L.ncand; d[4] = L.flags; } }
 }
 
+// adopt the bound state as the post-reset state of a new episode (known-answer tests, checkpoints): delay lines filled with it,
+// counters cleared, no reset pending
+__global__ void __launch_bounds__(64) k_tree_begin(const TreeModel* tm, TreeTask T, TreeBuffers B, TreeEnvBuffers E) {
+  BLOCK_SHARED(TreeLDS, L);
+  int e = blockIdx.x, lane = wave_lane(), N = T.n_envs;
+  tree::load_state(tm, L, B, e, N);
+  if (lane < T.npos) {
+    float v = L.qpos[T.obs_qposadr[lane]];
+    if (T.obs_is_gripper[lane]) v = tree::convert_gripper(v, T.grip[0], T.grip[1], T.grip[4], T.grip[5]);
+    for (int r = 0; r < T_RING; r++) E.ring_pos[((size_t)r * T.npos + lane) * N + e] = v;
+  }
+  if (lane < T.nvel) for (int r = 0; r < T_RING; r++) E.ring_vel[((size_t)r * T.nvel + lane) * N + e] = L.qvel[lane];
+  if (lane == 0) { E.step_count[e] = 0; E.ep_return[e] = 0.f; E.need_reset[e] = 0; E.success_state[e] = T.requires_handover ? 0 : 2; }
+}
+
 // one control step of every env: dm_control's Environment.step - an env whose last step was LAST resets and reports FIRST
 // (the action is ignored), the others apply the action, run n_substeps and report observation, reward, discount, step type
 __global__ void __launch_bounds__(64) k_tree_step(const TreeModel* tm, const DevModel* gm, TreeTask T, TreeBuffers B, TreeEnvBuffers E, const float* action,
@@ -126,7 +141,11 @@ __global__ void __launch_bounds__(64) k_tree_step(const TreeModel* tm, const Dev
   int sc = E.step_count[e] + 1;
   tree::kinematics(tm, L);
   tree::write_obs(T, L, E, e, sc, false, obs);
-  float r = diverged ? 0.f : tree::task_reward(tm, T, L);
+  float r = 0.f;
+  if (!diverged) {
+    if (T.reward_mode == 0) r = tree::task_reward(tm, T, L);
+    else { int st = E.success_state[e]; r = tree::task_reward_contacts(tm, T, L, G, &st); if (lane == 0) E.success_state[e] = st; }
+  }
   bool success = (T.terminate_on_success && r >= 1.f) || diverged, timeout = sc >= T.last_step;
   tree::store_state(tm, L, B, e, N);
   if (lane < tm->nu) B.ctrl[(size_t)lane * N + e] = L.ctrl[lane];
@@ -135,7 +154,7 @@ __global__ void __launch_bounds__(64) k_tree_step(const TreeModel* tm, const Dev
     unsigned char st = (success || timeout) ? 2 : 1;
     step_type[e] = st; E.need_reset[e] = st == 2;
     E.step_count[e] = sc; E.ep_return[e] += r;
-    if (B.diag) { int* d = B.diag + 8 * e; d[0] = L.ncon; d[1] = L.nrow; d[2] = L.iters; d[3] = L.ncand; d[4] = L.flags; }
+    if (B.diag) { int* d = B.diag + 8 * e; d[0] = L.ncon; d[1] = L.nrow; d[2] = L.iters; d[3] = L.ncand; d[4] = L.flags; d[5] = E.success_state[e]; }
   }
 }
 
@@ -300,6 +319,8 @@ int tree_build(so101_tree* s, const BlobView& b) {
             t_upload(s, b.F("geom_rbound"), &G.geom_rbound) && t_upload(s, vx, &G.vx) && t_upload(s, vy, &G.vy) && t_upload(s, vz, &G.vz) &&
             t_upload(s, pairs, &G.pair) && t_upload(s, packed, &G.pair_packed) && t_upload(s, b.I("geom_body"), &M.geom_body) &&
             t_upload(s, b.F("geom_solmix"), &M.geom_solmix) && t_upload(s, b.I("geom_priority"), &M.geom_priority);
+  M.geom_class = nullptr;
+  if (ok && b.count("task_geom_class") >= ng) ok = t_upload(s, b.I("task_geom_class"), &M.geom_class);
   if (!ok) return SO101_ERR_HIP;
   // task layer (hand-over scenes): absent from the bare-arm blob
   TreeTask& T = s->task;
@@ -314,6 +335,7 @@ int tree_build(so101_tree* s, const BlobView& b) {
     if (nbox > 2 || npos > TU || npos > 64) return fail("task dimensions out of range");
     for (const Need& a : tneed) if (b.count(a.name) < a.count) return fail(std::string("blob entry missing or too short: ") + a.name);
     T.obj_body = b.I("task_object_body")[0]; T.con_body = b.I("task_container_body")[0]; T.nbox = (int)nbox;
+    T.dist_threshold = b.count("task_dist_threshold") ? b.F("task_dist_threshold")[0] : 0.f;
     if (T.obj_body <= 0 || T.obj_body >= M.nbody || T.con_body <= 0 || T.con_body >= M.nbody || jt[T.obj_body] != TJ_FREE || jt[T.con_body] != TJ_FREE)
       return fail("task bodies must be free bodies");
     T.npos = (int)npos; T.nvel = M.njnt;
@@ -370,6 +392,11 @@ int so101_tree_create(const void* blob, size_t bytes, int n_envs, int hip_device
     void* p = nullptr;
     if (!t_ok(s, hipMalloc(&p, (size_t)n_envs), "hipMalloc(need_reset)")) rc = SO101_ERR_HIP;
     else { s->owned.push_back(p); s->env.need_reset = (unsigned char*)p; (void)hipMemset(p, 1, (size_t)n_envs); }
+  }
+  if (rc == SO101_OK) {
+    void* p = nullptr;
+    if (!t_ok(s, hipMalloc(&p, (size_t)n_envs * sizeof(int)), "hipMalloc(success_state)")) rc = SO101_ERR_HIP;
+    else { s->owned.push_back(p); s->env.success_state = (int*)p; (void)hipMemset(p, 0, (size_t)n_envs * sizeof(int)); }
   }
   if (rc != SO101_OK) { g_tree_error = s->err; for (void* p : s->owned) (void)hipFree(p); delete s; return rc; }
   s->iterations = s->hm.iterations; s->tolerance = s->hm.tolerance;
@@ -440,6 +467,9 @@ int so101_tree_configure_env(so101_tree* s, const so101_tree_config* c) {
   TreeTask& T = s->task;
   T.n_substeps = c->n_substeps; T.last_step = c->last_step; T.settle_max = c->settle_max_substeps; T.terminate_on_success = c->terminate_on_success;
   T.seed = c->seed; T.env_id_base = c->env_id_base;
+  if (c->reward_mode != 0 && c->reward_mode != 1) { s->err = "so101_tree_configure_env: reward_mode must be 0 or 1"; return SO101_ERR_ARG; }
+  if (c->reward_mode == 1 && !s->hm.geom_class) { s->err = "so101_tree_configure_env: the model blob carries no task_geom_class (contact-sequence reward)"; return SO101_ERR_STATE; }
+  T.reward_mode = c->reward_mode; T.requires_handover = c->reward_requires_handover;
   return so101_tree_configure(s, c->solver_iterations, c->solver_tolerance);
 }
 
@@ -459,6 +489,14 @@ int so101_tree_step(so101_tree* s, const float* action, float* obs, float* rewar
   (void)hipSetDevice(s->device);
   hipLaunchKernelGGL(k_tree_step, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, s->dg, task_now(s), s->buf, s->env, action, obs, reward, discount, step_type);
   return t_ok(s, hipGetLastError(), "k_tree_step") ? SO101_OK : SO101_ERR_HIP;
+}
+
+int so101_tree_begin_episode(so101_tree* s, void* stream) {
+  if (!s) return SO101_ERR_ARG;
+  if (!s->bound || !s->env_bound) { s->err = "so101_tree_begin_episode before so101_tree_bind_state / so101_tree_bind_env"; return SO101_ERR_STATE; }
+  (void)hipSetDevice(s->device);
+  hipLaunchKernelGGL(k_tree_begin, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, task_now(s), s->buf, s->env);
+  return t_ok(s, hipGetLastError(), "k_tree_begin") ? SO101_OK : SO101_ERR_HIP;
 }
 
 int so101_tree_get_diag(so101_tree* s, int* out /* [n_envs][8] device or host-visible memory */, void* stream) {

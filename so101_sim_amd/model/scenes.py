@@ -175,6 +175,19 @@ def compile_aloha_scene(object_name: str | None, assets: str | None = None,
                                mesh_scale=cfg["container_mesh_scale"])
     out = mjcf.finalize(sc)
     m = out["model"]
+    # geom classes of the contact-sequence reward (hand_over.py:286-303): object, container, and the geoms below each arm's gripper_link
+    names = out["meta"]["body_names"]
+    parent = list(m["body_parent"])
+
+    def below(body, root):
+        while body != 0:
+            if body == root:
+                return True
+            body = parent[body]
+        return False
+    lg, rg = names.index("left/gripper_link"), names.index("right/gripper_link")
+    m["task_geom_class"] = np.array([(1 if b == obj else 0) | (2 if b == con else 0) | (4 if below(b, lg) else 0) | (8 if below(b, rg) else 0)
+                                     for b in m["geom_body"]], np.int32)
     boxes = cfg["overlap_boxes"] if cfg else []
     z = ALOHA_TABLE_HEIGHT + ALOHA_RESET_HEIGHT
     m.update(

@@ -34,7 +34,7 @@ EXPORTS = (
     "so101_get_returns", "so101_get_diag", "so101_get_events", "so101_debug_forward", "so101_debug_candidates", "so101_debug_stages", "so101_get_info", "so101_debug_chain_stats", "so101_last_error",
     "so101_tree_create", "so101_tree_destroy", "so101_tree_dims", "so101_tree_bind_state", "so101_tree_configure", "so101_tree_physics",
     "so101_tree_debug_forward", "so101_tree_get_diag", "so101_tree_last_error", "so101_tree_obs_dim", "so101_tree_bind_env",
-    "so101_tree_configure_env", "so101_tree_reset", "so101_tree_step",
+    "so101_tree_configure_env", "so101_tree_reset", "so101_tree_step", "so101_tree_begin_episode",
 )
 
 
@@ -221,7 +221,8 @@ class Sim:
 
 class TreeConfig(C.Structure):
     _fields_ = [("n_substeps", C.c_int), ("last_step", C.c_int), ("settle_max_substeps", C.c_int), ("terminate_on_success", C.c_int),
-                ("solver_iterations", C.c_int), ("solver_tolerance", C.c_float), ("seed", C.c_uint64), ("env_id_base", C.c_uint64)]
+                ("solver_iterations", C.c_int), ("solver_tolerance", C.c_float), ("seed", C.c_uint64), ("env_id_base", C.c_uint64),
+                ("reward_mode", C.c_int), ("reward_requires_handover", C.c_int)]
 
 
 TREE_DBG = dict(COUNTS=0, BIAS=8, QSM=40, QACC=72, XPOS=104, M=200, CON=1224, FORCE=1864)
@@ -250,6 +251,7 @@ class TreeSim:
         L.so101_tree_configure_env.argtypes = [C.c_void_p, C.POINTER(TreeConfig)]
         L.so101_tree_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.so101_tree_step.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        L.so101_tree_begin_episode.argtypes = [C.c_void_p, C.c_void_p]
         self.n_envs = int(n_envs)
         h = C.c_void_p()
         rc = L.so101_tree_create(blob_f32, len(blob_f32), self.n_envs, int(device), C.byref(h))
@@ -262,7 +264,7 @@ class TreeSim:
         self.nq, self.nv, self.nu, self.nbody, self.ngeom, self.debug_dim, self.max_contacts = list(d)
         self.obs_dim = int(L.so101_tree_obs_dim(h))
         self.cfg = TreeConfig(n_substeps=10, last_step=1 << 30, settle_max_substeps=1000, terminate_on_success=1, solver_iterations=0,
-                              solver_tolerance=-1.0, seed=0, env_id_base=0)
+                              solver_tolerance=-1.0, seed=0, env_id_base=0, reward_mode=0, reward_requires_handover=0)
 
     def close(self):
         if getattr(self, "h", None):
@@ -310,3 +312,6 @@ class TreeSim:
 
     def step(self, action, obs, reward, discount, step_type, stream: int = 0):
         self._check(self.L.so101_tree_step(self.h, action, obs, reward, discount, step_type, stream), "so101_tree_step")
+
+    def begin_episode(self, stream: int = 0):
+        self._check(self.L.so101_tree_begin_episode(self.h, stream), "so101_tree_begin_episode")

@@ -292,6 +292,9 @@ class TreeArraySim:
     def reset(self):
         self.sim.reset(None, self.stream())
 
+    def begin_episode(self):
+        self.sim.begin_episode(self.stream())
+
     def step(self, action):
         self._put(self.action, action)
         p = self.ptr

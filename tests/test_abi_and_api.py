@@ -66,8 +66,7 @@ def test_factory_errors_like_reference():
         task_suite.create_task_env("Nope", time_limit=1.0)
     with pytest.raises(NotImplementedError):
         task_suite.create_task_env("BowlOnRack", time_limit=1.0)              # ALOHA tasks other than the hand-over: registry key exists, not built
-    with pytest.raises(NotImplementedError):
-        task_suite.HandOver(object_name="banana", reward_based_on_overlap=False)
+    assert task_suite.HandOver(object_name="banana", reward_based_on_overlap=False, reward_requires_handover=True).reward_requires_handover
     with pytest.raises(ValueError, match="Invalid object name"):
         task_suite.HandOver(object_name="mug")
     t = task_suite.HandOver(object_name="pen", control_timestep=0.02, cameras=())

@@ -124,13 +124,13 @@ def test_rollout_against_the_oracle(name):
 
 
 # ---------------------------------------------------------------------------------------------- env layer (hand-over tasks)
-def check_env(name, backend, n, steps, settle, seed=7):
+def check_env(name, backend, n, steps, settle, seed=7, n_substeps=10):
     """so101_tree_step against oracle/aloha_env.py: FIRST after the in-call reset, observations (delay lines included), reward,
     discount and step type step by step, the time limit's LAST, then the auto-reset's FIRST."""
     from oracle.aloha_env import AlohaOracleEnv
     raw64, raw32 = _blobs(name)
     sim = TreeArraySim(raw32, n, backend=backend)
-    sim.enable_env(seed=seed, env_id_base=3, last_step=steps, settle_max_substeps=settle)
+    sim.enable_env(seed=seed, env_id_base=3, last_step=steps, settle_max_substeps=settle, n_substeps=n_substeps)
     obs, r, d, st = sim.step(np.zeros((n, 14)))
     assert np.all(st == 0) and np.all(r == 0) and np.all(d == 1)
     q, v, w = sim.get_state()
@@ -138,7 +138,7 @@ def check_env(name, backend, n, steps, settle, seed=7):
     assert np.all((flags & ~32) == 0)                      # (32: settle budget used up - expected with the short budgets of the CPU runs)
     envs = []
     for e in range(n):
-        oe = AlohaOracleEnv(raw64, seed=seed, env_id=3 + e, last_step=steps, settle_max_substeps=settle)
+        oe = AlohaOracleEnv(raw64, seed=seed, env_id=3 + e, last_step=steps, settle_max_substeps=settle, n_substeps=n_substeps)
         o0 = oe.reset()
         qo, vo, _ = oe.o.get_state()
         # placement draws are the same counter-RNG values; the settle is `settle` substeps of contact dynamics in fp32 / fp64
@@ -169,7 +169,7 @@ def check_env(name, backend, n, steps, settle, seed=7):
 
 
 def test_emulated_env_step():
-    check_env("banana", "emu", 1, 1, 2)
+    check_env("banana", "emu", 1, 1, 2, n_substeps=3)
 
 
 @pytest.mark.gpu
@@ -257,3 +257,82 @@ def test_aloha_episode_properties_over_a_full_time_limit():
     assert early == flagged                       # nothing but a physics error (or a success, which random actions do not reach) ends an episode early
     assert early <= 0.002 * n * 500, early        # physics errors: fewer than 2 per 1000 env-steps
     env.close()
+
+
+# ---------------------------------------------------------------------------------------------- contact-sequence reward (hand_over.py:286-338)
+def _scripted_states(raw64, which, n):
+    """start states for the contact-sequence reward: arms at home, the container where a reset left it, the object
+    'in_bowl'    dropped from 6 cm above the container's centre region  (state 2 -> reward 1 once it rests there)
+    'on_right'   dropped onto the right arm's gripper                     (state 0 -> 1: the right gripper touches the object)"""
+    o = Oracle(raw64)
+    Q, V = [], []
+    for e in range(n):
+        o.env_config(seed=21, env_id=e)
+        o.env_reset()
+        q, v, _ = o.get_state()
+        q, v = q.copy(), np.zeros_like(v)
+        if which == "in_bowl":
+            q[16:19] = q[23:26] + np.array([-0.025 + 0.004 * e, -0.07, 0.09])
+            q[19:23] = [1, 0, 0, 0]
+        else:
+            p, _ = o.body_pose(18)                            # right/gripper_base
+            q[16:19] = np.asarray(p) + np.array([0.0, 0.0, 0.08])
+            q[19:23] = [np.cos(0.4), 0, 0, np.sin(0.4)]
+        Q.append(q); V.append(v)
+    return np.array(Q).T, np.array(V).T
+
+
+def check_contact_reward(backend, which, requires_handover, n, steps, n_substeps=10):
+    from oracle.aloha_env import AlohaOracleEnv
+    from so101_sim_amd.model import blob as blobfmt
+    raw64, raw32 = _blobs("banana")
+    m = blobfmt.unpack(raw64)
+    cls, bodies, thr = np.asarray(m["task_geom_class"]), (int(m["task_object_body"][0]), int(m["task_container_body"][0])), float(m["task_dist_threshold"][0])
+    Q, V = _scripted_states(raw64, which, n)
+    home = np.tile(np.concatenate([scenes.ALOHA_HOME_CTRL] * 2)[:, None], (1, n))
+    sim = TreeArraySim(raw32, n, backend=backend)
+    sim.enable_env(seed=21, reward_mode=1, reward_requires_handover=int(requires_handover), last_step=10_000, n_substeps=n_substeps)
+    sim.set_state(Q, V, home, np.zeros_like(V))
+    sim.begin_episode()
+    envs = []
+    for e in range(n):
+        oe = AlohaOracleEnv(raw64, reward_based_on_overlap=False, reward_requires_handover=requires_handover, geom_class=cls, bodies=bodies, dist_threshold=thr,
+                            n_substeps=n_substeps)
+        oe.begin(Q[:, e], V[:, e], np.zeros(28), home[:, e])
+        envs.append(oe)
+    a = np.tile(np.concatenate([scenes.ALOHA_HOME_CTRL] * 2), (n, 1))
+    a[:, 6] = a[:, 13] = -0.06135                            # grippers closed (FOLLOWER_GRIPPER_CLOSE)
+    done = np.zeros(n, dtype=bool)
+    seen_states, rewards = set(), np.zeros(n)
+    for k in range(steps):
+        obs, r, d, st = sim.step(a)
+        fsm = sim.get_diag()[:, 5]
+        for e in range(n):
+            if done[e]:
+                continue
+            o1, r1, d1, s1 = envs[e].step(a[e])
+            assert (r[e], d[e], st[e]) == (r1, d1, s1), (k, e, r[e], r1, st[e], s1)
+            assert fsm[e] == envs[e].success_state
+            seen_states.add(int(fsm[e])); rewards[e] += r[e]
+            done[e] = st[e] == 2
+        if done.all():
+            break
+    return seen_states, rewards, done
+
+
+def test_emulated_contact_sequence_reward_counts_states():
+    seen, rewards, done = check_contact_reward("emu", "on_right", True, 1, 1, n_substeps=3)
+    assert seen <= {0, 1} and rewards.sum() == 0
+
+
+@pytest.mark.gpu
+def test_contact_sequence_reward_against_the_oracle():
+    # the object dropped into the bowl: the default sequence (starting in its last state) pays once the object rests there
+    seen, rewards, done = check_contact_reward("gpu", "in_bowl", False, 8, 120)
+    assert seen == {2} and done.sum() >= 6 and np.all(rewards[done] == 1.0), (seen, rewards, done)
+    # the same with reward_requires_handover: no gripper ever touches the object, the sequence stays in state 0 and nothing is paid
+    seen, rewards, done = check_contact_reward("gpu", "in_bowl", True, 4, 60)
+    assert seen == {0} and rewards.sum() == 0 and not done.any()
+    # the object dropped onto the right gripper: 0 -> 1 (and no further: the left gripper never touches it)
+    seen, rewards, done = check_contact_reward("gpu", "on_right", True, 4, 30)
+    assert seen <= {0, 1} and 1 in seen and rewards.sum() == 0
