@@ -13,6 +13,8 @@ Workloads (BASELINE.json `configs`):
              with the jaw closing; contact-heavy, the reward = 1 branch fires.
   mixed      configs[3]: 16384 x SO100HandOverBanana + 16384 x SO100HandOverPen (two handles, two streams), per-env
              prop mass scale ~ U(0.5, 1.5) on top of the reference's pose randomisation.
+  aloha      (not a BASELINE.json config) HandOverBanana of the ALOHA bimanual robot on the general-tree engine,
+             4096 envs per GPU, random joint targets around the home pose.
 Weak scaling: every rank owns --envs-per-gpu envs (global env ids rank*N ...), no data-path collective; episode
 returns are all-gathered over RCCL for logging (so101_sim_amd.distributed, outside the timed region).
 
@@ -169,12 +171,66 @@ def resolve_factory(spec: str):
     return getattr(importlib.import_module(mod), fn)
 
 
+def run_aloha(args, torch, sdist, dev, rank, world, hbm_measured):
+    """`--workload aloha`: HandOverBanana on the general-tree engine - the ALOHA bimanual robot, nq 30 / nv 28 /
+    nu 14 -, uniform random joint targets around the home pose, resets inside the step calls.  Same contract as the other
+    workloads: W untimed steps, K timed steps between barrier + synchronize, max over ranks, one JSON line."""
+    import numpy as np
+    from so101_sim_amd import build as sbuild, task_suite
+    from so101_sim_amd.model import scenes
+    N = args.envs_per_gpu or 4096
+    env = task_suite.create_task_env("HandOverBanana", time_limit=10.0, random_state=0, n_envs=N, device=dev,
+                                     env_id_base=sdist.shard_base(rank, N), solver_iterations=args.solver_iterations, solver_tolerance=args.solver_tolerance)
+    env.reset()
+    gen = torch.Generator(device=dev); gen.manual_seed(1 + rank)
+    spec = env.action_spec()
+    lo, hi = torch.tensor(spec.minimum, device=dev), torch.tensor(spec.maximum, device=dev)
+    home = torch.tensor(np.concatenate([scenes.ALOHA_HOME_CTRL] * 2), dtype=torch.float32, device=dev)
+    total = args.warmup + args.steps
+    tape = torch.clamp(home + 0.5 * (torch.rand(total, N, 14, device=dev, generator=gen) - 0.5), lo, hi)     # actions resident in HBM
+    for k in range(args.warmup):
+        env.step_tensor(tape[k])
+    sdist.barrier(); torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    reward_sum = torch.zeros((), device=dev)
+    for k in range(args.steps):
+        _, r, _, _ = env.step_tensor(tape[args.warmup + k])
+        reward_sum += r.sum()
+    sdist.barrier(); torch.cuda.synchronize(dev)
+    elapsed = sdist.max_over_ranks(time.perf_counter() - t0, dev)
+    d = env.diagnostics().cpu().numpy()
+    all_returns = sdist.all_gather_returns(env.episode_returns())
+    if rank == 0:
+        algo = 4 * (14 + 2 * (30 + 28) + 2 * 28 + 74 + 2 * (14 + 16) + 2 + 4) + 1      # action, state r+w, warm start r+w, obs, delay lines r+w, reward / discount, counters, step type
+        achieved = algo * N / (elapsed / args.steps) / 1e9
+        print(json.dumps({
+            "metric": "env_steps_per_sec", "value": world * N * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"HandOverBanana (ALOHA bimanual, task_suite.py:63; nq 30 / nv 28 / nu 14), uniform random joint targets around the home pose, "
+                                   f"500-step episodes with the reference reset inside the step calls; {N} lock-step envs per GPU, proprioceptive obs "
+                                   "(not a BASELINE.json config: SURVEY 8f-1)",
+                       "envs_per_gpu": N, "global_envs": world * N, "substeps_per_step": 10, "solver": "newton", "engine": "general tree (csrc/so101_tree.hpp)",
+                       "parallelism": f"env-shard x{world}", "build": sbuild.source_hash()},
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": hbm_measured, "unit": "GB/s", "frac": achieved / hbm_measured if hbm_measured else None,
+                         "traffic": None, "peak_spec": HBM_SPEC_GBS, "frac_of_spec": achieved / HBM_SPEC_GBS, "kernel": "k_tree_step (one launch per control step)",
+                         "kernel_ms": 1e3 * elapsed / args.steps, "launches_per_step": 1,
+                         "note": f"algorithmic bytes {algo} B per env-step; the kernel is bound by its instruction count (profiles/r03_aloha_pmc.txt: 101 k vector "
+                                 "wave-instructions per env-substep), not by HBM"},
+            "diag_mean": {"contacts": float(d[:, 0].mean()), "constraint_rows": float(d[:, 1].mean()), "solver_iterations": float(d[:, 2].mean()),
+                          "narrowphase_candidates": float(d[:, 3].mean())},
+            "flagged_envs_last_step": int((d[:, 4] != 0).sum()),
+            "mean_reward_per_env_step": float(reward_sum) / (N * args.steps), "mean_episode_return": float(all_returns.mean().item())}))
+    env.close()
+    sdist.finalize()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", choices=("handover", "pickplace", "mixed"), default="handover")
+    ap.add_argument("--workload", choices=("handover", "pickplace", "mixed", "aloha"), default="handover")
     ap.add_argument("--envs-per-gpu", type=int, default=0, help="0 = the workload's BASELINE.json size")
     ap.add_argument("--solver", choices=("newton", "pgs"), default="newton",
                     help="newton = MuJoCo's default, which the reference scene uses (it sets no <option solver>)")
@@ -220,6 +276,8 @@ def main():
     # roofline denominator first: a few seconds of streaming copies, which also take the GPU out of its idle power state
     # before anything is timed (a fresh box otherwise spends the first timed steps ramping its clocks)
     hbm_measured = measure_hbm_copy(torch, dev, reps=20) if (rank == 0 and on_gpu) else None
+    if args.workload == "aloha":
+        return run_aloha(args, torch, sdist, dev, rank, world, hbm_measured)
     N = args.envs_per_gpu or DEFAULT_ENVS[args.workload]
     cwd = os.getcwd()
     os.chdir("/tmp")          # calibration offsets OFF (reference looks the JSON up relative to the CWD)

@@ -26,6 +26,7 @@ timeout 900 python bench.py --steps 1500 --warmup 10 --no-cpu-baseline --repeats
 [ -x $R/ab/mfma_hessian ] && timeout 120 $R/ab/mfma_hessian > $O/${TAG}_mfma_hessian.txt 2>&1
 timeout 600 python scripts/gpu_reset_cost.py 2>&1 | tail -6 > $O/${TAG}_reset_cost.txt
 # ALOHA hand-over on the general-tree engine: throughput at three batch sizes, stage times, kernel stats
+timeout 600 python bench.py --workload aloha --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/${TAG}_bench_aloha.json
 timeout 600 python scripts/gpu_aloha_bench.py banana 2>/dev/null | grep workload > $O/${TAG}_aloha_bench.json
 timeout 600 python scripts/gpu_aloha_bench.py pen 2>/dev/null | grep workload > $O/${TAG}_aloha_bench_pen.json
 timeout 600 python scripts/gpu_tree_phases.py 2>/dev/null | grep mask > $O/${TAG}_aloha_phases.txt
