@@ -320,6 +320,7 @@ def check_contact_reward(backend, which, requires_handover, n, steps, n_substeps
     return seen_states, rewards, done
 
 
+@pytest.mark.skipif(not __import__("os").environ.get("SO101_SLOW_TESTS"), reason="emulated run of a path the GPU tests cover; set SO101_SLOW_TESTS=1")
 def test_emulated_contact_sequence_reward_counts_states():
     seen, rewards, done = check_contact_reward("emu", "on_right", True, 1, 1, n_substeps=3)
     assert seen <= {0, 1} and rewards.sum() == 0
