@@ -394,10 +394,14 @@ def check_contact_rich(make_sim, blobs, golden, count=4, verbose=False, max_disc
     measured on MI355X: <= 1.6e-5 on the twelve golden states).
 
     The MPR penetration query is a discontinuous function of the state where a thin plate (a 2 mm finger pad) is buried
-    centimetres deep in a hull: the portal it ends on, hence the depth, jumps.  A state whose comparison fails is
-    therefore re-examined ONCE in its neighbourhood: the kernel's answer is accepted only if the fp64 oracle returns
-    the same contact list and the same qacc somewhere within 1e-6 rad of the state, and at most `max_discontinuous` of
-    the states may need that (the count is returned; on MI355X one of the twelve golden states does).  MuJoCo's EPA has no such jumps - known deviation."""
+    centimetres deep in a hull: the portal it ends on, hence the depth, jumps, and fp32 and fp64 can land on different sides.
+    A state whose contact lists disagree is therefore checked in two separate, deterministic steps instead (round 3; the
+    random search for a nearby agreeing oracle state of rounds 1-2 is gone): (1) SOLVER - the oracle solves with the KERNEL's
+    contact list (orc_inject_contacts) and must reproduce the kernel's constrained acceleration to 1e-4; (2) GEOMETRY - every
+    contact of the kernel's list is held against the definition of a penetration depth (oracle/geomcheck.py: overlap along its
+    normal >= its depth, depth >= the minimum translation found by brute force, depth <= 2 x that minimum).  At most
+    `max_discontinuous` of the states may need that (the list is returned; on MI355X one of the twelve golden states does).
+    MuJoCo's EPA has no such jumps - known deviation."""
     states = golden["contact_rich_states"]["states"][:count]
     n = len(states)
     Q = np.array([s["qpos"] for s in states]).T
@@ -424,17 +428,24 @@ def check_contact_rich(make_sim, blobs, golden, count=4, verbose=False, max_disc
         err = np.abs(d["qacc"] - a).max() / np.abs(a).max()
         if problems or err > 1e-4:
             discontinuous.append(e)
-            prng, found = np.random.RandomState(1234 + e), False
-            for _ in range(40):
-                q = Q[:, e].copy()
-                q[:6] += prng.uniform(-1e-6, 1e-6, 6)
-                a, ref = oracle_eval(q, e)
-                p2, t, l = _compare_contact_lists(d["contacts"], ref)
-                err = np.abs(d["qacc"] - a).max() / np.abs(a).max()
-                if not p2 and err <= 1e-4:
-                    found = True
-                    break
-            assert found, (e, problems)
+            # (1) the solver on the kernel's own contact list
+            o = Oracle(blobs["f64"])
+            o.set_state(Q[:, e], V[:, e], W[:, e])
+            o.set_ctrl(A[:, e])
+            o.inject_contacts(d["contacts"])
+            o.forward()
+            a2 = o.qacc()[0]
+            err = np.abs(d["qacc"] - a2).max() / np.abs(a2).max()
+            assert err <= 1e-4, (e, "solver on the kernel's contacts", err, problems)
+            # (2) the kernel's contacts against the definition
+            from oracle import geomcheck as gc
+            from so101_sim_amd.model import blob as blobfmt
+            o.inject_contacts([])
+            o.forward()
+            rows = gc.check_contacts(gc.Scene.from_oracle(blobfmt.unpack(blobs["f64"]), o), d["contacts"])
+            for r in rows:
+                assert r["along"] - r["depth"] >= -5e-6 and r["depth"] - r["mtd"] >= -5e-6 - 2e-3 * r["mtd"] and r["minimality"] <= 2.0, (e, r)
+            t, l = len(ref), 0
         total += t
         loose += l
         pairs = [(c["geom1"], c["geom2"]) for c in ref]
