@@ -132,14 +132,27 @@ def test_pickplace_pool_against_oracle(blobs):
     simg = ArraySim(blobs["f32"], len(grasp), backend="gpu", last_step=500)
     simg.set_state(PQ[:, grasp], PV[:, grasp], PC[:, grasp], np.zeros((18, len(grasp))))
     dbgg = simg.debug_forward()
-    narrow_differs = 0
+    #     Round 3: what bounds the kernel's answers is no longer only "how often does it differ from the fp64 twin" but the
+    #     DEFINITION of a penetration depth (oracle/geomcheck.py, no shared algorithm): every contacting pair of every grasp entry
+    #     has overlap along its normal >= its depth >= the brute-forced minimum translation; the depth is the minimum translation
+    #     within 25 % for >= 95 % of the pairs and within a factor 2 for >= 99 % (measured, seeds 3 / 4: 98.8 / 99.7 % and 100 %,
+    #     worst 1.74; the fp64 oracle's own worst pair on seed 3 is 77 x - a pad edge in a hull, the MPR failure the flat-face
+    #     rule of DESIGN.md section 4 does not catch).
+    from oracle import geomcheck as gc
+    from so101_sim_amd.model import blob as blobfmt
+    model = blobfmt.unpack(blobs["f64"])
+    narrow_differs, rows = 0, []
     for j, k in enumerate(grasp):
         o = Oracle(blobs["f64"])
         o.set_state(PQ[:, k], PV[:, k], np.zeros(18))
         o.set_ctrl(PC[:, k])
         o.forward()
         narrow_differs += bool(pc._compare_contact_lists(dbgg[j]["contacts"], o.contacts())[0])
+        rows += gc.check_contacts(gc.Scene.from_oracle(model, o), dbgg[j]["contacts"])
     assert narrow_differs <= len(grasp) // 2, narrow_differs
+    mini = np.array([r["minimality"] for r in rows])
+    assert len(rows) >= 200 and min(r["along"] - r["depth"] for r in rows) >= -5e-6 and min(r["depth"] - r["mtd"] for r in rows) >= -5e-6
+    assert np.median(mini) <= 1.002 and np.mean(mini <= 1.25) >= 0.95 and np.mean(mini <= 2.0) >= 0.99, (np.median(mini), np.mean(mini <= 1.25), np.mean(mini <= 2.0), mini.max())
     idx = list(range(0, 8)) + list(range(half, half + 8))
     sim = ArraySim(blobs["f32"], len(idx), backend="gpu", last_step=500)
     sim.set_state(PQ[:, idx], PV[:, idx], PC[:, idx], np.zeros((18, len(idx))))
