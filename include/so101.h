@@ -299,6 +299,9 @@ int so101_tree_obs_dim(const so101_tree* sim);
 int so101_tree_bind_env(so101_tree* sim, float* ring_pos, float* ring_vel, float* ep_return, int32_t* step_count, int32_t* episode);
 int so101_tree_configure_env(so101_tree* sim, const so101_tree_config* cfg);
 int so101_tree_reset(so101_tree* sim, const uint8_t* mask, void* hip_stream);
+/* PropPlacer(settle_physics=True) alone, for callers that draw the placements themselves: physics steps on the bound state with the
+ * one-dof joints held until the props rest (|qvel| < 1e-3, |qacc| < 1e-2) or settle_max_substeps is used up (diag flag 32) */
+int so101_tree_settle(so101_tree* sim, void* hip_stream);
 /* adopt the bound state (qpos, qvel, ctrl) as the post-reset state of a new episode: delay lines filled with it, counters cleared */
 int so101_tree_begin_episode(so101_tree* sim, void* hip_stream);
 int so101_tree_step(so101_tree* sim, const float* action /*[n_envs][nu]*/, float* obs, float* reward, float* discount, uint8_t* step_type,

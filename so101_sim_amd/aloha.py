@@ -72,7 +72,7 @@ def aloha_action_spec(ctrlrange: np.ndarray, waist_joint_limit: float = np.pi / 
 class AlohaEnvironment:
     def __init__(self, task: HandOverTask, n_envs: int = 1, time_limit: float = float("inf"), random_state=None, device=None,
                  env_id_base: int = 0, solver_iterations: int = 0, solver_tolerance: float = -1.0, settle_max_substeps: int = 1000,
-                 physics_state: bool | None = None):
+                 physics_state: bool | None = None, seed_compatible: bool = True):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("so101_sim_amd needs a ROCm GPU (MI355X): the step path has no CPU fallback")
@@ -80,15 +80,31 @@ class AlohaEnvironment:
         self.task = task
         self.n_envs = N = int(n_envs)
         self.device = torch.device(device if device is not None else "cuda:0")
+        # N = 1: the reference's placements come from np.random.RandomState(seed) inside dm_control's PropPlacers.  With
+        # seed_compatible (default) a single env draws them from the same generator in the same order - object position (3 draws,
+        # hand_over.py:36-40), object yaw (1, :41-49), container position (3 per attempt, <= 20 attempts against collisions, :51-56) -
+        # and lets the kernels settle (so101_tree_settle).  Batches key the kernels' counter RNG by (seed, env id, episode) instead.
+        self._seed_compatible = bool(seed_compatible) and int(n_envs) == 1
+        self._np_random = random_state if isinstance(random_state, np.random.RandomState) else (
+            np.random.RandomState() if random_state is None else np.random.RandomState(int(random_state)))
+        self._pending_first = False
         if isinstance(random_state, np.random.RandomState):
-            seed = int(random_state.randint(0, 2**31 - 1))
+            seed = 0 if self._seed_compatible else int(random_state.randint(0, 2**31 - 1))
         elif random_state is None:
             seed = int.from_bytes(os.urandom(4), "little")
         else:
             seed = int(random_state)
         self.seed = seed
         blob, self.meta = scenes.load_aloha_blob(task.object_name, "f32")
-        self._ctrlrange = np.asarray(blobfmt.unpack(blob)["act_ctrlrange"], dtype=np.float64).reshape(-1, 2)
+        m = blobfmt.unpack(blob)
+        self._ctrlrange = np.asarray(m["act_ctrlrange"], dtype=np.float64).reshape(-1, 2)
+        con_body, obj_body = int(np.asarray(m["task_container_body"]).ravel()[0]), int(np.asarray(m["task_object_body"]).ravel()[0])
+        qadr = np.asarray(m["body_qposadr"])
+        m64 = blobfmt.unpack(scenes.load_aloha_blob(task.object_name, "f64")[0])      # (the distributions' bounds unrounded: the draws must be the reference's, bit for bit)
+        self._placer = dict(obj_lo=np.asarray(m64["task_obj_pos_lo"], dtype=np.float64), obj_hi=np.asarray(m64["task_obj_pos_hi"], dtype=np.float64),
+                            yaw=np.asarray(m64["task_obj_yaw"], dtype=np.float64), con_lo=np.asarray(m64["task_con_pos_lo"], dtype=np.float64),
+                            con_hi=np.asarray(m64["task_con_pos_hi"], dtype=np.float64), qo=int(qadr[obj_body]), qc=int(qadr[con_body]),
+                            con_geoms=set(np.nonzero(np.asarray(m["geom_body"]) == con_body)[0].tolist()))
         with torch.cuda.device(self.device):
             self.sim = native.TreeSim(blob, N, device=self.device.index or 0)
         s = self.sim
@@ -197,9 +213,53 @@ class AlohaEnvironment:
             return TimeStep(st, float(self.reward[0]), float(self.discount[0]), obs)
         return TimeStep(self.step_type, self.reward, self.discount, obs)
 
+    def _container_collides(self) -> bool:
+        if not hasattr(self, "_dbg"):
+            self._dbg = self.torch.zeros(1, self.sim.debug_dim, device=self.device)
+        self.sim.debug_forward(self._dbg.data_ptr(), self._stream())
+        r = self._dbg[0].cpu().numpy()
+        D = native.TREE_DBG
+        for k in range(int(r[D["COUNTS"]])):
+            if int(r[D["CON"] + 10 * k + 7]) in self._placer["con_geoms"] or int(r[D["CON"] + 10 * k + 8]) in self._placer["con_geoms"]:
+                return True
+        return False
+
+    def _reset_seed_compatible(self):
+        """placements from numpy's generator in dm_control's PropPlacer order, settle and episode start by the kernels"""
+        torch, P, rs, s = self.torch, self._placer, self._np_random, self.sim
+        opos = rs.uniform(P["obj_lo"], P["obj_hi"])
+        yaw = rs.uniform(P["yaw"][0], P["yaw"][1])
+        q = np.zeros(s.nq)
+        q[:16] = np.concatenate([scenes.ALOHA_HOME_QPOS, scenes.ALOHA_HOME_QPOS])           # aloha2_task.py:374-377
+        q[P["qo"]:P["qo"] + 3] = opos
+        q[P["qo"] + 3:P["qo"] + 7] = [np.cos(0.5 * yaw), 0.0, 0.0, np.sin(0.5 * yaw)]
+        q[P["qc"] + 3] = 1.0
+        self.ctrl.copy_(torch.as_tensor(np.concatenate([scenes.ALOHA_HOME_CTRL, scenes.ALOHA_HOME_CTRL]), dtype=torch.float32, device=self.device).unsqueeze(1))
+        placed = False
+        for _ in range(20):                                                                  # PropPlacer max_attempts_per_prop
+            q[P["qc"]:P["qc"] + 3] = rs.uniform(P["con_lo"], P["con_hi"])
+            self.qpos.copy_(torch.as_tensor(q, dtype=torch.float32, device=self.device).unsqueeze(1))
+            self.qvel.zero_(); self.warm.zero_()
+            if not self._container_collides():
+                placed = True
+                break
+        if not placed:
+            raise RuntimeError("Failed to place the container without collisions in 20 attempts (dm_control PropPlacer raises here too)")
+        self.placements = dict(object_position=opos.copy(), object_yaw=float(yaw), container_position=q[P["qc"]:P["qc"] + 3].copy())
+        s.settle(self._stream())
+        s.begin_episode(self._stream())
+        self.episode += 1
+        if int(self.diagnostics()[0, 4]) & 32:
+            import warnings
+            warnings.warn("Failed to settle physics within the settle budget (dm_control warns likewise)")
+
     def reset(self) -> TimeStep:
         """every env starts a new episode; returns FIRST"""
-        self.sim.reset(None, self._stream())
+        if self._seed_compatible:
+            self._reset_seed_compatible()
+        else:
+            self.sim.reset(None, self._stream())
+        self._pending_first = False
         self.torch.cuda.current_stream(self.device).synchronize()
         # the FIRST observation is written by the step kernel for an env that resets inside a step call; for an explicit reset it
         # is assembled here from the state the reset left
@@ -223,7 +283,11 @@ class AlohaEnvironment:
         a = torch.as_tensor(np.asarray(action) if not torch.is_tensor(action) else action, dtype=torch.float32, device=self.device)
         if a.dim() == 1:
             a = a.unsqueeze(0)
+        if self._pending_first:                # the step after LAST restarts the episode and reports FIRST (dm_control); the host draws
+            return self.reset()                # the next placements, the kernels' own auto-reset is not used
         self.step_tensor(a)
+        if self._seed_compatible and int(self.step_type[0]) == 2:
+            self._pending_first = True
         return self._timestep()
 
     def episode_returns(self):

@@ -79,6 +79,35 @@ __global__ void __launch_bounds__(64) k_tree_reset(const TreeModel* tm, const De
   if (lane == 0) { E.need_reset[e] = 0; if (B.diag) { int* d = B.diag + 8 * e; d[0] = L.ncon; d[1] = L.nrow; d[2] = L.iters; d[3] = L.ncand; d[4] = L.flags; } }
 }
 
+// settle the bound state with the one-dof joints held (dm_control's PropPlacer(settle_physics=True) alone, for callers that draw the
+// placements themselves): until |qvel| < 1e-3 and |qacc| < 1e-2 over the props' dofs or the budget ends (flag 32)
+__global__ void __launch_bounds__(64) k_tree_settle(const TreeModel* tm, const DevModel* gm, TreeTask T, TreeBuffers B) {
+  BLOCK_SHARED(TreeLDS, L);
+  int e = blockIdx.x, lane = wave_lane(), N = T.n_envs;
+  if (lane == 0) L.flags = 0;
+  tree::load_state(tm, L, B, e, N);
+  TreeScratch G = tree::scratch_of(B, e);
+  float q0 = lane < tm->njnt ? L.qpos[lane] : 0.f, v0 = lane < tm->njnt ? L.qvel[lane] : 0.f;
+  bool settled = T.settle_max == 0;
+  for (int k = 0; k < T.settle_max && !settled; k++) {
+    tree::forward(tm, gm, L, G, T.iterations, T.tolerance);
+    tree::euler(tm, L);
+    bool ok = true;
+    if (lane < tm->nq) ok = ok && fabsf(L.qpos[lane]) <= 1e10f;
+    if (lane < tm->nv) ok = ok && fabsf(L.qvel[lane]) <= 1e10f && fabsf(L.qacc[lane]) <= 1e10f;
+    if (wave_ballot(!ok) != 0ull) { if (lane == 0) L.flags |= 8; break; }
+    if (lane < tm->njnt) { L.qpos[lane] = q0; L.qvel[lane] = v0; }
+    wave_sync();
+    float mv = 0.f, ma = 0.f;
+    if (lane >= tm->njnt && lane < tm->nv) { mv = fabsf(L.qvel[lane]); ma = fabsf(L.qacc[lane]); }
+    mv = wave_max_f(mv); ma = wave_max_f(ma);
+    settled = mv < 1e-3f && ma < 1e-2f;
+  }
+  if (!settled && lane == 0) L.flags |= 32;
+  tree::store_state(tm, L, B, e, N);
+  if (lane == 0 && B.diag) { int* d = B.diag + 8 * e; d[0] = L.ncon; d[1] = L.nrow; d[2] = L.iters; d[3] = L.ncand; d[4] = L.flags; }
+}
+
 // adopt the bound state as the post-reset state of a new episode (known-answer tests, checkpoints): delay lines filled with it,
 // counters cleared, no reset pending
 __global__ void __launch_bounds__(64) k_tree_begin(const TreeModel* tm, TreeTask T, TreeBuffers B, TreeEnvBuffers E) {
@@ -489,6 +518,14 @@ int so101_tree_step(so101_tree* s, const float* action, float* obs, float* rewar
   (void)hipSetDevice(s->device);
   hipLaunchKernelGGL(k_tree_step, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, s->dg, task_now(s), s->buf, s->env, action, obs, reward, discount, step_type);
   return t_ok(s, hipGetLastError(), "k_tree_step") ? SO101_OK : SO101_ERR_HIP;
+}
+
+int so101_tree_settle(so101_tree* s, void* stream) {
+  if (!s) return SO101_ERR_ARG;
+  if (!s->bound) { s->err = "so101_tree_settle before so101_tree_bind_state"; return SO101_ERR_STATE; }
+  (void)hipSetDevice(s->device);
+  hipLaunchKernelGGL(k_tree_settle, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, s->dg, task_now(s), s->buf);
+  return t_ok(s, hipGetLastError(), "k_tree_settle") ? SO101_OK : SO101_ERR_HIP;
 }
 
 int so101_tree_begin_episode(so101_tree* s, void* stream) {

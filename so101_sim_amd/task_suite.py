@@ -98,7 +98,7 @@ def create_task_env(
         )
     n_envs = int(kwargs.pop("n_envs", 1))
     env_kwargs = {k: kwargs.pop(k) for k in ("device", "solver_iterations", "solver_tolerance", "env_id_base", "settle_max_substeps", "solver",
-                                                 "prefetch_resets", "physics_state")
+                                                 "prefetch_resets", "physics_state", "seed_compatible")
                   if k in kwargs}
 
     task_class, task_kwargs = TASK_FACTORIES[task_name]
@@ -117,4 +117,5 @@ def create_task_env(
         return _aloha.AlohaEnvironment(task_instance, n_envs=n_envs, time_limit=time_limit, random_state=random_state, **env_kwargs)
     if n_envs == 1:
         return _env.SingleEnvironment(task_instance, time_limit=time_limit, random_state=random_state, **env_kwargs)
+    env_kwargs.pop("seed_compatible", None)            # (single envs only: batches key the kernels' counter RNG)
     return _env.BatchedEnvironment(task_instance, n_envs=n_envs, time_limit=time_limit, random_state=random_state, **env_kwargs)

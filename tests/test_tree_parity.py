@@ -337,3 +337,35 @@ def test_contact_sequence_reward_against_the_oracle():
     # the object dropped onto the right gripper: 0 -> 1 (and no further: the left gripper never touches it)
     seen, rewards, done = check_contact_reward("gpu", "on_right", True, 4, 30)
     assert seen <= {0, 1} and 1 in seen and rewards.sum() == 0
+
+
+@pytest.mark.gpu
+def test_single_aloha_env_reset_is_seed_compatible_with_the_reference():
+    """N = 1: the placements are numpy RandomState draws in dm_control's PropPlacer order (hand_over.py:208-236): object position,
+    object yaw, container position (re-drawn while it collides), so an int seed reproduces what the reference would place."""
+    from so101_sim_amd import task_suite
+    for seed in (0, 7):
+        env = task_suite.create_task_env("HandOverBanana", time_limit=1.0, random_state=seed)
+        ts = env.reset()
+        rs = np.random.RandomState(seed)
+        opos = rs.uniform([0.12, -0.1, 0.1], [0.18, 0.1, 0.1])
+        yaw = rs.uniform(-0.1 * np.pi - 0.5 * np.pi, 0.1 * np.pi - 0.5 * np.pi)
+        cpos = rs.uniform([-0.18, -0.1, 0.1], [-0.12, 0.1, 0.1])            # (the bowl region is clear of everything: first draw accepted)
+        P = env.placements
+        np.testing.assert_allclose(P["object_position"], opos, rtol=0, atol=0)
+        assert P["object_yaw"] == yaw
+        np.testing.assert_allclose(P["container_position"], cpos, rtol=0, atol=0)
+        st = ts.observation["physics_state"]
+        assert np.abs(st[16:18] - opos[:2]).max() < 0.03 and np.abs(st[23:25] - cpos[:2]).max() < 0.01     # settled near where they were dropped
+        assert abs(st[18] - 0.0316) < 3e-3 and abs(st[25] - 0.0325) < 3e-3                                   # resting on the table top
+        np.testing.assert_allclose(st[:16], np.concatenate([scenes.ALOHA_HOME_QPOS] * 2), atol=1e-6)
+        # a second episode continues the same generator
+        for _ in range(60):
+            ts = env.step(np.concatenate([scenes.ALOHA_HOME_CTRL] * 2))
+            if ts.last():
+                break
+        ts = env.step(np.zeros(14))
+        assert ts.first()
+        opos2 = rs.uniform([0.12, -0.1, 0.1], [0.18, 0.1, 0.1])
+        np.testing.assert_allclose(env.placements["object_position"], opos2, rtol=0, atol=0)
+        env.close()
