@@ -118,6 +118,10 @@ class Oracle:
     def set_solver(self, iterations=0, tolerance=-1.0):
         self.L.orc_set_solver(self.h, int(iterations), float(tolerance))
 
+    def set_narrowphase(self, epa: bool):
+        self.L.orc_set_narrowphase.argtypes = [C.c_void_p, C.c_int]
+        self.L.orc_set_narrowphase(self.h, int(bool(epa)))
+
     def set_solver_type(self, newton: bool):
         self.L.orc_set_solver_type(self.h, int(bool(newton)))
 

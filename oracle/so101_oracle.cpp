@@ -172,6 +172,8 @@ struct orc_sim {
   int iterations; real tolerance; bool collide = true;
   std::vector<real> mass0, inertia0, invweight0;     // unscaled prop masses (orc_set_mass_scale)
   std::vector<Contact> injected;                      // orc_inject_contacts
+  int narrow = 0;              // 0 = MPR (what the kernels run), 1 = MPR portal expanded by EPA to the nearest face of the Minkowski difference
+  int epa_iters = 0;           // (statistics: polytope expansions of the last forward)
   int solver = 1;              // 1 = Newton (mujoco default; the reference scene sets no solver), 0 = PGS (north_star)
   int ls_evals = 0;
   // env layer
@@ -513,6 +515,77 @@ void interior_point(const orc_sim* s, int g, const real* target, real* out) {
   for (int k = 0; k < 3; k++) out[k] = P[k] + w[k];
 }
 
+// EPA (expanding polytope) from the tetrahedron MPR ends with - its interior point v0 and the portal v1 v2 v3, which contains the
+// origin -: the face of the polytope nearest to the origin is pushed out along its normal until the support point in that direction
+// lies on it (within tol).  That face is then a face of the Minkowski difference A - B, and its distance the MINIMUM translation
+// that separates the geoms - what mujoco >= 3.3's native GJK / EPA reports.  Vertices carry their witness points.
+struct EpaFace { int a, b, c; real n[3], d; bool alive; };
+bool epa_penetration(const orc_sim* s, int g1, int g2, const real* org, const MV& v0, const MV& v1, const MV& v2, const MV& v3,
+                     real tol, real* depth, real* dir, real* pos, int* iters_out) {
+  std::vector<MV> V = {v0, v1, v2, v3};
+  std::vector<EpaFace> F;
+  auto add_face = [&](int a, int b, int c) {
+    EpaFace f; f.a = a; f.b = b; f.c = c; f.alive = true;
+    real e1[3], e2[3];
+    for (int k = 0; k < 3; k++) { e1[k] = V[b].v[k] - V[a].v[k]; e2[k] = V[c].v[k] - V[a].v[k]; }
+    cross3(f.n, e1, e2);
+    real len = norm3(f.n);
+    if (len < 1e-14) { f.d = 1e30; f.n[0] = f.n[1] = f.n[2] = 0; f.alive = false; F.push_back(f); return; }
+    for (int k = 0; k < 3; k++) f.n[k] /= len;
+    f.d = dot3(f.n, V[a].v);
+    if (f.d < 0) { std::swap(f.b, f.c); for (int k = 0; k < 3; k++) f.n[k] = -f.n[k]; f.d = -f.d; }      // outward: the origin is inside
+    F.push_back(f);
+  };
+  add_face(1, 2, 3); add_face(0, 1, 2); add_face(0, 2, 3); add_face(0, 3, 1);
+  int best = -1;
+  for (int it = 0; it < 64; it++) {
+    best = -1;
+    for (size_t i = 0; i < F.size(); i++) if (F[i].alive && (best < 0 || F[i].d < F[best].d)) best = (int)i;
+    if (best < 0) return false;
+    MV w;
+    mdsupport(s, g1, g2, F[best].n, org, &w);
+    real reach = dot3(F[best].n, w.v) - F[best].d;
+    bool dup = false;
+    for (const MV& x : V) if (std::fabs(x.v[0] - w.v[0]) + std::fabs(x.v[1] - w.v[1]) + std::fabs(x.v[2] - w.v[2]) < 1e-12) dup = true;
+    if (reach <= tol || dup || V.size() >= 60) break;
+    if (iters_out) (*iters_out)++;
+    int wi = (int)V.size();
+    V.push_back(w);
+    // faces that see the new vertex go; the boundary of the hole (edges shared with a face that stays) is closed with new faces
+    std::vector<std::pair<int, int>> edges;
+    std::vector<char> vis(F.size(), 0);
+    for (size_t i = 0; i < F.size(); i++) if (F[i].alive && dot3(F[i].n, w.v) - F[i].d > 0) vis[i] = 1;
+    for (size_t i = 0; i < F.size(); i++) if (vis[i]) {
+      int e[3][2] = {{F[i].a, F[i].b}, {F[i].b, F[i].c}, {F[i].c, F[i].a}};
+      for (auto& ed : e) {
+        bool shared_with_visible = false;
+        for (size_t j = 0; j < F.size(); j++) if (j != i && vis[j]) {
+          int g[3][2] = {{F[j].a, F[j].b}, {F[j].b, F[j].c}, {F[j].c, F[j].a}};
+          for (auto& gd : g) if (gd[0] == ed[1] && gd[1] == ed[0]) shared_with_visible = true;
+        }
+        if (!shared_with_visible) edges.push_back({ed[0], ed[1]});
+      }
+    }
+    for (size_t i = 0; i < F.size(); i++) if (vis[i]) F[i].alive = false;
+    for (auto& ed : edges) add_face(ed.first, ed.second, wi);
+  }
+  const EpaFace& f = F[best];
+  *depth = f.d;
+  for (int k = 0; k < 3; k++) dir[k] = f.n[k];
+  // witness: the projection of the origin onto the face, in barycentric coordinates of the face's vertices
+  real p[3] = {f.d * f.n[0], f.d * f.n[1], f.d * f.n[2]}, e1[3], e2[3], ep[3];
+  for (int k = 0; k < 3; k++) { e1[k] = V[f.b].v[k] - V[f.a].v[k]; e2[k] = V[f.c].v[k] - V[f.a].v[k]; ep[k] = p[k] - V[f.a].v[k]; }
+  real d11 = dot3(e1, e1), d12 = dot3(e1, e2), d22 = dot3(e2, e2), r1 = dot3(ep, e1), r2 = dot3(ep, e2), den = d11 * d22 - d12 * d12;
+  real wb = den > 1e-30 ? (d22 * r1 - d12 * r2) / den : 0, wc = den > 1e-30 ? (d11 * r2 - d12 * r1) / den : 0;
+  wb = std::min(std::max(wb, 0.0), 1.0); wc = std::min(std::max(wc, 0.0), 1.0 - wb);
+  real wa = 1 - wb - wc;
+  for (int k = 0; k < 3; k++) {
+    real p1 = wa * V[f.a].a[k] + wb * V[f.b].a[k] + wc * V[f.c].a[k], p2 = wa * V[f.a].b[k] + wb * V[f.b].b[k] + wc * V[f.c].b[k];
+    pos[k] = 0.5 * (p1 + p2) + org[k];
+  }
+  return true;
+}
+
 // MPR penetration (libccd ccdMPRPenetration restated).  Returns true when the geoms intersect and
 // fills depth, dir (from g1 into g2) and pos (world).
 bool mpr_penetration(const orc_sim* s, int g1, int g2, real* depth, real* dir, real* pos) {
@@ -605,6 +678,12 @@ bool mpr_penetration(const orc_sim* s, int g1, int g2, real* depth, real* dir, r
     portal_dir(d);
     mdsupport(s, g1, g2, d, org, &v4);
     if (reach_tol(v4, d) || it > m.mpr_iter) {
+      if (s->narrow == 1) {
+        int n_it = 0;
+        bool ok = epa_penetration(s, g1, g2, org, v0, v1, v2, v3, m.mpr_tol, depth, dir, pos, &n_it);
+        const_cast<orc_sim*>(s)->epa_iters += n_it;
+        if (ok) return true;
+      }
       real pd[3], bw[3];
       real d2 = origin_tri_dist2(v1.v, v2.v, v3.v, pd, bw);
       *depth = std::sqrt(d2);
@@ -1606,6 +1685,8 @@ void orc_set_mass_scale(orc_sim* s, const double* scale) {
   }
 }
 void orc_set_solver_type(orc_sim* s, int t) { s->solver = t; }
+void orc_set_narrowphase(orc_sim* s, int mode) { s->narrow = mode; }
+int orc_epa_iterations(const orc_sim* s) { return s->epa_iters; }
 int orc_ls_evals(const orc_sim* s) { return s->ls_evals; }
 void orc_set_state(orc_sim* s, const double* q, const double* v, const double* w) {
   if (q) std::copy(q, q + s->m.nq, s->qpos.begin());

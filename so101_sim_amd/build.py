@@ -17,6 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "libso101_hip.so")
 LIB_CLOCKS = os.path.join(CSRC, "libso101_hip_clocks.so")     # -DSO101_DEBUG_CLOCKS profiling build: its own file (SO101_HIP_LIB selects it)
+LIB_EPA = os.path.join(CSRC, "libso101_hip_epa.so")           # -DSO101_EPA: MPR portals expanded to the nearest face by EPA (so101_device.hpp); selected by SO101_HIP_LIB too
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-hip-fp32-correctly-rounded-divide-sqrt: v_rcp/v_sqrt based fp32 division and sqrt (<= ~2.5 ulp) instead of
 # the 10-15 instruction IEEE expansions; the solver is latency-bound and full of both (profiles/README.md).
@@ -48,28 +49,30 @@ def source_hash(clocks: bool = False) -> str:
     return h.hexdigest()[:16]
 
 
-def needs_build(clocks: bool = False) -> bool:
-    lib = LIB_CLOCKS if clocks else LIB
+def needs_build(clocks: bool = False, epa: bool = False) -> bool:
+    lib = LIB_EPA if epa else (LIB_CLOCKS if clocks else LIB)
     if not os.path.exists(lib):
         return True
     t = os.path.getmtime(lib)
     return any(os.path.getmtime(s) > t for s in sources())
 
 
-def build(force: bool = False, verbose: bool = False, clocks: bool = False) -> str:
-    lib = LIB_CLOCKS if clocks else LIB
-    if not (force or needs_build(clocks)):
+def build(force: bool = False, verbose: bool = False, clocks: bool = False, epa: bool = False) -> str:
+    lib = LIB_EPA if epa else (LIB_CLOCKS if clocks else LIB)
+    if not (force or needs_build(clocks, epa)):
         return lib
     os.makedirs(OBJ, exist_ok=True)
     flags = list(FLAGS)
     if clocks:
         flags.append("-DSO101_DEBUG_CLOCKS")      # stage clocks + SO101_DEBUG_* env vars for scripts/gpu_*.py
+    if epa:
+        flags.append("-DSO101_EPA")
     if verbose:
         flags.append("-Rpass-analysis=kernel-resource-usage")
     newest_header = max(os.path.getmtime(s) for s in sources() if not s.endswith(".hip"))
 
     def compile_one(src):
-        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + (".clk" if clocks else "") + ".o")
+        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + (".clk" if clocks else "") + (".epa" if epa else "") + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_header):
             return obj
         subprocess.check_call([HIPCC, *flags, "-c", "-o", obj, src])
@@ -83,4 +86,4 @@ def build(force: bool = False, verbose: bool = False, clocks: bool = False) -> s
 
 if __name__ == "__main__":
     import sys
-    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, clocks="--clocks" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, clocks="--clocks" in sys.argv, epa="--epa" in sys.argv))

@@ -665,6 +665,120 @@ DEV void interior_point(const GeomW& G, const float* target, float* out) {
   out[0] = G.p[0] + w[0]; out[1] = G.p[1] + w[1]; out[2] = G.p[2] + w[2];
 }
 
+// EPA (expanding polytope) from the tetrahedron the MPR query ends with - its interior point v0 and the portal v1 v2 v3, which
+// contains the origin: the face nearest to the origin is pushed out along its normal until the support point in that direction lies on
+// it.  That face is a face of the Minkowski difference and its distance the MINIMUM translation separating the geoms - what mujoco >=
+// 3.3's native GJK / EPA reports (the reference enables multiccd on top, so100_task.py:151); MPR's portal is only some face of an inner
+// approximation (DESIGN.md section 4 measures the difference against the brute-forced minimum).  Wave-parallel: lane k keeps vertex k
+// (with its witness points) and face k (vertex indices, unit normal, distance) in registers, at most 64 of each; one expansion =
+// wave-argmin over the faces, one support pair, a visibility ballot, a scan of the visible faces' edges for the horizon, and new faces
+// in the freed lanes.  Entirely wave-uniform control flow (G64 policy only).
+struct EpaFace { int a, b, c; float n[3], d; bool alive; };
+
+DEV void epa_make_face(bool doit, int a, int b, int c, float vx, float vy, float vz, EpaFace& F) {
+  // (every lane takes part in the exchanges; only `doit` lanes keep the result)
+  float A[3] = {wave_bcast_f(vx, a), wave_bcast_f(vy, a), wave_bcast_f(vz, a)};
+  float B[3] = {wave_bcast_f(vx, b), wave_bcast_f(vy, b), wave_bcast_f(vz, b)};
+  float C[3] = {wave_bcast_f(vx, c), wave_bcast_f(vy, c), wave_bcast_f(vz, c)};
+  float e1[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]}, e2[3] = {C[0] - A[0], C[1] - A[1], C[2] - A[2]}, n[3];
+  cross3(n, e1, e2);
+  float len = sqrtf(dot3(n, n));
+  bool ok = len > 1e-14f;
+  float inv = ok ? 1.f / len : 0.f;
+  n[0] *= inv; n[1] *= inv; n[2] *= inv;
+  float d = dot3(n, A);
+  bool flip = d < 0.f;                      // outward: the origin is inside the polytope
+  if (doit) {
+    F.a = a; F.b = flip ? c : b; F.c = flip ? b : c;
+    F.n[0] = flip ? -n[0] : n[0]; F.n[1] = flip ? -n[1] : n[1]; F.n[2] = flip ? -n[2] : n[2];
+    F.d = ok ? fabsf(d) : 3.0e38f; F.alive = ok;
+  }
+}
+
+template <class Cache, class GP>
+DEV bool epa_expand(const DevModel* m, const GeomW& G1, const GeomW& G2, const float* org, const MV& v0, const MV& v1, const MV& v2, const MV& v3,
+                    float tol, float* depth, float* dir, float* pos, const Cache& H1, const Cache& H2) {
+  __shared__ unsigned int epa_list[WAVE];                 // horizon edges of one expansion, in the order the new faces take them
+  int lane = wave_lane();
+  float vx = 0.f, vy = 0.f, vz = 0.f, ax = 0.f, ay = 0.f, az = 0.f, bx = 0.f, by = 0.f, bz = 0.f;
+#define EPA_PUT(k, X) if (lane == (k)) { vx = X.v[0]; vy = X.v[1]; vz = X.v[2]; ax = X.a[0]; ay = X.a[1]; az = X.a[2]; bx = X.b[0]; by = X.b[1]; bz = X.b[2]; }
+  EPA_PUT(0, v0) EPA_PUT(1, v1) EPA_PUT(2, v2) EPA_PUT(3, v3)
+  int nv = 4, nf = 4;
+  EpaFace F; F.a = F.b = F.c = 0; F.n[0] = F.n[1] = F.n[2] = 0.f; F.d = 3.0e38f; F.alive = false;
+  {
+    int a0 = lane == 0 ? 1 : 0, b0 = lane == 0 ? 2 : (lane == 1 ? 1 : (lane == 2 ? 2 : 3)), c0 = lane == 0 ? 3 : (lane == 1 ? 2 : (lane == 2 ? 3 : 1));
+    epa_make_face(lane < 4, lane < 4 ? a0 : 0, lane < 4 ? b0 : 0, lane < 4 ? c0 : 0, vx, vy, vz, F);
+  }
+  int best = 0; float bd = 0.f, bn[3] = {0.f, 0.f, 0.f};
+  for (int it = 0; it < 48; it++) {
+    float key = F.alive ? -F.d : -3.0e38f; int idx = lane;
+    wave_argmax(key, idx);
+    if (key <= -3.0e38f) return false;
+    best = idx; bd = -key;
+    bn[0] = wave_bcast_f(F.n[0], best); bn[1] = wave_bcast_f(F.n[1], best); bn[2] = wave_bcast_f(F.n[2], best);
+    MV w;
+    mdsupport<Cache, GP>(m, G1, G2, bn, org, w, H1, H2);
+    float reach = dot3(bn, w.v) - bd;
+    bool dup = lane < nv && fabsf(vx - w.v[0]) + fabsf(vy - w.v[1]) + fabsf(vz - w.v[2]) < 1e-9f;
+    if (reach <= tol || wave_ballot(dup) != 0ull || nv >= WAVE || nf + 2 > WAVE) break;
+    int wi = nv;
+    EPA_PUT(wi, w)
+    nv++;
+    bool vis = F.alive && (F.n[0] * w.v[0] + F.n[1] * w.v[1] + F.n[2] * w.v[2] - F.d > 0.f);
+    unsigned long long vmask = wave_ballot(vis);
+    int nvis = __popcll(vmask);
+    int packed = F.a | (F.b << 8) | (F.c << 16) | ((vis ? 1 : 0) << 24);
+    // horizon: an edge of a visible face whose reversed edge belongs to no other visible face
+    bool s0 = false, s1 = false, s2 = false;
+    for (int j = 0; j < nf; j++) {
+      int pj = wave_bcast_i(packed, j);
+      if (!((pj >> 24) & 1)) continue;
+      int ja = pj & 255, jb = (pj >> 8) & 255, jc = (pj >> 16) & 255;
+#define EPA_REV(x, y) ((ja == (y) && jb == (x)) || (jb == (y) && jc == (x)) || (jc == (y) && ja == (x)))
+      bool other = j != lane;
+      s0 = s0 || (other && EPA_REV(F.a, F.b)); s1 = s1 || (other && EPA_REV(F.b, F.c)); s2 = s2 || (other && EPA_REV(F.c, F.a));
+    }
+    bool h0 = vis && !s0, h1 = vis && !s1, h2 = vis && !s2;
+    unsigned long long m0 = wave_ballot(h0), m1 = wave_ballot(h1), m2 = wave_ballot(h2);
+    int K = __popcll(m0) + __popcll(m1) + __popcll(m2);
+    int base = wave_prefix(m0) + wave_prefix(m1) + wave_prefix(m2);
+    wave_sync();
+    if (h0) epa_list[base] = (unsigned int)(F.a | (F.b << 8));
+    if (h1) epa_list[base + (h0 ? 1 : 0)] = (unsigned int)(F.b | (F.c << 8));
+    if (h2) epa_list[base + (h0 ? 1 : 0) + (h1 ? 1 : 0)] = (unsigned int)(F.c | (F.a << 8));
+    wave_sync();
+    int extra = K > nvis ? K - nvis : 0;
+    if (nf + extra > WAVE) extra = WAVE - nf;
+    bool fresh = lane >= nf && lane < nf + extra;
+    int r = vis ? wave_prefix(vmask) : (nvis + lane - nf);
+    bool make = (vis || fresh) && r < K;
+    unsigned int e = epa_list[make ? r : 0];
+    if (vis) { F.alive = false; F.d = 3.0e38f; }
+    epa_make_face(make, make ? (int)(e & 255u) : 0, make ? (int)(e >> 8) : 0, make ? wi : 0, vx, vy, vz, F);
+    nf += extra;
+  }
+#undef EPA_PUT
+#undef EPA_REV
+  *depth = bd; dir[0] = bn[0]; dir[1] = bn[1]; dir[2] = bn[2];
+  int ia = wave_bcast_i(F.a, best), ib = wave_bcast_i(F.b, best), ic = wave_bcast_i(F.c, best);
+  float A[3] = {wave_bcast_f(vx, ia), wave_bcast_f(vy, ia), wave_bcast_f(vz, ia)}, B[3] = {wave_bcast_f(vx, ib), wave_bcast_f(vy, ib), wave_bcast_f(vz, ib)},
+        C[3] = {wave_bcast_f(vx, ic), wave_bcast_f(vy, ic), wave_bcast_f(vz, ic)};
+  float p[3] = {bd * bn[0], bd * bn[1], bd * bn[2]}, e1[3], e2[3], ep[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) { e1[i] = B[i] - A[i]; e2[i] = C[i] - A[i]; ep[i] = p[i] - A[i]; }
+  float d11 = dot3(e1, e1), d12 = dot3(e1, e2), d22 = dot3(e2, e2), r1 = dot3(ep, e1), r2 = dot3(ep, e2), den = d11 * d22 - d12 * d12;
+  float wb = den > 1e-30f ? (d22 * r1 - d12 * r2) / den : 0.f, wc = den > 1e-30f ? (d11 * r2 - d12 * r1) / den : 0.f;
+  wb = fminf(fmaxf(wb, 0.f), 1.f); wc = fminf(fmaxf(wc, 0.f), 1.f - wb);
+  float wa = 1.f - wb - wc;
+  float PA[3] = {wave_bcast_f(ax, ia), wave_bcast_f(ay, ia), wave_bcast_f(az, ia)}, PB[3] = {wave_bcast_f(ax, ib), wave_bcast_f(ay, ib), wave_bcast_f(az, ib)},
+        PC[3] = {wave_bcast_f(ax, ic), wave_bcast_f(ay, ic), wave_bcast_f(az, ic)};
+  float QA[3] = {wave_bcast_f(bx, ia), wave_bcast_f(by, ia), wave_bcast_f(bz, ia)}, QB[3] = {wave_bcast_f(bx, ib), wave_bcast_f(by, ib), wave_bcast_f(bz, ib)},
+        QC[3] = {wave_bcast_f(bx, ic), wave_bcast_f(by, ic), wave_bcast_f(bz, ic)};
+#pragma unroll
+  for (int i = 0; i < 3; i++) pos[i] = 0.5f * ((wa * PA[i] + wb * PB[i] + wc * PC[i]) + (wa * QA[i] + wb * QB[i] + wc * QC[i])) + org[i];
+  return true;
+}
+
 // MPR penetration query (XenoCollide / libccd ccdMPRPenetration).  Entirely wave-uniform control flow.
 template <class Cache, class GP = G64>
 DEV bool mpr_penetration(const DevModel* m, const GeomW& G1, const GeomW& G2, float* depth, float* dir, float* pos,
@@ -747,6 +861,11 @@ DEV bool mpr_penetration(const DevModel* m, const GeomW& G1, const GeomW& G2, fl
       if (!(isz(dv4) || dv4 > 0.f)) return false;     // cannot encapsule origin
       if (reached || it > 100) return false;
     } else if (reached || it > mpr_iter) {
+#ifdef SO101_EPA      // the EPA build of the library (build.py --epa, libso101_hip_epa.so): every non-flat pair's portal is expanded to the nearest face
+      if constexpr (GP::N == WAVE) {
+        if (epa_expand<Cache, GP>(m, G1, G2, org, v0, v1, v2, v3, mpr_tol, depth, dir, pos, H1, H2)) return true;
+      }
+#endif
       float pd[3], bw[3];
       float d2 = origin_tri_dist2(v1.v, v2.v, v3.v, pd, bw);
       *depth = sqrtf(d2);
