@@ -234,6 +234,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=0, help="0 = the workload's BASELINE.json size")
     ap.add_argument("--solver", choices=("newton", "pgs"), default="newton",
                     help="newton = MuJoCo's default, which the reference scene uses (it sets no <option solver>)")
+    ap.add_argument("--narrowphase", choices=("mpr", "epa"), default="mpr", help="epa: the -DSO101_EPA build of the library (minimum translation instead of MPR's portal depth)")
     ap.add_argument("--no-prefetch", action="store_true", help="settle auto-resets inside the step call")
     ap.add_argument("--fused", action="store_true", help="one fused k_step launch per control step instead of the pipeline")
     ap.add_argument("--pipeline", type=int, default=-1, help="step path: 3 merged launches, 2 per-env chained, 1 launch chains, 0 fused (-1 = library default)")
@@ -283,6 +284,8 @@ def main():
     os.chdir("/tmp")          # calibration offsets OFF (reference looks the JSON up relative to the CWD)
     kw = dict(time_limit=10.0, random_state=0, device=dev, solver_iterations=args.solver_iterations,
               solver_tolerance=args.solver_tolerance, solver=args.solver, prefetch_resets=not args.no_prefetch)
+    if args.narrowphase != "mpr":
+        kw["narrowphase"] = args.narrowphase
     if args.env_factory:
         make = resolve_factory(args.env_factory)
     else:
@@ -476,7 +479,7 @@ def main():
             "config": {"workload": f"{names[args.workload]}; {n_local} lock-step envs per GPU, proprioceptive obs"
                                    + (f" (BASELINE.json configs[{cfg_index}]" + (" per-GPU share)" if cfg_index == 4 else ")") if cfg_index else ""),
                        "envs_per_gpu": n_local, "global_envs": world * n_local, "substeps_per_step": 10,
-                       "solver": args.solver, "reset_prefetch": not args.no_prefetch, "pipeline": path,
+                       "solver": args.solver, "narrowphase": args.narrowphase, "reset_prefetch": not args.no_prefetch, "pipeline": path,
                        "solver_iterations": args.solver_iterations or 100,
                        "solver_tolerance": args.solver_tolerance if args.solver_tolerance >= 0 else 1e-8,
                        "parallelism": f"env-shard x{world}", "build": build_hash},

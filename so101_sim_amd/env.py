@@ -102,7 +102,7 @@ class BatchedEnvironment:
     def __init__(self, task: SO100HandOverTask, n_envs: int = 1, time_limit: float = float("inf"),
                  random_state=None, device=None, env_id_base: int = 0, solver_iterations: int = 0,
                  solver_tolerance: float = -1.0, settle_max_substeps: int = 1000, solver: str = "newton",
-                 prefetch_resets: bool = True, physics_state: bool = False):
+                 prefetch_resets: bool = True, physics_state: bool = False, narrowphase: str = "mpr"):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("so101_sim_amd needs a ROCm GPU (MI355X): the step path has no CPU fallback")
@@ -120,7 +120,14 @@ class BatchedEnvironment:
         blob, self.meta = scenes.load_blob(task.object_name, "f32")
         dev_index = self.device.index or 0
         with torch.cuda.device(self.device):
-            self.sim = native.Sim(blob, self.n_envs, device=dev_index, seed=seed)
+            # narrowphase = "epa": the -DSO101_EPA build of the library - the penetration of non-flat convex pairs is the minimum
+            # translation (MPR's final portal expanded by EPA, as mujoco's native GJK / EPA reports it) instead of MPR's portal
+            # depth; 3x fewer physics errors under random actions, 25-35 % slower (profiles/README.md)
+            if narrowphase not in ("mpr", "epa"):
+                raise ValueError(f"narrowphase must be 'mpr' or 'epa', got {narrowphase!r}")
+            from . import build as _build
+            self.narrowphase = narrowphase
+            self.sim = native.Sim(blob, self.n_envs, device=dev_index, seed=seed, lib_path=_build.LIB_EPA if narrowphase == "epa" else None)
         N = self.n_envs
         z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=self.device)
         self.qpos, self.qvel, self.ctrl, self.warm = z(20, N), z(18, N), z(6, N), z(18, N)
@@ -157,7 +164,7 @@ class BatchedEnvironment:
         # what a settled reset state depends on besides (env id, episode) and the mass scale: the key of the on-disk store
         self._settle_key = dict(
             blob_sha256=hashlib.sha256(blob).hexdigest(), seed=seed, env_id_base=int(env_id_base), n_envs=N,
-            solver=str(solver).lower(), solver_iterations=int(solver_iterations), solver_tolerance=float(solver_tolerance),
+            solver=str(solver).lower(), narrowphase=narrowphase, solver_iterations=int(solver_iterations), solver_tolerance=float(solver_tolerance),
             settle_max_substeps=int(settle_max_substeps), action_offset=[float(x) for x in task.calibration.homing_offsets])
 
     # ------------------------------------------------------------------ specs

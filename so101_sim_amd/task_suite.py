@@ -87,7 +87,7 @@ def create_task_env(
     name explicitly are silently dropped (task_suite.py:134-144) — for `SO100HandOver`, whose signature
     is `(object_name, reward_based_on_overlap=True, **kwargs)`, that is everything except those two.
     Batched extension: `n_envs`, `device`, `solver` ("newton" | "pgs"), `solver_iterations`, `solver_tolerance`,
-    `settle_max_substeps`, `prefetch_resets`, `env_id_base`, `physics_state` (batched `physics_state` /
+    `settle_max_substeps`, `prefetch_resets`, `env_id_base`, `narrowphase` ("mpr" | "epa"), `physics_state` (batched `physics_state` /
     `delayed_physics_state` observables, off by default: 38 + 38 floats per env and step) are consumed here and never
     reach the task.
     """
@@ -98,7 +98,7 @@ def create_task_env(
         )
     n_envs = int(kwargs.pop("n_envs", 1))
     env_kwargs = {k: kwargs.pop(k) for k in ("device", "solver_iterations", "solver_tolerance", "env_id_base", "settle_max_substeps", "solver",
-                                                 "prefetch_resets", "physics_state", "seed_compatible")
+                                                 "prefetch_resets", "physics_state", "seed_compatible", "narrowphase")
                   if k in kwargs}
 
     task_class, task_kwargs = TASK_FACTORIES[task_name]
@@ -112,7 +112,7 @@ def create_task_env(
 
     task_instance = task_class(**kwargs)
     if isinstance(task_instance, _aloha.HandOverTask):
-        for k in ("solver", "prefetch_resets"):          # knobs of the SO100 kernels only
+        for k in ("solver", "prefetch_resets", "narrowphase"):          # knobs of the SO100 kernels only
             env_kwargs.pop(k, None)
         return _aloha.AlohaEnvironment(task_instance, n_envs=n_envs, time_limit=time_limit, random_state=random_state, **env_kwargs)
     if n_envs == 1:
