@@ -87,6 +87,14 @@ def test_pipelined_step_matches_fused(make_sim, golden):
     pc.check_pipeline_identical(make_sim, golden, n=8, steps=6)
 
 
+def test_epa_build_pipelined_step_matches_fused(blobs, golden):
+    """The -DSO101_EPA library (narrowphase="epa"): its launch chains, its fused step and its reset prefetch are the same device functions
+    in the same order as well - bit-identical rollouts from the contact-rich states, across an auto-reset, at one slice and at four."""
+    make = lambda n, seed=0, **cfg: ArraySim(blobs["f32"], n, backend="gpu", seed=seed, epa=True, **cfg)
+    pc.check_pipeline_identical(make, golden, n=8, steps=6, pipelines=(0, 1))
+    pc.check_pipeline_identical(make, golden, n=512, steps=5, seed=13, all_reset_last=False, pipelines=(0, 1))
+
+
 def test_three_launch_chains_match_fused(make_sim, golden):
     """n >= 64: so101_step cuts the cost-sorted envs into three slices on separate streams; still bit-identical to the
     fused single-launch step (different random actions per env, so the slices really differ in cost)."""
