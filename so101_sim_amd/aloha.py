@@ -290,6 +290,20 @@ class AlohaEnvironment:
             self._pending_first = True
         return self._timestep()
 
+    def compute_settled(self, n_episodes: int, first_episode: int = 0):
+        """Placement + settle of the first episodes of every env, done once at the width of the machine (one launch per episode) and
+        attached: the resets of those episodes - explicit or inside step calls - become copies, bit-identical to settling in place.
+        Batches only (a seed-compatible single env draws its placements on the host)."""
+        if self._seed_compatible:
+            raise RuntimeError("a seed-compatible single env draws its placements from numpy's generator; nothing to precompute")
+        torch, s, N = self.torch, self.sim, self.n_envs
+        z = lambda *sh, dt=torch.float32: torch.zeros(*sh, dtype=dt, device=self.device)
+        self._store = (z(n_episodes, s.nq, N), z(n_episodes, s.nv, N), z(n_episodes, s.nv, N), z(n_episodes, N, dt=torch.int32))
+        s.compute_settled(first_episode, n_episodes, *(t.data_ptr() for t in self._store), self._stream())
+        self.torch.cuda.current_stream(self.device).synchronize()
+        s.set_settled_store(first_episode, n_episodes, *(t.data_ptr() for t in self._store))
+        return self._store
+
     def episode_returns(self):
         return self.ep_return
 

@@ -981,6 +981,10 @@ struct TreeTask {
   unsigned long long seed, env_id_base;
 };
 struct TreeEnvBuffers { float *ring_pos, *ring_vel, *ep_return; int *step_count, *episode; unsigned char* need_reset; int* success_state; };
+// Settled-state store (so101_tree_set_settled_store): the results of placement + settle for episodes first .. first + count - 1 of every
+// env, computed once by so101_tree_compute_settled and kept by the caller.  The settled state of an episode is a pure function of (seed,
+// global env id, episode, configuration), so a reset that finds its entry copies the same bits it would have computed.
+struct TreeStore { const float *qpos, *qvel, *warm; const int* flags; int first, count; };     // [count][nq|nv|nv][N], [count][N]
 
 namespace tree {
 
@@ -1039,9 +1043,8 @@ DEV float task_reward_contacts(const TreeModel* tm, const TreeTask& T, const Tre
 
 // env.reset(): arms at the home pose, object and container placed (container by rejection, <= 20 tries), settled with the arms held
 // (aloha2_task.py:369-383, hand_over.py:208-236,340-346).  Same counter-RNG draws as the SO100 reset and the oracle.
-DEV void env_reset(const TreeModel* tm, const DevModel* gm, const TreeTask& T, TreeLDS& L, const TreeScratch& G, const TreeBuffers& B, const TreeEnvBuffers& E, int e) {
-  int lane = wave_lane(), N = T.n_envs;
-  unsigned int episode = (unsigned int)E.episode[e];
+DEV void env_settle(const TreeModel* tm, const DevModel* gm, const TreeTask& T, TreeLDS& L, const TreeScratch& G, int e, unsigned int episode) {
+  int lane = wave_lane();
   unsigned long long env_id = T.env_id_base + (unsigned long long)e;
   if (lane < tm->nq) L.qpos[lane] = lane < tm->njnt ? T.home_qpos[lane] : 0.f;
   if (lane < tm->nv) { L.qvel[lane] = 0.f; L.warm[lane] = 0.f; L.qacc[lane] = 0.f; }
@@ -1087,6 +1090,24 @@ DEV void env_reset(const TreeModel* tm, const DevModel* gm, const TreeTask& T, T
   }
   if (!settled && lane == 0) L.flags |= 32;
   wave_sync();
+}
+
+// env.reset(): the settled state of the episode from the store when it holds it, computed otherwise; then the episode starts -
+// delay lines padded with the reset-time value (task_suite.py:154 INITIAL_VALUE), counters cleared
+DEV void env_reset(const TreeModel* tm, const DevModel* gm, const TreeTask& T, TreeLDS& L, const TreeScratch& G, const TreeBuffers& B, const TreeEnvBuffers& E,
+                   const TreeStore& S, int e) {
+  int lane = wave_lane(), N = T.n_envs;
+  unsigned int episode = (unsigned int)E.episode[e];
+  if (S.qpos && episode - (unsigned int)S.first < (unsigned int)S.count) {
+    size_t k = episode - (unsigned int)S.first;
+    if (lane < tm->nq) L.qpos[lane] = S.qpos[(k * tm->nq + lane) * N + e];
+    if (lane < tm->nv) { L.qvel[lane] = S.qvel[(k * tm->nv + lane) * N + e]; L.warm[lane] = S.warm[(k * tm->nv + lane) * N + e]; L.qacc[lane] = 0.f; }
+    if (lane < tm->nu) L.ctrl[lane] = T.home_ctrl[lane];
+    if (lane == 0) { L.ncon = 0; L.nrow = 0; L.iters = 0; L.ncand = 0; L.flags |= S.flags[k * N + e]; }
+    wave_sync();
+  } else {
+    env_settle(tm, gm, T, L, G, e, episode);
+  }
   // delay lines padded with the reset-time value (task_suite.py:154 INITIAL_VALUE)
   if (lane < T.npos) {
     float v = L.qpos[T.obs_qposadr[lane]];

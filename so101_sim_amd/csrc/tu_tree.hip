@@ -66,17 +66,33 @@ __global__ void __launch_bounds__(64) k_tree_forward(const TreeModel* tm, const 
 }
 
 // env.reset() of the envs whose mask byte is set (NULL: all), then the FIRST observation is what the next step call reports
-__global__ void __launch_bounds__(64) k_tree_reset(const TreeModel* tm, const DevModel* gm, TreeTask T, TreeBuffers B, TreeEnvBuffers E, const unsigned char* mask) {
+__global__ void __launch_bounds__(64) k_tree_reset(const TreeModel* tm, const DevModel* gm, TreeTask T, TreeBuffers B, TreeEnvBuffers E, TreeStore S, const unsigned char* mask) {
   BLOCK_SHARED(TreeLDS, L);
   int e = blockIdx.x, lane = wave_lane(), N = T.n_envs;
   if (mask && !mask[e]) return;
   if (lane == 0) L.flags = 0;
   wave_sync();
   TreeScratch G = tree::scratch_of(B, e);
-  tree::env_reset(tm, gm, T, L, G, B, E, e);
+  tree::env_reset(tm, gm, T, L, G, B, E, S, e);
   tree::store_state(tm, L, B, e, N);
   if (lane < tm->nu) B.ctrl[(size_t)lane * N + e] = L.ctrl[lane];
   if (lane == 0) { E.need_reset[e] = 0; if (B.diag) { int* d = B.diag + 8 * e; d[0] = L.ncon; d[1] = L.nrow; d[2] = L.iters; d[3] = L.ncand; d[4] = L.flags; } }
+}
+
+// placement + settle of episode `episode` of every env into row k of caller-owned tables (so101_tree_compute_settled): what env_reset()
+// would compute for that episode, without touching any env state
+__global__ void __launch_bounds__(64) k_tree_settle_table(const TreeModel* tm, const DevModel* gm, TreeTask T, TreeBuffers B, unsigned int episode, int k,
+                                                          float* qpos, float* qvel, float* warm, int* flags) {
+  BLOCK_SHARED(TreeLDS, L);
+  int e = blockIdx.x, lane = wave_lane(), N = T.n_envs;
+  if (lane == 0) L.flags = 0;
+  wave_sync();
+  TreeScratch G = tree::scratch_of(B, e);
+  tree::env_settle(tm, gm, T, L, G, e, episode);
+  size_t kk = (size_t)k;
+  if (lane < tm->nq) qpos[(kk * tm->nq + lane) * N + e] = L.qpos[lane];
+  if (lane < tm->nv) { qvel[(kk * tm->nv + lane) * N + e] = L.qvel[lane]; warm[(kk * tm->nv + lane) * N + e] = L.warm[lane]; }
+  if (lane == 0) flags[kk * N + e] = L.flags;
 }
 
 // settle the bound state with the one-dof joints held (dm_control's PropPlacer(settle_physics=True) alone, for callers that draw the
@@ -125,7 +141,7 @@ __global__ void __launch_bounds__(64) k_tree_begin(const TreeModel* tm, TreeTask
 
 // one control step of every env: dm_control's Environment.step - an env whose last step was LAST resets and reports FIRST
 // (the action is ignored), the others apply the action, run n_substeps and report observation, reward, discount, step type
-__global__ void __launch_bounds__(64) k_tree_step(const TreeModel* tm, const DevModel* gm, TreeTask T, TreeBuffers B, TreeEnvBuffers E, const float* action,
+__global__ void __launch_bounds__(64) k_tree_step(const TreeModel* tm, const DevModel* gm, TreeTask T, TreeBuffers B, TreeEnvBuffers E, TreeStore S, const float* action,
                                                   float* obs, float* reward, float* discount, unsigned char* step_type) {
   BLOCK_SHARED(TreeLDS, L);
   int e = blockIdx.x, lane = wave_lane(), N = T.n_envs;
@@ -133,7 +149,7 @@ __global__ void __launch_bounds__(64) k_tree_step(const TreeModel* tm, const Dev
   wave_sync();
   TreeScratch G = tree::scratch_of(B, e);
   if (E.need_reset[e]) {
-    tree::env_reset(tm, gm, T, L, G, B, E, e);
+    tree::env_reset(tm, gm, T, L, G, B, E, S, e);
     tree::kinematics(tm, L);
     tree::write_obs(T, L, E, e, 0, true, obs);
     tree::store_state(tm, L, B, e, N);
@@ -198,6 +214,7 @@ struct so101_tree {
   bool bound = false, env_bound = false, has_task = false;
   TreeTask task{};
   TreeEnvBuffers env{};
+  TreeStore store{};
   int iterations = 0; float tolerance = 0.f;
   std::vector<void*> owned;
   std::string err;
@@ -205,6 +222,18 @@ struct so101_tree {
 
 namespace {
 thread_local std::string g_tree_error;
+
+// every entry point that touches HIP runs with the handle's device current and restores the caller's device on exit
+struct TreeDeviceGuard {
+  int prev = -1, dev;
+  bool ok;
+  explicit TreeDeviceGuard(so101_tree* s) : dev(s->device) {
+    ok = hipGetDevice(&prev) == hipSuccess && (prev == dev || hipSetDevice(dev) == hipSuccess);
+    if (!ok) s->err = "hipSetDevice: cannot make the handle's device current";
+  }
+  ~TreeDeviceGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+};
+#define TREE_GUARD(s) TreeDeviceGuard guard_(s); if (!guard_.ok) return SO101_ERR_HIP
 
 void tq2m(float* m, const float* q) {
   float w = q[0], x = q[1], y = q[2], z = q[3];
@@ -405,7 +434,8 @@ int so101_tree_create(const void* blob, size_t bytes, int n_envs, int hip_device
   so101_tree* s = new so101_tree();
   s->n_envs = n_envs; s->device = hip_device;
   int rc = SO101_OK;
-  if (!t_ok(s, hipSetDevice(hip_device), "hipSetDevice")) rc = SO101_ERR_HIP;
+  TreeDeviceGuard guard(s);                       // (the caller's current device is restored on every return path)
+  if (!guard.ok) rc = SO101_ERR_HIP;
   if (rc == SO101_OK) rc = tree_build(s, b);
   if (rc == SO101_OK) {
     void* p = nullptr;
@@ -435,8 +465,11 @@ int so101_tree_create(const void* blob, size_t bytes, int n_envs, int hip_device
 
 void so101_tree_destroy(so101_tree* s) {
   if (!s) return;
-  (void)hipSetDevice(s->device);
-  for (void* p : s->owned) (void)hipFree(p);
+  {
+    TreeDeviceGuard guard(s);
+    (void)hipDeviceSynchronize();                 // nothing of this handle may still be running on buffers that are about to go
+    for (void* p : s->owned) (void)hipFree(p);
+  }
   delete s;
 }
 
@@ -465,7 +498,7 @@ int so101_tree_configure(so101_tree* s, int solver_iterations, float solver_tole
 int so101_tree_physics(so101_tree* s, int n_substeps, void* stream) {
   if (!s || n_substeps < 0) return SO101_ERR_ARG;
   if (!s->bound) { s->err = "so101_tree_physics before so101_tree_bind_state"; return SO101_ERR_STATE; }
-  (void)hipSetDevice(s->device);
+  TREE_GUARD(s);
   hipLaunchKernelGGL(k_tree_physics, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, s->dg, s->buf, s->n_envs, n_substeps, s->iterations, s->tolerance);
   return t_ok(s, hipGetLastError(), "k_tree_physics") ? SO101_OK : SO101_ERR_HIP;
 }
@@ -473,7 +506,7 @@ int so101_tree_physics(so101_tree* s, int n_substeps, void* stream) {
 int so101_tree_debug_forward(so101_tree* s, float* out, void* stream) {
   if (!s || !out) return SO101_ERR_ARG;
   if (!s->bound) { s->err = "so101_tree_debug_forward before so101_tree_bind_state"; return SO101_ERR_STATE; }
-  (void)hipSetDevice(s->device);
+  TREE_GUARD(s);
   static const int phases = getenv("SO101_TREE_PHASES") ? atoi(getenv("SO101_TREE_PHASES")) : 0x7f;      // timing runs only
   hipLaunchKernelGGL(k_tree_forward, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, s->dg, s->buf, s->n_envs, s->iterations, s->tolerance, out, phases);
   return t_ok(s, hipGetLastError(), "k_tree_forward") ? SO101_OK : SO101_ERR_HIP;
@@ -507,23 +540,43 @@ static TreeTask task_now(so101_tree* s) { TreeTask T = s->task; T.n_envs = s->n_
 int so101_tree_reset(so101_tree* s, const uint8_t* mask, void* stream) {
   if (!s) return SO101_ERR_ARG;
   if (!s->bound || !s->env_bound) { s->err = "so101_tree_reset before so101_tree_bind_state / so101_tree_bind_env"; return SO101_ERR_STATE; }
-  (void)hipSetDevice(s->device);
-  hipLaunchKernelGGL(k_tree_reset, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, s->dg, task_now(s), s->buf, s->env, mask);
+  TREE_GUARD(s);
+  hipLaunchKernelGGL(k_tree_reset, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, s->dg, task_now(s), s->buf, s->env, s->store, mask);
   return t_ok(s, hipGetLastError(), "k_tree_reset") ? SO101_OK : SO101_ERR_HIP;
 }
 
 int so101_tree_step(so101_tree* s, const float* action, float* obs, float* reward, float* discount, uint8_t* step_type, void* stream) {
   if (!s || !action || !obs || !reward || !discount || !step_type) { if (s) s->err = "so101_tree_step: NULL argument"; return SO101_ERR_ARG; }
   if (!s->bound || !s->env_bound) { s->err = "so101_tree_step before so101_tree_bind_state / so101_tree_bind_env"; return SO101_ERR_STATE; }
-  (void)hipSetDevice(s->device);
-  hipLaunchKernelGGL(k_tree_step, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, s->dg, task_now(s), s->buf, s->env, action, obs, reward, discount, step_type);
+  TREE_GUARD(s);
+  hipLaunchKernelGGL(k_tree_step, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, s->dg, task_now(s), s->buf, s->env, s->store, action, obs, reward, discount, step_type);
   return t_ok(s, hipGetLastError(), "k_tree_step") ? SO101_OK : SO101_ERR_HIP;
+}
+
+int so101_tree_compute_settled(so101_tree* s, int first_episode, int count, float* qpos, float* qvel, float* warmstart, int32_t* flags, void* stream) {
+  if (!s || !qpos || !qvel || !warmstart || !flags || first_episode < 0 || count <= 0) { if (s) s->err = "so101_tree_compute_settled: bad argument"; return SO101_ERR_ARG; }
+  if (!s->has_task) { s->err = "so101_tree_compute_settled: the model carries no task"; return SO101_ERR_STATE; }
+  TREE_GUARD(s);
+  for (int k = 0; k < count; k++) {      // one launch per episode: the per-env scratch is used by one wavefront at a time
+    hipLaunchKernelGGL(k_tree_settle_table, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, s->dg, task_now(s), s->buf, (unsigned int)(first_episode + k), k,
+                       qpos, qvel, warmstart, flags);
+    if (!t_ok(s, hipGetLastError(), "k_tree_settle_table")) return SO101_ERR_HIP;
+  }
+  return SO101_OK;
+}
+
+int so101_tree_set_settled_store(so101_tree* s, int first_episode, int count, const float* qpos, const float* qvel, const float* warmstart, const int32_t* flags) {
+  if (!s) return SO101_ERR_ARG;
+  if (count > 0 && (!qpos || !qvel || !warmstart || !flags || first_episode < 0)) { s->err = "so101_tree_set_settled_store: bad argument"; return SO101_ERR_ARG; }
+  s->store = TreeStore{};
+  if (count > 0) { s->store.qpos = qpos; s->store.qvel = qvel; s->store.warm = warmstart; s->store.flags = flags; s->store.first = first_episode; s->store.count = count; }
+  return SO101_OK;
 }
 
 int so101_tree_settle(so101_tree* s, void* stream) {
   if (!s) return SO101_ERR_ARG;
   if (!s->bound) { s->err = "so101_tree_settle before so101_tree_bind_state"; return SO101_ERR_STATE; }
-  (void)hipSetDevice(s->device);
+  TREE_GUARD(s);
   hipLaunchKernelGGL(k_tree_settle, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, s->dg, task_now(s), s->buf);
   return t_ok(s, hipGetLastError(), "k_tree_settle") ? SO101_OK : SO101_ERR_HIP;
 }
@@ -531,14 +584,14 @@ int so101_tree_settle(so101_tree* s, void* stream) {
 int so101_tree_begin_episode(so101_tree* s, void* stream) {
   if (!s) return SO101_ERR_ARG;
   if (!s->bound || !s->env_bound) { s->err = "so101_tree_begin_episode before so101_tree_bind_state / so101_tree_bind_env"; return SO101_ERR_STATE; }
-  (void)hipSetDevice(s->device);
+  TREE_GUARD(s);
   hipLaunchKernelGGL(k_tree_begin, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, task_now(s), s->buf, s->env);
   return t_ok(s, hipGetLastError(), "k_tree_begin") ? SO101_OK : SO101_ERR_HIP;
 }
 
 int so101_tree_get_diag(so101_tree* s, int* out /* [n_envs][8] device or host-visible memory */, void* stream) {
   if (!s || !out) return SO101_ERR_ARG;
-  (void)hipSetDevice(s->device);
+  TREE_GUARD(s);
   return t_ok(s, hipMemcpyAsync(out, s->buf.diag, (size_t)s->n_envs * 8 * sizeof(int), hipMemcpyDefault, (hipStream_t)stream), "hipMemcpyAsync(diag)") ? SO101_OK : SO101_ERR_HIP;
 }
 

@@ -34,7 +34,7 @@ EXPORTS = (
     "so101_get_returns", "so101_get_diag", "so101_get_events", "so101_debug_forward", "so101_debug_candidates", "so101_debug_stages", "so101_get_info", "so101_debug_chain_stats", "so101_last_error",
     "so101_tree_create", "so101_tree_destroy", "so101_tree_dims", "so101_tree_bind_state", "so101_tree_configure", "so101_tree_physics",
     "so101_tree_debug_forward", "so101_tree_get_diag", "so101_tree_last_error", "so101_tree_obs_dim", "so101_tree_bind_env",
-    "so101_tree_configure_env", "so101_tree_reset", "so101_tree_step", "so101_tree_begin_episode", "so101_tree_settle",
+    "so101_tree_configure_env", "so101_tree_reset", "so101_tree_step", "so101_tree_begin_episode", "so101_tree_settle", "so101_tree_compute_settled", "so101_tree_set_settled_store",
 )
 
 
@@ -253,6 +253,8 @@ class TreeSim:
         L.so101_tree_step.argtypes = [C.c_void_p] + [C.c_void_p] * 6
         L.so101_tree_begin_episode.argtypes = [C.c_void_p, C.c_void_p]
         L.so101_tree_settle.argtypes = [C.c_void_p, C.c_void_p]
+        L.so101_tree_compute_settled.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
+        L.so101_tree_set_settled_store.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4
         self.n_envs = int(n_envs)
         h = C.c_void_p()
         rc = L.so101_tree_create(blob_f32, len(blob_f32), self.n_envs, int(device), C.byref(h))
@@ -319,3 +321,9 @@ class TreeSim:
 
     def settle(self, stream: int = 0):
         self._check(self.L.so101_tree_settle(self.h, stream), "so101_tree_settle")
+
+    def compute_settled(self, first_episode, count, qpos, qvel, warm, flags, stream: int = 0):
+        self._check(self.L.so101_tree_compute_settled(self.h, int(first_episode), int(count), qpos, qvel, warm, flags, stream), "so101_tree_compute_settled")
+
+    def set_settled_store(self, first_episode, count, qpos, qvel, warm, flags):
+        self._check(self.L.so101_tree_set_settled_store(self.h, int(first_episode), int(count), qpos, qvel, warm, flags), "so101_tree_set_settled_store")

@@ -369,3 +369,29 @@ def test_single_aloha_env_reset_is_seed_compatible_with_the_reference():
         opos2 = rs.uniform([0.12, -0.1, 0.1], [0.18, 0.1, 0.1])
         np.testing.assert_allclose(env.placements["object_position"], opos2, rtol=0, atol=0)
         env.close()
+
+
+@pytest.mark.gpu
+def test_settled_store_of_the_tree_engine_is_bit_identical():
+    """compute_settled(): the settle results of the first episodes of every env, computed ahead of time; the resets that find them copy -
+    the rollout across two auto-resets is bit-identical to the one that settles inside the step calls."""
+    import torch
+    from so101_sim_amd import task_suite
+    n = 64
+    traces = []
+    for store in (False, True):
+        env = task_suite.create_task_env("HandOverBanana", time_limit=0.1, random_state=5, n_envs=n, settle_max_substeps=200)
+        if store:
+            env.compute_settled(3)
+        g = torch.Generator(device=env.device); g.manual_seed(2)
+        home = torch.tensor(np.concatenate([scenes.ALOHA_HOME_CTRL] * 2), dtype=torch.float32, device=env.device)
+        env.reset()
+        tr = [env.qpos.clone(), env.qvel.clone()]
+        for k in range(13):                     # LAST on steps 5 and 11 (time limit 0.1 s), FIRST on 6 and 12: episodes 0, 1, 2
+            obs, r, d, st = env.step_tensor(home + 0.3 * (torch.rand(n, 14, generator=g, device=env.device) - 0.5))
+            tr += [obs.clone(), st.clone().float(), env.qpos.clone(), env.qvel.clone()]
+        assert int(env.episode[0]) == 3
+        traces.append(tr)
+        env.close()
+    for a, b in zip(*traces):
+        assert torch.equal(a, b)
