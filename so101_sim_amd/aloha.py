@@ -72,7 +72,7 @@ def aloha_action_spec(ctrlrange: np.ndarray, waist_joint_limit: float = np.pi / 
 class AlohaEnvironment:
     def __init__(self, task: HandOverTask, n_envs: int = 1, time_limit: float = float("inf"), random_state=None, device=None,
                  env_id_base: int = 0, solver_iterations: int = 0, solver_tolerance: float = -1.0, settle_max_substeps: int = 1000,
-                 physics_state: bool | None = None, seed_compatible: bool = True):
+                 physics_state: bool | None = None, seed_compatible: bool = True, narrowphase: str = "mpr"):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("so101_sim_amd needs a ROCm GPU (MI355X): the step path has no CPU fallback")
@@ -106,7 +106,11 @@ class AlohaEnvironment:
                             con_hi=np.asarray(m64["task_con_pos_hi"], dtype=np.float64), qo=int(qadr[obj_body]), qc=int(qadr[con_body]),
                             con_geoms=set(np.nonzero(np.asarray(m["geom_body"]) == con_body)[0].tolist()))
         with torch.cuda.device(self.device):
-            self.sim = native.TreeSim(blob, N, device=self.device.index or 0)
+            if narrowphase not in ("mpr", "epa"):
+                raise ValueError(f"narrowphase must be 'mpr' or 'epa', got {narrowphase!r}")
+            from . import build as _build
+            self.narrowphase = narrowphase       # "epa": the -DSO101_EPA build of the library (env.py)
+            self.sim = native.TreeSim(blob, N, device=self.device.index or 0, lib_path=_build.LIB_EPA if narrowphase == "epa" else None)
         s = self.sim
         if (s.nu, s.obs_dim) != (NPOS, 3 * NPOS + 2 * NVEL):
             raise RuntimeError("unexpected model dimensions for an ALOHA hand-over scene")

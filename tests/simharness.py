@@ -204,17 +204,18 @@ class ArraySim:
 class TreeArraySim:
     """The general-tree engine (so101_tree_*, the ALOHA scenes) behind the same two backends."""
 
-    def __init__(self, blob_f32: bytes, n_envs: int, backend: str = "gpu"):
+    def __init__(self, blob_f32: bytes, n_envs: int, backend: str = "gpu", epa: bool = False):
         self.N, self.backend = n_envs, backend
         if backend == "gpu":
             import torch
+            from so101_sim_amd import build as sbuild
             self.torch = torch
             self.dev = torch.device("cuda:0")
-            self.sim = native.TreeSim(blob_f32, n_envs, device=0)
+            self.sim = native.TreeSim(blob_f32, n_envs, device=0, lib_path=sbuild.LIB_EPA if epa else None)
             z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=self.dev)
             i32 = torch.int32
         else:
-            self.sim = native.TreeSim(blob_f32, n_envs, device=0, lib_path=build_emu())
+            self.sim = native.TreeSim(blob_f32, n_envs, device=0, lib_path=build_emu(epa))
             z = lambda *s, dt=np.float32: np.zeros(s, dtype=dt)
             i32 = np.int32
         s = self.sim
