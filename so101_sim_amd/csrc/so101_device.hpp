@@ -715,7 +715,7 @@ DEV bool epa_expand(const DevModel* m, const GeomW& G1, const GeomW& G2, const f
     wave_argmax(key, idx);
     if (key <= -3.0e38f) return false;
     best = idx; bd = -key;
-    bn[0] = wave_bcast_f(F.n[0], best); bn[1] = wave_bcast_f(F.n[1], best); bn[2] = wave_bcast_f(F.n[2], best);
+    bn[0] = wave_get_f(F.n[0], best); bn[1] = wave_get_f(F.n[1], best); bn[2] = wave_get_f(F.n[2], best);
     MV w;
     mdsupport<Cache, GP>(m, G1, G2, bn, org, w, H1, H2);
     float reach = dot3(bn, w.v) - bd;
@@ -730,9 +730,9 @@ DEV bool epa_expand(const DevModel* m, const GeomW& G1, const GeomW& G2, const f
     int packed = F.a | (F.b << 8) | (F.c << 16) | ((vis ? 1 : 0) << 24);
     // horizon: an edge of a visible face whose reversed edge belongs to no other visible face
     bool s0 = false, s1 = false, s2 = false;
-    for (int j = 0; j < nf; j++) {
-      int pj = wave_bcast_i(packed, j);
-      if (!((pj >> 24) & 1)) continue;
+    for (unsigned long long rest = vmask; rest != 0ull; rest &= rest - 1ull) {      // the visible faces only (a handful of the polytope's)
+      int j = (int)__builtin_ctzll(rest);
+      int pj = wave_get_i(packed, j);                     // (v_readlane: j is wave-uniform)
       int ja = pj & 255, jb = (pj >> 8) & 255, jc = (pj >> 16) & 255;
 #define EPA_REV(x, y) ((ja == (y) && jb == (x)) || (jb == (y) && jc == (x)) || (jc == (y) && ja == (x)))
       bool other = j != lane;

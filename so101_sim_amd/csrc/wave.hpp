@@ -138,6 +138,7 @@ __device__ __forceinline__ int wave_uniform_i(int v) { return __builtin_amdgcn_r
 // value of lane `src` (wave-uniform src): v_readlane, the result lives in an SGPR
 __device__ __forceinline__ float wave_get_f(float v, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src)); }
 
+__device__ __forceinline__ int wave_get_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }       // (wave-uniform src)
 __device__ __forceinline__ float wave_bcast_f(float v, int src) { return __shfl(v, src); }
 __device__ __forceinline__ int wave_bcast_i(int v, int src) { return __shfl(v, src); }
 

@@ -59,6 +59,7 @@ template <class T> inline T* uniform_ptr(T* p) { return p; }
 #define SO101_NOINLINE
 inline float wave_get_f(float v, int src) { emu_xchg_f[threadIdx.x] = v; __syncthreads(); float r = emu_xchg_f[src]; __syncthreads(); return r; }
 inline float wave_bcast_f(float v, int src) { emu_xchg_f[threadIdx.x] = v; __syncthreads(); float r = emu_xchg_f[src]; __syncthreads(); return r; }
+inline int wave_get_i(int v, int src) { emu_xchg_i[threadIdx.x] = v; __syncthreads(); int r = emu_xchg_i[src]; __syncthreads(); return r; }
 inline int wave_bcast_i(int v, int src) { emu_xchg_i[threadIdx.x] = v; __syncthreads(); int r = emu_xchg_i[src]; __syncthreads(); return r; }
 inline void wave_argmax(float& val, int& idx) {
   emu_xchg_f[threadIdx.x] = val; emu_xchg_i[threadIdx.x] = idx; __syncthreads();
