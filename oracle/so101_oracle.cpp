@@ -532,13 +532,21 @@ bool epa_penetration(const orc_sim* s, int g1, int g2, const real* org, const MV
     real len = norm3(f.n);
     if (len < 1e-14) { f.d = 1e30; f.n[0] = f.n[1] = f.n[2] = 0; f.alive = false; F.push_back(f); return; }
     for (int k = 0; k < 3; k++) f.n[k] /= len;
-    f.d = dot3(f.n, V[a].v);
-    if (f.d < 0) { std::swap(f.b, f.c); for (int k = 0; k < 3; k++) f.n[k] = -f.n[k]; f.d = -f.d; }      // outward: the origin is inside
+    f.d = dot3(f.n, V[a].v);          // (no per-face flip: consistent winding by construction, as in the kernels)
     F.push_back(f);
   };
-  add_face(1, 2, 3); add_face(0, 1, 2); add_face(0, 2, 3); add_face(0, 3, 1);
+  {
+    real e1[3], e2[3], nn[3], to0[3];
+    for (int k = 0; k < 3; k++) { e1[k] = v2.v[k] - v1.v[k]; e2[k] = v3.v[k] - v1.v[k]; to0[k] = v0.v[k] - v1.v[k]; }
+    cross3(nn, e1, e2);
+    bool swap = dot3(nn, to0) > 0;
+    if (!swap) { add_face(1, 2, 3); add_face(0, 2, 1); add_face(0, 3, 2); add_face(0, 1, 3); }
+    else { add_face(1, 3, 2); add_face(0, 1, 2); add_face(0, 2, 3); add_face(0, 3, 1); }
+  }
   int best = -1;
-  for (int it = 0; it < 64; it++) {
+  bool converged = false;
+  const int max_expansions = 30;          // as the kernels: 4 + 2 x 30 faces fill their 64 face lanes
+  for (int it = 0; it <= max_expansions; it++) {
     best = -1;
     for (size_t i = 0; i < F.size(); i++) if (F[i].alive && (best < 0 || F[i].d < F[best].d)) best = (int)i;
     if (best < 0) return false;
@@ -547,7 +555,8 @@ bool epa_penetration(const orc_sim* s, int g1, int g2, const real* org, const MV
     real reach = dot3(F[best].n, w.v) - F[best].d;
     bool dup = false;
     for (const MV& x : V) if (std::fabs(x.v[0] - w.v[0]) + std::fabs(x.v[1] - w.v[1]) + std::fabs(x.v[2] - w.v[2]) < 1e-12) dup = true;
-    if (reach <= tol || dup || V.size() >= 60) break;
+    if (reach <= tol) { converged = true; break; }
+    if (dup || it == max_expansions) break;
     if (iters_out) (*iters_out)++;
     int wi = (int)V.size();
     V.push_back(w);
@@ -569,6 +578,7 @@ bool epa_penetration(const orc_sim* s, int g1, int g2, const real* org, const MV
     for (size_t i = 0; i < F.size(); i++) if (vis[i]) F[i].alive = false;
     for (auto& ed : edges) add_face(ed.first, ed.second, wi);
   }
+  if (!converged) return false;           // an inner bound only (a tiny sphere deep inside a mesh): the caller keeps MPR's answer
   const EpaFace& f = F[best];
   *depth = f.d;
   for (int k = 0; k < 3; k++) dir[k] = f.n[k];
@@ -673,17 +683,17 @@ bool mpr_penetration(const orc_sim* s, int g1, int g2, real* depth, real* dir, r
     if (reach_tol(v4, d) || guard > 100) return false;
     expand(v4);
   }
+  if (s->narrow == 1) {       // EPA takes over as soon as the portal encloses the origin: the tetrahedron v0 v1 v2 v3 contains it from here on,
+    int n_it = 0;             // and MPR's own refinement of the portal towards the surface is work EPA does anyway
+    bool ok = epa_penetration(s, g1, g2, org, v0, v1, v2, v3, m.mpr_tol, depth, dir, pos, &n_it);
+    const_cast<orc_sim*>(s)->epa_iters += n_it;
+    if (ok) return true;
+  }
   // find penetration
   for (int it = 0;; it++) {
     portal_dir(d);
     mdsupport(s, g1, g2, d, org, &v4);
     if (reach_tol(v4, d) || it > m.mpr_iter) {
-      if (s->narrow == 1) {
-        int n_it = 0;
-        bool ok = epa_penetration(s, g1, g2, org, v0, v1, v2, v3, m.mpr_tol, depth, dir, pos, &n_it);
-        const_cast<orc_sim*>(s)->epa_iters += n_it;
-        if (ok) return true;
-      }
       real pd[3], bw[3];
       real d2 = origin_tri_dist2(v1.v, v2.v, v3.v, pd, bw);
       *depth = std::sqrt(d2);

@@ -673,6 +673,7 @@ DEV void interior_point(const GeomW& G, const float* target, float* out) {
 // (with its witness points) and face k (vertex indices, unit normal, distance) in registers, at most 64 of each; one expansion =
 // wave-argmin over the faces, one support pair, a visibility ballot, a scan of the visible faces' edges for the horizon, and new faces
 // in the freed lanes.  Entirely wave-uniform control flow (G64 policy only).
+#define EPA_MAX_EXPANSIONS 30     // 4 + 2 x 30 faces fill the 64 face lanes
 struct EpaFace { int a, b, c; float n[3], d; bool alive; };
 
 DEV void epa_make_face(bool doit, int a, int b, int c, float vx, float vy, float vz, EpaFace& F) {
@@ -687,11 +688,12 @@ DEV void epa_make_face(bool doit, int a, int b, int c, float vx, float vy, float
   float inv = ok ? 1.f / len : 0.f;
   n[0] *= inv; n[1] *= inv; n[2] *= inv;
   float d = dot3(n, A);
-  bool flip = d < 0.f;                      // outward: the origin is inside the polytope
+  // (no per-face flip: the winding is consistent by construction - the first tetrahedron is oriented as a whole, a new face takes its
+  //  horizon edge in the direction the removed face had it - and a per-face sign test turns a face the origin lies ON inside out)
   if (doit) {
-    F.a = a; F.b = flip ? c : b; F.c = flip ? b : c;
-    F.n[0] = flip ? -n[0] : n[0]; F.n[1] = flip ? -n[1] : n[1]; F.n[2] = flip ? -n[2] : n[2];
-    F.d = ok ? fabsf(d) : 3.0e38f; F.alive = ok;
+    F.a = a; F.b = b; F.c = c;
+    F.n[0] = n[0]; F.n[1] = n[1]; F.n[2] = n[2];
+    F.d = ok ? d : 3.0e38f; F.alive = ok;
   }
 }
 
@@ -706,11 +708,17 @@ DEV bool epa_expand(const DevModel* m, const GeomW& G1, const GeomW& G2, const f
   int nv = 4, nf = 4;
   EpaFace F; F.a = F.b = F.c = 0; F.n[0] = F.n[1] = F.n[2] = 0.f; F.d = 3.0e38f; F.alive = false;
   {
-    int a0 = lane == 0 ? 1 : 0, b0 = lane == 0 ? 2 : (lane == 1 ? 1 : (lane == 2 ? 2 : 3)), c0 = lane == 0 ? 3 : (lane == 1 ? 2 : (lane == 2 ? 3 : 1));
-    epa_make_face(lane < 4, lane < 4 ? a0 : 0, lane < 4 ? b0 : 0, lane < 4 ? c0 : 0, vx, vy, vz, F);
+    // faces (1 2 3), (0 2 1), (0 3 2), (0 1 3): consistently wound; outward when (v2 - v1) x (v3 - v1) points away from v0, else all four swapped
+    float e1[3] = {v2.v[0] - v1.v[0], v2.v[1] - v1.v[1], v2.v[2] - v1.v[2]}, e2[3] = {v3.v[0] - v1.v[0], v3.v[1] - v1.v[1], v3.v[2] - v1.v[2]}, nn[3];
+    cross3(nn, e1, e2);
+    float to0[3] = {v0.v[0] - v1.v[0], v0.v[1] - v1.v[1], v0.v[2] - v1.v[2]};
+    bool swap = dot3(nn, to0) > 0.f;
+    int a0 = lane == 0 ? 1 : 0, b0 = lane == 0 ? 2 : (lane == 1 ? 2 : (lane == 2 ? 3 : 1)), c0 = lane == 0 ? 3 : (lane == 1 ? 1 : (lane == 2 ? 2 : 3));
+    epa_make_face(lane < 4, lane < 4 ? a0 : 0, lane < 4 ? (swap ? c0 : b0) : 0, lane < 4 ? (swap ? b0 : c0) : 0, vx, vy, vz, F);
   }
   int best = 0; float bd = 0.f, bn[3] = {0.f, 0.f, 0.f};
-  for (int it = 0; it < 48; it++) {
+  bool converged = false;
+  for (int it = 0; it <= EPA_MAX_EXPANSIONS; it++) {
     float key = F.alive ? -F.d : -3.0e38f; int idx = lane;
     wave_argmax(key, idx);
     if (key <= -3.0e38f) return false;
@@ -720,7 +728,12 @@ DEV bool epa_expand(const DevModel* m, const GeomW& G1, const GeomW& G2, const f
     mdsupport<Cache, GP>(m, G1, G2, bn, org, w, H1, H2);
     float reach = dot3(bn, w.v) - bd;
     bool dup = lane < nv && fabsf(vx - w.v[0]) + fabsf(vy - w.v[1]) + fabsf(vz - w.v[2]) < 1e-9f;
-    if (reach <= tol || wave_ballot(dup) != 0ull || nv >= WAVE || nf + 2 > WAVE) break;
+#ifdef SO101_EPA_TRACE
+    { bool anydup = wave_ballot(dup) != 0ull; if (lane == 0) fprintf(stderr, "  epa it %d best %d bd %.7g reach %.3g nv %d nf %d dup %d w %.6f %.6f %.6f\n", it, best, bd, reach, nv, nf, (int)anydup, w.v[0], w.v[1], w.v[2]); }
+#endif
+    if (reach <= tol) { converged = true; break; }
+    // (a support point the polytope already has, although the face claims room beyond it: rounding has made the polytope inconsistent)
+    if (wave_ballot(dup) != 0ull || it == EPA_MAX_EXPANSIONS || nv >= WAVE || nf + 2 > WAVE) break;
     int wi = nv;
     EPA_PUT(wi, w)
     nv++;
@@ -741,6 +754,9 @@ DEV bool epa_expand(const DevModel* m, const GeomW& G1, const GeomW& G2, const f
     bool h0 = vis && !s0, h1 = vis && !s1, h2 = vis && !s2;
     unsigned long long m0 = wave_ballot(h0), m1 = wave_ballot(h1), m2 = wave_ballot(h2);
     int K = __popcll(m0) + __popcll(m1) + __popcll(m2);
+#ifdef SO101_EPA_TRACE
+    if (lane == 0) fprintf(stderr, "     nvis %d K %d\n", nvis, K);
+#endif
     int base = wave_prefix(m0) + wave_prefix(m1) + wave_prefix(m2);
     wave_sync();
     if (h0) epa_list[base] = (unsigned int)(F.a | (F.b << 8));
@@ -759,6 +775,9 @@ DEV bool epa_expand(const DevModel* m, const GeomW& G1, const GeomW& G2, const f
   }
 #undef EPA_PUT
 #undef EPA_REV
+  // a polytope that has not reached the surface after EPA_MAX_EXPANSIONS (a 0.6 mm sphere deep inside a mesh: the difference is
+  // curved everywhere) is an INNER bound, its nearest face too shallow: the caller falls back to MPR's own answer
+  if (!converged) return false;
   *depth = bd; dir[0] = bn[0]; dir[1] = bn[1]; dir[2] = bn[2];
   int ia = wave_bcast_i(F.a, best), ib = wave_bcast_i(F.b, best), ic = wave_bcast_i(F.c, best);
   float A[3] = {wave_bcast_f(vx, ia), wave_bcast_f(vy, ia), wave_bcast_f(vz, ia)}, B[3] = {wave_bcast_f(vx, ib), wave_bcast_f(vy, ib), wave_bcast_f(vz, ib)},
@@ -851,7 +870,14 @@ DEV bool mpr_penetration(const DevModel* m, const GeomW& G1, const GeomW& G2, fl
     cross3(d, va, vb); normalize3(d);
     if (!inside) {
       dt = dot3(d, v1.v);
-      if (isz(dt) || dt > 0.f) { inside = true; it = -1; continue; }   // portal encapsules origin: start penetration phase
+      if (isz(dt) || dt > 0.f) {                                        // portal encapsules origin: start penetration phase
+#ifdef SO101_EPA      // the EPA build of the library (build.py --epa, libso101_hip_epa.so): EPA takes over here - the tetrahedron v0 v1 v2 v3 contains the
+        if constexpr (GP::N == WAVE) {          // origin from now on, and MPR's own refinement of the portal towards the surface is work EPA does anyway
+          if (epa_expand<Cache, GP>(m, G1, G2, org, v0, v1, v2, v3, mpr_tol, depth, dir, pos, H1, H2)) return true;
+        }
+#endif
+        inside = true; it = -1; continue;
+      }
     }
     mdsupport<Cache, GP>(m, G1, G2, d, org, v4, H1, H2);
     float dv1 = dot3(v1.v, d), dv2 = dot3(v2.v, d), dv3 = dot3(v3.v, d), dv4 = dot3(v4.v, d);
@@ -861,11 +887,6 @@ DEV bool mpr_penetration(const DevModel* m, const GeomW& G1, const GeomW& G2, fl
       if (!(isz(dv4) || dv4 > 0.f)) return false;     // cannot encapsule origin
       if (reached || it > 100) return false;
     } else if (reached || it > mpr_iter) {
-#ifdef SO101_EPA      // the EPA build of the library (build.py --epa, libso101_hip_epa.so): every non-flat pair's portal is expanded to the nearest face
-      if constexpr (GP::N == WAVE) {
-        if (epa_expand<Cache, GP>(m, G1, G2, org, v0, v1, v2, v3, mpr_tol, depth, dir, pos, H1, H2)) return true;
-      }
-#endif
       float pd[3], bw[3];
       float d2 = origin_tri_dist2(v1.v, v2.v, v3.v, pd, bw);
       *depth = sqrtf(d2);

@@ -122,7 +122,7 @@ class BatchedEnvironment:
         with torch.cuda.device(self.device):
             # narrowphase = "epa": the -DSO101_EPA build of the library - the penetration of non-flat convex pairs is the minimum
             # translation (MPR's final portal expanded by EPA, as mujoco's native GJK / EPA reports it) instead of MPR's portal
-            # depth; 3x fewer physics errors under random actions, 11-27 % slower (profiles/README.md)
+            # depth; 3x fewer physics errors under random actions, 5-15 % slower (profiles/README.md)
             if narrowphase not in ("mpr", "epa"):
                 raise ValueError(f"narrowphase must be 'mpr' or 'epa', got {narrowphase!r}")
             from . import build as _build
