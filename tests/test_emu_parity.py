@@ -10,7 +10,7 @@ from tests.simharness import ArraySim
 
 
 # Emulated runs of code that the GPU tests cover at full size (tests/test_gpu_parity.py) and that cost minutes under the lane-thread
-# emulator: run them with SO101_SLOW_TESTS=1; the default CPU suite keeps the default step path and the reset prefetch.
+# emulator: run them with SO101_SLOW_TESTS=1; the default CPU suite keeps the forward stages, the control step, the env semantics and the default step path against the fused one.
 SLOW = pytest.mark.skipif(not os.environ.get("SO101_SLOW_TESTS"), reason="emulated run of a path the GPU tests cover; set SO101_SLOW_TESTS=1")
 
 @pytest.fixture(scope="module")
@@ -40,6 +40,7 @@ def test_env_semantics(make_sim, blobs):
     pc.check_env_semantics(make_sim, blobs, n=1, settle=6, steps=4, last_step=3, iterations=10)     # full delay-line wrap: GPU suite
 
 
+@SLOW
 def test_divergence_handling(make_sim, blobs):
     pc.check_divergence_handling(make_sim, blobs)
 
@@ -48,6 +49,7 @@ def test_contact_rich_states(make_sim, blobs, golden):
     pc.check_contact_rich(make_sim, blobs, golden, count=4)
 
 
+@SLOW
 def test_reset_prefetch_is_bit_identical(make_sim):
     pc.check_prefetch_identical(make_sim, n=1, settle=4, steps=4, last_step=1)
 
