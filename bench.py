@@ -153,9 +153,33 @@ def spawn_ranks(n: int) -> int:
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True if r == 0 else None))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [q.wait() for q in procs[1:]]
-    sys.stdout.write(out or "")
+    # rank 0's line is read by a thread while ALL children are polled: a rank that dies before or during the rendezvous would
+    # otherwise leave rank 0 (and this parent, blocked in communicate()) waiting for the process group's timeout
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rcs = [None] * n
+    while any(c is None for c in rcs):
+        for r, q in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = q.poll()
+        failed = [r for r, c in enumerate(rcs) if c not in (None, 0)]
+        if failed:
+            for r, q in enumerate(procs):
+                if rcs[r] is None:
+                    q.terminate()
+            for r, q in enumerate(procs):
+                if rcs[r] is None:
+                    try:
+                        rcs[r] = q.wait(timeout=10)
+                    except subprocess.TimeoutExpired:
+                        q.kill()
+                        rcs[r] = q.wait()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    sys.stdout.write("".join(c or "" for c in chunks))
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
     if bad:
@@ -215,7 +239,7 @@ def run_aloha(args, torch, sdist, dev, rank, world, hbm_measured):
                        "envs_per_gpu": N, "global_envs": world * N, "substeps_per_step": 10, "solver": "newton", "engine": "general tree (csrc/so101_tree.hpp)",
                        "resets": (f"settled-state store computed before the timed region ({t_store:.1f} s for {2 + (args.warmup + args.steps) // 500} episodes per env)"
                                   if args.settled_store else "placement + settle inside the step calls"),
-                       "parallelism": f"env-shard x{world}", "build": sbuild.source_hash()},
+                       "parallelism": f"env-shard x{world}", "build": sbuild.source_hash(mpr=args.narrowphase == "mpr")},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": hbm_measured, "unit": "GB/s", "frac": achieved / hbm_measured if hbm_measured else None,
                          "traffic": None, "peak_spec": HBM_SPEC_GBS, "frac_of_spec": achieved / HBM_SPEC_GBS, "kernel": "k_tree_step (one launch per control step)",
                          "kernel_ms": 1e3 * elapsed / args.steps, "launches_per_step": 1,
@@ -238,7 +262,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=0, help="0 = the workload's BASELINE.json size")
     ap.add_argument("--solver", choices=("newton", "pgs"), default="newton",
                     help="newton = MuJoCo's default, which the reference scene uses (it sets no <option solver>)")
-    ap.add_argument("--narrowphase", choices=("mpr", "epa"), default="mpr", help="epa: the -DSO101_EPA build of the library (minimum translation instead of MPR's portal depth)")
+    ap.add_argument("--narrowphase", choices=("mpr", "epa"), default="epa", help="epa (default): minimum translation, what mujoco >= 3.3 reports; mpr: the -DSO101_MPR build of the library (MPR's portal depth, built on demand)")
     ap.add_argument("--no-prefetch", action="store_true", help="settle auto-resets inside the step call")
     ap.add_argument("--fused", action="store_true", help="one fused k_step launch per control step instead of the pipeline")
     ap.add_argument("--pipeline", type=int, default=-1, help="step path: 3 merged launches, 2 per-env chained, 1 launch chains, 0 fused (-1 = library default)")
@@ -250,7 +274,7 @@ def main():
     ap.add_argument("--pool-size", type=int, default=4096, help="pickplace: states in the pre-grasp pool")
     ap.add_argument("--settled-store", action="store_true", help="aloha: precompute the settled reset states of the run's episodes (outside the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--repeats", type=int, default=5, help="timed windows of --steps steps; `value` is the first one, all are in `repeats`")
+    ap.add_argument("--repeats", type=int, default=5, help="timed windows of --steps steps; `value` is their mean, all are in `repeats`")
     ap.add_argument("--device", choices=("cuda", "cpu"), default="cuda", help="cpu: tests only (gloo, needs --env-factory)")
     ap.add_argument("--env-factory", default="", help="module:callable replacing task_suite.create_task_env (tests)")
     args = ap.parse_args()
@@ -289,7 +313,7 @@ def main():
     os.chdir("/tmp")          # calibration offsets OFF (reference looks the JSON up relative to the CWD)
     kw = dict(time_limit=10.0, random_state=0, device=dev, solver_iterations=args.solver_iterations,
               solver_tolerance=args.solver_tolerance, solver=args.solver, prefetch_resets=not args.no_prefetch)
-    if args.narrowphase != "mpr":
+    if args.narrowphase != "epa":
         kw["narrowphase"] = args.narrowphase
     if args.env_factory:
         make = resolve_factory(args.env_factory)
@@ -425,14 +449,15 @@ def main():
         for k, s in enumerate(streams):
             ticks[k].append(Tick(s))
         sync()
+        own = time.perf_counter() - t0             # this rank's own time, before it waits for the others
         sdist.barrier()
         host = time.perf_counter() - t0
         dev_ms = max(t[0].ms_until(t[-1]) for t in ticks) / args.steps
         segs = [max(t[j].ms_until(t[j + 1]) for t in ticks) for j in range(len(ticks[0]) - 1)] if segment else []
-        return host, dev_ms, segs
+        return host, dev_ms, segs, own
 
-    elapsed, kernel_ms, segments = timed_window(segment=100 if args.steps >= 500 else 0)
-    elapsed = sdist.max_over_ranks(elapsed, dev)
+    elapsed_local, kernel_ms, segments, own_local = timed_window(segment=100 if args.steps >= 500 else 0)
+    elapsed = sdist.max_over_ranks(elapsed_local, dev)
     events_first = {}
     for env in envs:
         for k, v in env.events().items():
@@ -459,6 +484,8 @@ def main():
         for r in range(n_more):
             rep_elapsed.append(sdist.max_over_ranks(1e-3 * max(m[r].ms_until(m[r + 1]) for m in marks), dev))
 
+    # what the process group itself reports (backend, world size, which ranks answered) + every rank's own ms per step of the first window
+    dist_info = sdist.evidence(1e3 * own_local / args.steps, dev)
     # logging-only exchange: episode returns all-gathered over RCCL/xGMI (not in the timed region)
     returns = torch.cat([env.episode_returns() for env in envs])
     all_returns = sdist.all_gather_returns(returns)
@@ -468,8 +495,13 @@ def main():
 
     path = 0 if args.fused else (args.pipeline if args.pipeline >= 0 else 1)
     if rank == 0:
-        build_hash = sbuild.source_hash()
-        value = world * n_local * args.steps / elapsed
+        build_hash = sbuild.source_hash(mpr=args.narrowphase == "mpr")
+        # `value` = the MEAN over all timed windows (each EXACTLY --steps steps; the first one host-clocked between barrier +
+        # synchronize, the others back to back behind it, cut with device events), not the first - and usually best - window alone
+        rep_values = [world * n_local * args.steps / e for e in rep_elapsed]
+        first_window = rep_values[0]
+        elapsed_mean = sum(rep_elapsed) / len(rep_elapsed)
+        value = world * n_local * args.steps / elapsed_mean
         achieved = ALGO_BYTES_PER_ENV_STEP * n_local / (kernel_ms * 1e-3) / 1e9
         pmc = load_pmc(build_hash) if args.workload == "handover" and N == 4096 and path == 1 else None
         env_steps = n_local * args.steps
@@ -479,8 +511,10 @@ def main():
         cfg_index = {"handover": 1 if N == 4096 else (4 if N == 32768 else None), "pickplace": 2 if N == 16384 else None, "mixed": 3 if N == 32768 else None}[args.workload]
         out = {
             "metric": "env_steps_per_sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed_mean / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "first_window": {"value": first_window, "ms_per_step": 1e3 * elapsed / args.steps},
+            "dist": dist_info,
             "config": {"workload": f"{names[args.workload]}; {n_local} lock-step envs per GPU, proprioceptive obs"
                                    + (f" (BASELINE.json configs[{cfg_index}]" + (" per-GPU share)" if cfg_index == 4 else ")") if cfg_index else ""),
                        "envs_per_gpu": n_local, "global_envs": world * n_local, "substeps_per_step": 10,
@@ -512,13 +546,12 @@ def main():
             "mean_episode_return": float(all_returns.mean().item()),
         }
         import statistics
-        rep_values = [world * n_local * args.steps / e for e in rep_elapsed]
         out["repeats"] = {"n": len(rep_values), "values": rep_values, "mean": statistics.fmean(rep_values),
                           "std": statistics.pstdev(rep_values) if len(rep_values) > 1 else 0.0,
-                          "note": "`value` is the first window: the --steps steps that follow the warm-up, bracketed by barrier + synchronize "
-                                  "on both sides (host clock).  The others are further windows of the same length run back to back "
-                                  "behind it, timed with device events at the window boundaries (max over launch streams and ranks) and "
-                                  "one synchronize at the end"}
+                          "note": "`value` is the mean over these windows (total steps / total time).  The first window is the --steps steps "
+                                  "that follow the warm-up, bracketed by barrier + synchronize on both sides (host clock; `first_window`).  "
+                                  "The others are further windows of the same length run back to back behind it, timed with device events "
+                                  "at the window boundaries (max over launch streams and ranks) and one synchronize at the end"}
         if segments:
             seg_rates = [n_local * 100 / (ms * 1e-3) for ms in segments]
             out["sustained"] = {"steps": args.steps, "env_steps_per_s": value,

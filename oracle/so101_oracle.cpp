@@ -172,7 +172,7 @@ struct orc_sim {
   int iterations; real tolerance; bool collide = true;
   std::vector<real> mass0, inertia0, invweight0;     // unscaled prop masses (orc_set_mass_scale)
   std::vector<Contact> injected;                      // orc_inject_contacts
-  int narrow = 0;              // 0 = MPR (what the kernels run), 1 = MPR portal expanded by EPA to the nearest face of the Minkowski difference
+  int narrow = 1;              // 1 (default, what the kernels run) = MPR portal expanded by EPA to the nearest face of the Minkowski difference (minimum translation: mujoco >= 3.3's native GJK / EPA), 0 = MPR's own depth (the -DSO101_MPR option of the kernels)
   int epa_iters = 0;           // (statistics: polytope expansions of the last forward)
   int solver = 1;              // 1 = Newton (mujoco default; the reference scene sets no solver), 0 = PGS (north_star)
   int ls_evals = 0;
@@ -579,11 +579,28 @@ bool epa_penetration(const orc_sim* s, int g1, int g2, const real* org, const MV
     for (auto& ed : edges) add_face(ed.first, ed.second, wi);
   }
   if (!converged) return false;           // an inner bound only (a tiny sphere deep inside a mesh): the caller keeps MPR's answer
+  *depth = F[best].d;
+  for (int k = 0; k < 3; k++) dir[k] = F[best].n[k];
+  // witness: the projection of the origin onto the face, in barycentric coordinates of the face's vertices.  A flat facet of the
+  // Minkowski difference (an edge against an edge, a face against an edge) is triangulated by the polytope and its triangles are
+  // coplanar up to rounding: among the faces coplanar with the nearest one (plane distance within tol, normal within 1e-5) the
+  // witness is interpolated on the one that contains the projection best (largest smallest barycentric weight), as in the kernels.
+  real p[3] = {F[best].d * F[best].n[0], F[best].d * F[best].n[1], F[best].d * F[best].n[2]}, e1[3], e2[3], ep[3];
+  {
+    int wbest = -1; real wscore = -1e30;
+    for (size_t i = 0; i < F.size(); i++) {
+      const EpaFace& g = F[i];
+      if (!g.alive || g.d - F[best].d > tol || dot3(g.n, F[best].n) < 1 - 1e-5) continue;
+      for (int k = 0; k < 3; k++) { e1[k] = V[g.b].v[k] - V[g.a].v[k]; e2[k] = V[g.c].v[k] - V[g.a].v[k]; ep[k] = p[k] - V[g.a].v[k]; }
+      real q11 = dot3(e1, e1), q12 = dot3(e1, e2), q22 = dot3(e2, e2), s1 = dot3(ep, e1), s2 = dot3(ep, e2), qden = q11 * q22 - q12 * q12;
+      if (!(qden > 1e-30)) continue;
+      real ub = (q22 * s1 - q12 * s2) / qden, uc = (q11 * s2 - q12 * s1) / qden;
+      real score = std::min(1 - ub - uc, std::min(ub, uc));
+      if (score > wscore) { wscore = score; wbest = (int)i; }
+    }
+    if (wbest >= 0) best = wbest;
+  }
   const EpaFace& f = F[best];
-  *depth = f.d;
-  for (int k = 0; k < 3; k++) dir[k] = f.n[k];
-  // witness: the projection of the origin onto the face, in barycentric coordinates of the face's vertices
-  real p[3] = {f.d * f.n[0], f.d * f.n[1], f.d * f.n[2]}, e1[3], e2[3], ep[3];
   for (int k = 0; k < 3; k++) { e1[k] = V[f.b].v[k] - V[f.a].v[k]; e2[k] = V[f.c].v[k] - V[f.a].v[k]; ep[k] = p[k] - V[f.a].v[k]; }
   real d11 = dot3(e1, e1), d12 = dot3(e1, e2), d22 = dot3(e2, e2), r1 = dot3(ep, e1), r2 = dot3(ep, e2), den = d11 * d22 - d12 * d12;
   real wb = den > 1e-30 ? (d22 * r1 - d12 * r2) / den : 0, wc = den > 1e-30 ? (d11 * r2 - d12 * r1) / den : 0;

@@ -56,8 +56,9 @@ void orc_set_mass_scale(orc_sim*, const double* scale /*[nfree]*/);
 void orc_inject_contacts(orc_sim*, int n, const double* rows);
 // 1 = Newton (default: mujoco's default solver, mj_solNewton restated), 0 = PGS (BASELINE north_star)
 void orc_set_solver_type(orc_sim*, int type);
-// penetration query of non-flat convex pairs: 0 = MPR (default; what the kernels run), 1 = MPR's final tetrahedron expanded by EPA to
-// the nearest face of the Minkowski difference (the minimum translation, as mujoco >= 3.3's native GJK / EPA reports it)
+// penetration query of non-flat convex pairs: 1 (default; what the kernels run) = MPR's final tetrahedron expanded by EPA to the nearest
+// face of the Minkowski difference (the minimum translation, as mujoco >= 3.3's native GJK / EPA reports it); 0 = MPR's own portal depth
+// (the -DSO101_MPR option of the kernels)
 void orc_set_narrowphase(orc_sim*, int mode);
 int orc_epa_iterations(const orc_sim*);
 int orc_ls_evals(const orc_sim*);

@@ -1,5 +1,5 @@
 """Failure rates over long random-action rollouts (run through gpurun): physics errors, overflows and unsettled resets per env-step for the
-SO100 hand-over with the default (MPR) and the EPA narrowphase, and physics errors of the ALOHA hand-over on the general-tree engine.
+SO100 hand-over with the default (EPA) narrowphase and the MPR option, and physics errors of the ALOHA hand-over on the general-tree engine.
     python scripts/gpu_soak_rates.py > gpurun_out/r03_soak_rates.json"""
 import json
 import os
@@ -15,7 +15,7 @@ from so101_sim_amd import task_suite      # noqa: E402
 
 out = []
 N, STEPS = 4096, 3000
-for narrow in ("mpr", "epa"):
+for narrow in ("epa", "mpr"):
     env = task_suite.create_task_env("SO100HandOverBanana", time_limit=10.0, random_state=0, n_envs=N, narrowphase=narrow)
     spec = env.action_spec()
     lo, hi = torch.tensor(spec.minimum, device=env.device), torch.tensor(spec.maximum, device=env.device)

@@ -72,7 +72,7 @@ def aloha_action_spec(ctrlrange: np.ndarray, waist_joint_limit: float = np.pi / 
 class AlohaEnvironment:
     def __init__(self, task: HandOverTask, n_envs: int = 1, time_limit: float = float("inf"), random_state=None, device=None,
                  env_id_base: int = 0, solver_iterations: int = 0, solver_tolerance: float = -1.0, settle_max_substeps: int = 1000,
-                 physics_state: bool | None = None, seed_compatible: bool = True, narrowphase: str = "mpr"):
+                 physics_state: bool | None = None, seed_compatible: bool = True, narrowphase: str = "epa"):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("so101_sim_amd needs a ROCm GPU (MI355X): the step path has no CPU fallback")
@@ -109,8 +109,8 @@ class AlohaEnvironment:
             if narrowphase not in ("mpr", "epa"):
                 raise ValueError(f"narrowphase must be 'mpr' or 'epa', got {narrowphase!r}")
             from . import build as _build
-            self.narrowphase = narrowphase       # "epa": the -DSO101_EPA build of the library (env.py)
-            self.sim = native.TreeSim(blob, N, device=self.device.index or 0, lib_path=_build.LIB_EPA if narrowphase == "epa" else None)
+            self.narrowphase = narrowphase       # "mpr": the -DSO101_MPR build of the library, built on demand (env.py)
+            self.sim = native.TreeSim(blob, N, device=self.device.index or 0, lib_path=_build.build(mpr=True) if narrowphase == "mpr" else None)
         s = self.sim
         if (s.nu, s.obs_dim) != (NPOS, 3 * NPOS + 2 * NVEL):
             raise RuntimeError("unexpected model dimensions for an ALOHA hand-over scene")

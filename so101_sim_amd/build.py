@@ -17,7 +17,8 @@ CSRC = os.path.join(_HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(CSRC, "libso101_hip.so")
 LIB_CLOCKS = os.path.join(CSRC, "libso101_hip_clocks.so")     # -DSO101_DEBUG_CLOCKS profiling build: its own file (SO101_HIP_LIB selects it)
-LIB_EPA = os.path.join(CSRC, "libso101_hip_epa.so")           # -DSO101_EPA: MPR portals expanded to the nearest face by EPA (so101_device.hpp); selected by SO101_HIP_LIB too
+LIB_MPR = os.path.join(CSRC, "libso101_hip_mpr.so")           # -DSO101_MPR: the narrowphase="mpr" option - MPR's own portal depth instead of the EPA expansion to the nearest face that the
+                                                              # default library runs (so101_device.hpp); built on demand, not by __graft_entry__.build()
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-hip-fp32-correctly-rounded-divide-sqrt: v_rcp/v_sqrt based fp32 division and sqrt (<= ~2.5 ulp) instead of
 # the 10-15 instruction IEEE expansions; the solver is latency-bound and full of both (profiles/README.md).
@@ -38,41 +39,49 @@ def sources():
     return translation_units() + sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + [os.path.join(root, "include", "so101.h")]
 
 
-def source_hash(clocks: bool = False) -> str:
-    """Hash of every source AND the compiler flags the library is built from (bench.py keys PMC traffic files by it; the
-    settled-state cache and the bench line carry it)."""
+def variant_flags(clocks: bool = False, mpr: bool = False):
+    return (["-DSO101_DEBUG_CLOCKS"] if clocks else []) + (["-DSO101_MPR"] if mpr else [])
+
+
+def lib_path(clocks: bool = False, mpr: bool = False) -> str:
+    if clocks and mpr:
+        return os.path.join(CSRC, "libso101_hip_mpr_clocks.so")
+    return LIB_MPR if mpr else (LIB_CLOCKS if clocks else LIB)
+
+
+def source_hash(clocks: bool = False, mpr: bool = False) -> str:
+    """Hash of every source AND the compiler flags the library is built from - the variant defines included, so that the
+    MPR option and the default library never share a hash (bench.py keys PMC traffic files by it; the settled-state cache
+    and the bench line carry it)."""
     h = hashlib.sha256()
-    h.update(" ".join(FLAGS + (["-DSO101_DEBUG_CLOCKS"] if clocks else [])).encode())
+    h.update(" ".join(FLAGS + variant_flags(clocks, mpr)).encode())
     for p in sources():
         h.update(os.path.basename(p).encode())
         h.update(open(p, "rb").read())
     return h.hexdigest()[:16]
 
 
-def needs_build(clocks: bool = False, epa: bool = False) -> bool:
-    lib = LIB_EPA if epa else (LIB_CLOCKS if clocks else LIB)
+def needs_build(clocks: bool = False, mpr: bool = False) -> bool:
+    lib = lib_path(clocks, mpr)
     if not os.path.exists(lib):
         return True
     t = os.path.getmtime(lib)
     return any(os.path.getmtime(s) > t for s in sources())
 
 
-def build(force: bool = False, verbose: bool = False, clocks: bool = False, epa: bool = False) -> str:
-    lib = LIB_EPA if epa else (LIB_CLOCKS if clocks else LIB)
-    if not (force or needs_build(clocks, epa)):
+def build(force: bool = False, verbose: bool = False, clocks: bool = False, mpr: bool = False) -> str:
+    lib = lib_path(clocks, mpr)
+    if not (force or needs_build(clocks, mpr)):
         return lib
     os.makedirs(OBJ, exist_ok=True)
-    flags = list(FLAGS)
-    if clocks:
-        flags.append("-DSO101_DEBUG_CLOCKS")      # stage clocks + SO101_DEBUG_* env vars for scripts/gpu_*.py
-    if epa:
-        flags.append("-DSO101_EPA")
+    # -DSO101_DEBUG_CLOCKS: stage clocks + SO101_DEBUG_* env vars for scripts/gpu_*.py; -DSO101_MPR: see LIB_MPR
+    flags = list(FLAGS) + variant_flags(clocks, mpr)
     if verbose:
         flags.append("-Rpass-analysis=kernel-resource-usage")
     newest_header = max(os.path.getmtime(s) for s in sources() if not s.endswith(".hip"))
 
     def compile_one(src):
-        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + (".clk" if clocks else "") + (".epa" if epa else "") + ".o")
+        obj = os.path.join(OBJ, os.path.basename(src)[:-4] + (".clk" if clocks else "") + (".mpr" if mpr else "") + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_header):
             return obj
         subprocess.check_call([HIPCC, *flags, "-c", "-o", obj, src])
@@ -86,4 +95,4 @@ def build(force: bool = False, verbose: bool = False, clocks: bool = False, epa:
 
 if __name__ == "__main__":
     import sys
-    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, clocks="--clocks" in sys.argv, epa="--epa" in sys.argv))
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, clocks="--clocks" in sys.argv, mpr="--mpr" in sys.argv))

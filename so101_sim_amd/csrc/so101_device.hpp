@@ -779,6 +779,28 @@ DEV bool epa_expand(const DevModel* m, const GeomW& G1, const GeomW& G2, const f
   // curved everywhere) is an INNER bound, its nearest face too shallow: the caller falls back to MPR's own answer
   if (!converged) return false;
   *depth = bd; dir[0] = bn[0]; dir[1] = bn[1]; dir[2] = bn[2];
+  // Witness face.  A flat facet of the Minkowski difference (an edge against an edge, a face against an edge) is triangulated by the
+  // polytope; its triangles are coplanar up to rounding, so WHICH of them has the smallest plane distance is decided by the last bit,
+  // and the projection of the origin may lie in a neighbour of the winner (a 6 cm hull edge across the 1 m table edge: the clamped
+  // barycentric weights of the wrong sliver put the contact 1.2 cm away).  Among the faces coplanar with the nearest one (plane
+  // distance within tol, normal within 1e-5) the witness is therefore interpolated on the one that contains the projection best
+  // (largest smallest barycentric weight; lane = face, one pass).  Depth and normal stay those of the nearest face.
+  {
+    float p0[3] = {bd * bn[0], bd * bn[1], bd * bn[2]};
+    float fA[3] = {wave_bcast_f(vx, F.a), wave_bcast_f(vy, F.a), wave_bcast_f(vz, F.a)}, fB[3] = {wave_bcast_f(vx, F.b), wave_bcast_f(vy, F.b), wave_bcast_f(vz, F.b)},
+          fC[3] = {wave_bcast_f(vx, F.c), wave_bcast_f(vy, F.c), wave_bcast_f(vz, F.c)};
+    float g1[3], g2[3], gp[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { g1[i] = fB[i] - fA[i]; g2[i] = fC[i] - fA[i]; gp[i] = p0[i] - fA[i]; }
+    float q11 = dot3(g1, g1), q12 = dot3(g1, g2), q22 = dot3(g2, g2), s1 = dot3(gp, g1), s2 = dot3(gp, g2), qden = q11 * q22 - q12 * q12;
+    bool okf = qden > 1e-30f;
+    float ub = okf ? (q22 * s1 - q12 * s2) / qden : 0.f, uc = okf ? (q11 * s2 - q12 * s1) / qden : 0.f;
+    float score = fminf(1.f - ub - uc, fminf(ub, uc));
+    bool elig = F.alive && okf && F.d - bd <= tol && F.n[0] * bn[0] + F.n[1] * bn[1] + F.n[2] * bn[2] >= 1.f - 1e-5f;
+    float key = elig ? score : -3.0e38f; int widx = lane;
+    wave_argmax(key, widx);
+    if (key > -3.0e38f) best = widx;
+  }
   int ia = wave_bcast_i(F.a, best), ib = wave_bcast_i(F.b, best), ic = wave_bcast_i(F.c, best);
   float A[3] = {wave_bcast_f(vx, ia), wave_bcast_f(vy, ia), wave_bcast_f(vz, ia)}, B[3] = {wave_bcast_f(vx, ib), wave_bcast_f(vy, ib), wave_bcast_f(vz, ib)},
         C[3] = {wave_bcast_f(vx, ic), wave_bcast_f(vy, ic), wave_bcast_f(vz, ic)};
@@ -871,7 +893,7 @@ DEV bool mpr_penetration(const DevModel* m, const GeomW& G1, const GeomW& G2, fl
     if (!inside) {
       dt = dot3(d, v1.v);
       if (isz(dt) || dt > 0.f) {                                        // portal encapsules origin: start penetration phase
-#ifdef SO101_EPA      // the EPA build of the library (build.py --epa, libso101_hip_epa.so): EPA takes over here - the tetrahedron v0 v1 v2 v3 contains the
+#ifndef SO101_MPR     // (default; -DSO101_MPR = build.py --mpr, libso101_hip_mpr.so, keeps MPR's own answer): EPA takes over here - the tetrahedron v0 v1 v2 v3 contains the
         if constexpr (GP::N == WAVE) {          // origin from now on, and MPR's own refinement of the portal towards the surface is work EPA does anyway
           if (epa_expand<Cache, GP>(m, G1, G2, org, v0, v1, v2, v3, mpr_tol, depth, dir, pos, H1, H2)) return true;
         }

@@ -91,6 +91,24 @@ def max_over_ranks(value: float, device=None) -> float:
     return float(t.item())
 
 
+def evidence(per_rank_value: float = 0.0, device=None) -> dict:
+    """What the initialised process group itself says about the run, for the bench line: backend, world size as the
+    GROUP reports it (not the environment), the rank ids that answered an all-gather, and one float per rank (bench.py: each rank's
+    own ms per step, before the MAX).  A plain single-process run reports backend None, world size 1."""
+    import torch
+    import torch.distributed as dist
+    if not _active():
+        return {"backend": None, "world_size": 1, "ranks_reporting": 1, "ranks": [0], "per_rank": [float(per_rank_value)]}
+    world = dist.get_world_size()
+    dev = device if device is not None else "cpu"
+    mine = torch.tensor([float(dist.get_rank()), float(per_rank_value)], dtype=torch.float64, device=dev)
+    got = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine)
+    ranks = sorted({int(g[0].item()) for g in got})
+    return {"backend": dist.get_backend(), "world_size": world, "ranks_reporting": len(ranks), "ranks": ranks,
+            "per_rank": [float(g[1].item()) for g in got]}
+
+
 def all_gather_returns(local_returns):
     """Concatenate per-rank episode-return vectors in rank order (ranks may own different counts)."""
     import torch

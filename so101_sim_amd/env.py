@@ -102,7 +102,7 @@ class BatchedEnvironment:
     def __init__(self, task: SO100HandOverTask, n_envs: int = 1, time_limit: float = float("inf"),
                  random_state=None, device=None, env_id_base: int = 0, solver_iterations: int = 0,
                  solver_tolerance: float = -1.0, settle_max_substeps: int = 1000, solver: str = "newton",
-                 prefetch_resets: bool = True, physics_state: bool = False, narrowphase: str = "mpr"):
+                 prefetch_resets: bool = True, physics_state: bool = False, narrowphase: str = "epa"):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("so101_sim_amd needs a ROCm GPU (MI355X): the step path has no CPU fallback")
@@ -120,14 +120,15 @@ class BatchedEnvironment:
         blob, self.meta = scenes.load_blob(task.object_name, "f32")
         dev_index = self.device.index or 0
         with torch.cuda.device(self.device):
-            # narrowphase = "epa": the -DSO101_EPA build of the library - the penetration of non-flat convex pairs is the minimum
-            # translation (MPR's final portal expanded by EPA, as mujoco's native GJK / EPA reports it) instead of MPR's portal
-            # depth; 3x fewer physics errors under random actions, 5-15 % slower (profiles/README.md)
+            # narrowphase = "epa" (default): the penetration of non-flat convex pairs is the minimum translation (MPR's final portal
+            # expanded by EPA to the nearest face of the Minkowski difference, as mujoco >= 3.3's native GJK / EPA reports it - the
+            # reference pins mujoco>=3.3.3, requirements.txt:7).  "mpr": the -DSO101_MPR build of the library (built on demand) keeps
+            # MPR's portal depth: 5-15 % faster, 3x the physics errors under random actions (profiles/README.md)
             if narrowphase not in ("mpr", "epa"):
                 raise ValueError(f"narrowphase must be 'mpr' or 'epa', got {narrowphase!r}")
             from . import build as _build
             self.narrowphase = narrowphase
-            self.sim = native.Sim(blob, self.n_envs, device=dev_index, seed=seed, lib_path=_build.LIB_EPA if narrowphase == "epa" else None)
+            self.sim = native.Sim(blob, self.n_envs, device=dev_index, seed=seed, lib_path=_build.build(mpr=True) if narrowphase == "mpr" else None)
         N = self.n_envs
         z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=self.device)
         self.qpos, self.qvel, self.ctrl, self.warm = z(20, N), z(18, N), z(6, N), z(18, N)
@@ -273,7 +274,7 @@ class BatchedEnvironment:
         from . import build
         key = dict(self._settle_key)
         key["mass_scale_sha256"] = hashlib.sha256(self.mass_scale.detach().cpu().numpy().tobytes()).hexdigest()
-        key["build"] = build.source_hash()       # settled states are only bit-identical within one build of the kernels
+        key["build"] = build.source_hash(mpr=self.narrowphase == "mpr")       # settled states are only bit-identical within one build of the kernels
         return key
 
     def compute_settled(self, n_episodes: int, first_episode: int = 0):

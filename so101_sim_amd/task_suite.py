@@ -87,7 +87,7 @@ def create_task_env(
     name explicitly are silently dropped (task_suite.py:134-144) — for `SO100HandOver`, whose signature
     is `(object_name, reward_based_on_overlap=True, **kwargs)`, that is everything except those two.
     Batched extension: `n_envs`, `device`, `solver` ("newton" | "pgs"), `solver_iterations`, `solver_tolerance`,
-    `settle_max_substeps`, `prefetch_resets`, `env_id_base`, `narrowphase` ("mpr" | "epa"), `physics_state` (batched `physics_state` /
+    `settle_max_substeps`, `prefetch_resets`, `env_id_base`, `narrowphase` ("epa" default | "mpr"), `physics_state` (batched `physics_state` /
     `delayed_physics_state` observables, off by default: 38 + 38 floats per env and step) are consumed here and never
     reach the task.
     """

@@ -357,16 +357,18 @@ def check_pipeline_identical(make_sim, golden, n=4, steps=3, seed=9, settle=20, 
 
 
 def _compare_contact_lists(mine_list, ref_list):
-    """-> (problems, total, loose).  problems: list of strings, empty when the two contact lists agree.
-    Tolerance: same pairs in the same order with the same number of contacts (a contact may be missing on one side only
-    if it is shallower than 2e-6 m); distance 5e-6 m + 1e-4 relative; position 2e-5 m and normal 1e-4, except for
-    ill-conditioned MPR contacts (counted in `loose`): a hull vertex on the rim of the static puck, an edge on an edge -
-    the penetration direction is the normal of the last portal triangle and the fp64 query itself turns by degrees
-    under 1e-7 perturbations there; those must agree in depth, roughly in direction (cos >= 0.9) and place (1 mm) and
-    be shallow (< 1 mm)."""
+    """-> (problems, total, loose, witness).  problems: list of strings, empty when the two contact lists agree.
+    Both sides run the default narrowphase (EPA: the nearest face of the Minkowski difference is exact, there is no portal to
+    land beside).  Tolerance: same pairs in the same order with the same number of contacts (a contact may be missing on one side
+    only if it is shallower than 2e-6 m); distance 5e-6 m + 1e-4 relative and normal 1e-4 for EVERY contact.  `loose` counts the
+    contacts whose normals differ by more than 1e-4 but less than 1e-2 (a curved geom makes the difference curved: the face EPA
+    stops on is exact to sqrt(tol / radius)); beyond 1e-2 it is a problem.  The witness POINT on a flat facet (a hull face against
+    a face or an edge) is not unique - it depends on how the polytope triangulates the facet - so a position difference above
+    2e-5 m is counted in `witness`, must stay inside the contact patch (1.5 cm) and is bounded by the callers; the solver is
+    then compared on the kernel's own contact list."""
     by_pair = lambda cons: {k: [c for c in cons if (c["geom1"], c["geom2"]) == k] for k in dict.fromkeys((c["geom1"], c["geom2"]) for c in cons)}
     mine, ref = by_pair(mine_list), by_pair(ref_list)
-    problems, total, loose = [], 0, 0
+    problems, total, loose, witness = [], 0, 0, 0
     for k in list(dict.fromkeys(list(mine) + list(ref))):
         cm, cr = mine.get(k, []), ref.get(k, [])
         if len(cm) != len(cr):
@@ -379,29 +381,26 @@ def _compare_contact_lists(mine_list, ref_list):
                 problems.append(f"{k}: dist {c1['dist']:.6f} vs {c2['dist']:.6f}")
                 continue
             dn, dp = np.abs(c1["normal"] - c2["normal"]).max(), np.abs(c1["pos"] - c2["pos"]).max()
-            if dn <= 1e-4 and dp <= 2e-5:
-                continue
-            loose += 1
-            if not (float(np.dot(c1["normal"], c2["normal"])) >= 0.9 and dp <= 1e-3 and abs(c2["dist"]) <= 1e-3):
-                problems.append(f"{k}: normal {dn:.2e} pos {dp:.2e} at depth {c2['dist']:.6f}")
-    return problems, total, loose
+            if dn > 1e-4:
+                loose += 1
+                if dn > 1e-2:
+                    problems.append(f"{k}: normal {dn:.2e} at depth {c2['dist']:.6f}")
+                    continue
+            if dp > 2e-5:
+                witness += 1
+                if dp > 1.5e-2:
+                    problems.append(f"{k}: pos {dp:.2e} at depth {c2['dist']:.6f}")
+    return problems, total, loose, witness
 
 
-def check_contact_rich(make_sim, blobs, golden, count=4, verbose=False, max_discontinuous=0.1):
-    """Arm self-collision / arm-table / arm-prop contact states (20-40 simultaneous contacts, captured from a
-    random-action rollout): the SAME contact list as the oracle (pair by pair, contact by contact, in order, tolerances
-    in _compare_contact_lists) and the same constrained acceleration (1e-4 of max|qacc|; Newton converged on both sides;
-    measured on MI355X: <= 1.6e-5 on the twelve golden states).
-
-    The MPR penetration query is a discontinuous function of the state where a thin plate (a 2 mm finger pad) is buried
-    centimetres deep in a hull: the portal it ends on, hence the depth, jumps, and fp32 and fp64 can land on different sides.
-    A state whose contact lists disagree is therefore checked in two separate, deterministic steps instead (round 3; the
-    random search for a nearby agreeing oracle state of rounds 1-2 is gone): (1) SOLVER - the oracle solves with the KERNEL's
-    contact list (orc_inject_contacts) and must reproduce the kernel's constrained acceleration to 1e-4; (2) GEOMETRY - every
-    contact of the kernel's list is held against the definition of a penetration depth (oracle/geomcheck.py: overlap along its
-    normal >= its depth, depth >= the minimum translation found by brute force, depth <= 2 x that minimum).  At most
-    `max_discontinuous` of the states may need that (the list is returned; on MI355X one of the twelve golden states does).
-    MuJoCo's EPA has no such jumps - known deviation."""
+def check_contact_rich(make_sim, blobs, golden, count=4, verbose=False):
+    """Arm self-collision / arm-table / arm-prop contact states (20-40 simultaneous contacts, captured from random-action
+    rollouts, the last ones under the EPA narrowphase): the SAME contact list as the oracle - pair by pair, contact by contact,
+    in order, depth and normal of every contact (tolerances in _compare_contact_lists; no state may disagree: EPA returns an
+    exact face of the Minkowski difference, so fp32 and fp64 have no portal to land on different sides of) - and the same
+    constrained acceleration: 1e-4 of max|qacc| against the oracle's own solve where every witness point agrees, and against
+    the oracle solving on the KERNEL's contact list (orc_inject_contacts) where a witness point sits elsewhere on a flat facet
+    (at most 5 % of the contacts)."""
     states = golden["contact_rich_states"]["states"][:count]
     n = len(states)
     Q = np.array([s["qpos"] for s in states]).T
@@ -412,53 +411,35 @@ def check_contact_rich(make_sim, blobs, golden, count=4, verbose=False, max_disc
     sim.set_state(Q, V, A, W)
     dbg = sim.debug_forward()
 
-    def oracle_eval(q, e):
-        o = Oracle(blobs["f64"])
-        o.set_state(q, V[:, e], W[:, e])
-        o.set_ctrl(A[:, e])
-        o.forward()
-        return o.qacc()[0], o.contacts()
-
-    worst, seen_arm_arm, seen_multi, total, loose, discontinuous = 0.0, False, False, 0, 0, []
+    worst, seen_arm_arm, seen_multi, total, loose, witness = 0.0, False, False, 0, 0, 0
     for e in range(n):
         d = dbg[e]
         assert d["overflow"] == 0
-        a, ref = oracle_eval(Q[:, e], e)
-        problems, t, l = _compare_contact_lists(d["contacts"], ref)
-        err = np.abs(d["qacc"] - a).max() / np.abs(a).max()
-        if problems or err > 1e-4:
-            discontinuous.append(e)
-            # (1) the solver on the kernel's own contact list
-            o = Oracle(blobs["f64"])
-            o.set_state(Q[:, e], V[:, e], W[:, e])
-            o.set_ctrl(A[:, e])
+        o = Oracle(blobs["f64"])
+        o.set_state(Q[:, e], V[:, e], W[:, e])
+        o.set_ctrl(A[:, e])
+        o.forward()
+        a, ref = o.qacc()[0], o.contacts()
+        problems, t, l, w = _compare_contact_lists(d["contacts"], ref)
+        assert not problems, (e, problems)
+        if w:
             o.inject_contacts(d["contacts"])
             o.forward()
-            a2 = o.qacc()[0]
-            err = np.abs(d["qacc"] - a2).max() / np.abs(a2).max()
-            assert err <= 1e-4, (e, "solver on the kernel's contacts", err, problems)
-            # (2) the kernel's contacts against the definition
-            from oracle import geomcheck as gc
-            from so101_sim_amd.model import blob as blobfmt
-            o.inject_contacts([])
-            o.forward()
-            rows = gc.check_contacts(gc.Scene.from_oracle(blobfmt.unpack(blobs["f64"]), o), d["contacts"])
-            for r in rows:
-                assert r["along"] - r["depth"] >= -5e-6 and r["depth"] - r["mtd"] >= -5e-6 - 2e-3 * r["mtd"] and r["minimality"] <= 2.0, (e, r)
-            t, l = len(ref), 0
-        total += t
-        loose += l
+            a = o.qacc()[0]
+        err = np.abs(d["qacc"] - a).max() / np.abs(a).max()
+        assert err <= 1e-4, (e, err, w)
+        total, loose, witness = total + t, loose + l, witness + w
         pairs = [(c["geom1"], c["geom2"]) for c in ref]
         seen_multi = seen_multi or len(set(pairs)) < len(pairs)
         seen_arm_arm = seen_arm_arm or any(_arm_geom(g1) and _arm_geom(g2) for g1, g2 in pairs)
         worst = max(worst, err)
         if verbose:
-            print(e, "ncon", len(ref), "qacc rel err", err, "neighbourhood" if e in discontinuous else "")
+            print(e, "ncon", len(ref), "qacc rel err", err, "loose", l, "witness", w)
     assert seen_arm_arm, "fixture must contain arm-arm contacts"
     assert seen_multi, "fixture must contain a pair with several contacts (flat-face patch)"
-    assert loose <= 0.1 * total, (loose, total)
-    assert len(discontinuous) <= max_discontinuous * n, discontinuous
-    return worst, discontinuous
+    assert loose <= 0.02 * total, (loose, total)
+    assert witness <= 0.05 * total, (witness, total)
+    return worst, (total, loose, witness)
 
 
 def check_divergence_handling(make_sim, blobs):

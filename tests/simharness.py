@@ -19,14 +19,14 @@ EMU_LIB = os.path.join(_HERE, "hostemu", "_build", "libso101_emu.so")
 NQ, NV, NU = 20, 18, 6
 
 
-def build_emu(epa: bool = False):
-    """epa: the -DSO101_EPA build of the kernel source (MPR portals expanded by EPA, so101_device.hpp)"""
-    subprocess.check_call(["make", "-C", os.path.join(_HERE, "hostemu"), "-s"] + (["epa"] if epa else []))
-    return EMU_LIB.replace("libso101_emu.so", "libso101_emu_epa.so") if epa else EMU_LIB
+def build_emu(mpr: bool = False):
+    """mpr: the -DSO101_MPR build of the kernel source (MPR's own portal depth instead of the EPA expansion, so101_device.hpp)"""
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "hostemu"), "-s"] + (["mpr"] if mpr else []))
+    return EMU_LIB.replace("libso101_emu.so", "libso101_emu_mpr.so") if mpr else EMU_LIB
 
 
 class ArraySim:
-    def __init__(self, blob_f32: bytes, n_envs: int, backend: str = "gpu", seed: int = 0, epa: bool = False, **cfg):
+    def __init__(self, blob_f32: bytes, n_envs: int, backend: str = "gpu", seed: int = 0, mpr: bool = False, **cfg):
         self.N = n_envs
         self.backend = backend
         if backend == "gpu":
@@ -34,11 +34,11 @@ class ArraySim:
             from so101_sim_amd import build as sbuild
             self.torch = torch
             self.dev = torch.device("cuda:0")
-            self.sim = native.Sim(blob_f32, n_envs, device=0, seed=seed, lib_path=sbuild.LIB_EPA if epa else None)
+            self.sim = native.Sim(blob_f32, n_envs, device=0, seed=seed, lib_path=sbuild.build(mpr=True) if mpr else None)
             z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=self.dev)
             i32, u8 = torch.int32, torch.uint8
         else:
-            self.sim = native.Sim(blob_f32, n_envs, device=0, seed=seed, lib_path=build_emu(epa))
+            self.sim = native.Sim(blob_f32, n_envs, device=0, seed=seed, lib_path=build_emu(mpr))
             z = lambda *s, dt=np.float32: np.zeros(s, dtype=dt)
             i32, u8 = np.int32, np.uint8
         N = n_envs
@@ -204,18 +204,18 @@ class ArraySim:
 class TreeArraySim:
     """The general-tree engine (so101_tree_*, the ALOHA scenes) behind the same two backends."""
 
-    def __init__(self, blob_f32: bytes, n_envs: int, backend: str = "gpu", epa: bool = False):
+    def __init__(self, blob_f32: bytes, n_envs: int, backend: str = "gpu", mpr: bool = False):
         self.N, self.backend = n_envs, backend
         if backend == "gpu":
             import torch
             from so101_sim_amd import build as sbuild
             self.torch = torch
             self.dev = torch.device("cuda:0")
-            self.sim = native.TreeSim(blob_f32, n_envs, device=0, lib_path=sbuild.LIB_EPA if epa else None)
+            self.sim = native.TreeSim(blob_f32, n_envs, device=0, lib_path=sbuild.build(mpr=True) if mpr else None)
             z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=self.dev)
             i32 = torch.int32
         else:
-            self.sim = native.TreeSim(blob_f32, n_envs, device=0, lib_path=build_emu(epa))
+            self.sim = native.TreeSim(blob_f32, n_envs, device=0, lib_path=build_emu(mpr))
             z = lambda *s, dt=np.float32: np.zeros(s, dtype=dt)
             i32 = np.int32
         s = self.sim

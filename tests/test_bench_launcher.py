@@ -27,7 +27,15 @@ def test_gpus_2_spawns_two_ranks_and_reports_the_whole_job():
     # MAX over ranks: rank 1 sleeps 30 ms per step, rank 0 10 ms; the job time is rank 1's
     assert out["ms_per_step"] >= 30.0 * 0.9
     assert abs(out["value"] - 16 * 4 / (out["ms_per_step"] * 4e-3)) < 1e-6 * out["value"]
-    assert out["repeats"]["n"] == 2 and out["repeats"]["values"][0] == out["value"]
+    # `value` is the mean over the windows (total steps / total time); the first window stays in the line as a field
+    assert out["repeats"]["n"] == 2 and out["repeats"]["values"][0] == out["first_window"]["value"]
+    tot = sum(16 * 4 / v for v in out["repeats"]["values"])
+    assert abs(out["value"] - 2 * 16 * 4 / tot) < 1e-6 * out["value"]
+    # evidence from the initialised process group itself (not from the environment): backend, world size, the ranks that answered
+    # an all-gather, every rank's own ms per step (rank 0 sleeps 10 ms per step, rank 1 30 ms)
+    d = out["dist"]
+    assert d["backend"] == "gloo" and d["world_size"] == 2 and d["ranks_reporting"] == 2 and d["ranks"] == [0, 1]
+    assert len(d["per_rank"]) == 2 and 10.0 * 0.9 <= d["per_rank"][0] < d["per_rank"][1] and d["per_rank"][1] >= 30.0 * 0.9
     # returns gathered in rank order over global env ids 0..15: (warm-up 1 + 2 windows x 4 steps) x id; mean id = 7.5
     assert abs(out["mean_episode_return"] - 9 * 7.5) < 1e-4
 
@@ -42,6 +50,7 @@ def test_single_rank_line_has_the_contract_keys():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "repeats"):
+              "dtype", "data", "config", "roofline", "repeats", "first_window", "dist"):
         assert k in out
+    assert out["dist"] == {"backend": None, "world_size": 1, "ranks_reporting": 1, "ranks": [0], "per_rank": out["dist"]["per_rank"]}
     assert out["n_gpus"] == 1 and out["vs_baseline"] is None and out["scaling"] == "weak"

@@ -1,15 +1,17 @@
 """Narrowphase answers against the DEFINITION of what mujoco >= 3.3's GJK / EPA returns for a penetrating convex pair: the
-minimum translation that separates it (oracle/geomcheck.py: support functions only, brute force over directions - no MPR, no
-shared algorithm).  The oracle's and the kernel's MPR agree with each other by construction; this is the check that does not.
+minimum translation that separates it (oracle/geomcheck.py: support functions only, brute force over directions - no MPR, no EPA,
+no shared algorithm).  The oracle's and the kernel's narrowphase agree with each other by construction; this is the check that
+does not.
 
-For every contacting pair of the twelve contact-rich fixture states (arm on the table, on the props, on itself; props on the
-table and on each other):
+For every contacting pair of the contact-rich fixture states (arm on the table, on the props, on itself; props on the table and
+on each other):
     consistency  o(n) / d   overlap along the reported normal over the reported depth   (1 = the reported plane really supports)
     minimality   d / d*     reported depth over the smallest overlap found over all directions   (1 = the minimum translation)
-Measured (fp64 oracle, 111 pairs): minimality median 1.000, 89 % of the pairs within 2 %, 95.5 % within 25 %, worst 1.59 - deep
-(1-4 cm) penetrations of arm links into each other and into the table / a hull, where the single MPR query ends on a portal
-away from the closest face; consistency 1.000 for 89 %, worst case a 0.06 mm contact of the puck's rim with a bowl hull.
-Flat-face contacts (closed form) are exact."""
+The DEFAULT narrowphase (MPR's final tetrahedron expanded by EPA to the nearest face of the Minkowski difference) must return the
+minimum translation on every pair (worst 1.000).  The MPR OPTION (-DSO101_MPR, narrowphase="mpr", orc_set_narrowphase(0)) keeps
+its measured distribution: median 1.000, 89 % of the pairs within 2 %, 95.5 % within 25 %, worst 1.59 - deep (1-4 cm)
+penetrations of arm links into each other and into the table / a hull, where the single MPR query ends on a portal away from
+the closest face.  Flat-face contacts (closed form) are exact in both."""
 import json
 import os
 
@@ -27,7 +29,7 @@ def _states():
     return json.load(open(os.path.join(ROOT, "tests", "golden", "contact_rich_states.json")))["states"]
 
 
-def _oracle_at(blobs, st, epa=False):
+def _oracle_at(blobs, st, epa=True):
     o = Oracle(blobs["f64"])
     o.set_narrowphase(epa)
     o.set_state(np.array(st["qpos"]), np.array(st["qvel"]), np.array(st["warm"]))
@@ -88,11 +90,11 @@ def test_support_functions_against_brute_force(blobs):
     assert {gc.BOX, gc.CYLINDER, gc.CAPSULE} <= seen
 
 
-def test_oracle_contacts_against_the_minimum_translation(blobs):
+def test_oracle_mpr_option_against_the_minimum_translation(blobs):
     model = blobfmt.unpack(blobs["f64"])
     rows = []
-    for st in _states():
-        o = _oracle_at(blobs, st)
+    for st in _states()[:12]:
+        o = _oracle_at(blobs, st, epa=False)
         rows += gc.check_contacts(gc.Scene.from_oracle(model, o), o.contacts())
     _assert_distribution(rows, 1e-9)
 
@@ -112,12 +114,12 @@ def test_resting_props_are_exact(blobs, golden):
         assert abs(r["consistency"] - 1) <= 2e-3 and abs(r["minimality"] - 1) <= 2e-3, r
 
 
-def _kernel_rows(blobs, backend, epa=False, compare=False):
+def _kernel_rows(blobs, backend, epa=True, compare=False, states=None):
     from tests.simharness import ArraySim
     from tests import parity_cases as pc
     model = blobfmt.unpack(blobs["f64"])
-    states = _states()
-    sim = ArraySim(blobs["f32"], len(states), backend=backend, epa=epa)
+    states = _states() if states is None else states
+    sim = ArraySim(blobs["f32"], len(states), backend=backend, mpr=not epa)
     sim.set_state(np.array([s["qpos"] for s in states]).T, np.array([s["qvel"] for s in states]).T,
                   np.array([s["action"] for s in states]).T, np.array([s["warm"] for s in states]).T)
     dbg = sim.debug_forward()
@@ -147,19 +149,23 @@ def _kernel_rows(blobs, backend, epa=False, compare=False):
     return (rows, differ) if compare else rows
 
 
-def test_emulated_kernel_contacts_against_the_minimum_translation(blobs):
-    """The kernels' own contact lists (the same device code compiled for the host, tests/hostemu): body poses from the oracle at
-    the same state (kinematics agree to 2e-6, tests/test_gpu_parity.py), contacts from so101_debug_forward."""
-    _assert_distribution(_kernel_rows(blobs, "emu"), 5e-6)
+@pytest.mark.skipif(not os.environ.get("SO101_SLOW_TESTS"), reason="emulated run of the MPR option (40 s + an emulator build); set SO101_SLOW_TESTS=1")
+def test_emulated_kernel_mpr_option_against_the_minimum_translation(blobs):
+    """The MPR option's own contact lists (the same device code compiled for the host with -DSO101_MPR, tests/hostemu): body poses from
+    the oracle at the same state (kinematics agree to 2e-6, tests/test_gpu_parity.py), contacts from so101_debug_forward."""
+    _assert_distribution(_kernel_rows(blobs, "emu", epa=False, states=_states()[:12]), 5e-6)
 
 
 @pytest.mark.gpu
-def test_kernel_contacts_against_the_minimum_translation(blobs):
-    """The same on the GPU, through the C ABI."""
-    _assert_distribution(_kernel_rows(blobs, "gpu"), 5e-6)
+def test_kernel_mpr_option_against_the_minimum_translation(blobs):
+    """The same on the GPU, through the C ABI (libso101_hip_mpr.so, built on demand)."""
+    _assert_distribution(_kernel_rows(blobs, "gpu", epa=False, states=_states()[:12]), 5e-6)
 
 
-# ---------------------------------------------------------------------------------------------- EPA (the -DSO101_EPA build, DESIGN.md section 4)
+# ---------------------------------------------------------------------------------------------- the default narrowphase: EPA (DESIGN.md section 4)
+MAX_WITNESS_DIFFERS = 4               # contacts (of ~150) whose witness point sits elsewhere on the same flat facet (a face against an edge: no unique point)
+
+
 def _assert_epa(rows, abs_tol):
     d, along, mtd = (np.array([r[k] for r in rows]) for k in ("depth", "along", "mtd"))
     m = d / np.maximum(mtd, 1e-12)
@@ -170,9 +176,9 @@ def _assert_epa(rows, abs_tol):
     assert np.mean(m[big] <= 1.02) >= 0.99 and m[big].max() <= 1.10, (np.mean(m[big] <= 1.02), m[big].max())
 
 
-def test_oracle_epa_returns_the_minimum_translation(blobs):
-    """orc_set_narrowphase(1): MPR's final tetrahedron expanded by EPA.  On the twelve contact-rich states every one of the 111
-    contacting pairs then reports the brute-forced minimum translation (MPR: 89 % within 2 %, worst 1.59)."""
+def test_oracle_returns_the_minimum_translation(blobs):
+    """The oracle's default (orc_set_narrowphase(1)): MPR's final tetrahedron expanded by EPA.  On the contact-rich states every one
+    of the contacting pairs reports the brute-forced minimum translation (the MPR option: 89 % within 2 %, worst 1.59)."""
     model = blobfmt.unpack(blobs["f64"])
     rows = []
     for st in _states():
@@ -183,33 +189,38 @@ def test_oracle_epa_returns_the_minimum_translation(blobs):
     assert m.max() <= 1.001
 
 
-@pytest.mark.skipif(not os.environ.get("SO101_SLOW_TESTS"), reason="emulated run of what the GPU test below covers (40 s + an emulator build); set SO101_SLOW_TESTS=1")
-def test_emulated_kernel_epa_returns_the_minimum_translation(blobs):
-    rows, differ = _kernel_rows(blobs, "emu", epa=True, compare=True)
+def test_emulated_kernel_returns_the_minimum_translation(blobs):
+    """The kernels' own contact lists (the same device code compiled for the host, tests/hostemu) on the first twelve states."""
+    rows, differ = _kernel_rows(blobs, "emu", compare=True, states=_states()[:12])
     _assert_epa(rows, 5e-6)
-    assert differ <= 8               # contacts (of 150) whose witness point sits elsewhere on the same facet
+    assert differ <= MAX_WITNESS_DIFFERS
 
 
 @pytest.mark.gpu
-def test_kernel_epa_returns_the_minimum_translation(blobs):
-    """The EPA build of the library on the GPU: the minimum translation for every pair; depth and normal of every contact equal to the
-    fp64 oracle's EPA answer (an exact face has no portal to land beside), the witness point within the contact patch, the solver
+def test_kernel_returns_the_minimum_translation(blobs):
+    """The library on the GPU, through the C ABI: the minimum translation for every pair; depth and normal of every contact equal to
+    the fp64 oracle's answer (an exact face has no portal to land beside), the witness point within the contact patch, the solver
     exact on the kernel's list."""
-    rows, differ = _kernel_rows(blobs, "gpu", epa=True, compare=True)
+    rows, differ = _kernel_rows(blobs, "gpu", compare=True)
     _assert_epa(rows, 5e-6)
-    assert differ <= 8
+    assert differ <= MAX_WITNESS_DIFFERS
 
 
 @pytest.mark.gpu
-def test_epa_option_through_the_python_api(blobs):
-    """narrowphase="epa" selects the EPA build end to end: the env steps, one control step from the contact-rich states stays close to
-    the fp64 oracle running EPA (the witness point on a flat facet is not unique, so contact torques - hence the step - agree only to
-    ~1e-2 on these deep-contact states), and the settled-state cache key tells the two builds apart."""
+def test_narrowphase_option_through_the_python_api(blobs):
+    """The default library runs EPA end to end and narrowphase="mpr" selects the -DSO101_MPR build (built on demand): the env steps, one
+    control step from the contact-rich states stays close to the fp64 oracle (the witness point on a flat facet is not unique, so
+    contact torques - hence the step - agree only to ~1e-2 on these deep-contact states), and the settled-state cache key and the
+    build hash tell the two builds apart."""
     import torch
     from so101_sim_amd import task_suite
     from tests.simharness import ArraySim
-    env = task_suite.create_task_env("SO100HandOverBanana", time_limit=10.0, random_state=3, n_envs=256, narrowphase="epa")
-    assert env.narrowphase == "epa" and env.sim.L._name.endswith("libso101_hip_epa.so") and env.settled_cache_key()["narrowphase"] == "epa"
+    env = task_suite.create_task_env("SO100HandOverBanana", time_limit=10.0, random_state=3, n_envs=64, narrowphase="mpr")
+    assert env.narrowphase == "mpr" and env.sim.L._name.endswith("libso101_hip_mpr.so") and env.settled_cache_key()["narrowphase"] == "mpr"
+    env.reset()
+    env.close()
+    env = task_suite.create_task_env("SO100HandOverBanana", time_limit=10.0, random_state=3, n_envs=256)
+    assert env.narrowphase == "epa" and env.sim.L._name.endswith("libso101_hip.so") and env.settled_cache_key()["narrowphase"] == "epa"
     env.reset()
     spec = env.action_spec()
     lo, hi = torch.tensor(spec.minimum, device=env.device), torch.tensor(spec.maximum, device=env.device)
@@ -219,7 +230,7 @@ def test_epa_option_through_the_python_api(blobs):
     assert bool(torch.isfinite(obs).all()) and bool(torch.isfinite(env.qpos).all())
     env.close()
     states = _states()
-    sim = ArraySim(blobs["f32"], len(states), backend="gpu", epa=True)
+    sim = ArraySim(blobs["f32"], len(states), backend="gpu")
     Q, V = np.array([s["qpos"] for s in states]).T, np.array([s["qvel"] for s in states]).T
     A, W = np.array([s["action"] for s in states]).T, np.array([s["warm"] for s in states]).T
     sim.set_state(Q, V, A, W)
@@ -228,7 +239,7 @@ def test_epa_option_through_the_python_api(blobs):
     for e, st in enumerate(states):
         if np.abs(V[:, e]).max() > 50:          # (one fixture state was captured in the middle of a blow-up, |qvel| 5e4: nothing to compare)
             continue
-        o = Oracle(blobs["f64"]); o.set_narrowphase(True)
+        o = Oracle(blobs["f64"])
         o.set_state(Q[:, e], V[:, e], W[:, e]); o.set_ctrl(A[:, e]); o.substeps(10)
         q, v, _ = o.get_state()
         assert np.abs(q1[:, e] - q).max() < 2e-2, (e, np.abs(q1[:, e] - q).max())       # (measured 9e-3 on the state with the deepest arm contacts)

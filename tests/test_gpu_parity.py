@@ -87,12 +87,18 @@ def test_pipelined_step_matches_fused(make_sim, golden):
     pc.check_pipeline_identical(make_sim, golden, n=8, steps=6)
 
 
-def test_epa_build_pipelined_step_matches_fused(blobs, golden):
-    """The -DSO101_EPA library (narrowphase="epa"): its launch chains, its fused step and its reset prefetch are the same device functions
-    in the same order as well - bit-identical rollouts from the contact-rich states, across an auto-reset, at one slice and at four."""
-    make = lambda n, seed=0, **cfg: ArraySim(blobs["f32"], n, backend="gpu", seed=seed, epa=True, **cfg)
+def test_four_launch_chains_match_fused_at_512_envs(make_sim, golden):
+    """512 envs: four slices on four streams, across an auto-reset, against the fused step, bit for bit."""
+    pc.check_pipeline_identical(make_sim, golden, n=512, steps=5, seed=13, all_reset_last=False, pipelines=(0, 1))
+
+
+def test_mpr_option_pipelined_step_matches_fused(blobs, golden):
+    """The -DSO101_MPR library (narrowphase="mpr", built on demand): the same sources with MPR's own portal depth instead of the EPA
+    expansion - its launch chains and its fused step are bit-identical too, and it is a different library with a different build hash."""
+    from so101_sim_amd import build
+    assert build.source_hash(mpr=True) != build.source_hash() and build.lib_path(mpr=True) != build.lib_path()
+    make = lambda n, seed=0, **cfg: ArraySim(blobs["f32"], n, backend="gpu", seed=seed, mpr=True, **cfg)
     pc.check_pipeline_identical(make, golden, n=8, steps=6, pipelines=(0, 1))
-    pc.check_pipeline_identical(make, golden, n=512, steps=5, seed=13, all_reset_last=False, pipelines=(0, 1))
 
 
 def test_three_launch_chains_match_fused(make_sim, golden):

@@ -119,40 +119,41 @@ def test_pickplace_pool_against_oracle(blobs):
     PQ, PV, PC = (t.cpu().numpy().astype(np.float64) for t in pregrasp.build_pickplace_pool(env, pool_size=n, seed=3))
     env.close()
     half = n // 2
-    # ---- forward pass at 8 grasp + 8 drop entries
-    # (a) narrowphase: the kernel's contact list against the oracle's (tolerances of _compare_contact_lists).  A thin
-    #     finger pad touching a hull with an edge or a corner is where the MPR query is ill-conditioned (fp32 and fp64
-    #     end on different portals); such entries are counted, not hidden, and must stay a minority.
+    # ---- forward pass at all 32 grasp entries + 8 drop entries
+    # (a) narrowphase: the kernel's contact list against the oracle's (tolerances of _compare_contact_lists: depth and normal of
+    #     EVERY contact).  With the default narrowphase (EPA: an exact face of the Minkowski difference) NO entry may differ -
+    #     `narrow_differs == 0`; with the MPR option fp32 and fp64 ended on different portals on 12 / 3 / 6 of 32 entries (seeds
+    #     3 / 4 / 5) where a thin finger pad touches a hull with an edge or a corner.  Only the witness point on a flat facet,
+    #     which is not unique, may sit elsewhere (counted; at most 3 % of the contacts).
     # (b) solver: with the KERNEL's contact list injected into the oracle, constraint rows + Newton solve must agree to
     #     1e-3 of max|qacc| on every entry - stiff pad contacts (solimp clamped to 0.9999) squeezing a 70 g banana are
     #     the case in which a cost-based fp32 termination stops early (so101_newton.hpp, decrement test).
-    #     The count is taken over ALL 32 grasp entries of the pool (round 2 looked at 8 of them and allowed 4): which entries sit
-    #     on such a corner changes with the last bit of the rollout that built the pool - seeds 3 / 4 / 5 give 12 / 3 / 6 of 32.
     grasp = list(range(half))
     simg = ArraySim(blobs["f32"], len(grasp), backend="gpu", last_step=500)
     simg.set_state(PQ[:, grasp], PV[:, grasp], PC[:, grasp], np.zeros((18, len(grasp))))
     dbgg = simg.debug_forward()
-    #     Round 3: what bounds the kernel's answers is no longer only "how often does it differ from the fp64 twin" but the
-    #     DEFINITION of a penetration depth (oracle/geomcheck.py, no shared algorithm): every contacting pair of every grasp entry
-    #     has overlap along its normal >= its depth >= the brute-forced minimum translation; the depth is the minimum translation
-    #     within 25 % for >= 95 % of the pairs and within a factor 2 for >= 99 % (measured, seeds 3 / 4: 98.8 / 99.7 % and 100 %,
-    #     worst 1.74; the fp64 oracle's own worst pair on seed 3 is 77 x - a pad edge in a hull, the MPR failure the flat-face
-    #     rule of DESIGN.md section 4 does not catch).
+    #     Independently of the fp64 twin, the DEFINITION of a penetration depth (oracle/geomcheck.py, no shared algorithm) bounds
+    #     every contacting pair of every grasp entry: overlap along its normal >= its depth >= the brute-forced minimum
+    #     translation, and the depth IS the minimum translation (within 2 % for >= 99 % of the pairs, worst <= 1.10).
     from oracle import geomcheck as gc
     from so101_sim_amd.model import blob as blobfmt
     model = blobfmt.unpack(blobs["f64"])
-    narrow_differs, rows = 0, []
+    narrow_differs, rows, n_contacts, n_witness = 0, [], 0, 0
     for j, k in enumerate(grasp):
         o = Oracle(blobs["f64"])
         o.set_state(PQ[:, k], PV[:, k], np.zeros(18))
         o.set_ctrl(PC[:, k])
         o.forward()
-        narrow_differs += bool(pc._compare_contact_lists(dbgg[j]["contacts"], o.contacts())[0])
+        problems, t, l, w = pc._compare_contact_lists(dbgg[j]["contacts"], o.contacts())
+        narrow_differs += bool(problems) or l > 0
+        n_contacts += t; n_witness += w
         rows += gc.check_contacts(gc.Scene.from_oracle(model, o), dbgg[j]["contacts"])
-    assert narrow_differs <= len(grasp) // 2, narrow_differs
+    assert narrow_differs == 0, narrow_differs
+    assert n_contacts >= 300 and n_witness <= 0.03 * n_contacts, (n_witness, n_contacts)
     mini = np.array([r["minimality"] for r in rows])
-    assert len(rows) >= 200 and min(r["along"] - r["depth"] for r in rows) >= -5e-6 and min(r["depth"] - r["mtd"] for r in rows) >= -5e-6
-    assert np.median(mini) <= 1.002 and np.mean(mini <= 1.25) >= 0.95 and np.mean(mini <= 2.0) >= 0.99, (np.median(mini), np.mean(mini <= 1.25), np.mean(mini <= 2.0), mini.max())
+    deep = np.array([r["depth"] for r in rows]) > 1e-4        # (relative numbers only where the depth is above the arithmetic's position noise)
+    assert len(rows) >= 200 and min(r["along"] - r["depth"] for r in rows) >= -5e-6 and min(r["depth"] - r["mtd"] for r in rows) >= -5e-6 - 2e-3 * max(r["mtd"] for r in rows)
+    assert np.median(mini) <= 1.002 and np.mean(mini[deep] <= 1.02) >= 0.99 and mini[deep].max() <= 1.10, (np.median(mini), np.mean(mini[deep] <= 1.02), mini[deep].max())
     idx = list(range(0, 8)) + list(range(half, half + 8))
     sim = ArraySim(blobs["f32"], len(idx), backend="gpu", last_step=500)
     sim.set_state(PQ[:, idx], PV[:, idx], PC[:, idx], np.zeros((18, len(idx))))
@@ -163,8 +164,8 @@ def test_pickplace_pool_against_oracle(blobs):
         o.set_state(PQ[:, k], PV[:, k], np.zeros(18))
         o.set_ctrl(PC[:, k])
         o.forward()
-        problems, _, _ = pc._compare_contact_lists(dbg[j]["contacts"], o.contacts())
-        assert not (problems and j >= 8), (j, problems)               # drop entries: no pad contacts, must agree
+        problems, _, l, _ = pc._compare_contact_lists(dbg[j]["contacts"], o.contacts())
+        assert not problems and l == 0, (j, problems, l)
         ncon.append(len(o.contacts()))
         o.inject_contacts(dbg[j]["contacts"])
         o.forward()
@@ -174,10 +175,11 @@ def test_pickplace_pool_against_oracle(blobs):
     assert np.mean(ncon[:8]) >= 12, ncon                            # contact-heavy: banana + bowl on the table + the gripper
     # ---- one control step (ten substeps, jaws closing) from ALL 32 grasp entries and 8 drop entries: task outputs exact.
     # Drop entries: states to the free-space bound (arm parked), contact-phase bound when the banana already touches the rim.
-    # Grasp entries: ten substeps of stiff pad contacts amplify a narrowphase difference of the first substep, so the bound
-    # is a distribution - the typical entry agrees like any contact phase (measured median 1.6e-5 rad / 9e-4 rad/s), at least
-    # 60 % are inside 2e-3 rad / 0.1 rad/s (measured 69-75 %), and the worst, on the entries counted in (a), stay inside
-    # 5e-2 rad / 20 rad/s (measured 0.033 / 9.1).  Round 2 checked 8 entries against the last bound only.
+    # Grasp entries: ten substeps of stiff pad contacts amplify any difference of the first substep, so the bound is a
+    # distribution: the typical entry agrees like any contact phase (median <= 2e-4 rad / 1e-2 rad/s), at least 90 % are inside
+    # 2e-3 rad / 0.1 rad/s, and the worst stays inside 2e-2 rad / 1 rad/s (round 3, MPR on both sides: 69-75 % and 0.033 / 9.1,
+    # held by a bound of 5e-2 / 20 that checked nothing; EPA, round 3: 29 of 32, worst 5.7e-3 / 0.25 - entries whose witness
+    # point sits elsewhere on a flat facet).
     idx2 = grasp + list(range(half, half + 8))
     sim = ArraySim(blobs["f32"], len(idx2), backend="gpu", last_step=500)
     sim.set_state(PQ[:, idx2], PV[:, idx2], PC[:, idx2], np.zeros((18, len(idx2))))
@@ -198,14 +200,14 @@ def test_pickplace_pool_against_oracle(blobs):
         dq, dv = np.abs(q1[:, j] - qo).max(), np.abs(v1[:, j] - vo).max()
         if j < len(grasp):
             gq.append(dq); gv.append(dv)
-            assert dq <= 5e-2 and dv <= 20.0, (j, dq, dv)
+            assert dq <= 2e-2 and dv <= 1.0, (j, dq, dv)
         else:
             touching = ncon[8 + j - len(grasp)] > 13
             tq, tv = (2e-3, 0.1) if touching else (2e-5, 5e-3)
             assert dq <= tq and dv <= tv, (j, dq, dv)
     gq, gv = np.array(gq), np.array(gv)
     assert np.median(gq) <= 2e-4 and np.median(gv) <= 1e-2, (np.median(gq), np.median(gv))
-    assert np.mean((gq <= 2e-3) & (gv <= 0.1)) >= 0.6, (np.sort(gq)[-12:], np.sort(gv)[-12:])
+    assert np.mean((gq <= 2e-3) & (gv <= 0.1)) >= 0.9, (np.sort(gq)[-12:], np.sort(gv)[-12:])
     # ---- jaws squeezing a banana of randomised mass: GPU vs oracle with the same scale, and the scale matters
     g8 = list(range(8))
     scale = np.random.RandomState(2).uniform(0.5, 1.5, size=(2, 8))
@@ -224,7 +226,7 @@ def test_pickplace_pool_against_oracle(blobs):
         o.env_begin()
         o.env_step(act[j].astype(np.float64))
         qo, vo, _ = o.get_state()
-        assert np.abs(qs[:, j] - qo).max() <= 5e-2 and np.abs(vs[:, j] - vo).max() <= 20.0, (j, np.abs(qs[:, j] - qo).max(), np.abs(vs[:, j] - vo).max())
+        assert np.abs(qs[:, j] - qo).max() <= 2e-2 and np.abs(vs[:, j] - vo).max() <= 1.0, (j, np.abs(qs[:, j] - qo).max(), np.abs(vs[:, j] - vo).max())
         changed = max(changed, np.abs(vs[:, j] - v1[:, j]).max())
     assert changed > 1e-3, "the mass scale must change how the gripper moves the banana"
     # ---- the reward = 1 branch: drop entries until the banana rests in the bowl
@@ -375,8 +377,8 @@ def test_mixed_suite_at_full_size_with_oracle_slices(blobs, blobs_pen):
 def test_failure_rates_on_the_headline_workload():
     """4096 envs x 500 control steps of uniform random actions over the action spec (seeded): how often the physics diverge
     (the episode then ends like a dm_control PhysicsError), how often a contact or arm-contact pool overflows, and that
-    no candidate list overflows and the scheduler never aborts.  Bounds = about twice what was measured (7.2e-5 divergences per
-    env-step: 141-151 in 2.05 M; DESIGN.md section 4 on why uniform random actions do that).  At five points of the rollout
+    no candidate list overflows and the scheduler never aborts.  Bounds: 5e-5 divergences per env-step (measured with the default
+    narrowphase: 2.5e-5, 306 in 12.3 M; the MPR option: 7.2e-5; DESIGN.md section 4 on why uniform random actions do that).  At five points of the rollout
     one control step of 24 envs is repeated by the fp64 oracle from the same live state (one-step parity on rollout states)."""
     import torch
     n, steps = 4096, 500
@@ -415,15 +417,17 @@ def test_failure_rates_on_the_headline_workload():
             qo, vo, _ = o.get_state()
             err.append((np.abs(q1[:, e].cpu().numpy() - qo).max(), np.abs(v1[:, e].cpu().numpy() - vo).max()))
     err = np.array(err)
-    # measured: median 7e-7 rad / 4e-5 rad/s, 90 % inside 2e-3 rad / 0.1 rad/s, worst 0.012 rad / 1.8 rad/s (MPR portal differences)
+    # bar: >= 90 % inside 2e-3 rad / 0.1 rad/s, worst <= 2e-2 rad / 1 rad/s (round 3 under MPR: median 7e-7 / 4e-5, 90 %, worst 0.012 / 1.8)
     assert len(err) >= 100
     assert np.median(err[:, 0]) <= 2e-5 and np.median(err[:, 1]) <= 2e-3, (np.median(err[:, 0]), np.median(err[:, 1]))
-    assert np.mean((err[:, 0] <= 2e-3) & (err[:, 1] <= 0.1)) >= 0.8 and err[:, 0].max() <= 5e-2 and err[:, 1].max() <= 20.0, (
+    assert np.mean((err[:, 0] <= 2e-3) & (err[:, 1] <= 0.1)) >= 0.9 and err[:, 0].max() <= 2e-2 and err[:, 1].max() <= 1.0, (
         np.mean((err[:, 0] <= 2e-3) & (err[:, 1] <= 0.1)), err[:, 0].max(), err[:, 1].max())
     ev = env.events()
     per = {k: v / (n * steps) for k, v in ev.items()}
-    assert per["diverged"] <= 1.5e-4, ev
-    assert per["contact_overflow"] <= 5e-5 and per["arm_pool_overflow"] <= 5e-5, ev
+    assert per["diverged"] <= 5e-5, ev
+    # (arm-pool overflows: more than 40 contacts on arm links - the arm jammed into the bowl's 53 hulls; with exact faces such envs stay
+    #  in deep contact instead of blowing up: measured 6.9e-5 per env-step over 12.3 M, the MPR option 1.1e-5)
+    assert per["contact_overflow"] <= 5e-5 and per["arm_pool_overflow"] <= 1.5e-4, ev
     assert ev["candidate_overflow"] == 0 and ev["scheduler_abort"] == 0 and ev["placement_rejected"] == 0, ev
     assert bool(torch.isfinite(env.qpos).all())
     env.close()
@@ -678,64 +682,3 @@ def test_config0_single_env_500_random_steps(blobs):
         assert ts.discount == 1.0 and ts.reward == 0.0
     assert env.step(np.zeros(6, dtype=np.float32)).first()
     env.close()
-
-
-def test_pickplace_pool_contacts_agree_exactly_under_epa(blobs):
-    """The round-2 verdict asked for `narrow_differs == 0` on the pre-grasp pool.  With MPR, fp32 and fp64 end on different portals on
-    12 / 3 / 6 of 32 grasp entries (seeds 3 / 4 / 5, test above); with the EPA build (narrowphase="epa", oracle orc_set_narrowphase(1))
-    the face of the Minkowski difference is exact: every contact of every grasp entry has the oracle's depth and normal - 0 of 32
-    entries differ on all three seeds -, and only the witness point on a flat facet, which is not unique, may sit elsewhere (measured
-    2 / 0 / 5 of ~400 contacts)."""
-    from so101_sim_amd import pregrasp
-    n = 64
-    env = _batched_env("SO100HandOverBanana", n)
-    PQ, PV, PC = (t.cpu().numpy().astype(np.float64) for t in pregrasp.build_pickplace_pool(env, pool_size=n, seed=3))
-    env.close()
-    grasp = list(range(n // 2))
-    sim = ArraySim(blobs["f32"], len(grasp), backend="gpu", last_step=500, epa=True)
-    sim.set_state(PQ[:, grasp], PV[:, grasp], PC[:, grasp], np.zeros((18, len(grasp))))
-    dbg = sim.debug_forward()
-    total = witness_only = 0
-    for j, k in enumerate(grasp):
-        o = Oracle(blobs["f64"])
-        o.set_narrowphase(True)
-        o.set_state(PQ[:, k], PV[:, k], np.zeros(18))
-        o.set_ctrl(PC[:, k])
-        o.forward()
-        mine, ref = dbg[j]["contacts"], o.contacts()
-        assert [(c["geom1"], c["geom2"]) for c in mine] == [(c["geom1"], c["geom2"]) for c in ref], j
-        for a, r in zip(mine, ref):
-            assert abs(a["dist"] - r["dist"]) < 5e-6 + 1e-4 * abs(r["dist"]) and a["normal"] @ r["normal"] > 1 - 1e-4, (j, a, r)
-            assert np.abs(a["pos"] - r["pos"]).max() < 1.5e-2
-            total += 1
-            witness_only += np.abs(a["pos"] - r["pos"]).max() > 2e-5
-    assert total >= 300 and witness_only <= 0.03 * total, (witness_only, total)
-
-
-def test_grasp_one_step_rollout_under_epa(blobs):
-    """One control step from the 32 grasp entries of the pre-grasp pool (finger pads squeezing the banana), EPA build against the fp64
-    oracle running EPA.  The verdict's bar for this comparison was 2e-3 rad / 0.1 rad/s; with MPR 21 of 32 entries meet it (p90 of the
-    position difference 1.4e-2, worst 3.8e-2; velocities up to 8 rad/s); with exact faces 29 of 32 do, p90 2.6e-5, worst 5.7e-3 / 0.25
-    - the remaining three are entries whose witness point sits elsewhere on a flat facet."""
-    from so101_sim_amd import pregrasp
-    n = 64
-    env = _batched_env("SO100HandOverBanana", n)
-    PQ, PV, PC = (t.cpu().numpy().astype(np.float64) for t in pregrasp.build_pickplace_pool(env, pool_size=n, seed=3))
-    env.close()
-    grasp = list(range(n // 2))
-    sim = ArraySim(blobs["f32"], len(grasp), backend="gpu", last_step=500, epa=True)
-    sim.set_state(PQ[:, grasp], PV[:, grasp], PC[:, grasp], np.zeros((18, len(grasp))))
-    sim.physics(10)
-    q1, v1, _ = sim.get_state()
-    dq, dv = [], []
-    for j, k in enumerate(grasp):
-        o = Oracle(blobs["f64"])
-        o.set_narrowphase(True)
-        o.set_state(PQ[:, k], PV[:, k], np.zeros(18))
-        o.set_ctrl(PC[:, k])
-        o.substeps(10)
-        q, v, _ = o.get_state()
-        dq.append(np.abs(q1[:, j] - q).max()); dv.append(np.abs(v1[:, j] - v).max())
-    dq, dv = np.array(dq), np.array(dv)
-    assert np.sum((dq <= 2e-3) & (dv <= 0.1)) >= 27, (dq, dv)
-    assert np.percentile(dq, 90) <= 2e-4 and dq.max() <= 2e-2 and dv.max() <= 1.0, (np.percentile(dq, 90), dq.max(), dv.max())

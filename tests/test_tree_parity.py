@@ -41,9 +41,16 @@ def _scene_states(raw64, n, seed):
     return [np.array(x).T for x in (Q, V, W, CT)]
 
 
-def check_forward(name, backend, n, seed=0, max_loose=0.1, epa=False):
+def check_forward(name, backend, n, seed=0, mpr=False):
+    """Forward dynamics of the general-tree engine against the fp64 oracle, contact by contact.  Default narrowphase (EPA: an exact face
+    of the Minkowski difference) - depth 2e-6 + 1e-4 relative, normal 1e-6, position 2e-5 for every contact, except: `loose` (depth or
+    normal beyond that; at most 2 % of the contacts, and then within 1e-4 m / cos 0.999) and `witness` (depth and normal tight, the
+    witness point elsewhere on a flat facet - not unique there; at most 5 %, inside the patch).  Accelerations: 1e-4 against the
+    oracle's own solve when every contact is tight, else 1e-4 against the oracle solving on the KERNEL's contact list - there is no
+    looser fallback.  mpr=True (the -DSO101_MPR option): fp32 and fp64 MPR end on neighbouring portals for centimetre-deep hull pairs;
+    only the counts are bounded there (<= 20 %) and the solver is compared on the kernel's list."""
     raw64, raw32 = _blobs(name)
-    sim = TreeArraySim(raw32, n, backend=backend, epa=epa)
+    sim = TreeArraySim(raw32, n, backend=backend, mpr=mpr)
     nv = sim.sim.nv
     if name is None:
         Q, V, CT = _bare_states(n, seed); W = np.zeros((nv, n))
@@ -52,9 +59,10 @@ def check_forward(name, backend, n, seed=0, max_loose=0.1, epa=False):
     sim.set_state(Q, V, CT, W)
     dbg = sim.debug_forward()
     o = Oracle(raw64)
-    o.set_narrowphase(epa)
-    with_contacts = loose = total = 0
+    o.set_narrowphase(not mpr)
+    with_contacts = loose = witness = total = 0
     for e in range(n):
+        o.inject_contacts([])
         o.set_state(Q[:, e], V[:, e], W[:, e]); o.set_ctrl(CT[:, e]); o.forward()
         d = dbg[e]
         qa, qs = o.qacc()
@@ -68,17 +76,30 @@ def check_forward(name, backend, n, seed=0, max_loose=0.1, epa=False):
         oc = o.contacts()
         assert d["ncon"] == len(oc) and d["nrow"] == o.nefc
         assert [(c["geom1"], c["geom2"]) for c in d["contacts"]] == [(c["geom1"], c["geom2"]) for c in oc]
-        loose_here = 0
+        off_here = 0
         for a, b in zip(d["contacts"], oc):
-            tight = abs(a["dist"] - b["dist"]) < 2e-6 and np.abs(a["pos"] - b["pos"]).max() < 2e-5 and a["normal"] @ b["normal"] > 1 - 1e-6
-            if not tight:        # an ill-conditioned MPR query (hull against hull): fp32 and fp64 end on neighbouring portals
-                assert abs(a["dist"] - b["dist"]) < 1e-3 and np.abs(a["pos"] - b["pos"]).max() < 1e-3 and a["normal"] @ b["normal"] > 0.9, (a, b)
-                loose_here += 1
-        loose += loose_here; total += len(oc)
-        tol = 1e-4 if loose_here == 0 else 0.2
-        assert np.abs(d["qacc"] - qa).max() <= tol * max(1.0, np.abs(qa).max()), (e, np.abs(d["qacc"] - qa).max(), np.abs(qa).max())
+            face = abs(a["dist"] - b["dist"]) < 2e-6 + 1e-4 * abs(b["dist"]) and a["normal"] @ b["normal"] > 1 - 1e-6
+            if not face:
+                if mpr:
+                    assert abs(a["dist"] - b["dist"]) < 1e-3 and np.abs(a["pos"] - b["pos"]).max() < 1e-3 and a["normal"] @ b["normal"] > 0.9, (a, b)
+                else:
+                    assert abs(a["dist"] - b["dist"]) < 1e-4 and np.abs(a["pos"] - b["pos"]).max() < 1.5e-2 and a["normal"] @ b["normal"] > 0.999, (a, b)
+                loose += 1; off_here += 1
+            elif np.abs(a["pos"] - b["pos"]).max() >= 2e-5:
+                assert np.abs(a["pos"] - b["pos"]).max() < 1.5e-2, (a, b)
+                witness += 1; off_here += 1
+        total += len(oc)
+        if off_here:
+            o.inject_contacts(d["contacts"])
+            o.forward()
+            qa = o.qacc()[0]
+        assert np.abs(d["qacc"] - qa).max() <= 1e-4 * max(1.0, np.abs(qa).max()), (e, off_here, np.abs(d["qacc"] - qa).max(), np.abs(qa).max())
         with_contacts += d["ncon"] > 0
-    assert loose <= max_loose * max(total, 1) + 1, (loose, total)
+    o.inject_contacts([])
+    if mpr:
+        assert loose + witness <= 0.2 * max(total, 1) + 1, (loose, witness, total)
+    else:
+        assert loose <= 0.02 * max(total, 1) + 1 and witness <= 0.05 * max(total, 1) + 1, (loose, witness, total)
     return with_contacts
 
 
@@ -114,17 +135,15 @@ def test_emulated_forward_hand_over_scene():
 @pytest.mark.parametrize("name", [None, "banana", "pen"])
 def test_forward_against_the_oracle(name):
     # (bare arms at random poses around home: the contacts are link-on-link and link-on-table hull pairs, a few of them centimetres
-    # deep - the states in which the fp32 and the fp64 MPR query end on neighbouring portals; measured 22 of 164 contacts)
-    assert check_forward(name, "gpu", 32, max_loose=0.2 if name is None else 0.1) >= (4 if name is None else 32)
+    # deep - where MPR and EPA differ most.  With exact faces fp32 and fp64 disagreed in depth or normal on 1 of the 164 contacts in
+    # round 3 (the MPR option: 22) and in the witness point alone on 4.)
+    assert check_forward(name, "gpu", 32) >= (4 if name is None else 32)
 
 
 @pytest.mark.gpu
-def test_forward_against_the_oracle_with_the_epa_build():
-    """The -DSO101_EPA library runs the general-tree engine with the same narrowphase switch (narrowphase="epa" on the ALOHA envs): forward
-    dynamics of the bare arms - link-on-link hull contacts, where MPR and EPA differ most - against the fp64 oracle running EPA.  With exact
-    faces fp32 and fp64 disagree in depth or normal on 1 of the 164 contacts (MPR: 22) and in the witness point alone - which is not
-    unique on a flat facet - on 4."""
-    assert check_forward(None, "gpu", 32, max_loose=0.05, epa=True) >= 4
+def test_forward_against_the_oracle_with_the_mpr_option():
+    """The -DSO101_MPR library (narrowphase="mpr" on the ALOHA envs) runs the general-tree engine with the same switch."""
+    assert check_forward(None, "gpu", 32, mpr=True) >= 4
 
 
 @pytest.mark.gpu
