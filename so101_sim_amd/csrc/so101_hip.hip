@@ -402,7 +402,7 @@ int so101_create(const void* blob, size_t bytes, int n_envs, int device, uint64_
     bool ok = dev_alloc(s, &W.pose, NDYN * 12 * n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.cand, MAXCAND * n, 0, "hipMalloc(pipe)") &&
               dev_alloc(s, &W.ncand, n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.work, 2 * MAXCAND * n, 0, "hipMalloc(pipe)") &&
               dev_alloc(s, &W.counters, (size_t)2 * MAXSUB * so101_sim::MAXGROUPS, 0, "hipMalloc(pipe)") &&
-              dev_alloc(s, &W.conres, CONRES_DIM * CONRES_PER_ENV * n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.cbase, n, 0, "hipMalloc(pipe)") &&
+              dev_alloc(s, &W.conres, CONRES_DIM * (CONRES_PER_ENV * n + (size_t)MAXCAND * so101_sim::MAXGROUPS), 0, "hipMalloc(pipe)") && dev_alloc(s, &W.cbase, n, 0, "hipMalloc(pipe)") &&
               dev_alloc(s, &W.active, n, 0, "hipMalloc(pipe)") &&
 #ifdef SO101_DEBUG_CLOCKS
               dev_alloc(s, &W.ticks, MAXCAND * n, 0, "hipMalloc(pipe)") &&
@@ -604,8 +604,11 @@ static int enqueue_pipelined(so101_sim* s, hipStream_t st, const so101::StepIO& 
     W.counters = s->pipe.counters + 2 * MAXSUB * g;
     W.work = s->pipe.work + (size_t)2 * MAXCAND * e0;
     W.work_cap = (unsigned int)ng * MAXCAND;
-    W.conres = s->pipe.conres + (size_t)e0 * CONRES_PER_ENV * CONRES_DIM;          // the slice's pool of contact records
-    W.conres_cap = (unsigned int)ng * CONRES_PER_ENV;
+    // the slice's pool of contact records: CONRES_PER_ENV per env plus a floor of MAXCAND, so that ONE env can always place every
+    // candidate the broadphase may hand over (a single env or a small batch is not cut off at 48 records; which env would lose
+    // records depended on the arrival order of the atomics in publish_candidates)
+    W.conres = s->pipe.conres + ((size_t)e0 * CONRES_PER_ENV + (size_t)g * MAXCAND) * CONRES_DIM;
+    W.conres_cap = (unsigned int)ng * CONRES_PER_ENV + MAXCAND;
     // persistent narrowphase waves (they pull work items until the list is empty): two per env of the slice, at
     // most what fills 256 CUs - a smaller narrowphase grid leaves slots to the other chains' solve kernels
     int nw = ng * 2 < 4096 ? ng * 2 : 4096;

@@ -177,7 +177,7 @@ struct EventBuffers {
 
 #define MAXSUB 32
 #define CONRES_DIM (4 + 4 * NCPP)
-#define CONRES_PER_ENV 48       // compact contact-record pool: records per env of a slice (mean use 12); overflow drops candidates and is counted
+#define CONRES_PER_ENV 48       // compact contact-record pool: records per env of a slice (mean use 12) + MAXCAND per slice (one env can always place all its candidates); overflow drops candidates and is counted
 
 // Scratch of the pipelined step (so101_pipeline.hpp)
 struct PipeBuffers {

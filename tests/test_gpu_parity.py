@@ -101,6 +101,11 @@ def test_mpr_option_pipelined_step_matches_fused(blobs, golden):
     pc.check_pipeline_identical(make, golden, n=8, steps=6, pipelines=(0, 1))
 
 
+def test_single_env_with_more_candidates_than_pool_records(make_sim):
+    pc.check_single_env_many_candidates(make_sim, n=1)
+    pc.check_single_env_many_candidates(make_sim, n=3)
+
+
 def test_three_launch_chains_match_fused(make_sim, golden):
     """n >= 64: so101_step cuts the cost-sorted envs into three slices on separate streams; still bit-identical to the
     fused single-launch step (different random actions per env, so the slices really differ in cost)."""
