@@ -241,7 +241,7 @@ def test_divergence_handling(make_sim, blobs):
 
 
 def test_contact_rich_states(make_sim, blobs, golden):
-    pc.check_contact_rich(make_sim, blobs, golden, count=12)
+    pc.check_contact_rich(make_sim, blobs, golden, count=24)
 
 
 @pytest.mark.parametrize("task_name", ["SO100HandOverBanana", "SO100HandOverPen"])
