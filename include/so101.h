@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SO101_ABI_VERSION 8      /* 8: the general-tree engine (so101_tree_*); everything of version 7 unchanged */
+#define SO101_ABI_VERSION 9      /* 9: so101_tree_config gains the observation delays, so101_tree_bind_physics_state; 8: the general-tree engine (so101_tree_*) */
 #define SO101_OBS_DIM 18      /* joints_pos(6, delayed) | undelayed_joints_pos(6) | commanded_joints_pos(6) */
 #define SO101_ACT_DIM 6
 #define SO101_SOLVER_PGS 0
@@ -279,9 +279,10 @@ int so101_tree_get_diag(so101_tree* sim, int32_t* out, void* hip_stream);
  * before_step with the gripper unit conversion (aloha2_task.py:316-349), n_substeps of physics, the observables of
  * aloha2_task.py:386-444 with their 0.1 s delay, the overlap reward and termination of hand_over.py:246-284 / aloha2_task.py:355-367,
  * reset = home pose + prop placement + settle (aloha2_task.py:369-383, hand_over.py:208-236).  Caller-owned per-env arrays
- * (device, env-fastest): ring_pos [5][npos][n_envs], ring_vel [5][nvel][n_envs] (npos = nu = 14, nvel = 16 for ALOHA), ep_return,
- * step_count, episode.  Observation row of so101_tree_step, so101_tree_obs_dim() = 3 npos + 2 nvel floats per env:
- *   joints_pos (delayed 5 control steps) | joints_vel (delayed) | undelayed_joints_pos | undelayed_joints_vel | commanded_joints_pos
+ * (device, env-fastest): ring_pos [joints_delay_steps][npos][n_envs], ring_vel [joints_delay_steps][nvel][n_envs] (npos = nu = 14,
+ * nvel = 16 for ALOHA; the delay as configured, 5 by default; with a delay of 0 the pointers are still required but never touched),
+ * ep_return, step_count, episode.  Observation row of so101_tree_step, so101_tree_obs_dim() = 3 npos + 2 nvel floats per env:
+ *   joints_pos (delayed) | joints_vel (delayed) | undelayed_joints_pos | undelayed_joints_vel | commanded_joints_pos
  * step_type 0 FIRST (the call after a LAST resets the env and ignores the action), 1 MID, 2 LAST; a physics error ends the
  * episode with reward 0 and discount 0.  Reset happens inside the step call (no prefetch yet). */
 typedef struct {
@@ -294,10 +295,18 @@ typedef struct {
   uint64_t seed, env_id_base;
   int reward_mode;           /* 0 overlap boxes (HandOver's default), 1 contact sequence (reward_based_on_overlap = False, hand_over.py:286-338) */
   int reward_requires_handover;   /* mode 1: start the sequence at "right gripper touches the object" instead of at its last state */
+  int joints_delay_steps;    /* delay of joints_pos / joints_vel in CONTROL steps (joints_observation_delay_secs / control_timestep,
+                                aloha2_task.py:153-155,236-243); < 0: the reference's default 5 (0.1 s); 0: undelayed; at most 64 */
+  int physics_delay_steps;   /* delay of delayed_physics_state (image_observation_delay_secs, aloha2_task.py:157-159,244-251); < 0: 15 (0.3 s) */
 } so101_tree_config;
 int so101_tree_obs_dim(const so101_tree* sim);
 int so101_tree_bind_env(so101_tree* sim, float* ring_pos, float* ring_vel, float* ep_return, int32_t* step_count, int32_t* episode);
 int so101_tree_configure_env(so101_tree* sim, const so101_tree_config* cfg);
+/* physics_state / delayed_physics_state (aloha2_task.py:244-251,441-444: qpos | qvel, and its copy of physics_delay_steps control
+ * steps ago, padded with the reset state) written by so101_tree_step / so101_tree_reset / so101_tree_begin_episode: caller-owned
+ * device buffers ring [physics_delay_steps][nq + nv][n_envs] (env-fastest), physics_state [n_envs][nq + nv], delayed [n_envs][nq + nv];
+ * all NULL switches the outputs off.  Replaces the host-side line of rounds 3 (reference test: aloha2_task_test.py:136-173). */
+int so101_tree_bind_physics_state(so101_tree* sim, float* ring, float* physics_state, float* delayed);
 int so101_tree_reset(so101_tree* sim, const uint8_t* mask, void* hip_stream);
 /* Settled-state store, as so101_compute_settled / so101_set_settled_store above: placement + settle of episodes first_episode ..
  * first_episode + count - 1 of every env into caller-owned device tables qpos [count][nq][n_envs], qvel / warmstart [count][nv][n_envs],

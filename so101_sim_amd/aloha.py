@@ -8,8 +8,10 @@ Every number comes from the kernels behind the `so101_tree_*` entry points of in
 array container.  n_envs == 1 yields numpy observations without the env dimension (what a caller of the reference sees), n_envs > 1
 torch tensors on the GPU with a leading env dimension.
 
-Not built: cameras (no renderer in this library), non-default observation delays and table height offset (the committed model
-blob is compiled for the reference's defaults).  Both reward modes are: the overlap boxes (default) and the contact sequence
+Not built: cameras (no renderer in this library) and a non-default table height offset (the committed model blob is compiled for
+the reference's default).  The observation delays ARE parameters (`joints_observation_delay_secs`, `image_observation_delay_secs`,
+aloha2_task.py:153-159: whole control steps, handed to the kernels by so101_tree_configure_env), and `physics_state` /
+`delayed_physics_state` come from a device-side delay line (so101_tree_bind_physics_state).  Both reward modes are built: the overlap boxes (default) and the contact sequence
 (`reward_based_on_overlap=False`, hand_over.py:286-338, with `reward_requires_handover`).
 """
 from __future__ import annotations
@@ -26,7 +28,7 @@ from .model import scenes
 
 DEFAULT_CONTROL_TIMESTEP = 0.02
 PHYSICS_TIMESTEP = 0.002
-_PHYSICS_DELAY_STEPS = 15          # 0.3 s / 0.02 s (aloha2_task.py:103,244-251)
+DEFAULT_JOINTS_DELAY_SECS, DEFAULT_PHYSICS_DELAY_SECS = 0.1, 0.3          # aloha2_task.py:102-103
 NPOS, NVEL = 14, 16
 
 # obs row of so101_tree_step (include/so101.h): joints_pos | joints_vel | undelayed_joints_pos | undelayed_joints_vel | commanded_joints_pos
@@ -50,9 +52,19 @@ class HandOverTask:
         self.waist_joint_limit = float(kwargs.pop("waist_joint_limit", np.pi / 2))
         if float(kwargs.pop("table_height_offset", scenes.ALOHA_TABLE_HEIGHT_OFFSET)) != scenes.ALOHA_TABLE_HEIGHT_OFFSET:
             raise NotImplementedError("the model blob is compiled for table_height_offset = 0.011 (aloha2_task.py:107)")
-        if float(kwargs.pop("joints_observation_delay_secs", 0.1)) != 0.1 or float(kwargs.pop("image_observation_delay_secs", 0.3)) != 0.3:
-            raise NotImplementedError("observation delays other than the reference's defaults (0.1 s joints, 0.3 s physics state)")
+        # observation delays (aloha2_task.py:153-159,236-251): dm_control delays an observable by delay_secs / physics_timestep
+        # substeps; the kernels keep one sample per control step, so a delay must be a whole number of control steps (0 = undelayed)
+        self.joints_observation_delay_secs = float(kwargs.pop("joints_observation_delay_secs", DEFAULT_JOINTS_DELAY_SECS))
+        self.image_observation_delay_secs = float(kwargs.pop("image_observation_delay_secs", DEFAULT_PHYSICS_DELAY_SECS))
+        self.joints_delay_steps = self._delay_steps(self.joints_observation_delay_secs, "joints_observation_delay_secs")
+        self.physics_delay_steps = self._delay_steps(self.image_observation_delay_secs, "image_observation_delay_secs")
         self._instruction = scenes.ALOHA_INSTRUCTIONS[object_name]
+
+    def _delay_steps(self, secs: float, name: str) -> int:
+        steps = secs / self.control_timestep
+        if secs < 0 or abs(steps - round(steps)) > 1e-9 or round(steps) > 64:
+            raise ValueError(f"{name} = {secs}: must be a whole number (0..64) of control steps of {self.control_timestep} s")
+        return int(round(steps))
 
     def get_instruction(self):
         return self._instruction
@@ -116,7 +128,8 @@ class AlohaEnvironment:
             raise RuntimeError("unexpected model dimensions for an ALOHA hand-over scene")
         z = lambda *sh, dt=torch.float32: torch.zeros(*sh, dtype=dt, device=self.device)
         self.qpos, self.qvel, self.ctrl, self.warm = z(s.nq, N), z(s.nv, N), z(s.nu, N), z(s.nv, N)
-        self._ring_pos, self._ring_vel = z(5, NPOS, N), z(5, NVEL, N)
+        jd, pd = task.joints_delay_steps, task.physics_delay_steps
+        self._ring_pos, self._ring_vel = z(max(jd, 1), NPOS, N), z(max(jd, 1), NVEL, N)
         self.ep_return, self.step_count, self.episode = z(N), z(N, dt=torch.int32), z(N, dt=torch.int32)
         self.obs, self.reward, self.discount = z(N, s.obs_dim), z(N), z(N)
         self.step_type = z(N, dt=torch.uint8)
@@ -129,12 +142,18 @@ class AlohaEnvironment:
         s.configure_env(n_substeps=nsub, last_step=self.last_step, settle_max_substeps=int(settle_max_substeps),
                         terminate_on_success=int(task.terminate_episode), solver_iterations=int(solver_iterations),
                         solver_tolerance=float(solver_tolerance), seed=seed, env_id_base=int(env_id_base),
-                        reward_mode=0 if task.reward_based_on_overlap else 1, reward_requires_handover=int(task.reward_requires_handover))
-        # physics_state / delayed_physics_state (aloha2_task.py:244-251,441-444): qpos | qvel and its copy of 15 control steps ago.
-        # The reference ties them to image_observation_enabled; for batches they are opt-in (58 + 58 floats per env and step).
+                        reward_mode=0 if task.reward_based_on_overlap else 1, reward_requires_handover=int(task.reward_requires_handover),
+                        joints_delay_steps=jd, physics_delay_steps=pd)
+        # physics_state / delayed_physics_state (aloha2_task.py:244-251,441-444): qpos | qvel and its copy of `pd` control steps ago,
+        # from a device-side delay line the step / reset kernels maintain.  The reference ties them to image_observation_enabled;
+        # for batches they are opt-in (58 + 58 floats per env and step).
         self._with_state = bool(task.image_observation_enabled if physics_state is None and N == 1 else physics_state)
-        self._ps_ring = None
         self._ps_dim = s.nq + s.nv
+        self.physics_state = self.delayed_physics_state = self._ps_ring = None
+        if self._with_state:
+            self._ps_ring = z(max(pd, 1), self._ps_dim, N)
+            self.physics_state, self.delayed_physics_state = z(N, self._ps_dim), z(N, self._ps_dim)
+            s.bind_physics_state(self._ps_ring.data_ptr(), self.physics_state.data_ptr(), self.delayed_physics_state.data_ptr())
 
     # ------------------------------------------------------------------ specs
     def action_spec(self) -> BoundedArray:
@@ -147,11 +166,12 @@ class AlohaEnvironment:
         spec["joints_vel"] = Array((NVEL,), np.float64, "joints_vel")
         if self._with_state:
             spec["physics_state"] = Array((self._ps_dim,), np.float64, "physics_state")
-        spec["undelayed_joints_pos"] = Array((NPOS,), np.float64, "undelayed_joints_pos")
-        spec["undelayed_joints_vel"] = Array((NVEL,), np.float64, "undelayed_joints_vel")
-        spec["delayed_joints_pos"] = Array((NPOS,), np.float64, "delayed_joints_pos")
-        spec["delayed_joints_vel"] = Array((NVEL,), np.float64, "delayed_joints_vel")
-        if self._with_state:
+        if self.task.joints_delay_steps:          # (the undelayed_* / delayed_* copies exist only with a joints delay, aloha2_task.py:236-243)
+            spec["undelayed_joints_pos"] = Array((NPOS,), np.float64, "undelayed_joints_pos")
+            spec["undelayed_joints_vel"] = Array((NVEL,), np.float64, "undelayed_joints_vel")
+            spec["delayed_joints_pos"] = Array((NPOS,), np.float64, "delayed_joints_pos")
+            spec["delayed_joints_vel"] = Array((NVEL,), np.float64, "delayed_joints_vel")
+        if self._with_state and self.task.physics_delay_steps:
             spec["delayed_physics_state"] = Array((self._ps_dim,), np.float64, "delayed_physics_state")
         return spec
 
@@ -159,42 +179,21 @@ class AlohaEnvironment:
     def _stream(self):
         return self.torch.cuda.current_stream(self.device).cuda_stream
 
-    def _physics_state(self):
-        return self.torch.cat([self.qpos.t(), self.qvel.t()], dim=1)
-
-    def _update_state_ring(self):
-        """host-side (torch) delay line of the physics state: envs that report FIRST refill their line with the reset state"""
-        if not self._with_state:
-            return None, None
-        torch = self.torch
-        ps = self._physics_state()
-        if self._ps_ring is None:
-            self._ps_ring = ps.unsqueeze(0).repeat(_PHYSICS_DELAY_STEPS, 1, 1)
-            self._ps_head = 0
-        first = (self.step_type == 0)
-        if bool(first.any()):
-            self._ps_ring[:, first] = ps[first]
-        delayed = self._ps_ring[self._ps_head].clone()
-        delayed[first] = ps[first]
-        self._ps_ring[self._ps_head] = torch.where(first.unsqueeze(1), self._ps_ring[self._ps_head], ps)
-        self._ps_head = (self._ps_head + 1) % _PHYSICS_DELAY_STEPS
-        return ps, delayed
-
     def _obs_dict(self):
-        ps, delayed = self._update_state_ring()
         o = collections.OrderedDict()
         cut = lambda k: self.obs[:, _SLICES[k][0]:_SLICES[k][1]]
         o["commanded_joints_pos"] = cut("commanded_joints_pos")
         o["joints_pos"] = cut("joints_pos")
         o["joints_vel"] = cut("joints_vel")
-        if ps is not None:
-            o["physics_state"] = ps
-        o["undelayed_joints_pos"] = cut("undelayed_joints_pos")
-        o["undelayed_joints_vel"] = cut("undelayed_joints_vel")
-        o["delayed_joints_pos"] = cut("joints_pos")
-        o["delayed_joints_vel"] = cut("joints_vel")
-        if delayed is not None:
-            o["delayed_physics_state"] = delayed
+        if self._with_state:
+            o["physics_state"] = self.physics_state
+        if self.task.joints_delay_steps:
+            o["undelayed_joints_pos"] = cut("undelayed_joints_pos")
+            o["undelayed_joints_vel"] = cut("undelayed_joints_vel")
+            o["delayed_joints_pos"] = cut("joints_pos")
+            o["delayed_joints_vel"] = cut("joints_vel")
+        if self._with_state and self.task.physics_delay_steps:
+            o["delayed_physics_state"] = self.delayed_physics_state
         if self.n_envs == 1:
             return collections.OrderedDict((k, v[0].double().cpu().numpy()) for k, v in o.items())
         return o

@@ -970,9 +970,12 @@ DEV void euler(const TreeModel* tm, TreeLDS& L) {
 // placement and the overlap reward; the SO100 counterpart is so101_env.hpp)
 }  // namespace tree
 
-#define T_RING 5               // joints_pos / joints_vel delay: 0.1 s = 5 control steps
+#define T_RING_DEFAULT 5       // joints_pos / joints_vel delay of the reference's default: 0.1 s = 5 control steps (aloha2_task.py:102)
+#define T_PS_DEFAULT 15        // delayed_physics_state: 0.3 s = 15 control steps (aloha2_task.py:103)
+#define T_DELAY_MAX 64
 struct TreeTask {
   int npos, nvel, obj_body, con_body, nbox, n_substeps, last_step, settle_max, terminate_on_success, n_envs, iterations;
+  int jdelay, pdelay;                      // observation delays in control steps (so101_tree_config): joints_pos / joints_vel, delayed_physics_state
   int reward_mode, requires_handover;      // 0 overlap boxes (the default), 1 contact sequence (hand_over.py:286-338)
   float dist_threshold, tolerance, grip[6];    // gripper limits: sim_qpos open, close, sim_ctrl open, close, follower open, close
   int obs_qposadr[TU], obs_is_gripper[TU], act_is_gripper[TU];
@@ -980,7 +983,10 @@ struct TreeTask {
   float obj_lo[3], obj_hi[3], obj_yaw[2], con_lo[3], con_hi[3], home_qpos[TQ], home_ctrl[TU];
   unsigned long long seed, env_id_base;
 };
-struct TreeEnvBuffers { float *ring_pos, *ring_vel, *ep_return; int *step_count, *episode; unsigned char* need_reset; int* success_state; };
+struct TreeEnvBuffers {
+  float *ring_pos, *ring_vel, *ep_return; int *step_count, *episode; unsigned char* need_reset; int* success_state;
+  float *ps_ring, *ps_out, *ps_delayed;    // so101_tree_bind_physics_state: delay line [pdelay][nq + nv][N], physics_state / delayed_physics_state [N][nq + nv]; NULL = off
+};
 // Settled-state store (so101_tree_set_settled_store): the results of placement + settle for episodes first .. first + count - 1 of every
 // env, computed once by so101_tree_compute_settled and kept by the caller.  The settled state of an episode is a pure function of (seed,
 // global env id, episode, configuration), so a reset that finds its entry copies the same bits it would have computed.
@@ -1092,6 +1098,40 @@ DEV void env_settle(const TreeModel* tm, const DevModel* gm, const TreeTask& T, 
   wave_sync();
 }
 
+// the episode starts: delay lines padded with the reset-time value (task_suite.py:154 INITIAL_VALUE); physics_state and its delayed
+// copy (aloha2_task.py:244-251,441-444: qpos | qvel, delayed by image_observation_delay_secs) both report the reset state
+DEV void fill_delay_lines(const TreeModel* tm, const TreeTask& T, const TreeLDS& L, const TreeEnvBuffers& E, int e) {
+  int lane = wave_lane(), N = T.n_envs;
+  if (lane < T.npos) {
+    float v = L.qpos[T.obs_qposadr[lane]];
+    if (T.obs_is_gripper[lane]) v = convert_gripper(v, T.grip[0], T.grip[1], T.grip[4], T.grip[5]);
+    for (int r = 0; r < T.jdelay; r++) E.ring_pos[((size_t)r * T.npos + lane) * N + e] = v;
+  }
+  if (lane < T.nvel) for (int r = 0; r < T.jdelay; r++) E.ring_vel[((size_t)r * T.nvel + lane) * N + e] = L.qvel[lane];
+  if (E.ps_out) {
+    int D = tm->nq + tm->nv;
+    for (int i = lane; i < D; i += WAVE) {
+      float v = i < tm->nq ? L.qpos[i] : L.qvel[i - tm->nq];
+      for (int r = 0; r < T.pdelay; r++) E.ps_ring[((size_t)r * D + i) * N + e] = v;
+      E.ps_out[(size_t)e * D + i] = v;
+      E.ps_delayed[(size_t)e * D + i] = v;
+    }
+  }
+}
+
+// physics_state / delayed_physics_state of control step sc (>= 1) from the integrated state in LDS
+DEV void write_physics_state(const TreeModel* tm, const TreeTask& T, const TreeLDS& L, const TreeEnvBuffers& E, int e, int sc) {
+  if (!E.ps_out) return;
+  int lane = wave_lane(), N = T.n_envs, D = tm->nq + tm->nv;
+  int slot = T.pdelay > 0 ? (sc - 1) % T.pdelay : 0;
+  for (int i = lane; i < D; i += WAVE) {
+    float v = i < tm->nq ? L.qpos[i] : L.qvel[i - tm->nq], delayed = v;
+    if (T.pdelay > 0) { size_t ri = ((size_t)slot * D + i) * N + e; delayed = E.ps_ring[ri]; E.ps_ring[ri] = v; }
+    E.ps_out[(size_t)e * D + i] = v;
+    E.ps_delayed[(size_t)e * D + i] = delayed;
+  }
+}
+
 // env.reset(): the settled state of the episode from the store when it holds it, computed otherwise; then the episode starts -
 // delay lines padded with the reset-time value (task_suite.py:154 INITIAL_VALUE), counters cleared
 DEV void env_reset(const TreeModel* tm, const DevModel* gm, const TreeTask& T, TreeLDS& L, const TreeScratch& G, const TreeBuffers& B, const TreeEnvBuffers& E,
@@ -1108,13 +1148,7 @@ DEV void env_reset(const TreeModel* tm, const DevModel* gm, const TreeTask& T, T
   } else {
     env_settle(tm, gm, T, L, G, e, episode);
   }
-  // delay lines padded with the reset-time value (task_suite.py:154 INITIAL_VALUE)
-  if (lane < T.npos) {
-    float v = L.qpos[T.obs_qposadr[lane]];
-    if (T.obs_is_gripper[lane]) v = convert_gripper(v, T.grip[0], T.grip[1], T.grip[4], T.grip[5]);
-    for (int r = 0; r < T_RING; r++) E.ring_pos[((size_t)r * T.npos + lane) * N + e] = v;
-  }
-  if (lane < T.nvel) for (int r = 0; r < T_RING; r++) E.ring_vel[((size_t)r * T.nvel + lane) * N + e] = L.qvel[lane];
+  fill_delay_lines(tm, T, L, E, e);
   if (lane == 0) { E.step_count[e] = 0; E.ep_return[e] = 0.f; E.episode[e] = (int)(episode + 1u); E.success_state[e] = T.requires_handover ? 0 : 2; }
 }
 
@@ -1124,20 +1158,20 @@ DEV int obs_dim(const TreeTask& T) { return 3 * T.npos + 2 * T.nvel; }
 DEV void write_obs(const TreeTask& T, const TreeLDS& L, const TreeEnvBuffers& E, int e, int sc, bool first, float* obs) {
   int lane = wave_lane(), N = T.n_envs, D = obs_dim(T);
   float* o = obs + (size_t)e * D;
-  int slot = first ? 0 : (sc - 1) % T_RING;
+  int slot = (first || T.jdelay == 0) ? 0 : (sc - 1) % T.jdelay;
   if (lane < T.npos) {
     float v = L.qpos[T.obs_qposadr[lane]], c = L.ctrl[lane];
     if (T.obs_is_gripper[lane]) { v = convert_gripper(v, T.grip[0], T.grip[1], T.grip[4], T.grip[5]); c = convert_gripper(c, T.grip[2], T.grip[3], T.grip[4], T.grip[5]); }
     size_t ri = ((size_t)slot * T.npos + lane) * N + e;
-    float delayed = E.ring_pos[ri];
-    if (!first) E.ring_pos[ri] = v;
+    float delayed = T.jdelay > 0 ? E.ring_pos[ri] : v;
+    if (!first && T.jdelay > 0) E.ring_pos[ri] = v;
     o[lane] = delayed; o[T.npos + T.nvel + lane] = v; o[2 * T.npos + 2 * T.nvel + lane] = c;
   }
   if (lane < T.nvel) {
     float v = L.qvel[lane];
     size_t ri = ((size_t)slot * T.nvel + lane) * N + e;
-    float delayed = E.ring_vel[ri];
-    if (!first) E.ring_vel[ri] = v;
+    float delayed = T.jdelay > 0 ? E.ring_vel[ri] : v;
+    if (!first && T.jdelay > 0) E.ring_vel[ri] = v;
     o[T.npos + lane] = delayed; o[2 * T.npos + T.nvel + lane] = v;
   }
 }

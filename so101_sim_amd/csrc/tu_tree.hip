@@ -130,12 +130,7 @@ __global__ void __launch_bounds__(64) k_tree_begin(const TreeModel* tm, TreeTask
   BLOCK_SHARED(TreeLDS, L);
   int e = blockIdx.x, lane = wave_lane(), N = T.n_envs;
   tree::load_state(tm, L, B, e, N);
-  if (lane < T.npos) {
-    float v = L.qpos[T.obs_qposadr[lane]];
-    if (T.obs_is_gripper[lane]) v = tree::convert_gripper(v, T.grip[0], T.grip[1], T.grip[4], T.grip[5]);
-    for (int r = 0; r < T_RING; r++) E.ring_pos[((size_t)r * T.npos + lane) * N + e] = v;
-  }
-  if (lane < T.nvel) for (int r = 0; r < T_RING; r++) E.ring_vel[((size_t)r * T.nvel + lane) * N + e] = L.qvel[lane];
+  tree::fill_delay_lines(tm, T, L, E, e);
   if (lane == 0) { E.step_count[e] = 0; E.ep_return[e] = 0.f; E.need_reset[e] = 0; E.success_state[e] = T.requires_handover ? 0 : 2; }
 }
 
@@ -186,6 +181,7 @@ __global__ void __launch_bounds__(64) k_tree_step(const TreeModel* tm, const Dev
   int sc = E.step_count[e] + 1;
   tree::kinematics(tm, L);
   tree::write_obs(T, L, E, e, sc, false, obs);
+  tree::write_physics_state(tm, T, L, E, e, sc);
   float r = 0.f;
   if (!diverged) {
     if (T.reward_mode == 0) r = tree::task_reward(tm, T, L);
@@ -523,6 +519,15 @@ int so101_tree_bind_env(so101_tree* s, float* ring_pos, float* ring_vel, float* 
   return SO101_OK;
 }
 
+int so101_tree_bind_physics_state(so101_tree* s, float* ring, float* physics_state, float* delayed) {
+  if (!s) return SO101_ERR_ARG;
+  if (!s->has_task) { s->err = "so101_tree_bind_physics_state: the model carries no task (bare-arm blob)"; return SO101_ERR_STATE; }
+  bool all = ring && physics_state && delayed, none = !ring && !physics_state && !delayed;
+  if (!all && !none) { s->err = "so101_tree_bind_physics_state: all three buffers or none"; return SO101_ERR_ARG; }
+  s->env.ps_ring = ring; s->env.ps_out = physics_state; s->env.ps_delayed = delayed;
+  return SO101_OK;
+}
+
 int so101_tree_configure_env(so101_tree* s, const so101_tree_config* c) {
   if (!s || !c) return SO101_ERR_ARG;
   if (c->n_substeps < 1 || c->n_substeps > 1000 || c->last_step < 1 || c->settle_max_substeps < 0) { s->err = "so101_tree_configure_env: value out of range"; return SO101_ERR_ARG; }
@@ -532,6 +537,10 @@ int so101_tree_configure_env(so101_tree* s, const so101_tree_config* c) {
   if (c->reward_mode != 0 && c->reward_mode != 1) { s->err = "so101_tree_configure_env: reward_mode must be 0 or 1"; return SO101_ERR_ARG; }
   if (c->reward_mode == 1 && !s->hm.geom_class) { s->err = "so101_tree_configure_env: the model blob carries no task_geom_class (contact-sequence reward)"; return SO101_ERR_STATE; }
   T.reward_mode = c->reward_mode; T.requires_handover = c->reward_requires_handover;
+  // observation delays in control steps; negative = the reference's defaults (0.1 s and 0.3 s at a 0.02 s control step)
+  int jd = c->joints_delay_steps < 0 ? T_RING_DEFAULT : c->joints_delay_steps, pd = c->physics_delay_steps < 0 ? T_PS_DEFAULT : c->physics_delay_steps;
+  if (jd > T_DELAY_MAX || pd > T_DELAY_MAX) { s->err = "so101_tree_configure_env: observation delay above 64 control steps"; return SO101_ERR_ARG; }
+  T.jdelay = jd; T.pdelay = pd;
   return so101_tree_configure(s, c->solver_iterations, c->solver_tolerance);
 }
 

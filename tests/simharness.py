@@ -284,12 +284,18 @@ class TreeArraySim:
         else:
             z = lambda *sh, dt=np.float32: np.zeros(sh, dtype=dt)
             i32, u8 = np.int32, np.uint8
-        self.ring_pos, self.ring_vel = z(5, s.nu, N), z(5, 16, N)
+        jd = cfg.get("joints_delay_steps", -1); jd = 5 if jd < 0 else jd
+        pd = cfg.get("physics_delay_steps", -1); pd = 15 if pd < 0 else pd
+        self.ring_pos, self.ring_vel = z(max(jd, 1), s.nu, N), z(max(jd, 1), 16, N)
         self.ep_return, self.step_count, self.episode = z(N), z(N, dt=i32), z(N, dt=i32)
         self.action, self.obs = z(N, s.nu), z(N, s.obs_dim)
         self.reward_, self.discount, self.step_type = z(N), z(N), z(N, dt=u8)
         p = self.ptr
         s.bind_env(p(self.ring_pos), p(self.ring_vel), p(self.ep_return), p(self.step_count), p(self.episode))
+        if cfg.pop("physics_state", False):
+            D = s.nq + s.nv
+            self.ps_ring, self.physics_state, self.delayed_physics_state = z(max(pd, 1), D, N), z(N, D), z(N, D)
+            s.bind_physics_state(p(self.ps_ring), p(self.physics_state), p(self.delayed_physics_state))
         s.configure_env(**cfg)
 
     def reset(self):

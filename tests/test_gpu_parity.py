@@ -20,7 +20,7 @@ def test_native_library_is_the_hip_build():
     import os
     from so101_sim_amd import native
     assert os.path.exists(native.LIB_PATH)
-    assert native.load_library().so101_version() == 8
+    assert native.load_library().so101_version() == 9
 
 
 def test_forward_stages(make_sim, blobs):

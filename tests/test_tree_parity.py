@@ -249,6 +249,80 @@ def test_python_dropin_api_of_the_aloha_hand_over(n_envs):
     env.close()
 
 
+def check_delay_lines(backend, n, steps, jd, pd, last_step, settle=2, n_substeps=10):
+    """Observation delays as configure-time parameters (so101_tree_config.joints_delay_steps / physics_delay_steps) and the
+    device-side physics_state line (so101_tree_bind_physics_state): joints_pos / joints_vel of control step k are the undelayed
+    values of step k - jd, delayed_physics_state the physics_state of step k - pd, both padded with the reset state and refilled
+    by the auto-reset inside a step call - replayed on the host, bit for bit."""
+    raw64, raw32 = _blobs("banana")
+    sim = TreeArraySim(raw32, n, backend=backend)
+    sim.enable_env(seed=5, last_step=last_step, settle_max_substeps=settle, n_substeps=n_substeps, joints_delay_steps=jd, physics_delay_steps=pd, physics_state=True)
+    rng = np.random.RandomState(1)
+    hist_j, hist_p = [[] for _ in range(n)], [[] for _ in range(n)]
+    resets = 0
+    for k in range(steps):
+        a = np.tile(np.concatenate([scenes.ALOHA_HOME_CTRL] * 2), (n, 1)) + 0.2 * rng.normal(size=(n, 14))
+        obs, r, d, st = sim.step(a)
+        q, v, _ = sim.get_state()
+        ps, dps = sim._get(sim.physics_state), sim._get(sim.delayed_physics_state)
+        np.testing.assert_array_equal(ps, np.concatenate([q, v]).T.astype(np.float32))          # physics_state = qpos | qvel of this step
+        for e in range(n):
+            if st[e] == 0:                                                                       # FIRST: the lines restart, padded with the reset state
+                hist_j[e], hist_p[e] = [], []
+                resets += 1
+            und = np.concatenate([obs[e, 30:44], obs[e, 44:60]])
+            hist_j[e].append(und); hist_p[e].append(ps[e].copy())
+            want_j = hist_j[e][max(len(hist_j[e]) - 1 - jd, 0)]
+            want_p = hist_p[e][max(len(hist_p[e]) - 1 - pd, 0)]
+            np.testing.assert_array_equal(np.concatenate([obs[e, 0:14], obs[e, 14:30]]), want_j, err_msg=f"joints line, step {k} env {e}")
+            np.testing.assert_array_equal(dps[e], want_p, err_msg=f"physics-state line, step {k} env {e}")
+    assert resets >= 2 * n                                                                      # the first call and at least one auto-reset per env
+
+
+def test_emulated_delay_lines():
+    check_delay_lines("emu", 1, 5, jd=1, pd=2, last_step=2, n_substeps=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("jd,pd", [(5, 15), (1, 1), (0, 0), (2, 3)])
+def test_observation_delays_are_configure_time_parameters(jd, pd):
+    check_delay_lines("gpu", 8, 40, jd=jd, pd=pd, last_step=17, settle=50)
+
+
+@pytest.mark.gpu
+def test_environment_with_delay():
+    """aloha2_task_test.py:136-173 through the Python surface: a task built with image_observation_delay_secs = 0.02 (one control
+    step at 50 Hz) - after reset() the first step's delayed_physics_state equals the reset's physics_state, the second step's equals
+    the first step's physics_state, bit for bit (the camera half of that test needs a renderer and is out of scope)."""
+    from so101_sim_amd import aloha
+    task = aloha.HandOverTask("banana", control_timestep=0.02, cameras=("overhead_cam",), image_observation_enabled=True, image_observation_delay_secs=0.02)
+    assert (task.joints_delay_steps, task.physics_delay_steps) == (5, 1)
+    env = aloha.AlohaEnvironment(task, n_envs=1, random_state=np.random.RandomState(seed=123), settle_max_substeps=100)
+    ts = env.reset()
+    assert "physics_state" in ts.observation
+    initial = ts.observation["physics_state"].copy()
+    action = np.zeros(env.action_spec().shape)
+    ts = env.step(action)
+    first = ts.observation["physics_state"].copy()
+    np.testing.assert_array_equal(ts.observation["delayed_physics_state"], initial)
+    ts1 = env.step(action)
+    np.testing.assert_array_equal(ts1.observation["delayed_physics_state"], first)
+    assert not np.array_equal(first, initial)
+    env.close()
+    # no delay at all: the reference then creates no undelayed_* / delayed_* copies (aloha2_task.py:236-251), and joints_pos is the current value
+    task0 = aloha.HandOverTask("banana", joints_observation_delay_secs=0.0, image_observation_delay_secs=0.0)
+    env0 = aloha.AlohaEnvironment(task0, n_envs=4, random_state=1, settle_max_substeps=100, physics_state=True)
+    assert list(env0.observation_spec().keys()) == ["commanded_joints_pos", "joints_pos", "joints_vel", "physics_state"]
+    env0.reset()
+    a = np.tile(np.concatenate([scenes.ALOHA_HOME_CTRL] * 2), (4, 1)).astype(np.float32); a[:, 1] += 0.3
+    ts = env0.step(a)
+    assert list(ts.observation.keys()) == ["commanded_joints_pos", "joints_pos", "joints_vel", "physics_state"]
+    np.testing.assert_array_equal(ts.observation["joints_pos"].cpu().numpy(), env0.obs[:, 30:44].cpu().numpy())
+    env0.close()
+    with pytest.raises(ValueError):
+        aloha.HandOverTask("banana", joints_observation_delay_secs=0.03)          # not a whole number of control steps
+
+
 @pytest.mark.gpu
 def test_aloha_episode_properties_over_a_full_time_limit():
     """512 ALOHA hand-over envs under uniform random actions over the whole action spec for one 10 s episode and the start of the
