@@ -34,7 +34,7 @@ EXPORTS = (
     "so101_get_returns", "so101_get_diag", "so101_get_events", "so101_debug_forward", "so101_debug_candidates", "so101_debug_stages", "so101_get_info", "so101_debug_chain_stats", "so101_last_error",
     "so101_tree_create", "so101_tree_destroy", "so101_tree_dims", "so101_tree_bind_state", "so101_tree_configure", "so101_tree_physics",
     "so101_tree_debug_forward", "so101_tree_get_diag", "so101_tree_last_error", "so101_tree_obs_dim", "so101_tree_bind_env",
-    "so101_tree_configure_env", "so101_tree_reset", "so101_tree_step", "so101_tree_begin_episode", "so101_tree_settle", "so101_tree_compute_settled", "so101_tree_set_settled_store",
+    "so101_tree_configure_env", "so101_tree_bind_physics_state", "so101_tree_reset", "so101_tree_step", "so101_tree_begin_episode", "so101_tree_settle", "so101_tree_compute_settled", "so101_tree_set_settled_store",
 )
 
 
