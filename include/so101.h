@@ -253,13 +253,17 @@ const char* so101_last_error(const so101_sim* sim);
 /* ---- general-tree engine (csrc/so101_tree.hpp): models outside the SO100 topology - the ALOHA hand-over scenes of
  * so101_sim/tasks/hand_over.py (two 8-dof arms with slide fingers coupled by joint equalities, position actuators, joint
  * damping; reference model so101_sim/assets/aloha/aloha_pbr.xml).  The blob is the f32 blob of
- * so101_sim_amd.model.scenes.compile_aloha_scene; limits: 32 bodies, 32 dofs, 16 actuators, 128 geoms, 64 contacts.
+ * so101_sim_amd.model.scenes.compile_aloha_scene / compile_dining_scene; limits: 32 bodies, 16 actuators and, per build, 32 dofs /
+ * 128 geoms / 64 contacts / 384 rows (ALOHA hand-over) or 64 dofs / 256 geoms / 128 contacts / 768 rows (Dining).
  * Physics entry points only so far (what dm_control's physics.step() does for these scenes); same conventions as above:
  * device pointers, env-fastest struct-of-arrays state [dim][n_envs], asynchronous on `hip_stream`. */
 typedef struct so101_tree so101_tree;
 int so101_tree_create(const void* model_blob, size_t blob_bytes, int n_envs, int hip_device, so101_tree** out);
 void so101_tree_destroy(so101_tree* sim);
-/* dims[7] = nq, nv, nu, nbody, ngeom, floats per env of so101_tree_debug_forward, contact capacity */
+/* dims[16] = nq, nv, nu, nbody, ngeom, floats per env of so101_tree_debug_forward, contact capacity; then the layout of that row for the
+ * handle's build - offsets of bias, qacc_smooth, qacc, body positions, mass matrix, contacts, normal forces, the row stride of the mass
+ * matrix - and the build itself (32 or 64: so101_tree_create takes the 32-dof / 128-geom / 64-contact build whenever the model fits it,
+ * otherwise the 64-dof / 256-geom / 128-contact one of the Dining scenes) */
 int so101_tree_dims(const so101_tree* sim, int* dims);
 int so101_tree_bind_state(so101_tree* sim, float* qpos, float* qvel, float* ctrl, float* warmstart);
 /* solver_iterations <= 0 / solver_tolerance < 0 keep the model's (100, 1e-8) */
@@ -268,8 +272,9 @@ int so101_tree_configure(so101_tree* sim, int solver_iterations, float solver_to
  * bound state, ctrl as bound */
 int so101_tree_physics(so101_tree* sim, int n_substeps, void* hip_stream);
 /* forward dynamics at the bound state without integrating; out[n_envs][dims[5]] floats: counts (contacts, rows, solver
- * iterations, candidates, flags, scalar rows) at 0, bias at 8, qacc_smooth at 40, qacc at 72, body positions at 104,
- * mass matrix [32][32] at 200, contacts [64][10] (position, normal, distance, geom1, geom2, condim) at 1224, normal forces at 1864 */
+ * iterations, candidates, flags, scalar rows) at 0, then bias, qacc_smooth, qacc, body positions, the mass matrix, contacts [.][10]
+ * (position, normal, distance, geom1, geom2, condim) and normal forces at the offsets so101_tree_dims reports (32-dof build: 8, 40, 72,
+ * 104, 200 [32][32], 1224, 1864) */
 int so101_tree_debug_forward(so101_tree* sim, float* out, void* hip_stream);
 /* out[n_envs][8] int32 of the last so101_tree_physics / so101_tree_step / so101_tree_reset: contacts, rows, solver iterations,
  * candidates, flags (1 candidate overflow, 2 contact overflow, 4 row overflow: contacts dropped, 8 physics diverged, 16 container
@@ -293,7 +298,8 @@ typedef struct {
   int solver_iterations;     /* <= 0: the model's */
   float solver_tolerance;    /* < 0: the model's */
   uint64_t seed, env_id_base;
-  int reward_mode;           /* 0 overlap boxes (HandOver's default), 1 contact sequence (reward_based_on_overlap = False, hand_over.py:286-338) */
+  int reward_mode;           /* 0 overlap boxes (HandOver's default; Dining 'bbox'), 1 contact sequence (reward_based_on_overlap = False,
+                                hand_over.py:286-338), 2 object touches receptacle (Dining 'contact', dining_place_in_container.py:126-154) */
   int reward_requires_handover;   /* mode 1: start the sequence at "right gripper touches the object" instead of at its last state */
   int joints_delay_steps;    /* delay of joints_pos / joints_vel in CONTROL steps (joints_observation_delay_secs / control_timestep,
                                 aloha2_task.py:153-155,236-243); < 0: the reference's default 5 (0.1 s); 0: undelayed; at most 64 */

@@ -30,13 +30,17 @@ def convert_gripper(v, a, b):
 
 class AlohaOracleEnv:
     def __init__(self, blob_f64: bytes, seed=0, env_id=0, last_step=1 << 30, settle_max_substeps=1000, reward_based_on_overlap=True,
-                 reward_requires_handover=False, geom_class=None, bodies=None, dist_threshold=0.0, n_substeps=10):
+                 reward_requires_handover=False, geom_class=None, bodies=None, dist_threshold=0.0, n_substeps=10, reward_touching=False,
+                 prop_dofadr=(16, 22)):
         """geom_class / bodies = (object body, container body) / dist_threshold: the model's task_geom_class, task bodies and
-        task_dist_threshold, needed by the contact-sequence reward only"""
+        task_dist_threshold, needed by the contact-sequence reward only.  reward_touching: the 'contact' reward of the Dining tasks
+        (dining_place_in_container.py:126-154) - 1 when a geom of the object (class 1) touches a geom of the receptacle (class 2) and
+        neither prop moves; prop_dofadr = first dof of (object, receptacle)."""
         self.o = Oracle(blob_f64)
         self.overlap, self.requires_handover = reward_based_on_overlap, reward_requires_handover
         self.geom_class, self.bodies, self.dist_threshold = geom_class, bodies, dist_threshold
         self.success_state = 2
+        self.touching, self.prop_dofadr = reward_touching, prop_dofadr
         self.n_substeps = n_substeps      # physics steps per control step (10 in the reference; the emulated CPU tests shorten it)
         self.o.env_config(seed=seed, env_id=env_id, settle_max_substeps=settle_max_substeps)
         self.last_step = last_step
@@ -97,6 +101,21 @@ class AlohaOracleEnv:
                 return 1.0
         return 0.0
 
+    def _touch_reward(self):
+        """dm_control reads physics.data.contact after physics.step(), whose legacy step ends with mj_step1: the contacts of the state
+        AFTER the last substep (forward() recomputes them there)."""
+        v = self.o.get_state()[1]
+        a, b = self.prop_dofadr
+        if max(np.abs(v[a:a + 3]).max(), np.abs(v[b:b + 3]).max()) >= 1e-3:        # any_props_moving: linear velocities only
+            return 0.0
+        self.o.forward()
+        cls = self.geom_class
+        for c in self.o.contacts():
+            c1, c2 = int(cls[c["geom1"]]), int(cls[c["geom2"]])
+            if ((c1 & 1) and (c2 & 2)) or ((c2 & 1) and (c1 & 2)):
+                return 1.0
+        return 0.0
+
     def step(self, action):
         """-> obs, reward, discount, step_type"""
         if self.need_reset:
@@ -109,7 +128,7 @@ class AlohaOracleEnv:
         self.step_count += 1
         dp, dv = self.ring_pos[0], self.ring_vel[0]          # the value of control step k - 5
         self.ring_pos.append(self._pos()); self.ring_vel.append(self._vel())
-        r = 0.0 if diverged else (float(self.o.reward()) if self.overlap else self._contact_reward())
+        r = 0.0 if diverged else (self._touch_reward() if self.touching else (float(self.o.reward()) if self.overlap else self._contact_reward()))
         success, timeout = r >= 1.0 or bool(diverged), self.step_count >= self.last_step
         st = 2 if (success or timeout) else 1
         self.need_reset = st == 2

@@ -145,6 +145,9 @@ struct Model {
   // task
   int obj_body, con_body, nbox;
   std::vector<real> box_pos, box_half, obj_lo, obj_hi, obj_yaw, con_lo, con_hi, home_ctrl;
+  int task_kind = 0;                                // 1: the Dining scene (tasks/base/dining.py:162-267)
+  std::vector<int> prop_bodies;                     // [6] in placer order plate, bowl, container, mug, pen, banana
+  std::vector<real> region_lo, region_hi;           // [6][3] top left / middle / right, bottom left / middle / right
 };
 
 struct Contact {
@@ -1608,13 +1611,31 @@ void env_reset(orc_sim* s) {
   } else
   for (int k = 0; k < 6; k++) { s->ctrl[k] = m.home_ctrl[k] + s->cfg.offsets[k]; s->cmd[k] = s->ctrl[k]; }
   int qo = m.body_qposadr[m.obj_body], qc = m.body_qposadr[m.con_body];
+  if (m.task_kind == 1) {
+    // Dining (dining.py:162-267): six region samples (three uniforms each), the top three regions shuffled among plate / bowl / container
+    // and the bottom three among mug / pen / banana (counter RNG: one of the six orders each; a single env of the product draws numpy's
+    // shuffle on the host instead), a uniform yaw per prop in placer order; collisions ignored, then settled
+    real smp[6][3];
+    for (int r = 0; r < 6; r++) for (int k = 0; k < 3; k++) smp[r][k] = U(m.region_lo[3 * r + k], m.region_hi[3 * r + k]);
+    static const int perm[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+    // (the index is taken from the 24-bit draw in single precision, as the kernels do: u * 6 rounds identically)
+    int pt = (int)((float)U(0, 1) * 6.0f), pb = (int)((float)U(0, 1) * 6.0f);
+    pt = std::min(pt, 5); pb = std::min(pb, 5);
+    for (int p = 0; p < 6; p++) {
+      int region = p < 3 ? perm[pt][p] : 3 + perm[pb][p - 3], qa = m.body_qposadr[m.prop_bodies[p]];
+      real yaw = U(m.obj_yaw[0], m.obj_yaw[1]);
+      for (int k = 0; k < 3; k++) s->qpos[qa + k] = smp[region][k];
+      s->qpos[qa + 3] = std::cos(0.5 * yaw); s->qpos[qa + 4] = 0; s->qpos[qa + 5] = 0; s->qpos[qa + 6] = std::sin(0.5 * yaw);
+    }
+  } else {
   // object: position then yaw (so100_hand_over.py:209-214), collisions ignored
   for (int k = 0; k < 3; k++) s->qpos[qo + k] = U(m.obj_lo[k], m.obj_hi[k]);
   real yaw = U(m.obj_yaw[0], m.obj_yaw[1]);
   s->qpos[qo + 3] = std::cos(0.5 * yaw); s->qpos[qo + 4] = 0; s->qpos[qo + 5] = 0; s->qpos[qo + 6] = std::sin(0.5 * yaw);
   s->qpos[qc + 3] = 1;
+  }
   // container: rejection-sampled until none of its geoms is in penetrating contact (<=20 tries)
-  for (int attempt = 0; attempt < 20; attempt++) {
+  for (int attempt = 0; attempt < (m.task_kind == 1 ? 0 : 20); attempt++) {
     for (int k = 0; k < 3; k++) s->qpos[qc + k] = U(m.con_lo[k], m.con_hi[k]);
     kinematics(s); collision(s);
     bool hit = false;
@@ -1676,6 +1697,8 @@ orc_sim* orc_create(const void* blob, size_t bytes) {
   m.box_pos = b.R("task_box_pos"); m.box_half = b.R("task_box_half"); m.obj_lo = b.R("task_obj_pos_lo");
   m.obj_hi = b.R("task_obj_pos_hi"); m.obj_yaw = b.R("task_obj_yaw"); m.con_lo = b.R("task_con_pos_lo");
   m.con_hi = b.R("task_con_pos_hi"); m.home_ctrl = b.R("task_home_ctrl");
+  if (b.has("task_kind")) m.task_kind = b.i("task_kind");
+  if (m.task_kind == 1) { m.prop_bodies = b.I("task_prop_bodies"); m.region_lo = b.R("task_region_lo"); m.region_hi = b.R("task_region_hi"); }
   s->qpos.assign(m.nq, 0); s->qvel.assign(m.nv, 0); s->ctrl.assign(m.nu, 0); s->warm.assign(m.nv, 0);
   s->qacc.assign(m.nv, 0); s->qacc_smooth.assign(m.nv, 0);
   for (int f = 0; f < m.nfree; f++) s->qpos[m.body_qposadr[m.free_body[f]] + 3] = 1;

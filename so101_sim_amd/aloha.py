@@ -60,6 +60,15 @@ class HandOverTask:
         self.physics_delay_steps = self._delay_steps(self.image_observation_delay_secs, "image_observation_delay_secs")
         self._instruction = scenes.ALOHA_INSTRUCTIONS[object_name]
 
+    scene = "hand_over"
+
+    def load_blob(self, real: str):
+        return scenes.load_aloha_blob(self.object_name, real)
+
+    @property
+    def reward_mode(self) -> int:          # so101_tree_config.reward_mode
+        return 0 if self.reward_based_on_overlap else 1
+
     def _delay_steps(self, secs: float, name: str) -> int:
         steps = secs / self.control_timestep
         if secs < 0 or abs(steps - round(steps)) > 1e-9 or round(steps) > 64:
@@ -68,6 +77,45 @@ class HandOverTask:
 
     def get_instruction(self):
         return self._instruction
+
+
+class DiningPlaceInContainerTask(HandOverTask):
+    """Host-side description of `DiningPlaceInContainer` (tasks/dining_place_in_container.py:26-160) on the `Dining` scene
+    (tasks/base/dining.py:39-267): the ALOHA robot and six free props (mug, pen, banana, plate, bowl, container); `task_id` names the
+    object / receptacle pair and its reward - 'banana' (into the bowl) and 'pen' (into the white cup): overlap boxes; 'mug' (onto the
+    plate): the mug touches the plate while neither moves."""
+
+    scene = "dining"
+
+    def __init__(self, task_id: str = "banana", **kwargs):
+        if task_id not in scenes.DINING_TASKS:
+            raise ValueError(f"Unknown task ID: {task_id}")                    # dining_place_in_container.py:83-84
+        cfg = scenes.DINING_TASKS[task_id]
+        self.task_id = task_id
+        self.object_name = cfg["object"]
+        self.receptacle_name = cfg["receptacle"]
+        self.reward_type = cfg["reward"]
+        self.reward_based_on_overlap = cfg["reward"] == "bbox"
+        self.reward_requires_handover = False
+        self.control_timestep = float(kwargs.pop("control_timestep", DEFAULT_CONTROL_TIMESTEP))
+        self.cameras = tuple(kwargs.pop("cameras", ()))
+        self.image_observation_enabled = bool(kwargs.pop("image_observation_enabled", True))
+        self.terminate_episode = bool(kwargs.pop("terminate_episode", True))
+        self.waist_joint_limit = float(kwargs.pop("waist_joint_limit", np.pi / 2))
+        if float(kwargs.pop("table_height_offset", scenes.ALOHA_TABLE_HEIGHT_OFFSET)) != scenes.ALOHA_TABLE_HEIGHT_OFFSET:
+            raise NotImplementedError("the model blob is compiled for table_height_offset = 0.011 (aloha2_task.py:107)")
+        self.joints_observation_delay_secs = float(kwargs.pop("joints_observation_delay_secs", DEFAULT_JOINTS_DELAY_SECS))
+        self.image_observation_delay_secs = float(kwargs.pop("image_observation_delay_secs", DEFAULT_PHYSICS_DELAY_SECS))
+        self.joints_delay_steps = self._delay_steps(self.joints_observation_delay_secs, "joints_observation_delay_secs")
+        self.physics_delay_steps = self._delay_steps(self.image_observation_delay_secs, "image_observation_delay_secs")
+        self._instruction = cfg["instruction"]
+
+    def load_blob(self, real: str):
+        return scenes.load_dining_blob(self.task_id, real)
+
+    @property
+    def reward_mode(self) -> int:
+        return scenes.DINING_REWARD_MODE[self.reward_type]
 
 
 def aloha_action_spec(ctrlrange: np.ndarray, waist_joint_limit: float = np.pi / 2) -> BoundedArray:
@@ -107,12 +155,15 @@ class AlohaEnvironment:
         else:
             seed = int(random_state)
         self.seed = seed
-        blob, self.meta = scenes.load_aloha_blob(task.object_name, "f32")
+        blob, self.meta = task.load_blob("f32")
         m = blobfmt.unpack(blob)
         self._ctrlrange = np.asarray(m["act_ctrlrange"], dtype=np.float64).reshape(-1, 2)
         con_body, obj_body = int(np.asarray(m["task_container_body"]).ravel()[0]), int(np.asarray(m["task_object_body"]).ravel()[0])
         qadr = np.asarray(m["body_qposadr"])
-        m64 = blobfmt.unpack(scenes.load_aloha_blob(task.object_name, "f64")[0])      # (the distributions' bounds unrounded: the draws must be the reference's, bit for bit)
+        m64 = blobfmt.unpack(task.load_blob("f64")[0])      # (the distributions' bounds unrounded: the draws must be the reference's, bit for bit)
+        if task.scene == "dining":
+            self._dining = dict(lo=np.asarray(m64["task_region_lo"], dtype=np.float64).reshape(6, 3), hi=np.asarray(m64["task_region_hi"], dtype=np.float64).reshape(6, 3),
+                                qadr=[int(qadr[b]) for b in np.asarray(m["task_prop_bodies"]).ravel()])
         self._placer = dict(obj_lo=np.asarray(m64["task_obj_pos_lo"], dtype=np.float64), obj_hi=np.asarray(m64["task_obj_pos_hi"], dtype=np.float64),
                             yaw=np.asarray(m64["task_obj_yaw"], dtype=np.float64), con_lo=np.asarray(m64["task_con_pos_lo"], dtype=np.float64),
                             con_hi=np.asarray(m64["task_con_pos_hi"], dtype=np.float64), qo=int(qadr[obj_body]), qc=int(qadr[con_body]),
@@ -125,7 +176,7 @@ class AlohaEnvironment:
             self.sim = native.TreeSim(blob, N, device=self.device.index or 0, lib_path=_build.build(mpr=True) if narrowphase == "mpr" else None)
         s = self.sim
         if (s.nu, s.obs_dim) != (NPOS, 3 * NPOS + 2 * NVEL):
-            raise RuntimeError("unexpected model dimensions for an ALOHA hand-over scene")
+            raise RuntimeError("unexpected model dimensions for an ALOHA scene")
         z = lambda *sh, dt=torch.float32: torch.zeros(*sh, dtype=dt, device=self.device)
         self.qpos, self.qvel, self.ctrl, self.warm = z(s.nq, N), z(s.nv, N), z(s.nu, N), z(s.nv, N)
         jd, pd = task.joints_delay_steps, task.physics_delay_steps
@@ -142,7 +193,7 @@ class AlohaEnvironment:
         s.configure_env(n_substeps=nsub, last_step=self.last_step, settle_max_substeps=int(settle_max_substeps),
                         terminate_on_success=int(task.terminate_episode), solver_iterations=int(solver_iterations),
                         solver_tolerance=float(solver_tolerance), seed=seed, env_id_base=int(env_id_base),
-                        reward_mode=0 if task.reward_based_on_overlap else 1, reward_requires_handover=int(task.reward_requires_handover),
+                        reward_mode=task.reward_mode, reward_requires_handover=int(task.reward_requires_handover),
                         joints_delay_steps=jd, physics_delay_steps=pd)
         # physics_state / delayed_physics_state (aloha2_task.py:244-251,441-444): qpos | qvel and its copy of `pd` control steps ago,
         # from a device-side delay line the step / reset kernels maintain.  The reference ties them to image_observation_enabled;
@@ -221,14 +272,47 @@ class AlohaEnvironment:
             self._dbg = self.torch.zeros(1, self.sim.debug_dim, device=self.device)
         self.sim.debug_forward(self._dbg.data_ptr(), self._stream())
         r = self._dbg[0].cpu().numpy()
-        D = native.TREE_DBG
+        D = self.sim.dbg
         for k in range(int(r[D["COUNTS"]])):
             if int(r[D["CON"] + 10 * k + 7]) in self._placer["con_geoms"] or int(r[D["CON"] + 10 * k + 8]) in self._placer["con_geoms"]:
                 return True
         return False
 
+    def _reset_seed_compatible_dining(self):
+        """Dining._sample_props + the two PropPlacers (dining.py:162-267) with numpy's generator, in the reference's order: six region
+        samples `uniform(low, high)` (top left / middle / right, bottom left / middle / right: three numbers each), `shuffle` of the top and
+        of the bottom ordering, then per prop in the order plate, bowl, container, mug, pen, banana one `uniform(-pi, pi)` yaw (positions
+        come from a deterministic Sequence); collisions ignored; settle and episode start by the kernels."""
+        torch, D, rs, s = self.torch, self._dining, self._np_random, self.sim
+        samples = [rs.uniform(low=D["lo"][r], high=D["hi"][r]) for r in range(6)]
+        top, bottom = [0, 1, 2], [3, 4, 5]
+        rs.shuffle(top)
+        rs.shuffle(bottom)
+        regions = [top[0], top[1], top[2], bottom[0], bottom[1], bottom[2]]          # plate, bowl, container, mug, pen, banana
+        q = np.zeros(s.nq)
+        q[:16] = np.concatenate([scenes.ALOHA_HOME_QPOS, scenes.ALOHA_HOME_QPOS])
+        yaws = []
+        for p in range(6):
+            yaw = rs.uniform(-np.pi, np.pi)
+            a = D["qadr"][p]
+            q[a:a + 3] = samples[regions[p]]
+            q[a + 3:a + 7] = [np.cos(0.5 * yaw), 0.0, 0.0, np.sin(0.5 * yaw)]
+            yaws.append(float(yaw))
+        self.ctrl.copy_(torch.as_tensor(np.concatenate([scenes.ALOHA_HOME_CTRL, scenes.ALOHA_HOME_CTRL]), dtype=torch.float32, device=self.device).unsqueeze(1))
+        self.qpos.copy_(torch.as_tensor(q, dtype=torch.float32, device=self.device).unsqueeze(1))
+        self.qvel.zero_(); self.warm.zero_()
+        self.placements = dict(zip(scenes.DINING_PLACER_ORDER, [dict(position=samples[regions[p]].copy(), yaw=yaws[p], region=int(regions[p])) for p in range(6)]))
+        s.settle(self._stream())
+        s.begin_episode(self._stream())
+        self.episode += 1
+        if int(self.diagnostics()[0, 4]) & 32:
+            import warnings
+            warnings.warn("Failed to settle physics within the settle budget (dm_control warns likewise)")
+
     def _reset_seed_compatible(self):
         """placements from numpy's generator in dm_control's PropPlacer order, settle and episode start by the kernels"""
+        if self.task.scene == "dining":
+            return self._reset_seed_compatible_dining()
         torch, P, rs, s = self.torch, self._placer, self._np_random, self.sim
         opos = rs.uniform(P["obj_lo"], P["obj_hi"])
         yaw = rs.uniform(P["yaw"][0], P["yaw"][1])

@@ -7,21 +7,60 @@
 // FIRST GPU path for these scenes, written for parity with the fp64 CPU restatement used by the tests (the same stages in the
 // same order); the SO100 kernels of so101_device.hpp / so101_newton.hpp stay the fast path for the headline workload.
 // The narrowphase (support functions, flat-face scan, MPR, patch contacts) is shared with them.
-#pragma once
 #include "so101_device.hpp"
 
+// Two builds of this file share one library (csrc/tu_tree.hip, csrc/tu_tree64.hip; TREE_VARIANT), each inside its own namespace:
+//   32 (ALOHA hand-over): 32 dofs, 40 positions, 128 geoms, 64 contacts, 384 rows - LDS 31 KB per env;
+//   64 (Dining, SURVEY 8f-4: two arms + six free props = 52 dofs, 240 geoms, ~105 contacts while the props land): 64 dofs, 64
+//      positions, 256 geoms, 128 contacts, 768 rows - LDS 70 KB per env, the Cholesky a call instead of inlined code.
+// so101_tree_create picks the build from the model's dimensions (csrc/tu_tree_api.hip).
+#ifndef TREE_VARIANT
+#define TREE_VARIANT 32
+#endif
+#undef TB
+#undef TV
+#undef TQ
+#undef TU
+#undef TJ
+#undef TE
+#undef TFR
+#undef TCON
+#undef TROW
+#undef TCAND
+#undef TGEOM
+#undef TJS
+#undef TREE_NS
+#undef T_SCRATCH
 #define TB 32          // bodies (world included)
-#define TV 32          // dofs
-#define TQ 40          // generalized positions
 #define TU 16          // actuators
 #define TJ 24          // one-dof joints
 #define TE 4           // joint equalities
 #define TFR 16         // dofs with frictionloss
-#define TCON 64        // contacts per env
-#define TROW 384       // constraint rows per env (6 per contact at most)
-#define TCAND 256      // broadphase candidates per env
-#define TGEOM 128      // collision geoms
-#define TJS 32         // row stride of the constraint Jacobian scratch
+#if TREE_VARIANT == 64
+#define TREE_NS tv64
+#define TV 64          // dofs
+#define TQ 64          // generalized positions
+#define TCON 128       // contacts per env
+#define TROW 768       // constraint rows per env (6 per contact at most)
+#define TCAND 512      // broadphase candidates per env
+#define TGEOM 256      // collision geoms
+#define TJS 64         // row stride of the constraint Jacobian scratch
+#undef TREE_CHOL_DEV
+#define TREE_CHOL_DEV __device__ __attribute__((noinline))      // 64 x 64 unrolled pivot steps: one copy of the code, called from the three sites
+#else
+#define TREE_NS tv32
+#define TV 32
+#define TQ 40
+#define TCON 64
+#define TROW 384
+#define TCAND 256
+#define TGEOM 128
+#define TJS 32
+#undef TREE_CHOL_DEV
+#define TREE_CHOL_DEV DEV
+#endif
+
+namespace TREE_NS {
 
 enum { TJ_NONE = 0, TJ_HINGE = 1, TJ_FREE = 2, TJ_SLIDE = 3 };
 enum { TR_FRICTION = 0, TR_LIMIT = 1, TR_CONTACT = 2, TR_EQUALITY = 3 };
@@ -31,7 +70,7 @@ struct TreeModel {
   float dt, grav[3], impratio, tolerance, meaninertia, pad2;
   int body_parent[TB], body_jnttype[TB], body_qposadr[TB], body_dofadr[TB], body_depth[TB], body_jnt[TB];
   unsigned int body_anc[TB];       // bit a: body a is this body or one of its ancestors
-  unsigned int body_dofs[TB];      // bit d: dof d moves this body
+  unsigned long long body_dofs[TB]; // bit d: dof d moves this body
   float body_pos[TB][3], body_quat[TB][4], body_ipos[TB][3], body_iquat[TB][4], body_mass[TB], body_inertia[TB][3], body_invweight0[TB][2];
   int dof_body[TV], dof_jnt[TV];   // joint index of a one-dof joint, -1 for the dofs of a free body
   float dof_armature[TV], dof_damping[TV], dof_frictionloss[TV], dof_invweight0[TV], dof_solref[TV][2], dof_solimp[TV][5];
@@ -185,7 +224,7 @@ DEV void kinematics(const TreeModel* tm, TreeLDS& L) {
 // ------------------------------------------------------------------ Cholesky: A = L L^T, lower part in place in LDS.  Lane i takes row i into
 // registers; column j of the factor travels between lanes with v_readlane (right-looking: a[i][k] -= L[i][j] L[k][j], j ascending).
 // Entries beyond n are never read back.
-DEV void chol_factor(float (*A)[TV + 1], int n) {
+TREE_CHOL_DEV void chol_factor(float (*A)[TV + 1], int n) {
   int lane = wave_lane(), row = lane < TV ? lane : 0;
   wave_sync();
   float a[TV];
@@ -555,10 +594,9 @@ DEV void make_constraints(const TreeModel* tm, TreeLDS& L, const TreeScratch& G)
   int nscalar = neq + nfric + nlim;
   int ncon = L.ncon;
   // first row of every contact
-  if (lane < ncon) L.cdim[lane] = L.con[lane].dim;
+  for (int c = lane; c < ncon; c += WAVE) L.cdim[c] = L.con[c].dim;
   wave_sync();
-  int crow = nscalar;
-  if (lane < ncon) { for (int k = 0; k < lane; k++) crow += L.cdim[k]; L.con[lane].row = crow; }
+  for (int c = lane; c < ncon; c += WAVE) { int crow = nscalar; for (int k = 0; k < c; k++) crow += L.cdim[k]; L.con[c].row = crow; }
   int nrow = nscalar, keep = 0;
   for (int k = 0; k < ncon; k++) {                     // contacts whose rows do not fit the row capacity are dropped (flag 4)
     if (nrow + L.cdim[k] > TROW) break;
@@ -630,7 +668,7 @@ DEV void make_constraints(const TreeModel* tm, TreeLDS& L, const TreeScratch& G)
       int d = lane;
       float jp[3] = {0.f, 0.f, 0.f}, jr[3] = {0.f, 0.f, 0.f};
       if (d < nv) {
-        bool in1 = (tm->body_dofs[b1] >> d) & 1u, in2 = (tm->body_dofs[b2] >> d) & 1u;
+        bool in1 = (tm->body_dofs[b1] >> d) & 1ull, in2 = (tm->body_dofs[b2] >> d) & 1ull;
         float sgn = (in2 ? 1.f : 0.f) - (in1 ? 1.f : 0.f);
         if (sgn != 0.f) {
           float t[3]; cross3(t, L.S[d], C.pos);
@@ -644,8 +682,8 @@ DEV void make_constraints(const TreeModel* tm, TreeLDS& L, const TreeScratch& G)
       }
     }
   }
-  if (lane < ncon) {
-    TCon& C = L.con[lane];
+  for (int ci = lane; ci < ncon; ci += WAVE) {
+    TCon& C = L.con[ci];
     int row = C.row, dim = C.dim;
     float imp, K, Bc; row_params(tm, C.solref, C.solimp, C.dist, &imp, &K, &Bc);
     float tran = tm->body_invweight0[C.b1][0] + tm->body_invweight0[C.b2][0], rot = tm->body_invweight0[C.b1][1] + tm->body_invweight0[C.b2][1];
@@ -754,8 +792,8 @@ DEV float total_cost(const TreeModel* tm, TreeLDS& L, const TreeScratch& G, bool
     part += scalar_block(G.etype[r], G.eD[r], G.eR[r], G.efl[r], G.ejar[r], &f, &h);
     G.ef[r] = f; G.ejv[r] = h;        // (ejv doubles as the scalar rows' second derivative until the line search fills it)
   }
-  if (lane < ncon) {
-    const TCon& C = L.con[lane];
+  for (int ci = lane; ci < ncon; ci += WAVE) {         // (one pass with at most 64 contacts; the 64-dof build holds up to 128)
+    const TCon& C = L.con[ci];
     int dim = C.dim, row = C.row;
     float r6[6], f6[6], D6[6], Hc[36];
 #pragma unroll
@@ -766,8 +804,8 @@ DEV float total_cost(const TreeModel* tm, TreeLDS& L, const TreeScratch& G, bool
     if (want) {
       bool any = false;
 #pragma unroll
-      for (int k = 0; k < 36; k++) { G.Hc[lane][k] = Hc[k]; any = any || Hc[k] != 0.f; }
-      L.hdim[lane] = any ? dim : 0;          // (0: the block is inactive, nothing to add to the Hessian)
+      for (int k = 0; k < 36; k++) { G.Hc[ci][k] = Hc[k]; any = any || Hc[k] != 0.f; }
+      L.hdim[ci] = any ? dim : 0;          // (0: the block is inactive, nothing to add to the Hessian)
     }
   }
   float cost = wave_sum_f(part);
@@ -876,8 +914,8 @@ DEV void solve_newton(const TreeModel* tm, TreeLDS& L, const TreeScratch& G, int
         scalar_block(G.etype[r], G.eD[r], G.eR[r], G.efl[r], G.ejar[r] + alpha * jv, &f, &h);
         a1 -= f * jv; a2 += jv * h * jv;
       }
-      if (lane < ncon) {
-        const TCon& C = L.con[lane];
+      for (int ci = lane; ci < ncon; ci += WAVE) {
+        const TCon& C = L.con[ci];
         int dim = C.dim, row = C.row;
         float r6[6], f6[6], D6[6], Hc[36], jv6[6];
 #pragma unroll
@@ -976,6 +1014,10 @@ DEV void euler(const TreeModel* tm, TreeLDS& L) {
 struct TreeTask {
   int npos, nvel, obj_body, con_body, nbox, n_substeps, last_step, settle_max, terminate_on_success, n_envs, iterations;
   int jdelay, pdelay;                      // observation delays in control steps (so101_tree_config): joints_pos / joints_vel, delayed_physics_state
+  // kind 1 = the Dining scene (tasks/base/dining.py:162-267): six free props dropped into six table regions, the three top and the three
+  // bottom regions shuffled among (plate, bowl, container) and (mug, pen, banana), a uniform yaw each, no rejection, then settled
+  int kind, prop_body[6];
+  float region_lo[6][3], region_hi[6][3];
   int reward_mode, requires_handover;      // 0 overlap boxes (the default), 1 contact sequence (hand_over.py:286-338)
   float dist_threshold, tolerance, grip[6];    // gripper limits: sim_qpos open, close, sim_ctrl open, close, follower open, close
   int obs_qposadr[TU], obs_is_gripper[TU], act_is_gripper[TU];
@@ -1030,10 +1072,14 @@ DEV float task_reward_contacts(const TreeModel* tm, const TreeTask& T, const Tre
   int lane = wave_lane(), ob = T.obj_body, cb = T.con_body;
   const float* vo = &L.qvel[tm->body_dofadr[ob]]; const float* vc = &L.qvel[tm->body_dofadr[cb]];
   bool moving = fmaxf(fabsf(vo[0]), fmaxf(fabsf(vo[1]), fabsf(vo[2]))) >= 1e-3f || fmaxf(fabsf(vc[0]), fmaxf(fabsf(vc[1]), fabsf(vc[2]))) >= 1e-3f;
-  int c1 = 0, c2 = 0;
-  if (lane < L.ncon) { c1 = tm->geom_class[L.con[lane].g1]; c2 = tm->geom_class[L.con[lane].g2]; }
-  auto touching = [&](int a, int b) { return wave_ballot(((c1 & a) && (c2 & b)) || ((c2 & a) && (c1 & b))) != 0ull; };
-  bool right_obj = touching(8, 1), left_obj = touching(4, 1), obj_con = touching(1, 2);
+  bool t81 = false, t41 = false, t12 = false;
+  for (int c = lane; c < L.ncon; c += WAVE) {
+    int c1 = tm->geom_class[L.con[c].g1], c2 = tm->geom_class[L.con[c].g2];
+    t81 = t81 || ((c1 & 8) && (c2 & 1)) || ((c2 & 8) && (c1 & 1));
+    t41 = t41 || ((c1 & 4) && (c2 & 1)) || ((c2 & 4) && (c1 & 1));
+    t12 = t12 || ((c1 & 1) && (c2 & 2)) || ((c2 & 1) && (c1 & 2));
+  }
+  bool right_obj = wave_ballot(t81) != 0ull, left_obj = wave_ballot(t41) != 0ull, obj_con = wave_ballot(t12) != 0ull;
   int st = *state_io;
   float r = 0.f;
   if (st == 0) { if (right_obj) st = 1; }
@@ -1047,6 +1093,46 @@ DEV float task_reward_contacts(const TreeModel* tm, const TreeTask& T, const Tre
   return r;
 }
 
+// reward 'contact' of the Dining tasks (dining_place_in_container.py:126-154, "put the red mug on the plate"): 1 when a geom of the
+// object touches a geom of the receptacle and neither prop moves (linear velocity, success_detector_utils.py:22-28).  dm_control
+// evaluates it on physics.data.contact after physics.step(), whose legacy step ends with mj_step1: the contacts of the state AFTER the
+// last substep - the caller runs kinematics + collision on the integrated state before calling this.
+DEV float task_reward_touching(const TreeModel* tm, const TreeTask& T, const TreeLDS& L) {
+  int lane = wave_lane(), ob = T.obj_body, cb = T.con_body;
+  const float* vo = &L.qvel[tm->body_dofadr[ob]]; const float* vc = &L.qvel[tm->body_dofadr[cb]];
+  bool moving = fmaxf(fabsf(vo[0]), fmaxf(fabsf(vo[1]), fabsf(vo[2]))) >= 1e-3f || fmaxf(fabsf(vc[0]), fmaxf(fabsf(vc[1]), fabsf(vc[2]))) >= 1e-3f;
+  bool t12 = false;
+  for (int c = lane; c < L.ncon; c += WAVE) {
+    int c1 = tm->geom_class[L.con[c].g1], c2 = tm->geom_class[L.con[c].g2];
+    t12 = t12 || ((c1 & 1) && (c2 & 2)) || ((c2 & 1) && (c1 & 2));
+  }
+  return (!moving && wave_ballot(t12) != 0ull) ? 1.f : 0.f;
+}
+
+// Dining placement (dining.py:162-228): region samples (draws 0-17: three uniforms per region, top left / middle / right, bottom left /
+// middle / right), the two shuffles (draws 18, 19: one of the six orders of three each - the batched envs' counter RNG; a single env
+// draws numpy's shuffle on the host instead), a yaw in [-pi, pi) per prop in placer order plate, bowl, container, mug, pen, banana
+// (draws 20-25).  One lane writes the 42 numbers.
+DEV void dining_place(const TreeModel* tm, const TreeTask& T, TreeLDS& L, unsigned long long env_id, unsigned int episode) {
+  if (wave_lane() == 0) {
+    float smp[6][3];
+    for (int r = 0; r < 6; r++)
+      for (int k = 0; k < 3; k++) smp[r][k] = T.region_lo[r][k] + rng_uniform(T.seed, env_id, episode, 3 * r + k) * (T.region_hi[r][k] - T.region_lo[r][k]);
+    const int perm[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+    int pt = (int)(rng_uniform(T.seed, env_id, episode, 18) * 6.f), pb = (int)(rng_uniform(T.seed, env_id, episode, 19) * 6.f);
+    pt = pt > 5 ? 5 : pt; pb = pb > 5 ? 5 : pb;
+    for (int p = 0; p < 6; p++) {
+      int region = p < 3 ? perm[pt][p] : 3 + perm[pb][p - 3];
+      int qa = tm->body_qposadr[T.prop_body[p]];
+      float yaw = T.obj_yaw[0] + rng_uniform(T.seed, env_id, episode, 20 + p) * (T.obj_yaw[1] - T.obj_yaw[0]);
+      float sn, cs; sincos_f(0.5f * yaw, &sn, &cs);
+      for (int k = 0; k < 3; k++) L.qpos[qa + k] = smp[region][k];
+      L.qpos[qa + 3] = cs; L.qpos[qa + 4] = 0.f; L.qpos[qa + 5] = 0.f; L.qpos[qa + 6] = sn;
+    }
+  }
+  wave_sync();
+}
+
 // env.reset(): arms at the home pose, object and container placed (container by rejection, <= 20 tries), settled with the arms held
 // (aloha2_task.py:369-383, hand_over.py:208-236,340-346).  Same counter-RNG draws as the SO100 reset and the oracle.
 DEV void env_settle(const TreeModel* tm, const DevModel* gm, const TreeTask& T, TreeLDS& L, const TreeScratch& G, int e, unsigned int episode) {
@@ -1057,7 +1143,8 @@ DEV void env_settle(const TreeModel* tm, const DevModel* gm, const TreeTask& T, 
   if (lane < tm->nu) L.ctrl[lane] = T.home_ctrl[lane];
   wave_sync();
   int qo = tm->body_qposadr[T.obj_body], qc = tm->body_qposadr[T.con_body];
-  if (lane == 0) {
+  if (T.kind == 1) dining_place(tm, T, L, env_id, episode);
+  if (T.kind == 0 && lane == 0) {
     for (int k = 0; k < 3; k++) L.qpos[qo + k] = T.obj_lo[k] + rng_uniform(T.seed, env_id, episode, k) * (T.obj_hi[k] - T.obj_lo[k]);
     float yaw = T.obj_yaw[0] + rng_uniform(T.seed, env_id, episode, 3) * (T.obj_yaw[1] - T.obj_yaw[0]);
     float sn, cs; sincos_f(0.5f * yaw, &sn, &cs);
@@ -1065,7 +1152,7 @@ DEV void env_settle(const TreeModel* tm, const DevModel* gm, const TreeTask& T, 
     L.qpos[qc + 3] = 1.f; L.qpos[qc + 4] = 0.f; L.qpos[qc + 5] = 0.f; L.qpos[qc + 6] = 0.f;
   }
   wave_sync();
-  bool placed = false;
+  bool placed = T.kind == 1;                                   // (Dining: ignore_collisions = True, dining.py:246)
   for (int attempt = 0; attempt < 20 && !placed; attempt++) {
     if (lane < 3) L.qpos[qc + lane] = T.con_lo[lane] + rng_uniform(T.seed, env_id, episode, 4 + 3 * attempt + lane) * (T.con_hi[lane] - T.con_lo[lane]);
     wave_sync();
@@ -1177,3 +1264,5 @@ DEV void write_obs(const TreeTask& T, const TreeLDS& L, const TreeEnvBuffers& E,
 }
 
 }  // namespace tree
+
+}  // namespace TREE_NS

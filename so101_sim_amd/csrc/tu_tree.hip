@@ -10,15 +10,37 @@
 #include <string>
 #include <vector>
 
+// so101_tree_debug_forward layout (floats per env; dims[7..14] of so101_tree_dims report it): counts, bias, qacc_smooth, qacc [TV each],
+// body positions [TB][3], mass matrix [TV][TV], contacts [TCON][10] (pos3 normal3 dist geom1 geom2 dim), normal forces [TCON]
+#undef TDBG_COUNTS
+#undef TDBG_BIAS
+#undef TDBG_QSM
+#undef TDBG_QACC
+#undef TDBG_XPOS
+#undef TDBG_M
+#undef TDBG_CON
+#undef TDBG_FORCE
+#undef TDBG_DIM
 #define TDBG_COUNTS 0        // ncon, nrow, iters, ncand, flags, nscalar
 #define TDBG_BIAS 8
-#define TDBG_QSM 40
-#define TDBG_QACC 72
-#define TDBG_XPOS 104        // [TB][3]
-#define TDBG_M 200           // [TV][TV]
-#define TDBG_CON 1224        // [TCON][10] pos3 normal3 dist geom1 geom2 dim
-#define TDBG_FORCE 1864      // [TCON] normal force of each contact
-#define TDBG_DIM 2048
+#define TDBG_QSM (TDBG_BIAS + TV)
+#define TDBG_QACC (TDBG_QSM + TV)
+#define TDBG_XPOS (TDBG_QACC + TV)     // [TB][3]
+#define TDBG_M (TDBG_XPOS + 3 * TB)    // [TV][TV]
+#define TDBG_CON (TDBG_M + TV * TV)    // [TCON][10]
+#define TDBG_FORCE (TDBG_CON + 10 * TCON)
+#define TDBG_DIM (((TDBG_FORCE + TCON) + 63) / 64 * 64)
+
+// entry points of this build: so101_tree32_* / so101_tree64_*; the public so101_tree_* of include/so101.h dispatch on the handle
+// (csrc/tu_tree_api.hip)
+#undef TAPI
+#undef TAPI_CAT
+#undef TAPI_CAT2
+#define TAPI_CAT2(v, name) so101_tree##v##_##name
+#define TAPI_CAT(v, name) TAPI_CAT2(v, name)
+#define TAPI(name) TAPI_CAT(TREE_VARIANT, name)
+
+namespace TREE_NS {
 
 __global__ void __launch_bounds__(64) k_tree_physics(const TreeModel* tm, const DevModel* gm, TreeBuffers B, int N, int nsub, int iterations, float tolerance) {
   BLOCK_SHARED(TreeLDS, L);
@@ -56,12 +78,12 @@ __global__ void __launch_bounds__(64) k_tree_forward(const TreeModel* tm, const 
     for (int r = 0; r < nv; r++) o[TDBG_M + r * TV + lane] = L.M[r][lane];
   }
   if (lane < nb) for (int k = 0; k < 3; k++) o[TDBG_XPOS + 3 * lane + k] = L.xpos[lane][k];
-  if (lane < L.ncon) {
-    const TCon& c = L.con[lane];
-    float* q = o + TDBG_CON + 10 * lane;
+  for (int ci = lane; ci < L.ncon; ci += WAVE) {
+    const TCon& c = L.con[ci];
+    float* q = o + TDBG_CON + 10 * ci;
     for (int k = 0; k < 3; k++) { q[k] = c.pos[k]; q[3 + k] = c.frame[k]; }
     q[6] = c.dist; q[7] = (float)c.g1; q[8] = (float)c.g2; q[9] = (float)c.dim;
-    o[TDBG_FORCE + lane] = L.nrow > 0 ? G.ef[c.row] : 0.f;
+    o[TDBG_FORCE + ci] = L.nrow > 0 ? G.ef[c.row] : 0.f;
   }
 }
 
@@ -185,6 +207,7 @@ __global__ void __launch_bounds__(64) k_tree_step(const TreeModel* tm, const Dev
   float r = 0.f;
   if (!diverged) {
     if (T.reward_mode == 0) r = tree::task_reward(tm, T, L);
+    else if (T.reward_mode == 2) { tree::collision(tm, gm, L); r = tree::task_reward_touching(tm, T, L); }     // (contacts of the post-step state)
     else { int st = E.success_state[e]; r = tree::task_reward_contacts(tm, T, L, G, &st); if (lane == 0) E.success_state[e] = st; }
   }
   bool success = (T.terminate_on_success && r >= 1.f) || diverged, timeout = sc >= T.last_step;
@@ -200,7 +223,7 @@ __global__ void __launch_bounds__(64) k_tree_step(const TreeModel* tm, const Dev
 }
 
 // ==================================================================================================== host side
-struct so101_tree {
+struct TreeHandle {
   int n_envs = 0, device = 0;
   TreeModel hm{};
   DevModel hg{};
@@ -223,7 +246,7 @@ thread_local std::string g_tree_error;
 struct TreeDeviceGuard {
   int prev = -1, dev;
   bool ok;
-  explicit TreeDeviceGuard(so101_tree* s) : dev(s->device) {
+  explicit TreeDeviceGuard(TreeHandle* s) : dev(s->device) {
     ok = hipGetDevice(&prev) == hipSuccess && (prev == dev || hipSetDevice(dev) == hipSuccess);
     if (!ok) s->err = "hipSetDevice: cannot make the handle's device current";
   }
@@ -237,13 +260,13 @@ void tq2m(float* m, const float* q) {
   m[3] = 2 * (x * y + w * z); m[4] = 1 - 2 * (x * x + z * z); m[5] = 2 * (y * z - w * x);
   m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = 1 - 2 * (x * x + y * y);
 }
-bool t_ok(so101_tree* s, hipError_t e, const char* what) {
+bool t_ok(TreeHandle* s, hipError_t e, const char* what) {
   if (e == hipSuccess) return true;
   s->err = std::string(what) + ": " + hipGetErrorString(e);
   return false;
 }
 template <class T>
-bool t_upload(so101_tree* s, const std::vector<T>& v, const T** out) {
+bool t_upload(TreeHandle* s, const std::vector<T>& v, const T** out) {
   void* p = nullptr;
   if (!t_ok(s, hipMalloc(&p, (v.size() ? v.size() : 1) * sizeof(T)), "hipMalloc(tree model)")) return false;
   s->owned.push_back(p);
@@ -252,7 +275,7 @@ bool t_upload(so101_tree* s, const std::vector<T>& v, const T** out) {
   return true;
 }
 
-int tree_build(so101_tree* s, const BlobView& b) {
+int tree_build(TreeHandle* s, const BlobView& b) {
   auto fail = [&](const std::string& msg) { s->err = msg; return (int)SO101_ERR_MODEL; };
   for (const char* n : {"nq", "nv", "nu", "nbody", "ngeom", "narm", "nfree", "npair", "nvert", "neq", "opt_iterations", "opt_mpr_iterations", "opt_cone_elliptic",
                         "opt_timestep", "opt_impratio", "opt_tolerance", "opt_mpr_tolerance", "stat_meaninertia"})
@@ -262,7 +285,7 @@ int tree_build(so101_tree* s, const BlobView& b) {
   M.npair = b.I("npair")[0]; M.njnt = b.I("narm")[0]; M.nfree = b.I("nfree")[0]; M.neq = b.I("neq")[0];
   int nvert = b.I("nvert")[0];
   if (M.nq > TQ || M.nv > TV || M.nu > TU || M.nbody > TB || M.ngeom > TGEOM || M.njnt > TJ || M.neq > TE || M.nq < 0 || M.nv < 0 || M.nbody < 1)
-    return fail("model dimensions outside the general-tree build (32 bodies, 32 dofs, 16 actuators, 128 geoms)");
+    return fail("model dimensions outside the general-tree builds (32 bodies, 64 dofs, 64 positions, 16 actuators, 256 geoms)");
   size_t nb = M.nbody, ng = M.ngeom, nv = M.nv, nj = M.njnt, nu = M.nu, ne = M.neq, np = M.npair;
   struct Need { const char* name; size_t count; };
   const Need arrays[] = {
@@ -296,7 +319,7 @@ int tree_build(so101_tree* s, const BlobView& b) {
     M.body_parent[i] = parent[i]; M.body_jnttype[i] = jt[i]; M.body_qposadr[i] = qadr[i]; M.body_dofadr[i] = dadr[i]; M.body_jnt[i] = -1;
     M.body_depth[i] = i == 0 ? 0 : M.body_depth[parent[i]] + 1;
     M.body_anc[i] = (i == 0 ? 0u : M.body_anc[parent[i]]) | (1u << i);
-    M.body_dofs[i] = i == 0 ? 0u : M.body_dofs[parent[i]];
+    M.body_dofs[i] = i == 0 ? 0ull : M.body_dofs[parent[i]];
     if (M.body_depth[i] > M.maxdepth) M.maxdepth = M.body_depth[i];
     for (int k = 0; k < 3; k++) { M.body_pos[i][k] = bpos[3 * i + k]; M.body_ipos[i][k] = ipos[3 * i + k]; M.body_inertia[i][k] = inertia[3 * i + k]; }
     for (int k = 0; k < 4; k++) { M.body_quat[i][k] = bquat[4 * i + k]; M.body_iquat[i][k] = iquat[4 * i + k]; }
@@ -304,7 +327,7 @@ int tree_build(so101_tree* s, const BlobView& b) {
     int ndof = jt[i] == TJ_FREE ? 6 : (jt[i] == TJ_HINGE || jt[i] == TJ_SLIDE ? 1 : 0);
     if (ndof && (dadr[i] < 0 || dadr[i] + ndof > M.nv)) return fail("body dof address out of range");
     if (ndof && (qadr[i] < 0 || qadr[i] + (ndof == 6 ? 7 : 1) > M.nq)) return fail("body qpos address out of range");
-    for (int k = 0; k < ndof; k++) M.body_dofs[i] |= 1u << (dadr[i] + k);
+    for (int k = 0; k < ndof; k++) M.body_dofs[i] |= 1ull << (dadr[i] + k);
   }
   auto dbody = b.I("dof_body");
   auto arma = b.F("dof_armature"), damp = b.F("dof_damping"), floss = b.F("dof_frictionloss"), dinv = b.F("dof_invweight0"), dsr = b.F("dof_solref"), dsi = b.F("dof_solimp");
@@ -404,6 +427,16 @@ int tree_build(so101_tree* s, const BlobView& b) {
     auto lo = b.F("task_obj_pos_lo"), hi = b.F("task_obj_pos_hi"), yaw = b.F("task_obj_yaw"), clo = b.F("task_con_pos_lo"), chi = b.F("task_con_pos_hi");
     for (int i = 0; i < 3; i++) { T.obj_lo[i] = lo[i]; T.obj_hi[i] = hi[i]; T.con_lo[i] = clo[i]; T.con_hi[i] = chi[i]; }
     T.obj_yaw[0] = yaw[0]; T.obj_yaw[1] = yaw[1];
+    T.kind = b.count("task_kind") ? b.I("task_kind")[0] : 0;
+    if (T.kind == 1) {                          // Dining (tasks/base/dining.py): six props, six regions
+      if (b.count("task_prop_bodies") < 6 || b.count("task_region_lo") < 18 || b.count("task_region_hi") < 18) return fail("dining blob: task_prop_bodies / task_region_lo / task_region_hi missing");
+      auto pbod = b.I("task_prop_bodies"); auto rlo = b.F("task_region_lo"), rhi = b.F("task_region_hi");
+      for (int k = 0; k < 6; k++) {
+        if (pbod[k] < 1 || pbod[k] >= M.nbody || jt[pbod[k]] != TJ_FREE) return fail("dining blob: task_prop_bodies must name free bodies");
+        T.prop_body[k] = pbod[k];
+        for (int i = 0; i < 3; i++) { T.region_lo[k][i] = rlo[3 * k + i]; T.region_hi[k][i] = rhi[3 * k + i]; }
+      }
+    } else if (T.kind != 0) return fail("unknown task_kind");
     auto hq = b.F("task_home_qpos"), hc = b.F("task_home_ctrl");
     for (int k = 0; k < M.njnt; k++) T.home_qpos[k] = hq[k];
     for (int k = 0; k < M.nu; k++) T.home_ctrl[k] = hc[k];
@@ -421,13 +454,13 @@ int tree_build(so101_tree* s, const BlobView& b) {
 
 extern "C" {
 
-int so101_tree_create(const void* blob, size_t bytes, int n_envs, int hip_device, so101_tree** out) {
+int TAPI(create)(const void* blob, size_t bytes, int n_envs, int hip_device, TreeHandle** out) {
   if (!out) return SO101_ERR_ARG;
   *out = nullptr;
   if (!blob || n_envs <= 0) { g_tree_error = "so101_tree_create: bad argument"; return SO101_ERR_ARG; }
   BlobView b;
   if (!b.parse(blob, bytes, g_tree_error)) return SO101_ERR_MODEL;
-  so101_tree* s = new so101_tree();
+  TreeHandle* s = new TreeHandle();
   s->n_envs = n_envs; s->device = hip_device;
   int rc = SO101_OK;
   TreeDeviceGuard guard(s);                       // (the caller's current device is restored on every return path)
@@ -459,7 +492,7 @@ int so101_tree_create(const void* blob, size_t bytes, int n_envs, int hip_device
   return SO101_OK;
 }
 
-void so101_tree_destroy(so101_tree* s) {
+void TAPI(destroy)(TreeHandle* s) {
   if (!s) return;
   {
     TreeDeviceGuard guard(s);
@@ -469,29 +502,30 @@ void so101_tree_destroy(so101_tree* s) {
   delete s;
 }
 
-const char* so101_tree_last_error(const so101_tree* s) { return s ? s->err.c_str() : g_tree_error.c_str(); }
+const char* TAPI(last_error)(const TreeHandle* s) { return s ? s->err.c_str() : g_tree_error.c_str(); }
 
-int so101_tree_dims(const so101_tree* s, int* dims /* nq nv nu nbody ngeom debug_dim max_contacts */) {
+int TAPI(dims)(const TreeHandle* s, int* dims /* [16]: nq nv nu nbody ngeom debug_dim max_contacts, then the debug layout (offsets of bias, qacc_smooth, qacc, xpos, M, contacts, forces; row stride of M) and the build (32 / 64) */) {
   if (!s || !dims) return SO101_ERR_ARG;
   dims[0] = s->hm.nq; dims[1] = s->hm.nv; dims[2] = s->hm.nu; dims[3] = s->hm.nbody; dims[4] = s->hm.ngeom; dims[5] = TDBG_DIM; dims[6] = TCON;
+  dims[7] = TDBG_BIAS; dims[8] = TDBG_QSM; dims[9] = TDBG_QACC; dims[10] = TDBG_XPOS; dims[11] = TDBG_M; dims[12] = TDBG_CON; dims[13] = TDBG_FORCE; dims[14] = TV; dims[15] = TREE_VARIANT;
   return SO101_OK;
 }
 
-int so101_tree_bind_state(so101_tree* s, float* qpos, float* qvel, float* ctrl, float* warmstart) {
+int TAPI(bind_state)(TreeHandle* s, float* qpos, float* qvel, float* ctrl, float* warmstart) {
   if (!s || !qpos || !qvel || !ctrl || !warmstart) { if (s) s->err = "so101_tree_bind_state: NULL buffer"; return SO101_ERR_ARG; }
   s->buf.qpos = qpos; s->buf.qvel = qvel; s->buf.ctrl = ctrl; s->buf.warm = warmstart;
   s->bound = true;
   return SO101_OK;
 }
 
-int so101_tree_configure(so101_tree* s, int solver_iterations, float solver_tolerance) {
+int TAPI(configure)(TreeHandle* s, int solver_iterations, float solver_tolerance) {
   if (!s) return SO101_ERR_ARG;
   s->iterations = solver_iterations > 0 ? solver_iterations : s->hm.iterations;
   s->tolerance = solver_tolerance >= 0.f ? solver_tolerance : s->hm.tolerance;
   return SO101_OK;
 }
 
-int so101_tree_physics(so101_tree* s, int n_substeps, void* stream) {
+int TAPI(physics)(TreeHandle* s, int n_substeps, void* stream) {
   if (!s || n_substeps < 0) return SO101_ERR_ARG;
   if (!s->bound) { s->err = "so101_tree_physics before so101_tree_bind_state"; return SO101_ERR_STATE; }
   TREE_GUARD(s);
@@ -499,7 +533,7 @@ int so101_tree_physics(so101_tree* s, int n_substeps, void* stream) {
   return t_ok(s, hipGetLastError(), "k_tree_physics") ? SO101_OK : SO101_ERR_HIP;
 }
 
-int so101_tree_debug_forward(so101_tree* s, float* out, void* stream) {
+int TAPI(debug_forward)(TreeHandle* s, float* out, void* stream) {
   if (!s || !out) return SO101_ERR_ARG;
   if (!s->bound) { s->err = "so101_tree_debug_forward before so101_tree_bind_state"; return SO101_ERR_STATE; }
   TREE_GUARD(s);
@@ -509,9 +543,9 @@ int so101_tree_debug_forward(so101_tree* s, float* out, void* stream) {
 }
 
 // ---- env layer (hand-over scenes)
-int so101_tree_obs_dim(const so101_tree* s) { return s && s->has_task ? 3 * s->task.npos + 2 * s->task.nvel : 0; }
+int TAPI(obs_dim)(const TreeHandle* s) { return s && s->has_task ? 3 * s->task.npos + 2 * s->task.nvel : 0; }
 
-int so101_tree_bind_env(so101_tree* s, float* ring_pos, float* ring_vel, float* ep_return, int32_t* step_count, int32_t* episode) {
+int TAPI(bind_env)(TreeHandle* s, float* ring_pos, float* ring_vel, float* ep_return, int32_t* step_count, int32_t* episode) {
   if (!s || !ring_pos || !ring_vel || !ep_return || !step_count || !episode) { if (s) s->err = "so101_tree_bind_env: NULL buffer"; return SO101_ERR_ARG; }
   if (!s->has_task) { s->err = "so101_tree_bind_env: the model carries no task (bare-arm blob)"; return SO101_ERR_STATE; }
   s->env.ring_pos = ring_pos; s->env.ring_vel = ring_vel; s->env.ep_return = ep_return; s->env.step_count = step_count; s->env.episode = episode;
@@ -519,7 +553,7 @@ int so101_tree_bind_env(so101_tree* s, float* ring_pos, float* ring_vel, float* 
   return SO101_OK;
 }
 
-int so101_tree_bind_physics_state(so101_tree* s, float* ring, float* physics_state, float* delayed) {
+int TAPI(bind_physics_state)(TreeHandle* s, float* ring, float* physics_state, float* delayed) {
   if (!s) return SO101_ERR_ARG;
   if (!s->has_task) { s->err = "so101_tree_bind_physics_state: the model carries no task (bare-arm blob)"; return SO101_ERR_STATE; }
   bool all = ring && physics_state && delayed, none = !ring && !physics_state && !delayed;
@@ -528,25 +562,25 @@ int so101_tree_bind_physics_state(so101_tree* s, float* ring, float* physics_sta
   return SO101_OK;
 }
 
-int so101_tree_configure_env(so101_tree* s, const so101_tree_config* c) {
+int TAPI(configure_env)(TreeHandle* s, const so101_tree_config* c) {
   if (!s || !c) return SO101_ERR_ARG;
   if (c->n_substeps < 1 || c->n_substeps > 1000 || c->last_step < 1 || c->settle_max_substeps < 0) { s->err = "so101_tree_configure_env: value out of range"; return SO101_ERR_ARG; }
   TreeTask& T = s->task;
   T.n_substeps = c->n_substeps; T.last_step = c->last_step; T.settle_max = c->settle_max_substeps; T.terminate_on_success = c->terminate_on_success;
   T.seed = c->seed; T.env_id_base = c->env_id_base;
-  if (c->reward_mode != 0 && c->reward_mode != 1) { s->err = "so101_tree_configure_env: reward_mode must be 0 or 1"; return SO101_ERR_ARG; }
-  if (c->reward_mode == 1 && !s->hm.geom_class) { s->err = "so101_tree_configure_env: the model blob carries no task_geom_class (contact-sequence reward)"; return SO101_ERR_STATE; }
+  if (c->reward_mode < 0 || c->reward_mode > 2) { s->err = "so101_tree_configure_env: reward_mode must be 0, 1 or 2"; return SO101_ERR_ARG; }
+  if (c->reward_mode != 0 && !s->hm.geom_class) { s->err = "so101_tree_configure_env: the model blob carries no task_geom_class (contact-sequence reward)"; return SO101_ERR_STATE; }
   T.reward_mode = c->reward_mode; T.requires_handover = c->reward_requires_handover;
   // observation delays in control steps; negative = the reference's defaults (0.1 s and 0.3 s at a 0.02 s control step)
   int jd = c->joints_delay_steps < 0 ? T_RING_DEFAULT : c->joints_delay_steps, pd = c->physics_delay_steps < 0 ? T_PS_DEFAULT : c->physics_delay_steps;
   if (jd > T_DELAY_MAX || pd > T_DELAY_MAX) { s->err = "so101_tree_configure_env: observation delay above 64 control steps"; return SO101_ERR_ARG; }
   T.jdelay = jd; T.pdelay = pd;
-  return so101_tree_configure(s, c->solver_iterations, c->solver_tolerance);
+  return TAPI(configure)(s, c->solver_iterations, c->solver_tolerance);
 }
 
-static TreeTask task_now(so101_tree* s) { TreeTask T = s->task; T.n_envs = s->n_envs; T.iterations = s->iterations; T.tolerance = s->tolerance; return T; }
+static TreeTask task_now(TreeHandle* s) { TreeTask T = s->task; T.n_envs = s->n_envs; T.iterations = s->iterations; T.tolerance = s->tolerance; return T; }
 
-int so101_tree_reset(so101_tree* s, const uint8_t* mask, void* stream) {
+int TAPI(reset)(TreeHandle* s, const uint8_t* mask, void* stream) {
   if (!s) return SO101_ERR_ARG;
   if (!s->bound || !s->env_bound) { s->err = "so101_tree_reset before so101_tree_bind_state / so101_tree_bind_env"; return SO101_ERR_STATE; }
   TREE_GUARD(s);
@@ -554,7 +588,7 @@ int so101_tree_reset(so101_tree* s, const uint8_t* mask, void* stream) {
   return t_ok(s, hipGetLastError(), "k_tree_reset") ? SO101_OK : SO101_ERR_HIP;
 }
 
-int so101_tree_step(so101_tree* s, const float* action, float* obs, float* reward, float* discount, uint8_t* step_type, void* stream) {
+int TAPI(step)(TreeHandle* s, const float* action, float* obs, float* reward, float* discount, uint8_t* step_type, void* stream) {
   if (!s || !action || !obs || !reward || !discount || !step_type) { if (s) s->err = "so101_tree_step: NULL argument"; return SO101_ERR_ARG; }
   if (!s->bound || !s->env_bound) { s->err = "so101_tree_step before so101_tree_bind_state / so101_tree_bind_env"; return SO101_ERR_STATE; }
   TREE_GUARD(s);
@@ -562,7 +596,7 @@ int so101_tree_step(so101_tree* s, const float* action, float* obs, float* rewar
   return t_ok(s, hipGetLastError(), "k_tree_step") ? SO101_OK : SO101_ERR_HIP;
 }
 
-int so101_tree_compute_settled(so101_tree* s, int first_episode, int count, float* qpos, float* qvel, float* warmstart, int32_t* flags, void* stream) {
+int TAPI(compute_settled)(TreeHandle* s, int first_episode, int count, float* qpos, float* qvel, float* warmstart, int32_t* flags, void* stream) {
   if (!s || !qpos || !qvel || !warmstart || !flags || first_episode < 0 || count <= 0) { if (s) s->err = "so101_tree_compute_settled: bad argument"; return SO101_ERR_ARG; }
   if (!s->has_task) { s->err = "so101_tree_compute_settled: the model carries no task"; return SO101_ERR_STATE; }
   TREE_GUARD(s);
@@ -574,7 +608,7 @@ int so101_tree_compute_settled(so101_tree* s, int first_episode, int count, floa
   return SO101_OK;
 }
 
-int so101_tree_set_settled_store(so101_tree* s, int first_episode, int count, const float* qpos, const float* qvel, const float* warmstart, const int32_t* flags) {
+int TAPI(set_settled_store)(TreeHandle* s, int first_episode, int count, const float* qpos, const float* qvel, const float* warmstart, const int32_t* flags) {
   if (!s) return SO101_ERR_ARG;
   if (count > 0 && (!qpos || !qvel || !warmstart || !flags || first_episode < 0)) { s->err = "so101_tree_set_settled_store: bad argument"; return SO101_ERR_ARG; }
   s->store = TreeStore{};
@@ -582,7 +616,7 @@ int so101_tree_set_settled_store(so101_tree* s, int first_episode, int count, co
   return SO101_OK;
 }
 
-int so101_tree_settle(so101_tree* s, void* stream) {
+int TAPI(settle)(TreeHandle* s, void* stream) {
   if (!s) return SO101_ERR_ARG;
   if (!s->bound) { s->err = "so101_tree_settle before so101_tree_bind_state"; return SO101_ERR_STATE; }
   TREE_GUARD(s);
@@ -590,7 +624,7 @@ int so101_tree_settle(so101_tree* s, void* stream) {
   return t_ok(s, hipGetLastError(), "k_tree_settle") ? SO101_OK : SO101_ERR_HIP;
 }
 
-int so101_tree_begin_episode(so101_tree* s, void* stream) {
+int TAPI(begin_episode)(TreeHandle* s, void* stream) {
   if (!s) return SO101_ERR_ARG;
   if (!s->bound || !s->env_bound) { s->err = "so101_tree_begin_episode before so101_tree_bind_state / so101_tree_bind_env"; return SO101_ERR_STATE; }
   TREE_GUARD(s);
@@ -598,10 +632,11 @@ int so101_tree_begin_episode(so101_tree* s, void* stream) {
   return t_ok(s, hipGetLastError(), "k_tree_begin") ? SO101_OK : SO101_ERR_HIP;
 }
 
-int so101_tree_get_diag(so101_tree* s, int* out /* [n_envs][8] device or host-visible memory */, void* stream) {
+int TAPI(get_diag)(TreeHandle* s, int* out /* [n_envs][8] device or host-visible memory */, void* stream) {
   if (!s || !out) return SO101_ERR_ARG;
   TREE_GUARD(s);
   return t_ok(s, hipMemcpyAsync(out, s->buf.diag, (size_t)s->n_envs * 8 * sizeof(int), hipMemcpyDefault, (hipStream_t)stream), "hipMemcpyAsync(diag)") ? SO101_OK : SO101_ERR_HIP;
 }
 
 }  // extern "C"
+}  // namespace TREE_NS

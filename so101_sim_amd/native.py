@@ -226,7 +226,7 @@ class TreeConfig(C.Structure):
                 ("joints_delay_steps", C.c_int), ("physics_delay_steps", C.c_int)]
 
 
-TREE_DBG = dict(COUNTS=0, BIAS=8, QSM=40, QACC=72, XPOS=104, M=200, CON=1224, FORCE=1864)
+TREE_DBG = dict(COUNTS=0, BIAS=8, QSM=40, QACC=72, XPOS=104, M=200, CON=1224, FORCE=1864, MSTRIDE=32)     # the 32-dof build; TreeSim.dbg is the handle's own
 
 
 class TreeSim:
@@ -263,9 +263,12 @@ class TreeSim:
             msg = L.so101_tree_last_error(None)
             raise RuntimeError(f"so101_tree_create failed ({rc}): {msg.decode() if msg else '?'}")
         self.h = h
-        d = (C.c_int * 7)()
+        d = (C.c_int * 16)()
         self._check(L.so101_tree_dims(h, d), "so101_tree_dims")
-        self.nq, self.nv, self.nu, self.nbody, self.ngeom, self.debug_dim, self.max_contacts = list(d)
+        self.nq, self.nv, self.nu, self.nbody, self.ngeom, self.debug_dim, self.max_contacts = list(d)[:7]
+        # layout of so101_tree_debug_forward's row for this handle's build (32 or 64 dofs) and the build itself
+        self.dbg = dict(COUNTS=0, BIAS=d[7], QSM=d[8], QACC=d[9], XPOS=d[10], M=d[11], CON=d[12], FORCE=d[13], MSTRIDE=d[14])
+        self.build = int(d[15])
         self.obs_dim = int(L.so101_tree_obs_dim(h))
         self.cfg = TreeConfig(n_substeps=10, last_step=1 << 30, settle_max_substeps=1000, terminate_on_success=1, solver_iterations=0,
                               solver_tolerance=-1.0, seed=0, env_id_base=0, reward_mode=0, reward_requires_handover=0,

@@ -32,7 +32,7 @@ def _unbuilt(name):
 
         def __init__(self, **kwargs):
             raise NotImplementedError(
-                f"{name} is an ALOHA bimanual task that is not built; this build covers the hand-over tasks (SO100 and ALOHA)")
+                f"{name} is an ALOHA bimanual task that is not built; this build covers the hand-over tasks (SO100 and ALOHA) and the Dining place-in-container tasks")
     _Unbuilt.__name__ = name
     return _Unbuilt
 
@@ -40,7 +40,7 @@ def _unbuilt(name):
 BlocksSpelling = _unbuilt("BlocksSpelling")
 BowlOnRack = _unbuilt("BowlOnRack")
 DesktopWrapHeadphone = _unbuilt("DesktopWrapHeadphone")
-DiningPlaceInContainer = _unbuilt("DiningPlaceInContainer")
+DiningPlaceInContainer = _aloha.DiningPlaceInContainerTask
 DrawerOpen = _unbuilt("DrawerOpen")
 HandOver = _aloha.HandOverTask
 LaptopClose = _unbuilt("LaptopClose")

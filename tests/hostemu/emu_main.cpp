@@ -14,3 +14,5 @@ thread_local EmuBlock* emu_blk;
 #include "../../so101_sim_amd/csrc/tu_pgs_a.hip"
 #include "../../so101_sim_amd/csrc/tu_pgs_b.hip"
 #include "../../so101_sim_amd/csrc/tu_tree.hip"
+#include "../../so101_sim_amd/csrc/tu_tree64.hip"
+#include "../../so101_sim_amd/csrc/tu_tree_api.hip"

@@ -35,7 +35,7 @@ struct EmuBlock {
   int xchg_i[64];
   float pv[64], px[64], py[64], pz[64];
   int pi[64];
-  alignas(64) unsigned char lds[65536];  // BLOCK_SHARED storage of kernels that may run concurrently
+  alignas(64) unsigned char lds[98304];  // BLOCK_SHARED storage of kernels that may run concurrently
 };
 extern thread_local EmuBlock* emu_blk;
 #define emu_barrier (emu_blk->barrier)

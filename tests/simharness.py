@@ -261,7 +261,7 @@ class TreeArraySim:
     def debug_forward(self):
         self.sim.debug_forward(self.ptr(self.dbg), self.stream())
         d = self._get(self.dbg).astype(np.float64)
-        D, nv, nb = native.TREE_DBG, self.sim.nv, self.sim.nbody
+        D, nv, nb = self.sim.dbg, self.sim.nv, self.sim.nbody
         out = []
         for e in range(self.N):
             r = d[e]
@@ -271,7 +271,7 @@ class TreeArraySim:
                          dim=int(r[D["CON"] + 10 * k + 9]), fn=r[D["FORCE"] + k]) for k in range(ncon)]
             out.append(dict(ncon=ncon, nrow=int(r[1]), iters=int(r[2]), ncand=int(r[3]), flags=int(r[4]), nscalar=int(r[5]),
                             bias=r[D["BIAS"]:D["BIAS"] + nv], qacc_smooth=r[D["QSM"]:D["QSM"] + nv], qacc=r[D["QACC"]:D["QACC"] + nv],
-                            xpos=r[D["XPOS"]:D["XPOS"] + 3 * nb].reshape(nb, 3), M=r[D["M"]:D["M"] + 32 * 32].reshape(32, 32)[:nv, :nv], contacts=cons))
+                            xpos=r[D["XPOS"]:D["XPOS"] + 3 * nb].reshape(nb, 3), M=r[D["M"]:D["M"] + D["MSTRIDE"] ** 2].reshape(D["MSTRIDE"], D["MSTRIDE"])[:nv, :nv], contacts=cons))
         return out
 
     # -- env layer (hand-over scenes)

@@ -1,0 +1,352 @@
+"""Dining place-in-container tasks (`DiningPlaceBananaInBowl`, `DiningPlacePenInContainer`, `DiningPlaceMugOnPlate`;
+reference so101_sim/tasks/base/dining.py:39-267, so101_sim/tasks/dining_place_in_container.py:26-160) on the 64-dof build of the
+general-tree engine (csrc/so101_tree.hpp, TREE_VARIANT 64).
+
+The reference holds no numeric test for these tasks (tasks/test/ covers aloha2_task and hand_over only), and MuJoCo is not
+installable: physics parity is against the fp64 oracle (which the SO100 / ALOHA fixtures pin), the placement is pinned by the
+reference's OWN `Dining._sample_props` executed on numpy generators (tests/golden/dining_placements.json, scripts/make_golden_dining.py),
+the overlap reward by the SAT fixture of tests/golden/sat_cases.json (same kernel function), the contact reward by its definition.
+Tolerances as in tests/test_tree_parity.py."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle
+from so101_sim_amd.model import blob as blobfmt
+from so101_sim_amd.model import scenes
+from tests.simharness import TreeArraySim
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOME_Q, HOME_C = np.concatenate([scenes.ALOHA_HOME_QPOS] * 2), np.concatenate([scenes.ALOHA_HOME_CTRL] * 2)
+
+
+@pytest.fixture(scope="module")
+def dining():
+    raw64, meta = scenes.load_dining_blob("banana", "f64")
+    raw32, _ = scenes.load_dining_blob("banana", "f32")
+    return dict(f64=raw64, f32=raw32, meta=meta, m=blobfmt.unpack(raw64))
+
+
+def test_compile_constants(dining):
+    m, meta = dining["m"], dining["meta"]
+    assert (int(m["nq"][0]), int(m["nv"][0]), int(m["nu"][0]), int(m["nbody"][0]), int(m["ngeom"][0])) == (58, 52, 14, 28, 240)
+    names = meta["body_names"]
+    assert names[22:] == ["mug", "pen", "banana", "plate", "bowl", "container"]                # attach order, dining.py:128-133
+    assert [names[b] for b in np.asarray(m["task_prop_bodies"])] == list(scenes.DINING_PLACER_ORDER)
+    gb = np.asarray(m["geom_body"])
+    assert [int((gb == b).sum()) for b in range(22, 28)] == [74, 1, 4, 18, 53, 52]
+    assert int(m["task_kind"][0]) == 1 and np.asarray(m["task_region_lo"]).reshape(6, 3)[0].tolist() == [-0.3, 0.1, 0.06]
+    # the three tasks share the scene and differ in the task entries only
+    for tid, (obj, con, nbox, mode) in dict(banana=("banana", "bowl", 1, 0), pen=("pen", "container", 2, 0), mug=("mug", "plate", 0, 2)).items():
+        mt = blobfmt.unpack(scenes.load_dining_blob(tid, "f64")[0])
+        assert (names[int(mt["task_object_body"][0])], names[int(mt["task_container_body"][0])], int(mt["task_nbox"][0])) == (obj, con, nbox)
+        assert scenes.DINING_REWARD_MODE[scenes.DINING_TASKS[tid]["reward"]] == mode
+        cls = np.asarray(mt["task_geom_class"])
+        assert set(gb[cls == 1]) == {names.index(obj)} and set(gb[cls == 2]) == {names.index(con)}
+        np.testing.assert_array_equal(np.asarray(mt["mesh_vert"]), np.asarray(m["mesh_vert"]))
+    # the banana box of the bowl, scaled with the bowl's meshes (dining_place_in_container.py:41-47)
+    np.testing.assert_allclose(np.asarray(m["task_box_pos"]).ravel(), np.array([-0.017, -0.045, 0.035]) * 1.5)
+
+
+def test_reference_sample_props_fixture_matches_the_host_placement():
+    """N = 1 draws its placements on the host from numpy's generator in the reference's order (so101_sim_amd/aloha.py
+    `_reset_seed_compatible_dining`); the region samples and both shuffles must equal what the reference's own
+    `Dining._sample_props` returned for the same seed (fixture), the yaws the six draws that follow."""
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "dining_placements.json")))
+    lo, hi = scenes.DINING_REGIONS[:, 0, :], scenes.DINING_REGIONS[:, 1, :]
+    for case in g["cases"]:
+        rs = np.random.RandomState(case["seed"])
+        samples = [rs.uniform(low=lo[r], high=hi[r]) for r in range(6)]
+        top, bottom = [0, 1, 2], [3, 4, 5]
+        rs.shuffle(top); rs.shuffle(bottom)
+        regions = top + bottom
+        for p, name in enumerate(scenes.DINING_PLACER_ORDER):
+            np.testing.assert_array_equal(samples[regions[p]], np.array(case["positions"][name]), err_msg=f"seed {case['seed']} {name}")
+        assert [float(rs.uniform(-np.pi, np.pi)) for _ in range(6)] == case["yaws_plate_bowl_container_mug_pen_banana"]
+    assert len({tuple(np.argsort([c["positions"][n][0] for n in ("plate", "bowl", "container")])) for c in g["cases"]}) > 1      # the shuffles do shuffle
+
+
+def _oracle_reset(dining, seed, env_id, settle=1000, task="banana"):
+    o = Oracle(scenes.load_dining_blob(task, "f64")[0])
+    o.env_config(seed=seed, env_id=env_id, settle_max_substeps=settle)
+    o.env_reset()
+    return o
+
+
+def test_oracle_reset_places_every_prop_in_its_region_and_settles(dining):
+    m = dining["m"]
+    qadr, props = np.asarray(m["body_qposadr"]), np.asarray(m["task_prop_bodies"])
+    lo, hi = scenes.DINING_REGIONS[:, 0, :], scenes.DINING_REGIONS[:, 1, :]
+    seen = set()
+    for env_id in range(4):
+        o = _oracle_reset(dining, 3, env_id)
+        q, v, _ = o.get_state()
+        np.testing.assert_allclose(q[:16], HOME_Q, atol=1e-12)                 # arms held at the home pose
+        regs = []
+        for p, b in enumerate(props):
+            x = q[qadr[b]:qadr[b] + 3]
+            ok = [r for r in (range(3) if p < 3 else range(3, 6)) if np.all(x[:2] >= lo[r][:2] - 0.02) and np.all(x[:2] <= hi[r][:2] + 0.02)]
+            assert len(ok) == 1, (env_id, p, x)                               # (2 cm: a prop slides a little while it settles)
+            regs.append(ok[0])
+            assert 0.02 < x[2] < 0.075                                         # resting on the table top (z = 0.03), dropped from 0.06
+        assert sorted(regs[:3]) == [0, 1, 2] and sorted(regs[3:]) == [3, 4, 5]
+        seen.add(tuple(regs))
+        assert np.abs(v[16:]).max() < 5e-2
+    assert len(seen) > 1
+
+
+def test_oracle_rewards(dining):
+    """'bbox' (banana into the bowl): 0 at the reset, 1 once the banana's box overlaps the bowl's box at rest.  'contact' (mug on the
+    plate): 0 at the reset (they rest in different regions), 1 when the mug stands on the plate at rest, 0 again while it moves."""
+    from oracle.aloha_env import AlohaOracleEnv
+    m = dining["m"]
+    qadr, dadr, names = np.asarray(m["body_qposadr"]), np.asarray(m["body_dofadr"]), dining["meta"]["body_names"]
+    o = _oracle_reset(dining, 5, 0)
+    assert o.reward() == 0.0
+    q, v, w = o.get_state()
+    bowl, banana = names.index("bowl"), names.index("banana")
+    q2 = q.copy()
+    q2[qadr[banana]:qadr[banana] + 3] = q[qadr[bowl]:qadr[bowl] + 3] + np.array([-0.0255, -0.0675, 0.06])
+    q2[qadr[banana] + 3:qadr[banana] + 7] = [1, 0, 0, 0]
+    o.set_state(q2, np.zeros_like(v), np.zeros_like(w))
+    assert o.reward() == 1.0
+    vm = np.zeros_like(v); vm[dadr[banana]] = 2e-3
+    o.set_state(q2, vm, np.zeros_like(w))
+    assert o.reward() == 0.0                                                   # a prop moves: no reward
+    # mug on the plate
+    mt = blobfmt.unpack(scenes.load_dining_blob("mug", "f64")[0])
+    mug, plate = names.index("mug"), names.index("plate")
+    env = AlohaOracleEnv(scenes.load_dining_blob("mug", "f64")[0], seed=5, env_id=0, reward_touching=True, geom_class=np.asarray(mt["task_geom_class"]),
+                         prop_dofadr=(int(dadr[mug]), int(dadr[plate])))
+    env.reset()
+    assert env.step(HOME_C_ACTION())[1] == 0.0
+    q, v, w = env.o.get_state()
+    q3 = q.copy()
+    # (set down from 0.4 mm above its rest height on the plate: dropped from 3 cm the 44 g mug arrives at 0.8 m/s = 1.5 mm per substep
+    #  and passes through the plate's 3 mm hull pieces - thin hulls at dt = 2 ms, the same in kernel and oracle)
+    q3[qadr[mug]:qadr[mug] + 3] = q[qadr[plate]:qadr[plate] + 3] + np.array([0.0, 0.0, 0.0045])
+    q3[qadr[mug] + 3:qadr[mug] + 7] = [1, 0, 0, 0]
+    env.begin(q3, np.zeros_like(v), np.zeros_like(w), HOME_C)
+    out = [env.step(HOME_C_ACTION())[1:] for _ in range(6)]
+    first = next(k for k, (r, d, st) in enumerate(out) if r == 1.0)
+    # settling first (linear velocity >= 1e-3: no reward), then at rest on the plate: reward 1, discount 0, LAST; the next call starts a new episode
+    assert 1 <= first <= 4 and all(o == (0.0, 1.0, 1) for o in out[:first]) and out[first] == (1.0, 0.0, 2) and out[first + 1][2] == 0, out
+
+
+def HOME_C_ACTION():
+    a = HOME_C.copy()
+    a[6] = a[13] = -0.06135 + (0.002 - 0.002) / 0.035 * (1.5155 + 0.06135)     # ctrl 0.002 in follower units
+    return a
+
+
+# ---------------------------------------------------------------------------------------------- kernels against the oracle
+def _dining_states(n, seed, settle=1000):
+    Q, V, W, CT = [], [], [], []
+    rng = np.random.RandomState(seed)
+    for e in range(n):
+        o = _oracle_reset(None, seed, e, settle=settle)
+        q, v, w = o.get_state()
+        a = HOME_C.copy()
+        a[:6] += 0.3 * rng.normal(size=6); a[7:13] += 0.3 * rng.normal(size=6)
+        a[6], a[13] = rng.uniform(0.002, 0.037, size=2)
+        Q.append(q); V.append(v); W.append(w); CT.append(a)
+    return [np.array(x).T for x in (Q, V, W, CT)]
+
+
+def check_forward(backend, n, seed=0, settle=1000, task="banana"):
+    """forward dynamics at post-reset states with random arm targets: kinematics 1e-6 m, M and bias 1e-5, contact lists as in
+    tests/test_tree_parity.py::check_forward (depth and normal of every contact), accelerations 1e-4 on the kernel's list"""
+    raw64, raw32 = scenes.load_dining_blob(task, "f64")[0], scenes.load_dining_blob(task, "f32")[0]
+    sim = TreeArraySim(raw32, n, backend=backend)
+    assert sim.sim.build == 64 and (sim.sim.nq, sim.sim.nv) == (58, 52)
+    Q, V, W, CT = _dining_states(n, seed, settle)
+    sim.set_state(Q, V, CT, W)
+    dbg = sim.debug_forward()
+    o = Oracle(raw64)
+    total = off = 0
+    for e in range(n):
+        o.inject_contacts([])
+        o.set_state(Q[:, e], V[:, e], W[:, e]); o.set_ctrl(CT[:, e]); o.forward()
+        d = dbg[e]
+        qa, qs = o.qacc()
+        assert d["flags"] == 0
+        xp = np.array([o.body_pose(b)[0] for b in range(sim.sim.nbody)])
+        assert np.abs(d["xpos"] - xp).max() < 1e-6
+        M = o.M()
+        assert np.abs(d["M"] - M).max() <= 1e-5 * np.abs(M).max()
+        assert np.abs(d["bias"] - o.bias()).max() <= 1e-5 * max(1.0, np.abs(o.bias()).max())
+        assert np.abs(d["qacc_smooth"] - qs).max() <= 1e-4 * max(1.0, np.abs(qs).max())
+        oc = o.contacts()
+        assert d["ncon"] == len(oc) and d["nrow"] == o.nefc, (d["ncon"], len(oc), d["nrow"], o.nefc)
+        assert [(c["geom1"], c["geom2"]) for c in d["contacts"]] == [(c["geom1"], c["geom2"]) for c in oc]
+        for a, b in zip(d["contacts"], oc):
+            assert abs(a["dist"] - b["dist"]) < 2e-6 + 1e-4 * abs(b["dist"]) and a["normal"] @ b["normal"] > 1 - 1e-6, (a, b)
+            assert np.abs(a["pos"] - b["pos"]).max() < 1.5e-2
+            off += np.abs(a["pos"] - b["pos"]).max() >= 2e-5
+        total += len(oc)
+        o.inject_contacts(d["contacts"]); o.forward()
+        qa = o.qacc()[0]
+        assert np.abs(d["qacc"] - qa).max() <= 1e-4 * max(1.0, np.abs(qa).max()), (e, np.abs(d["qacc"] - qa).max(), np.abs(qa).max())
+    assert total >= 20 * n and off <= 0.05 * total + 1, (off, total)
+
+
+def test_emulated_forward():
+    check_forward("emu", 1, settle=300)
+
+
+@pytest.mark.gpu
+def test_forward_against_the_oracle():
+    check_forward("gpu", 16)
+
+
+@pytest.mark.gpu
+def test_rollout_against_the_oracle():
+    """50 substeps from post-reset states with random arm targets: positions 1e-5, velocities 1e-4 (props resting, arms moving)"""
+    n, steps = 8, 5
+    raw64, raw32 = scenes.load_dining_blob("banana", "f64")[0], scenes.load_dining_blob("banana", "f32")[0]
+    sim = TreeArraySim(raw32, n, backend="gpu")
+    Q, V, W, CT = _dining_states(n, 1)
+    sim.set_state(Q, V, CT, W)
+    for _ in range(steps):
+        sim.physics(10)
+    q1, v1, _ = sim.get_state()
+    assert np.all(sim.get_diag()[:, 4] == 0)
+    o = Oracle(raw64)
+    for e in range(n):
+        o.set_state(Q[:, e], V[:, e], W[:, e]); o.set_ctrl(CT[:, e])
+        for _ in range(steps):
+            o.substeps(10, False)
+        q, v, _ = o.get_state()
+        assert np.abs(q1[:, e] - q).max() < 1e-5, np.abs(q1[:, e] - q).max()
+        assert np.abs(v1[:, e] - v).max() < 1e-4 * max(1.0, np.abs(v).max()), np.abs(v1[:, e] - v).max()
+        assert np.abs(q[:6] - Q[:6, e]).max() > 0.02
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("task", ["banana", "mug"])
+def test_env_against_the_oracle(task):
+    """so101_tree_step on the Dining scene against oracle/aloha_env.py: the in-call reset (placement draws exact, settled props within
+    2 mm), observations with their delay lines, reward (overlap boxes / mug touching the plate), discount, step type, the time limit."""
+    from oracle.aloha_env import AlohaOracleEnv
+    n, steps, seed = 8, 6, 11
+    raw64, raw32 = scenes.load_dining_blob(task, "f64")[0], scenes.load_dining_blob(task, "f32")[0]
+    m = blobfmt.unpack(raw64)
+    dadr = np.asarray(m["body_dofadr"])
+    mode = scenes.DINING_REWARD_MODE[scenes.DINING_TASKS[task]["reward"]]
+    sim = TreeArraySim(raw32, n, backend="gpu")
+    sim.enable_env(seed=seed, env_id_base=2, last_step=steps, reward_mode=mode)
+    obs, r, d, st = sim.step(np.zeros((n, 14)))
+    assert np.all(st == 0)
+    q, v, w = sim.get_state()
+    assert np.all((sim.get_diag()[:, 4] & ~32) == 0)
+    envs = []
+    for e in range(n):
+        oe = AlohaOracleEnv(raw64, seed=seed, env_id=2 + e, last_step=steps, reward_touching=mode == 2, geom_class=np.asarray(m["task_geom_class"]),
+                            prop_dofadr=(int(dadr[int(m["task_object_body"][0])]), int(dadr[int(m["task_container_body"][0])])))
+        oe.reset()
+        qo = oe.o.get_state()[0]
+        assert np.abs(q[:16, e] - qo[:16]).max() < 1e-6 and np.abs(q[16:, e] - qo[16:]).max() < 2e-3, np.abs(q[:, e] - qo).max()
+        oe.begin(q[:, e], v[:, e], w[:, e], HOME_C)
+        envs.append(oe)
+    rng = np.random.RandomState(seed)
+    for k in range(steps):
+        a = np.tile(HOME_C, (n, 1)) + 0.3 * rng.normal(size=(n, 14))
+        a[:, 6], a[:, 13] = rng.uniform(-0.06, 1.5, size=n), rng.uniform(-0.06, 1.5, size=n)
+        obs, r, d, st = sim.step(a)
+        for e in range(n):
+            o1, r1, d1, s1 = envs[e].step(a[e])
+            assert np.abs(obs[e] - o1).max() < 2e-4 * max(1.0, np.abs(o1).max()), (k, e)
+            assert (r[e], d[e], st[e]) == (r1, d1, s1)
+    assert np.all(st == 2) and np.all(d == 1)
+    assert np.all(sim.step(np.zeros((n, 14)))[3] == 0)
+
+
+@pytest.mark.gpu
+def test_rewards_on_scripted_states():
+    """The banana laid into the bowl / the mug set onto the plate from post-reset states: reward 1, discount 0, LAST on the same step as
+    the oracle; both rewards stay 0 where the props rest in their own regions."""
+    from oracle.aloha_env import AlohaOracleEnv
+    for task, obj, con, offset in (("banana", "banana", "bowl", np.array([-0.0255, -0.0675, 0.07])), ("mug", "mug", "plate", np.array([0.0, 0.0, 0.0045]))):
+        raw64, raw32 = scenes.load_dining_blob(task, "f64")[0], scenes.load_dining_blob(task, "f32")[0]
+        m = blobfmt.unpack(raw64)
+        names = scenes.load_dining_blob(task, "f64")[1]["body_names"]
+        qadr, dadr = np.asarray(m["body_qposadr"]), np.asarray(m["body_dofadr"])
+        mode = scenes.DINING_REWARD_MODE[scenes.DINING_TASKS[task]["reward"]]
+        n = 4
+        Q, V = [], []
+        for e in range(n):
+            o = _oracle_reset(None, 9, e, task=task)
+            q, v, _ = o.get_state()
+            if e % 2 == 0:
+                a, c = qadr[names.index(obj)], qadr[names.index(con)]
+                q[a:a + 3] = q[c:c + 3] + offset
+                q[a + 3:a + 7] = [1, 0, 0, 0]
+            Q.append(q); V.append(np.zeros_like(v))
+        Q, V = np.array(Q).T, np.array(V).T
+        sim = TreeArraySim(raw32, n, backend="gpu")
+        sim.enable_env(seed=9, last_step=10_000, reward_mode=mode)
+        sim.set_state(Q, V, np.tile(HOME_C[:, None], (1, n)), np.zeros_like(V))
+        sim.begin_episode()
+        envs = []
+        for e in range(n):
+            oe = AlohaOracleEnv(raw64, reward_touching=mode == 2, geom_class=np.asarray(m["task_geom_class"]),
+                                prop_dofadr=(int(dadr[names.index(obj)]), int(dadr[names.index(con)])))
+            oe.begin(Q[:, e], V[:, e], np.zeros(52), HOME_C)
+            envs.append(oe)
+        a = np.tile(HOME_C_ACTION(), (n, 1))
+        done = np.zeros(n, dtype=bool)
+        got = np.zeros(n)
+        for k in range(80):
+            obs, r, d, st = sim.step(a)
+            for e in range(n):
+                if done[e]:
+                    continue
+                _, r1, d1, s1 = envs[e].step(a[e])
+                assert (r[e], d[e], st[e]) == (r1, d1, s1), (task, k, e, r[e], r1)
+                got[e] += r[e]; done[e] = st[e] == 2
+        assert got[0] == 1.0 and got[2] == 1.0 and got[1] == 0.0 and got[3] == 0.0, (task, got)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["DiningPlaceBananaInBowl", "DiningPlacePenInContainer", "DiningPlaceMugOnPlate"])
+def test_python_dropin_api(name):
+    """create_task_env(...) constructs the three Dining tasks (task_suite.py:54-56), single env and batch: instruction, specs, FIRST,
+    the observation keys of AlohaTask, a few steps, the time limit."""
+    from so101_sim_amd import task_suite
+    instr = {"DiningPlaceBananaInBowl": "put the banana in the bowl", "DiningPlacePenInContainer": "put the pen in the white cup",
+             "DiningPlaceMugOnPlate": "put the red mug on the plate"}[name]
+    for n_envs in (1, 4):
+        env = task_suite.create_task_env(name, time_limit=0.1, random_state=3, n_envs=n_envs, physics_state=True)
+        assert env.task.get_instruction() == instr and env.sim.build == 64
+        assert env.action_spec().shape == (14,)
+        ts = env.reset()
+        assert ts.reward is None
+        get = (lambda v: np.asarray(v)) if n_envs == 1 else (lambda v: v.double().cpu().numpy())
+        assert get(ts.observation["physics_state"]).reshape(-1, 110).shape[0] == n_envs
+        a = np.tile(HOME_C_ACTION(), (n_envs, 1)).astype(np.float32)
+        types = []
+        for k in range(7):
+            ts = env.step(a[0] if n_envs == 1 else a)
+            types.append(int(np.asarray(get(ts.step_type)).reshape(-1)[0]) if n_envs > 1 else int(ts.step_type))
+        assert types == [1, 1, 1, 1, 2, 0, 1], types
+        env.close()
+
+
+@pytest.mark.gpu
+def test_single_env_reset_is_seed_compatible_with_the_reference():
+    """create_task_env('DiningPlaceBananaInBowl', random_state=seed) places the six props where the reference's own
+    `Dining._sample_props` + PropPlacer draws put them for np.random.RandomState(seed) (fixture), bit for bit before the settle."""
+    from so101_sim_amd import task_suite
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "dining_placements.json")))
+    for case in g["cases"][:3]:
+        env = task_suite.create_task_env("DiningPlaceBananaInBowl", time_limit=10.0, random_state=case["seed"], settle_max_substeps=0)
+        env.reset()
+        for name, yaw in zip(scenes.DINING_PLACER_ORDER, case["yaws_plate_bowl_container_mug_pen_banana"]):
+            np.testing.assert_array_equal(env.placements[name]["position"], np.array(case["positions"][name]))
+            assert env.placements[name]["yaw"] == yaw
+        q = env.qpos[:, 0].cpu().numpy()
+        a = env._dining["qadr"][0]
+        np.testing.assert_allclose(q[a:a + 3], np.array(case["positions"]["plate"]), atol=1e-7)       # (settle budget 0: the pose as placed)
+        env.close()
