@@ -202,8 +202,10 @@ def run_aloha(args, torch, sdist, dev, rank, world, hbm_measured):
     import numpy as np
     from so101_sim_amd import build as sbuild, task_suite
     from so101_sim_amd.model import scenes
-    N = args.envs_per_gpu or 4096
-    env = task_suite.create_task_env("HandOverBanana", time_limit=10.0, random_state=0, n_envs=N, device=dev,
+    dining = args.workload == "dining"
+    N = args.envs_per_gpu or (1024 if dining else 4096)
+    task_name = "DiningPlaceBananaInBowl" if dining else "HandOverBanana"
+    env = task_suite.create_task_env(task_name, time_limit=10.0, random_state=0, n_envs=N, device=dev, narrowphase=args.narrowphase,
                                      env_id_base=sdist.shard_base(rank, N), solver_iterations=args.solver_iterations, solver_tolerance=args.solver_tolerance)
     if args.settled_store:          # placement + settle of the episodes the run will start, done once before anything is timed
         t_store = time.perf_counter(); env.compute_settled(2 + (args.warmup + args.steps) // 500); t_store = time.perf_counter() - t_store
@@ -227,16 +229,18 @@ def run_aloha(args, torch, sdist, dev, rank, world, hbm_measured):
     d = env.diagnostics().cpu().numpy()
     all_returns = sdist.all_gather_returns(env.episode_returns())
     if rank == 0:
-        algo = 4 * (14 + 2 * (30 + 28) + 2 * 28 + 74 + 2 * (14 + 16) + 2 + 4) + 1      # action, state r+w, warm start r+w, obs, delay lines r+w, reward / discount, counters, step type
+        nq, nv = env.sim.nq, env.sim.nv
+        algo = 4 * (14 + 2 * (nq + nv) + 2 * nv + 74 + 2 * (14 + 16) + 2 + 4) + 1      # action, state r+w, warm start r+w, obs, delay lines r+w, reward / discount, counters, step type
         achieved = algo * N / (elapsed / args.steps) / 1e9
         print(json.dumps({
             "metric": "env_steps_per_sec", "value": world * N * args.steps / elapsed, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"HandOverBanana (ALOHA bimanual, task_suite.py:63; nq 30 / nv 28 / nu 14), uniform random joint targets around the home pose, "
-                                   f"500-step episodes with the reference reset inside the step calls; {N} lock-step envs per GPU, proprioceptive obs "
-                                   "(not a BASELINE.json config: SURVEY 8f-1)",
-                       "envs_per_gpu": N, "global_envs": world * N, "substeps_per_step": 10, "solver": "newton", "engine": "general tree (csrc/so101_tree.hpp)",
+            "config": {"workload": (f"{task_name} ({'Dining scene: ALOHA + six free props, task_suite.py:54' if dining else 'ALOHA bimanual, task_suite.py:63'}; nq {nq} / nv {nv} / nu 14), "
+                                    f"uniform random joint targets around the home pose, 500-step episodes with the reference reset inside the step calls; {N} lock-step "
+                                    f"envs per GPU, proprioceptive obs (not a BASELINE.json config: SURVEY 8f-{'4' if dining else '1'})"),
+                       "envs_per_gpu": N, "global_envs": world * N, "substeps_per_step": 10, "solver": "newton", "narrowphase": args.narrowphase,
+                       "engine": f"general tree, {env.sim.build}-dof build (csrc/so101_tree.hpp)",
                        "resets": (f"settled-state store computed before the timed region ({t_store:.1f} s for {2 + (args.warmup + args.steps) // 500} episodes per env)"
                                   if args.settled_store else "placement + settle inside the step calls"),
                        "parallelism": f"env-shard x{world}", "build": sbuild.source_hash(mpr=args.narrowphase == "mpr")},
@@ -244,7 +248,8 @@ def run_aloha(args, torch, sdist, dev, rank, world, hbm_measured):
                          "traffic": None, "peak_spec": HBM_SPEC_GBS, "frac_of_spec": achieved / HBM_SPEC_GBS, "kernel": "k_tree_step (one launch per control step)",
                          "kernel_ms": 1e3 * elapsed / args.steps, "launches_per_step": 1,
                          "note": f"algorithmic bytes {algo} B per env-step; the kernel is bound by its instruction count (profiles/r03_aloha_pmc.txt: 101 k vector "
-                                 "wave-instructions per env-substep), not by HBM"},
+                                 "wave-instructions per env-substep before the oriented-box filter of round 4), not by HBM"},
+            "dist": sdist.evidence(1e3 * elapsed / args.steps, dev),
             "diag_mean": {"contacts": float(d[:, 0].mean()), "constraint_rows": float(d[:, 1].mean()), "solver_iterations": float(d[:, 2].mean()),
                           "narrowphase_candidates": float(d[:, 3].mean())},
             "flagged_envs_last_step": int((d[:, 4] != 0).sum()),
@@ -258,7 +263,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", choices=("handover", "pickplace", "mixed", "aloha"), default="handover")
+    ap.add_argument("--workload", choices=("handover", "pickplace", "mixed", "aloha", "dining"), default="handover")
     ap.add_argument("--envs-per-gpu", type=int, default=0, help="0 = the workload's BASELINE.json size")
     ap.add_argument("--solver", choices=("newton", "pgs"), default="newton",
                     help="newton = MuJoCo's default, which the reference scene uses (it sets no <option solver>)")
@@ -306,7 +311,7 @@ def main():
     # roofline denominator first: a few seconds of streaming copies, which also take the GPU out of its idle power state
     # before anything is timed (a fresh box otherwise spends the first timed steps ramping its clocks)
     hbm_measured = measure_hbm_copy(torch, dev, reps=20) if (rank == 0 and on_gpu) else None
-    if args.workload == "aloha":
+    if args.workload in ("aloha", "dining"):
         return run_aloha(args, torch, sdist, dev, rank, world, hbm_measured)
     N = args.envs_per_gpu or DEFAULT_ENVS[args.workload]
     cwd = os.getcwd()

@@ -207,7 +207,8 @@ int so101_get_diag(so101_sim* sim, int32_t* out, void* hip_stream);
  *   4 reset: the container placer's 20 attempts all collided (dm_control's PropPlacer raises RuntimeError there;
  *     here the last sample is kept and the event is counted)         5 reset: the settle did not converge within
  *     settle_max_substeps (dm_control warns, examples/so101_rl_breakdown.ipynb:50-55)
- *   6 the chained step's watchdog ended a launch (scheduler protocol error: results of that step are invalid)
+ *   6 chained steps (pipeline = 2) ended by the watchdog (scheduler protocol error).  The abort is sticky: that step's results and
+ *     those of EVERY later chained step of the handle are invalid - each counts here - until so101_configure selects another step path
  * The same bits appear per env in diag word 4 for the most recent substep. */
 #define SO101_NEVENTS 8
 int so101_get_events(so101_sim* sim, uint64_t* out, int clear, void* hip_stream);

@@ -82,7 +82,8 @@ class AlohaOracleEnv:
         return self._obs(self.ring_pos[0], self.ring_vel[0])
 
     def _contact_reward(self):
-        """hand_over.py:286-338: the three-state sequence over the contacts of the last physics step"""
+        """hand_over.py:286-338: the three-state sequence over physics.data.contact (the contacts of the state after physics.step():
+        the caller has run forward() there); every call advances the state machine"""
         cls = self.geom_class
         pairs = [(int(cls[c["geom1"]]), int(cls[c["geom2"]])) for c in self.o.contacts()]
         touching = lambda a, b: any(((c1 & a) and (c2 & b)) or ((c2 & a) and (c1 & b)) for c1, c2 in pairs)
@@ -128,8 +129,19 @@ class AlohaOracleEnv:
         self.step_count += 1
         dp, dv = self.ring_pos[0], self.ring_vel[0]          # the value of control step k - 5
         self.ring_pos.append(self._pos()); self.ring_vel.append(self._vel())
-        r = 0.0 if diverged else (self._touch_reward() if self.touching else (float(self.o.reward()) if self.overlap else self._contact_reward()))
-        success, timeout = r >= 1.0 or bool(diverged), self.step_count >= self.last_step
+        # dm_control's Environment.step: reward = get_reward(); discount = get_discount() -> should_terminate_episode() -> get_reward();
+        # terminating = should_terminate_episode() -> get_reward()  (aloha2_task.py:353-367): three evaluations, and the contact
+        # sequence advances its state on each of them
+        if diverged:
+            r = r_disc = r_term = 0.0
+        elif self.touching:
+            r = r_disc = r_term = self._touch_reward()
+        elif self.overlap:
+            r = r_disc = r_term = float(self.o.reward())
+        else:
+            self.o.forward()
+            r = self._contact_reward(); r_disc = self._contact_reward(); r_term = self._contact_reward()
+        disc0, success, timeout = r_disc >= 1.0 or bool(diverged), r_term >= 1.0 or bool(diverged), self.step_count >= self.last_step
         st = 2 if (success or timeout) else 1
         self.need_reset = st == 2
-        return self._obs(dp, dv), r, 0.0 if success else 1.0, st
+        return self._obs(dp, dv), r, 0.0 if disc0 else 1.0, st

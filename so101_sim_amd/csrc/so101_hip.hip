@@ -609,9 +609,13 @@ static int enqueue_pipelined(so101_sim* s, hipStream_t st, const so101::StepIO& 
     // records depended on the arrival order of the atomics in publish_candidates)
     W.conres = s->pipe.conres + ((size_t)e0 * CONRES_PER_ENV + (size_t)g * MAXCAND) * CONRES_DIM;
     W.conres_cap = (unsigned int)ng * CONRES_PER_ENV + MAXCAND;
+    static const int chunk_env = getenv("SO101_NARROW_CHUNK") ? atoi(getenv("SO101_NARROW_CHUNK")) : 0;          // (kernel experiments)
+    W.narrow_chunk = (unsigned int)(chunk_env >= 1 && chunk_env <= NARROW_CHUNK ? chunk_env : (n <= 8192 ? 3 : NARROW_CHUNK));
     // persistent narrowphase waves (they pull work items until the list is empty): two per env of the slice, at
     // most what fills 256 CUs - a smaller narrowphase grid leaves slots to the other chains' solve kernels
-    int nw = ng * 2 < 4096 ? ng * 2 : 4096;
+    static const int nw_quarters = getenv("SO101_NARROW_WAVES_Q") ? atoi(getenv("SO101_NARROW_WAVES_Q")) : 8;      // (kernel experiments: quarter waves per env)
+    int nw = (int)((long long)ng * nw_quarters / 4);
+    nw = nw < 1 ? 1 : (nw < 4096 ? nw : 4096);
     if (G > 1 && !hip_ok(s, hipStreamWaitEvent(gs, s->step_begin, 0), "hipStreamWaitEvent")) return SO101_ERR_HIP;
     if (!hip_ok(s, hipMemsetAsync(W.counters, 0, sizeof(int) * 2 * MAXSUB, gs), "hipMemsetAsync(pipe)")) return SO101_ERR_HIP;
     if (s->cfg.pipeline == 3) {
@@ -690,6 +694,8 @@ static int enqueue_chained(so101_sim* s, hipStream_t st, const so101::StepIO& io
   so101::launch_order(st, s->pipe.cost, s->pipe.order, s->chain_cls, n);
   LAUNCH_CHECK(s, "k_order");
   if (!hip_ok(s, hipMemsetAsync(s->chain.chain_ctl, 0, sizeof(unsigned int), st), "hipMemsetAsync(chain)")) return SO101_ERR_HIP;
+  // (the per-step "abort counted" word; the abort word itself, chain_ctl[32], stays set: see k_chain)
+  if (!hip_ok(s, hipMemsetAsync(s->chain.chain_ctl + 33, 0, sizeof(unsigned int), st), "hipMemsetAsync(chain)")) return SO101_ERR_HIP;
   PipeBuffers W = s->pipe;
   W.conres = s->conres_full; W.conres_cap = 0u; W.mq_ctl = nullptr;
   so101::launch_pipe_begin(n, st, s->dm, P, s->buf, C, s->ev, W, io, s->need_reset, s->diag, 0, s->chain_params);

@@ -190,6 +190,7 @@ struct PipeBuffers {
                           // per work-list position of the current substep, [conres_cap][CONRES_DIM] per env slice (an env's
                           // records start at cbase[e]); conres_cap = 0 (pipelines 2, 3): [N][MAXCAND][CONRES_DIM]
   unsigned int conres_cap;
+  unsigned int narrow_chunk;   // k_narrow: candidate pairs per work-item fetch (1 .. NARROW_CHUNK), set per launch by the host
   int* cbase;             // [N] work-list position of the env's first candidate in the current substep
   unsigned char* active;  // [N] 0 not stepping in this call (auto-reset), 1 stepping, 2 diverged
   unsigned int* stage;    // [N][8] k_pipe_solve stage clocks of the last substep (10 ns ticks; SO101_DEBUG_CLOCKS builds)
@@ -224,7 +225,9 @@ struct ChainQueues {
 enum { CS_T_POP = 0, CS_T_IDLE, CS_T_NARROW, CS_T_SOLVE, CS_N_NARROW, CS_N_SOLVE, CS_N_IDLE, CS_WAVES, CS_T_LIFE, CS_N };
 struct SolveIO { float* obs; float* reward; float* discount; unsigned char* step_type; unsigned char* need_reset; int* diag; };
 #define STATE_AOS 64
+#ifndef NARROW_CHUNK
 #define NARROW_CHUNK 4     // candidate pairs per narrowphase work item
+#endif
 #define Q_NARROW 0         // queue index = type + class
 #define Q_SOLVE 2
 

@@ -250,23 +250,31 @@ TREE_CHOL_DEV void chol_factor(float (*A)[TV + 1], int n) {
   }
   wave_sync();
 }
-// x := A^-1 x for the factor above (x in LDS, n entries)
-DEV void chol_solve(float (*A)[TV + 1], int n, float* x) {
-  int lane = wave_lane();
-  for (int j = 0; j < n; j++) {
-    wave_sync();
-    float xj = x[j] / A[j][j];
-    wave_sync();
-    if (lane == j) x[j] = xj;
-    if (lane > j && lane < n) x[lane] -= A[lane][j] * xj;
+// x := A^-1 x for the factor above (x in LDS, n entries).  Register resident like the factorisation: lane i takes row i of L (forward
+// substitution) and column i of L (backward) into registers, the solved entries travel with v_readlane - two barriers instead of four per
+// row (the LDS version cost ~110 barriers per solve at 28 dofs; round 4).  Entries beyond n are never used.
+TREE_CHOL_DEV void chol_solve(float (*A)[TV + 1], int n, float* x) {
+  int lane = wave_lane(), row = lane < TV ? lane : 0;
+  wave_sync();
+  float a[TV], t[TV];
+#pragma unroll
+  for (int k = 0; k < TV; k++) { a[k] = A[row][k]; t[k] = A[k][row]; }       // (row stride TV + 1: both reads are conflict-free)
+  float y = lane < n ? x[row] : 0.f;
+#pragma unroll
+  for (int j = 0; j < TV; j++) {
+    if (j < n) {
+      float yj = wave_get_f(y, j) / wave_get_f(a[j], j);
+      if (lane == j) y = yj; else if (lane > j) y -= a[j] * yj;
+    }
   }
-  for (int j = n - 1; j >= 0; j--) {
-    wave_sync();
-    float xj = x[j] / A[j][j];
-    wave_sync();
-    if (lane == j) x[j] = xj;
-    if (lane < j) x[lane] -= A[j][lane] * xj;
+#pragma unroll
+  for (int j = TV - 1; j >= 0; j--) {
+    if (j < n) {
+      float xj = wave_get_f(y, j) / wave_get_f(a[j], j);
+      if (lane == j) y = xj; else if (lane < j) y -= t[j] * xj;
+    }
   }
+  if (lane < n) x[lane] = y;
   wave_sync();
 }
 
@@ -810,6 +818,33 @@ DEV float contact_block(const TCon& C, const float* D, int dim, const float* r, 
   }
   return 0.5f * Dm * sN * sN;
 }
+// first and second derivative of one contact block's cost along the line r + alpha dr (closed form per zone - the zone of the point
+// itself, as in mj_solNewton's line search; what the line search used to take from contact_block's full 6 x 6 Hessian)
+DEV void contact_line(const TCon& C, const float* D, int dim, const float* r, const float* dr, float* d1, float* d2) {
+  *d1 = 0.f; *d2 = 0.f;
+  if (dim == 1) { if (r[0] < 0.f) { *d1 = D[0] * r[0] * dr[0]; *d2 = D[0] * dr[0] * dr[0]; } return; }
+  float mu = C.mu, N = r[0] * mu, dN = dr[0] * mu, TT = 0.f, UdU = 0.f, dUdU = 0.f;
+#pragma unroll
+  for (int j = 1; j < 6; j++) {
+    float fr = j < dim ? C.fric[j - 1] : 0.f;
+    float u = j < dim ? r[j] * fr : 0.f, du = j < dim ? dr[j] * fr : 0.f;
+    TT += u * u; UdU += u * du; dUdU += du * du;
+  }
+  float T = sqrtf(TT);
+  if ((N >= mu * T) || (T <= 0.f && N >= 0.f)) return;
+  if ((mu * N + T <= 0.f) || (T <= 0.f && N < 0.f)) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; j++) if (j < dim) { a += D[j] * r[j] * dr[j]; b += D[j] * dr[j] * dr[j]; }
+    *d1 = a; *d2 = b;
+    return;
+  }
+  float Dm = D[0] / fmaxf(mu * mu * (1.f + mu * mu), MINVAL_F), sN = N - mu * T, iT = 1.f / T;
+  float dT = UdU * iT, ddT = (dUdU - dT * dT) * iT, dS = dN - mu * dT;
+  *d1 = Dm * sN * dS;
+  *d2 = Dm * (dS * dS - sN * mu * ddT);
+}
+
 // scalar rows: cost, force, second derivative
 DEV float scalar_block(int type, float D, float R, float fl, float r, float* force, float* h) {
   *h = 0.f;
@@ -970,16 +1005,11 @@ DEV void solve_newton(const TreeModel* tm, TreeLDS& L, const TreeScratch& G, int
       for (int ci = lane; ci < ncon; ci += WAVE) {
         const TCon& C = L.con[ci];
         int dim = C.dim, row = C.row;
-        float r6[6], f6[6], D6[6], Hc[36], jv6[6];
+        float r6[6], D6[6], jv6[6], c1, c2;
 #pragma unroll
         for (int j = 0; j < 6; j++) { jv6[j] = j < dim ? G.ejv[row + j] : 0.f; r6[j] = j < dim ? G.ejar[row + j] + alpha * jv6[j] : 0.f; D6[j] = j < dim ? G.eD[row + j] : 0.f; }
-        contact_block(C, D6, dim, r6, f6, Hc, true);
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-          a1 -= f6[j] * jv6[j];
-#pragma unroll
-          for (int k = 0; k < 6; k++) a2 += jv6[j] * Hc[j * 6 + k] * jv6[k];
-        }
+        contact_line(C, D6, dim, r6, jv6, &c1, &c2);
+        a1 += c1; a2 += c2;
       }
       float d1 = q1 + q2 * alpha + wave_sum_f(a1), d2 = q2 + wave_sum_f(a2);
       if (ls == 0) { d10 = fabsf(d1); if (!(d1 < 0.f)) break; }

@@ -97,9 +97,15 @@ __global__ void __launch_bounds__(64, 2) k_chain(const ChainParams* cp0) {
       const ChainParams* cp = cp0; LAUNDER_UNIFORM(cp);
       unsigned int* ctl = ldc(&cp->Q.chain_ctl);
       if (lane == 0) {
-        if (ld_agent(&ctl[0]) >= (unsigned int)ldc(&cp->P.n_envs) || ld_agent(&ctl[32]) != 0u) stop = 1;
-        else if (wall_clock64() - t_idle > CHAIN_WATCHDOG_TICKS) {
-          if (atom_add_agent(&ctl[32], 1u) == 0u) atomicAdd(ldc(&cp->E.events) + 6, 1ull);
+        // ctl[32]: abort word, STICKY across steps (after a watchdog abort the queues and pending counts are inconsistent: every later
+        // chained step of this handle ends at its first idle round and its results are invalid until the handle is reconfigured to
+        // another step path); ctl[33]: cleared by the host before every launch, so that EVERY aborted step counts once in events[6]
+        if (ld_agent(&ctl[0]) >= (unsigned int)ldc(&cp->P.n_envs)) stop = 1;
+        else if (ld_agent(&ctl[32]) != 0u) {
+          if (atom_add_agent(&ctl[33], 1u) == 0u) atomicAdd(ldc(&cp->E.events) + 6, 1ull);
+          stop = 1;
+        } else if (wall_clock64() - t_idle > CHAIN_WATCHDOG_TICKS) {
+          if (atom_add_agent(&ctl[32], 1u) == 0u && atom_add_agent(&ctl[33], 1u) == 0u) atomicAdd(ldc(&cp->E.events) + 6, 1ull);
           stop = 1;
         }
       }

@@ -20,14 +20,19 @@ __global__ void __launch_bounds__(64, 2) k_narrow(const DevModel* m, int N, Pipe
   const unsigned int* list = W.work + (size_t)(s & 1) * W.work_cap;
   for (;;) {
     int i0 = 0;
-    if (lane == 0) i0 = atomicAdd(&W.counters[2 * s + 1], NARROW_CHUNK);
+    // work items per fetch: a launch-time number (W.narrow_chunk, at most NARROW_CHUNK).  Smaller chunks balance the tail of a launch
+    // (a chunk of four EPA pairs is 45 us against a launch of ~100 us alone), larger ones save atomics: measured in round 4 at 4096 envs
+    // 1 / 2 / 3 / 4 / 8 pairs -> 509 / 678 / 688 / 661 / 584 k env-steps/s, at 32 768 envs 2 / 4 -> 912 / 962 k; the host picks 3 up to
+    // 8192 envs and 4 above
+    const int chunk = (int)W.narrow_chunk;
+    if (lane == 0) i0 = atomicAdd(&W.counters[2 * s + 1], chunk);
     i0 = wave_uniform_i(i0);
     if (i0 >= nwork) break;
     unsigned int wl = 0, cl = 0;
-    if (lane < NARROW_CHUNK && i0 + lane < nwork) { wl = list[i0 + lane]; cl = W.cand[wl]; }
+    if (lane < chunk && i0 + lane < nwork) { wl = list[i0 + lane]; cl = W.cand[wl]; }
     // not unrolled: four inlined copies of the MPR query are ~130 KB of code, more than the instruction cache holds
 #pragma unroll 1
-    for (int j = 0; j < NARROW_CHUNK; j++) {
+    for (int j = 0; j < chunk; j++) {
       if (i0 + j >= nwork) break;
       if ((unsigned int)(i0 + j) >= W.conres_cap) continue;       // no room for this candidate's contact record (counted by its env)
       unsigned long long t0 = SO101_CLOCK();

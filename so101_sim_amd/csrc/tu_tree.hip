@@ -206,17 +206,28 @@ __global__ void __launch_bounds__(64) k_tree_step(const TreeModel* tm, const Dev
   tree::kinematics(tm, L);
   tree::write_obs(T, L, E, e, sc, false, obs);
   tree::write_physics_state(tm, T, L, E, e, sc);
-  float r = 0.f;
+  // dm_control's Environment.step asks the task three times: get_reward, get_discount (-> should_terminate_episode -> get_reward) and
+  // should_terminate_episode (-> get_reward), aloha2_task.py:353-367.  For the overlap and touching rewards the three answers are the
+  // same; the contact sequence (hand_over.py:286-338) advances its state machine on EVERY call, so reward, discount and termination may
+  // each see a different state (0 -> 1 -> 2 and even the success within one control step).  Contacts: physics.data.contact after
+  // physics.step(), whose legacy step ends with mj_step1 - the contacts of the integrated state, recomputed here.
+  float r = 0.f, r_disc = 0.f, r_term = 0.f;
   if (!diverged) {
-    if (T.reward_mode == 0) r = tree::task_reward(tm, T, L);
-    else if (T.reward_mode == 2) { tree::collision(tm, gm, L); r = tree::task_reward_touching(tm, T, L); }     // (contacts of the post-step state)
-    else { int st = E.success_state[e]; r = tree::task_reward_contacts(tm, T, L, G, &st); if (lane == 0) E.success_state[e] = st; }
+    if (T.reward_mode == 0) r = r_disc = r_term = tree::task_reward(tm, T, L);
+    else if (T.reward_mode == 2) { tree::collision(tm, gm, L); r = r_disc = r_term = tree::task_reward_touching(tm, T, L); }
+    else {
+      tree::collision(tm, gm, L);
+      int st = E.success_state[e];
+      r = tree::task_reward_contacts(tm, T, L, G, &st);
+      if (T.terminate_on_success) { r_disc = tree::task_reward_contacts(tm, T, L, G, &st); r_term = tree::task_reward_contacts(tm, T, L, G, &st); }
+      if (lane == 0) E.success_state[e] = st;
+    }
   }
-  bool success = (T.terminate_on_success && r >= 1.f) || diverged, timeout = sc >= T.last_step;
+  bool disc0 = (T.terminate_on_success && r_disc >= 1.f) || diverged, success = (T.terminate_on_success && r_term >= 1.f) || diverged, timeout = sc >= T.last_step;
   tree::store_state(tm, L, B, e, N);
   if (lane < tm->nu) B.ctrl[(size_t)lane * N + e] = L.ctrl[lane];
   if (lane == 0) {
-    reward[e] = r; discount[e] = success ? 0.f : 1.f;
+    reward[e] = r; discount[e] = disc0 ? 0.f : 1.f;
     unsigned char st = (success || timeout) ? 2 : 1;
     step_type[e] = st; E.need_reset[e] = st == 2;
     E.step_count[e] = sc; E.ep_return[e] += r;
