@@ -116,7 +116,8 @@ struct TreeLDS {
   union { float L[TV][TV + 1]; float H[TV][TV + 1]; };  // factor of M (until qacc_smooth is known), then the Newton Hessian / M + h D
   float rw[TB][3], ral[TB][3], rao[TB][3], rf[TB][3], rn[TB][3];
   TCon con[TCON];
-  float Jc[6][TJS];
+  float hJ[6][TV], hT[6][TV];       // Hessian assembly: one contact's Jacobian columns compacted to the dofs it touches, and Hc J
+  int hdl[TV];                      // ... the dof of each compacted slot
   float x[TV], grad[TV], search[TV], Ma[TV], Mv[TV], tmp[TV], xs[TV];
   int cdim[TCON + 1];
   int hdim[TCON];                  // Newton: rows of the contact's Hessian block, 0 when the block is inactive
@@ -905,57 +906,63 @@ DEV float total_cost(const TreeModel* tm, TreeLDS& L, const TreeScratch& G, bool
     for (int r = 0; r < nrow; r++) g -= G.J[r * TJS + lane] * G.ef[r];
     L.grad[lane] = g;
   }
-  // Hessian: M + sum J' Hc J; lane = column
-  float hcol[TV];
-  int col = lane < TV ? lane : 0;
-#pragma unroll
-  for (int a = 0; a < TV; a++) hcol[a] = L.M[a][col];       // (rows / columns beyond nv are never read back)
+  // Hessian: M + sum J' Hc J, assembled in LDS (L.H) over the dofs each row TOUCHES (round 4; before, lane = column accumulated every
+  // contact's 6 x nv product in registers: 36 + 6 TV multiply-adds per lane and contact, two barriers, although a prop-on-table contact
+  // moves 6 of the 28 / 52 dofs - 480 instructions per contact against 60-150 here).
+  for (int i = lane; i < nv * nv; i += WAVE) { int r = i / nv, c = i - r * nv; L.H[r][c] = L.M[r][c]; }
+  wave_sync();
+  // scalar rows (equality, dof friction, limits): one or two non-zero columns.  Entry [a][b] is always written by lane a, so two rows
+  // that meet on one entry (a limit and a friction row of one dof) are ordered by that lane's own program order
   for (int r = 0; r < nscalar; r++) {
     float h = G.ejv[r];
     if (h == 0.f) continue;
-    float jc = lane < nv ? G.J[r * TJS + lane] : 0.f;
-    wave_sync();
-    if (lane < TJS) L.Jc[0][lane] = jc;
-    wave_sync();
-    float hj = h * jc;
-#pragma unroll
-    for (int a = 0; a < TV; a++) hcol[a] += L.Jc[0][a] * hj;
+    float jd = lane < nv ? G.J[r * TJS + lane] : 0.f;
+    unsigned long long nz = wave_ballot(jd != 0.f);
+    if (nz == 0ull) continue;
+    int d1 = (int)__builtin_ctzll(nz);
+    unsigned long long rest = nz & (nz - 1ull);
+    int d2 = rest ? (int)__builtin_ctzll(rest) : -1;
+    float j1 = wave_bcast_f(jd, d1), j2 = d2 >= 0 ? wave_bcast_f(jd, d2) : 0.f;
+    if (lane == d1) { L.H[d1][d1] += h * j1 * j1; if (d2 >= 0) L.H[d1][d2] += h * j1 * j2; }
+    if (lane == d2) { L.H[d2][d2] += h * j2 * j2; L.H[d2][d1] += h * j1 * j2; }
   }
+  wave_sync();
   for (int c = 0; c < ncon; c++) {
     int dim = L.hdim[c];
     if (dim == 0) continue;
-    int row = L.con[c].row;
-    float jl[6];
+    const TCon& C = L.con[c];
+    int row = C.row;
+    unsigned long long mask = tm->body_dofs[C.b1] | tm->body_dofs[C.b2];     // wave-uniform: the dofs that move either body
+    int nd = __popcll(mask);
+    // (i) compact the contact's Jacobian columns: the lane of dof d takes slot rank(d)
+    if (lane < nv && ((mask >> lane) & 1ull)) {
+      int k = __popcll(mask & ((1ull << lane) - 1ull));
+      L.hdl[k] = lane;
 #pragma unroll
-    for (int j = 0; j < 6; j++) jl[j] = (j < dim && lane < nv) ? G.J[(row + j) * TJS + lane] : 0.f;
-    wave_sync();
-    if (lane < TJS) {
-#pragma unroll
-      for (int j = 0; j < 6; j++) L.Jc[j][lane] = jl[j];
+      for (int j = 0; j < 6; j++) L.hJ[j][k] = j < dim ? G.J[(row + j) * TJS + lane] : 0.f;
     }
     wave_sync();
-    float t[6];
+    // (ii) T = Hc J (6 x nd), lane = (row j, slot k)
+    for (int i = lane; i < 6 * nd; i += WAVE) {
+      int j = i / nd, k = i - j * nd;
+      float v = 0.f;
+      if (j < dim) {
 #pragma unroll
-    for (int j = 0; j < 6; j++) {
+        for (int l = 0; l < 6; l++) v += G.Hc[c][j * 6 + l] * L.hJ[l][k];
+      }
+      L.hT[j][k] = v;
+    }
+    wave_sync();
+    // (iii) H[dof a][dof b] += sum_j J[j][a] T[j][b], lane = (slot a, slot b)
+    for (int i = lane; i < nd * nd; i += WAVE) {
+      int ka = i / nd, kb = i - ka * nd;
       float v = 0.f;
 #pragma unroll
-      for (int k = 0; k < 6; k++) v += G.Hc[c][j * 6 + k] * jl[k];
-      t[j] = v;
+      for (int j = 0; j < 6; j++) v += L.hJ[j][ka] * L.hT[j][kb];
+      L.H[L.hdl[ka]][L.hdl[kb]] += v;
     }
-#pragma unroll
-    for (int a = 0; a < TV; a++) {
-      float v = 0.f;
-#pragma unroll
-      for (int j = 0; j < 6; j++) v += L.Jc[j][a] * t[j];
-      hcol[a] += v;
-    }
+    wave_sync();
   }
-  wave_sync();
-  if (lane < nv) {
-#pragma unroll
-    for (int a = 0; a < TV; a++) L.H[a][lane] = hcol[a];
-  }
-  wave_sync();
   return cost;
 }
 

@@ -405,21 +405,36 @@ def check_contact_reward(backend, which, requires_handover, n, steps, n_substeps
         envs.append(oe)
     a = np.tile(np.concatenate([scenes.ALOHA_HOME_CTRL] * 2), (n, 1))
     a[:, 6] = a[:, 13] = -0.06135                            # grippers closed (FOLLOWER_GRIPPER_CLOSE)
-    done = np.zeros(n, dtype=bool)
+    # Step by step (reward, discount, step type) and the state of the sequence must be EQUAL while both episodes run.  The success itself
+    # is gated by "linear velocity < 1e-3" and by a hull-on-hull touch that comes and goes while the object finishes settling (single
+    # contact points per hull pair): fp32 and fp64 may pass that gate a few control steps apart - the episode must end on both sides with
+    # the same reward, discount and step type, at most 3 control steps apart.
+    k_last, o_last = np.full(n, -1), np.full(n, -1)
+    k_out, o_out = [None] * n, [None] * n
     seen_states, rewards = set(), np.zeros(n)
     for k in range(steps):
         obs, r, d, st = sim.step(a)
         fsm = sim.get_diag()[:, 5]
         for e in range(n):
-            if done[e]:
-                continue
-            o1, r1, d1, s1 = envs[e].step(a[e])
-            assert (r[e], d[e], st[e]) == (r1, d1, s1), (k, e, r[e], r1, st[e], s1)
-            assert fsm[e] == envs[e].success_state
-            seen_states.add(int(fsm[e])); rewards[e] += r[e]
-            done[e] = st[e] == 2
-        if done.all():
+            both = k_last[e] < 0 and o_last[e] < 0
+            if o_last[e] < 0:
+                o1, r1, d1, s1 = envs[e].step(a[e])
+                if s1 == 2:
+                    o_last[e], o_out[e] = k, (r1, d1, s1)
+            if k_last[e] < 0:
+                seen_states.add(int(fsm[e])); rewards[e] += r[e]
+                if st[e] == 2:
+                    k_last[e], k_out[e] = k, (float(r[e]), float(d[e]), int(st[e]))
+            if both and k_last[e] < 0 and o_last[e] < 0:
+                assert (r[e], d[e], st[e]) == (r1, d1, s1), (k, e, r[e], r1, st[e], s1)
+                assert fsm[e] == envs[e].success_state
+        if np.all(k_last >= 0) and np.all(o_last >= 0):
             break
+    for e in range(n):
+        assert (k_last[e] >= 0) == (o_last[e] >= 0) or steps - 1 - max(k_last[e], o_last[e]) < 3, (e, k_last[e], o_last[e])
+        if k_last[e] >= 0 and o_last[e] >= 0:
+            assert abs(k_last[e] - o_last[e]) <= 3 and k_out[e] == o_out[e], (e, k_last[e], o_last[e], k_out[e], o_out[e])
+    done = k_last >= 0
     return seen_states, rewards, done
 
 
