@@ -3,7 +3,7 @@
 # of scripts/gpu_profile.sh (rocprofv3 kernel stats + separate PMC passes).  Everything lands in gpurun_out/<tag>_*; the
 # files to keep are copied into profiles/ by hand.
 #   usage: bash scripts/gpu_round_report.sh r02
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out; mkdir -p $O
 cd $R
@@ -23,10 +23,15 @@ timeout 600 python bench.py --fused --no-cpu-baseline --steps 40 2>/dev/null | t
 timeout 600 python bench.py --pipeline 2 --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/${TAG}_bench_chained.json
 timeout 600 python bench.py --pipeline 3 --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/${TAG}_bench_merged.json
 timeout 900 python bench.py --steps 1500 --warmup 10 --no-cpu-baseline --repeats 1 2>/dev/null | tail -1 > $O/${TAG}_bench_1500.json
-[ -x $R/ab/mfma_hessian ] && timeout 120 $R/ab/mfma_hessian > $O/${TAG}_mfma_hessian.txt 2>&1
+timeout 600 python scripts/gpu_single_env_latency.py 2>/dev/null | tail -1 > $O/${TAG}_single_env_latency.json
+timeout 1200 python scripts/gpu_soak_rates.py 2>/dev/null | tail -1 > $O/${TAG}_soak_rates.json
 timeout 600 python scripts/gpu_reset_cost.py 2>&1 | tail -6 > $O/${TAG}_reset_cost.txt
 # ALOHA hand-over on the general-tree engine: throughput at three batch sizes, stage times, kernel stats
 timeout 600 python bench.py --workload aloha --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/${TAG}_bench_aloha.json
+timeout 900 python bench.py --workload aloha --steps 600 --warmup 5 2>/dev/null | tail -1 > $O/${TAG}_bench_aloha_600.json
+timeout 600 python bench.py --workload dining --steps 10 --warmup 3 2>/dev/null | tail -1 > $O/${TAG}_bench_dining.json
+timeout 600 python bench.py --workload dining --envs-per-gpu 4096 --steps 10 --warmup 3 2>/dev/null | tail -1 > $O/${TAG}_bench_dining_4096.json
+timeout 600 python bench.py --narrowphase mpr --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/${TAG}_bench_mpr_option.json
 timeout 600 python scripts/gpu_aloha_bench.py banana 2>/dev/null | grep workload > $O/${TAG}_aloha_bench.json
 timeout 600 python scripts/gpu_aloha_bench.py pen 2>/dev/null | grep workload > $O/${TAG}_aloha_bench_pen.json
 timeout 600 python scripts/gpu_tree_phases.py 2>/dev/null | grep mask > $O/${TAG}_aloha_phases.txt
