@@ -24,7 +24,7 @@ timeout 600 python bench.py --pipeline 2 --no-cpu-baseline --steps 20 --warmup 5
 timeout 600 python bench.py --pipeline 3 --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/${TAG}_bench_merged.json
 timeout 900 python bench.py --steps 1500 --warmup 10 --no-cpu-baseline --repeats 1 2>/dev/null | tail -1 > $O/${TAG}_bench_1500.json
 timeout 600 python scripts/gpu_single_env_latency.py 2>/dev/null | tail -1 > $O/${TAG}_single_env_latency.json
-timeout 1200 python scripts/gpu_soak_rates.py 2>/dev/null | tail -1 > $O/${TAG}_soak_rates.json
+timeout 1200 python scripts/gpu_soak_rates.py 2>/dev/null | grep "^{" > $O/${TAG}_soak_rates.json
 timeout 600 python scripts/gpu_reset_cost.py 2>&1 | tail -6 > $O/${TAG}_reset_cost.txt
 # ALOHA hand-over on the general-tree engine: throughput at three batch sizes, stage times, kernel stats
 timeout 600 python bench.py --workload aloha --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/${TAG}_bench_aloha.json

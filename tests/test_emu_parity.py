@@ -60,7 +60,7 @@ def test_settled_store_is_bit_identical(make_sim):
 
 
 def test_pipelined_step_matches_fused(make_sim, golden):
-    pc.check_pipeline_identical(make_sim, golden, n=1, steps=1, settle=1, pipelines=(0, 1))
+    pc.check_pipeline_identical(make_sim, golden, n=1, steps=1, settle=1, pipelines=(0, 1), first_state=9)
 
 
 @SLOW
