@@ -507,7 +507,9 @@ DEV void load_geom(const DevModel* m, const EnvLDS& L, int g, GeomW& G) {
 // the vertex traffic (205 -> ~10 vector loads per candidate pair).  Only k_narrow can afford the registers; the fused
 // kernels use NoCache and scan memory.  Both variants visit the vertices in the same order with the same
 // arithmetic, so they return the same vertex.
+#ifndef HULL_K
 #define HULL_K 8
+#endif
 struct HullCache { float x[HULL_K], y[HULL_K], z[HULL_K]; };
 struct NoCache {};
 

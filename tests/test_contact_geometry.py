@@ -124,7 +124,7 @@ def _kernel_rows(blobs, backend, epa=True, compare=False, states=None):
                   np.array([s["action"] for s in states]).T, np.array([s["warm"] for s in states]).T)
     dbg = sim.debug_forward()
     rows = []
-    differ = 0
+    differ = ncon = 0
     for e, st in enumerate(states):
         o = _oracle_at(blobs, st, epa)
         rows += gc.check_contacts(gc.Scene.from_oracle(model, o), dbg[e]["contacts"])
@@ -141,12 +141,13 @@ def _kernel_rows(blobs, backend, epa=True, compare=False, states=None):
                 assert abs(a["dist"] - b["dist"]) < 5e-6 + 1e-4 * abs(b["dist"]) and a["normal"] @ b["normal"] > 1 - 1e-4, (e, a, b)
                 assert np.abs(a["pos"] - b["pos"]).max() < 1.5e-2, (e, a, b)
                 differ += np.abs(a["pos"] - b["pos"]).max() > 2e-5
+                ncon += 1
             o2 = _oracle_at(blobs, st, epa)
             o2.inject_contacts(mine)
             o2.forward()
             qa = o2.qacc()[0]
             assert np.abs(dbg[e]["qacc"] - qa).max() <= 1e-4 * np.abs(qa).max(), (e, np.abs(dbg[e]["qacc"] - qa).max() / np.abs(qa).max())
-    return (rows, differ) if compare else rows
+    return (rows, differ, ncon) if compare else rows
 
 
 @pytest.mark.skipif(not os.environ.get("SO101_SLOW_TESTS"), reason="emulated run of the MPR option (40 s + an emulator build); set SO101_SLOW_TESTS=1")
@@ -163,7 +164,8 @@ def test_kernel_mpr_option_against_the_minimum_translation(blobs):
 
 
 # ---------------------------------------------------------------------------------------------- the default narrowphase: EPA
-MAX_WITNESS_DIFFERS = 4               # contacts (of ~150) whose witness point sits elsewhere on the same flat facet (a face against an edge: no unique point)
+MAX_WITNESS_FRACTION = 0.025          # contacts whose witness point sits elsewhere on the same flat facet (a hull face against an edge or a face: no unique
+                                      # point): measured 2 of 150 (first twelve states, emulated) and 6 of 404 (24 states, MI355X); round 3, before the witness-face rule: 8 of 150
 
 
 def _assert_epa(rows, abs_tol):
@@ -191,9 +193,9 @@ def test_oracle_returns_the_minimum_translation(blobs):
 
 def test_emulated_kernel_returns_the_minimum_translation(blobs):
     """The kernels' own contact lists (the same device code compiled for the host, tests/hostemu) on the first twelve states."""
-    rows, differ = _kernel_rows(blobs, "emu", compare=True, states=_states()[:12])
+    rows, differ, ncon = _kernel_rows(blobs, "emu", compare=True, states=_states()[:12])
     _assert_epa(rows, 5e-6)
-    assert differ <= MAX_WITNESS_DIFFERS
+    assert differ <= MAX_WITNESS_FRACTION * ncon, (differ, ncon)
 
 
 @pytest.mark.gpu
@@ -201,9 +203,9 @@ def test_kernel_returns_the_minimum_translation(blobs):
     """The library on the GPU, through the C ABI: the minimum translation for every pair; depth and normal of every contact equal to
     the fp64 oracle's answer (an exact face has no portal to land beside), the witness point within the contact patch, the solver
     exact on the kernel's list."""
-    rows, differ = _kernel_rows(blobs, "gpu", compare=True)
+    rows, differ, ncon = _kernel_rows(blobs, "gpu", compare=True)
     _assert_epa(rows, 5e-6)
-    assert differ <= MAX_WITNESS_DIFFERS
+    assert differ <= MAX_WITNESS_FRACTION * ncon, (differ, ncon)
 
 
 @pytest.mark.gpu
