@@ -401,7 +401,7 @@ int so101_create(const void* blob, size_t bytes, int n_envs, int device, uint64_
     PipeBuffers& W = s->pipe;
     bool ok = dev_alloc(s, &W.pose, NDYN * 12 * n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.cand, MAXCAND * n, 0, "hipMalloc(pipe)") &&
               dev_alloc(s, &W.ncand, n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.work, 2 * MAXCAND * n, 0, "hipMalloc(pipe)") &&
-              dev_alloc(s, &W.counters, (size_t)2 * MAXSUB * so101_sim::MAXGROUPS, 0, "hipMalloc(pipe)") &&
+              dev_alloc(s, &W.counters, (size_t)4 * MAXSUB * so101_sim::MAXGROUPS, 0, "hipMalloc(pipe)") &&
               dev_alloc(s, &W.conres, CONRES_DIM * (CONRES_PER_ENV * n + (size_t)MAXCAND * so101_sim::MAXGROUPS), 0, "hipMalloc(pipe)") && dev_alloc(s, &W.cbase, n, 0, "hipMalloc(pipe)") &&
               dev_alloc(s, &W.active, n, 0, "hipMalloc(pipe)") &&
 #ifdef SO101_DEBUG_CLOCKS
@@ -601,7 +601,7 @@ static int enqueue_pipelined(so101_sim* s, hipStream_t st, const so101::StepIO& 
     if (ng <= 0) continue;
     hipStream_t gs = G == 1 ? st : s->group_stream[g];
     PipeBuffers W = s->pipe;
-    W.counters = s->pipe.counters + 2 * MAXSUB * g;
+    W.counters = s->pipe.counters + 4 * MAXSUB * g;      // [MAXSUB][2] work items / cursor, then [MAXSUB][2] heavy / light items (so101_pipeline.hpp)
     W.work = s->pipe.work + (size_t)2 * MAXCAND * e0;
     W.work_cap = (unsigned int)ng * MAXCAND;
     // the slice's pool of contact records: CONRES_PER_ENV per env plus a floor of MAXCAND, so that ONE env can always place every
@@ -610,14 +610,20 @@ static int enqueue_pipelined(so101_sim* s, hipStream_t st, const so101::StepIO& 
     W.conres = s->pipe.conres + ((size_t)e0 * CONRES_PER_ENV + (size_t)g * MAXCAND) * CONRES_DIM;
     W.conres_cap = (unsigned int)ng * CONRES_PER_ENV + MAXCAND;
     static const int chunk_env = getenv("SO101_NARROW_CHUNK") ? atoi(getenv("SO101_NARROW_CHUNK")) : 0;          // (kernel experiments)
-    W.narrow_chunk = (unsigned int)(chunk_env >= 1 && chunk_env <= NARROW_CHUNK ? chunk_env : (n <= 8192 ? 3 : NARROW_CHUNK));
-    // persistent narrowphase waves (they pull work items until the list is empty): two per env of the slice, at
+    static const int chunk_env_l = getenv("SO101_NARROW_CHUNK_LIGHT") ? atoi(getenv("SO101_NARROW_CHUNK_LIGHT")) : 0;
+    // measured at 4096 envs (heavy / light pairs per fetch -> env-steps/s): 3/3 707 k, 1/3 684 k, 2/3 712 k, 2/4 720 k, 1/4 692 k, 2/2 679 k
+    int ch = chunk_env >= 1 && chunk_env <= NARROW_CHUNK ? chunk_env : (n <= 8192 ? 2 : NARROW_CHUNK);
+    int cl = chunk_env_l >= 1 && chunk_env_l <= NARROW_CHUNK ? chunk_env_l : NARROW_CHUNK;
+    W.narrow_chunk = (unsigned int)ch | ((unsigned int)cl << 4);        // heavy region | light region
+    // persistent narrowphase waves (they pull work items until the list is empty): 1.5 - 2 per env of the slice, at
     // most what fills 256 CUs - a smaller narrowphase grid leaves slots to the other chains' solve kernels
-    static const int nw_quarters = getenv("SO101_NARROW_WAVES_Q") ? atoi(getenv("SO101_NARROW_WAVES_Q")) : 8;      // (kernel experiments: quarter waves per env)
+    // (round 4, with the heavy-first work list: 1.5 waves per env 725 k, 2 per env 718 k, 2.5 per env 697 k env-steps/s at 4096 envs)
+    static const int nw_env = getenv("SO101_NARROW_WAVES_Q") ? atoi(getenv("SO101_NARROW_WAVES_Q")) : 0;      // (kernel experiments: quarter waves per env)
+    const int nw_quarters = nw_env > 0 ? nw_env : (n <= 8192 ? 6 : 8);
     int nw = (int)((long long)ng * nw_quarters / 4);
     nw = nw < 1 ? 1 : (nw < 4096 ? nw : 4096);
     if (G > 1 && !hip_ok(s, hipStreamWaitEvent(gs, s->step_begin, 0), "hipStreamWaitEvent")) return SO101_ERR_HIP;
-    if (!hip_ok(s, hipMemsetAsync(W.counters, 0, sizeof(int) * 2 * MAXSUB, gs), "hipMemsetAsync(pipe)")) return SO101_ERR_HIP;
+    if (!hip_ok(s, hipMemsetAsync(W.counters, 0, sizeof(int) * 4 * MAXSUB, gs), "hipMemsetAsync(pipe)")) return SO101_ERR_HIP;
     if (s->cfg.pipeline == 3) {
       // merged launches: the narrowphase of substep k + 1 rides in the solve launch of substep k (so101_chain.hpp)
       size_t capg = 64; while (capg < (size_t)ng * (MAXCAND / NARROW_CHUNK)) capg <<= 1;

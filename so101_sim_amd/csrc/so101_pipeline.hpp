@@ -53,28 +53,53 @@ DEV void load_state_aos(EnvLDS& L, const DevBuffers& B, const PipeBuffers& W, in
   wave_sync();
 }
 
-// hands the candidates in L.cand (and the poses the narrowphase needs) to substep s
-DEV void publish_candidates(const EnvLDS& L, const PipeBuffers& W, int e, int N, int s) {
+// hands the candidates in L.cand (and the poses the narrowphase needs) to substep s.
+// Two orders.  RECORDS: the contact record of candidate k of env e lives at position cbase[e] + k of the slice's pool (contiguous per env, in
+// candidate order: gather_contacts reads them like that).  WORK LIST (launch chains, round 4): longest-processing-time first - pairs without a
+// box or the plane (hull against hull / capsule / cylinder: MPR + EPA, 13-48 us) fill the list from its front, the others (a flat face against
+// a hull: closed form, 6-11 us) from its end, and k_narrow walks front first; a launch of persistent wavefronts then ends on cheap items
+// instead of on an EPA chunk taken last.  The order only changes WHEN a pair is processed, never its result.
+DEV bool heavy_pair(const DevModel* m, int g1, int g2) {
+  int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+  return t1 != G_PLANE && t1 != G_BOX && t2 != G_PLANE && t2 != G_BOX;
+}
+DEV void publish_candidates(const DevModel* m, const EnvLDS& L, const PipeBuffers& W, int e, int N, int s) {
   int lane = wave_lane(), ncand = L.ncand;
   for (int i = lane; i < NDYN * 12; i += WAVE) {
     int b = i / 12, j = i % 12;
     W.pose[(size_t)e * (NDYN * 12) + i] = j < 3 ? L.xpos[b][j] : L.xmat[b][j - 3];
   }
-  int base = 0;
+  bool lpt = W.conres_cap != 0u;                       // (the queue-fed step paths keep the plain order)
+  int nheavy = 0;
+  if (lpt) for (int k0 = 0; k0 < ncand; k0 += WAVE) { int k = k0 + lane; nheavy += __popcll(wave_ballot(k < ncand && heavy_pair(m, L.cand[k][0], L.cand[k][1]))); }
+  int base = 0, hb = 0, lb = 0;
   if (lane == 0) {
     base = ncand ? atomicAdd(&W.counters[2 * s], ncand) : 0;
-    // the contact records of this substep live at the candidates' work-list positions: what does not fit the slice's pool is
+    // the contact records of this substep live at the candidates' record positions: what does not fit the slice's pool is
     // dropped from the solve (k_narrow skips those positions) and counted as a candidate overflow
     int room = (int)W.conres_cap - base, keep = ncand < room ? ncand : (room > 0 ? room : 0);
     W.cbase[e] = base;
     W.ncand[e] = keep | (((L.overflow & 1) | (keep < ncand ? 1 : 0)) << 16);
+    if (lpt) {
+      hb = nheavy ? atomicAdd(&W.counters[2 * MAXSUB + 2 * s], nheavy) : 0;
+      lb = ncand - nheavy ? atomicAdd(&W.counters[2 * MAXSUB + 2 * s + 1], ncand - nheavy) : 0;
+    }
   }
-  base = wave_bcast_i(base, 0);
+  base = wave_bcast_i(base, 0); hb = wave_bcast_i(hb, 0); lb = wave_bcast_i(lb, 0);
   unsigned int* list = W.work + (size_t)(s & 1) * W.work_cap;
-  for (int k = lane; k < ncand; k += WAVE) {
-    unsigned int w = (unsigned int)e * MAXCAND + k;
-    W.cand[w] = (unsigned int)L.cand[k][0] | ((unsigned int)L.cand[k][1] << 16);
-    list[base + k] = w;
+  int hseen = 0, lseen = 0;
+  for (int k0 = 0; k0 < ncand; k0 += WAVE) {
+    int k = k0 + lane;
+    bool in = k < ncand, heavy = in && lpt && heavy_pair(m, L.cand[in ? k : 0][0], L.cand[in ? k : 0][1]);
+    unsigned long long mh = wave_ballot(heavy), ml = wave_ballot(in && !heavy);
+    if (in) {
+      unsigned int w = (unsigned int)e * MAXCAND + k;
+      W.cand[w] = (unsigned int)L.cand[k][0] | ((unsigned int)L.cand[k][1] << 16);
+      if (!lpt) list[base + k] = w;
+      else if (heavy) list[hb + hseen + wave_prefix(mh)] = w;
+      else list[W.work_cap - 1u - (unsigned int)(lb + lseen + wave_prefix(ml))] = w;
+    }
+    hseen += __popcll(mh); lseen += __popcll(ml);
   }
 }
 

@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(64, 2) k_pipe_begin(const DevModel* m, StepPar
     ChainQ QS = chain_queue_of(Q, Q_SOLVE, e);
     if (publish_chain(L, W, Q, e, 0) == 0 && lane == 0) q_push_lane(QS, solve_item(e, 0));
   } else if (W.mq_ctl) publish_merged(L, W, e);          // pipeline = 3: chunks for the chain's first (narrowphase only) launch
-  else publish_candidates(L, W, e, N, 0);
+  else publish_candidates(m, L, W, e, N, 0);
 }
 
 namespace so101 {

@@ -17,26 +17,40 @@ __global__ void __launch_bounds__(64, 2) k_narrow(const DevModel* m, int N, Pipe
   // ran 26 % longer at an identical instruction count (measured: 287 us against 227 us per launch, 582 k against 685 k
   // env-steps/s); a scalar or a non-temporal load does not.  The count is final before this kernel starts.
   int nwork = ldc(&W.counters[2 * s]);
+  // heavy items (no box, no plane: MPR + EPA) fill the list from its front, the others from its end (publish_candidates): front first
+  const int nheavy = ldc(&W.counters[2 * MAXSUB + 2 * s]);
   const unsigned int* list = W.work + (size_t)(s & 1) * W.work_cap;
+  int last_i0 = 0;
   for (;;) {
     int i0 = 0;
-    // work items per fetch: a launch-time number (W.narrow_chunk, at most NARROW_CHUNK).  Smaller chunks balance the tail of a launch
-    // (a chunk of four EPA pairs is 45 us against a launch of ~100 us alone), larger ones save atomics: measured in round 4 at 4096 envs
-    // 1 / 2 / 3 / 4 / 8 pairs -> 509 / 678 / 688 / 661 / 584 k env-steps/s, at 32 768 envs 2 / 4 -> 912 / 962 k; the host picks 3 up to
-    // 8192 envs and 4 above
-    const int chunk = (int)W.narrow_chunk;
+    // work items per fetch: launch-time numbers (W.narrow_chunk, at most NARROW_CHUNK each).  Smaller chunks balance the tail of a launch
+    // (a chunk of four EPA pairs is 45-190 us against a launch of ~100 us alone), larger ones save atomics.  Measured in round 4 at 4096
+    // envs, one size: 1 / 2 / 3 / 4 / 8 pairs -> 509 / 678 / 688 / 661 / 584 k env-steps/s (32 768 envs: 2 / 4 -> 912 / 962 k); with the
+    // heavy-first list order and two sizes (heavy / light): 3/3 707 k, 2/3 712 k, 2/4 720 k, 1/4 692 k.  The host picks 2/4 up to 8192
+    // envs and 4/4 above.
+    // (two sizes: W.narrow_chunk & 15 pairs per fetch while this wavefront's LAST fetch started in the heavy region of the list,
+    //  W.narrow_chunk >> 4 once it has seen the light region - no extra read of the cursor's cache line)
+    const int chunk = last_i0 < nheavy ? (int)(W.narrow_chunk & 15u) : (int)(W.narrow_chunk >> 4);
     if (lane == 0) i0 = atomicAdd(&W.counters[2 * s + 1], chunk);
     i0 = wave_uniform_i(i0);
     if (i0 >= nwork) break;
+    last_i0 = i0;
     unsigned int wl = 0, cl = 0;
-    if (lane < chunk && i0 + lane < nwork) { wl = list[i0 + lane]; cl = W.cand[wl]; }
+    int rb = 0;
+    if (lane < chunk && i0 + lane < nwork) {
+      int i = i0 + lane;
+      wl = list[i < nheavy ? (unsigned int)i : W.work_cap - 1u - (unsigned int)(i - nheavy)];
+      cl = W.cand[wl];
+      rb = W.cbase[wl / MAXCAND];                 // the record of candidate k of env e sits at cbase[e] + k
+    }
     // not unrolled: four inlined copies of the MPR query are ~130 KB of code, more than the instruction cache holds
 #pragma unroll 1
     for (int j = 0; j < chunk; j++) {
       if (i0 + j >= nwork) break;
-      if ((unsigned int)(i0 + j) >= W.conres_cap) continue;       // no room for this candidate's contact record (counted by its env)
       unsigned long long t0 = SO101_CLOCK();
       unsigned int w = (unsigned int)__builtin_amdgcn_readlane((int)wl, j), c = (unsigned int)__builtin_amdgcn_readlane((int)cl, j);
+      unsigned int rec = (unsigned int)__builtin_amdgcn_readlane(rb, j) + w % MAXCAND;
+      if (rec >= W.conres_cap) continue;          // no room for this candidate's contact record (counted by its env)
       int e = (int)(w / MAXCAND), g1 = (int)(c & 0xffffu), g2 = (int)(c >> 16);
       const float* pose = W.pose + (size_t)e * (NDYN * 12);
       int d1 = ldc(ldc(&m->geom_dyn) + g1), d2 = ldc(ldc(&m->geom_dyn) + g2);
@@ -54,7 +68,7 @@ __global__ void __launch_bounds__(64, 2) k_narrow(const DevModel* m, int N, Pipe
       narrow_pair<HullCache>(m, G1, G2, g1, g2, pc);
 #endif
       if (lane == 0) {
-        float* r = W.conres + (size_t)(i0 + j) * CONRES_DIM;
+        float* r = W.conres + (size_t)rec * CONRES_DIM;
         r[0] = (float)__popc(pc.valid); r[1] = pc.nrm[0]; r[2] = pc.nrm[1]; r[3] = pc.nrm[2];
         int o = 4;                                     // valid slots are written compactly, in slot order
 #pragma unroll
@@ -102,7 +116,7 @@ __global__ void __launch_bounds__(64, 2) k_pipe_solve(const DevModel* m, StepPar
   SolveIO io{obs, reward, discount, step_type, need_reset, diag};
   if (pipe_solve_env<false>(m, L, P, B, E, W, e, s, last, act, io)) {
     unsigned long long q2 = SO101_CLOCK();
-    publish_candidates(L, W, e, P.n_envs, s + 1);
+    publish_candidates(m, L, W, e, P.n_envs, s + 1);
 #ifdef SO101_DEBUG_CLOCKS
     if (wave_lane() == 0) W.ticks[(size_t)e * MAXCAND + 240 + 13] = (unsigned int)(SO101_CLOCK() - q2);
 #endif
