@@ -229,6 +229,13 @@ def run_aloha(args, torch, sdist, dev, rank, world, hbm_measured):
     d = env.diagnostics().cpu().numpy()
     all_returns = sdist.all_gather_returns(env.episode_returns())
     if rank == 0:
+        # counters of exactly this build's k_tree_step at 4096 ALOHA envs, when a PMC pass of it is committed (scripts/gpu_pmc_tree.sh)
+        tree_hash = sbuild.source_hash(mpr=args.narrowphase == "mpr")
+        tree_pmc = None
+        pmc_path = os.path.join(ROOT, "profiles", f"pmc_tree_{tree_hash}.json")
+        if not dining and N == 4096 and os.path.exists(pmc_path):
+            with open(pmc_path) as fh:
+                tree_pmc = json.load(fh)
         nq, nv = env.sim.nq, env.sim.nv
         algo = 4 * (14 + 2 * (nq + nv) + 2 * nv + 74 + 2 * (14 + 16) + 2 + 4) + 1      # action, state r+w, warm start r+w, obs, delay lines r+w, reward / discount, counters, step type
         achieved = algo * N / (elapsed / args.steps) / 1e9
@@ -244,9 +251,15 @@ def run_aloha(args, torch, sdist, dev, rank, world, hbm_measured):
                        "resets": (f"settled-state store computed before the timed region ({t_store:.1f} s for {2 + (args.warmup + args.steps) // 500} episodes per env)"
                                   if args.settled_store else "placement + settle inside the step calls"),
                        "parallelism": f"env-shard x{world}", "build": sbuild.source_hash(mpr=args.narrowphase == "mpr")},
-            "roofline": {"bound": "valu", "achieved": achieved, "peak": hbm_measured, "unit": "GB/s", "frac": achieved / hbm_measured if hbm_measured else None,
-                         "traffic": None, "peak_spec": HBM_SPEC_GBS, "frac_of_spec": achieved / HBM_SPEC_GBS, "kernel": "k_tree_step (one launch per control step)",
+            "roofline": {"bound": "latency/valu", "achieved": achieved, "peak": hbm_measured, "unit": "GB/s", "frac": achieved / hbm_measured if hbm_measured else None,
+                         "traffic": (tree_pmc or {}).get("hbm_bytes_per_step"), "peak_spec": HBM_SPEC_GBS, "frac_of_spec": achieved / HBM_SPEC_GBS,
+                         "kernel": "k_tree_step (one launch per control step)",
                          "kernel_ms": 1e3 * elapsed / args.steps, "launches_per_step": 1,
+                         "compute": None if not tree_pmc else {
+                             "valu_tflops_equiv": tree_pmc["valu_insts_per_step"] * 64 * 2 / (elapsed / args.steps) / 1e12, "peak_tflops": VALU_PEAK_TFLOPS,
+                             "frac": tree_pmc["valu_insts_per_step"] * 64 * 2 / (elapsed / args.steps) / 1e12 / VALU_PEAK_TFLOPS,
+                             "valu_insts_per_env_substep": tree_pmc["valu_insts_per_step"] / (N * 10.0), "active_lane_fraction": tree_pmc.get("active_lane_fraction"),
+                             "wait_fraction": tree_pmc.get("wait_fraction"), "source": f"profiles/pmc_tree_{tree_hash}.json"},
                          "note": f"algorithmic bytes {algo} B per env-step; the kernel is bound by its instruction count (profiles/r03_aloha_pmc.txt: 101 k vector "
                                  "wave-instructions per env-substep before the oriented-box filter of round 4), not by HBM"},
             "dist": sdist.evidence(1e3 * elapsed / args.steps, dev),

@@ -3,12 +3,13 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-for c in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VALU" "SQ_IFETCH SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS"; do
+HASH=$(cd $R && python3 -c "from so101_sim_amd import build; print(build.source_hash())")
+for c in FETCH_SIZE WRITE_SIZE "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VALU" "SQ_IFETCH SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS" "SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU"; do
   n=$(echo $c | cut -d' ' -f1)
   rm -rf /tmp/pt_$n; timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pt_$n -- python3 $R/scripts/gpu_aloha_bench.py banana > $O/tree_pmc_$n.log 2>&1
 done
-python3 - <<'PY'
-import csv, glob, collections
+python3 - $HASH $O <<'PY'
+import csv, glob, collections, json, sys
 t = collections.defaultdict(float); n = collections.defaultdict(int)
 for f in glob.glob('/tmp/pt_*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
@@ -16,4 +17,13 @@ for f in glob.glob('/tmp/pt_*/**/*counter_collection.csv', recursive=True):
         if 'k_tree_step' in k and int(r.get('Grid_Size', r.get('Grid_Size_X', '0')) or 0) >= 4096 * 64:
             t[r['Counter_Name']] += float(r['Counter_Value']); n[r['Counter_Name']] += 1
 for k in sorted(t): print("k_tree_step (4096 envs)  %-30s %.4g per dispatch (%d dispatches)" % (k, t[k] / n[k], n[k]))
+m = {k: t[k] / n[k] for k in t}
+# what bench.py --workload aloha reports as roofline.traffic / roofline.compute (FETCH_SIZE doubled: gfx950 tallies 128-B requests at 64 B; KB)
+out = {"build": sys.argv[1], "workload": "scripts/gpu_aloha_bench.py banana: k_tree_step dispatches of 4096 envs (one control step each), mean",
+       "dispatches": max(n.values()) if n else 0, "per_step": m,
+       "hbm_bytes_per_step": (2 * m.get("FETCH_SIZE", 0.0) + m.get("WRITE_SIZE", 0.0)) * 1024.0,
+       "valu_insts_per_step": m.get("SQ_INSTS_VALU"), "salu_insts_per_step": m.get("SQ_INSTS_SALU"),
+       "wait_fraction": m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"] if m.get("SQ_WAVE_CYCLES") else None,
+       "active_lane_fraction": m["SQ_THREAD_CYCLES_VALU"] / (64.0 * m["SQ_ACTIVE_INST_VALU"]) if m.get("SQ_ACTIVE_INST_VALU") else None}
+json.dump(out, open(sys.argv[2] + "/pmc_tree_" + sys.argv[1] + ".json", "w"), indent=1)
 PY
