@@ -29,6 +29,7 @@
 #undef TCAND
 #undef TGEOM
 #undef TJS
+#undef TRL
 #undef TREE_NS
 #undef T_SCRATCH
 #define TB 32          // bodies (world included)
@@ -45,6 +46,7 @@
 #define TCAND 512      // broadphase candidates per env
 #define TGEOM 256      // collision geoms
 #define TJS 64         // row stride of the constraint Jacobian scratch
+#define TRL 0          // constraint rows kept in LDS (none: 70 KB of LDS per env already)
 #undef TREE_CHOL_DEV
 #define TREE_CHOL_DEV __device__ __attribute__((noinline))      // 64 x 64 unrolled pivot steps: one copy of the code, called from the three sites
 #else
@@ -56,6 +58,7 @@
 #define TCAND 256
 #define TGEOM 128
 #define TJS 32
+#define TRL 96         // constraint rows kept in LDS while a substep has no more (round 4): Jacobian + per-row vectors, 15 KB aliased with CRBA / RNE / collision scratch
 #undef TREE_CHOL_DEV
 #define TREE_CHOL_DEV DEV
 #endif
@@ -93,6 +96,7 @@ struct TreeBuffers { float *qpos, *qvel, *ctrl, *warm; float* scratch; int* diag
 // vectors of the solver and the contacts' Hessian blocks.  Written and read by the env's own wavefront only (through the CU's L1).
 #define T_SCRATCH (TROW * TJS + 8 * TROW + TCON * 36)       // floats per env
 struct TreeScratch {
+  float* global_base;              // the env's slice of the global scratch (the pointers below may point into LDS instead, see use_row_storage)
   float* J;                        // [TROW][TJS]
   float *eD, *eR, *earef, *efl, *ejar, *ef, *ejv;   // [TROW] each
   unsigned int* etype;             // [TROW]
@@ -108,13 +112,16 @@ struct TreeLDS {
   float qpos[TQ], qvel[TV], ctrl[TU], warm[TV], qacc[TV], qsm[TV], bias[TV], qfrc[TV], qact[TV];
   float xpos[TB][3], xquat[TB][4], xmat[TB][9], xipos[TB][3], ximat[TB][9];
   float S[TV][6];
-  union {                                                // two phases of a substep share this storage
-    float Ic[TB][36];                                    // CRBA: spatial inertia about the world origin, each body's own, then composite (in place)
+  union {                                                // the phases of a substep share this storage
+    struct {
+      float Ic[TB][36];                                  // CRBA: spatial inertia about the world origin, each body's own, then composite (in place)
+      float rw[TB][3], ral[TB][3], rao[TB][3], rf[TB][3], rn[TB][3];      // RNE
+    };
     struct { float aabb[6][TGEOM]; unsigned int cand[TCAND]; };   // collision: world boxes of the geoms, candidate pairs
+    struct { float xJ[(TRL ? TRL : 1) * TJS]; float xv[8 * (TRL ? TRL : 1)]; };      // constraints + solver: the rows' Jacobian and per-row vectors (nrow <= TRL)
   };
   float M[TV][TV + 1];
   union { float L[TV][TV + 1]; float H[TV][TV + 1]; };  // factor of M (until qacc_smooth is known), then the Newton Hessian / M + h D
-  float rw[TB][3], ral[TB][3], rao[TB][3], rf[TB][3], rn[TB][3];
   TCon con[TCON];
   float hJ[6][TV], hT[6][TV];       // Hessian assembly: one contact's Jacobian columns compacted to the dofs it touches, and Hc J
   int hdl[TV];                      // ... the dof of each compacted slot
@@ -129,6 +136,7 @@ namespace tree {
 DEV TreeScratch scratch_of(const TreeBuffers& B, int e) {
   float* base = B.scratch + (size_t)e * T_SCRATCH;
   TreeScratch G;
+  G.global_base = base;
   G.J = base; base += TROW * TJS;
   G.eD = base; G.eR = base + TROW; G.earef = base + 2 * TROW; G.efl = base + 3 * TROW; G.ejar = base + 4 * TROW; G.ef = base + 5 * TROW; G.ejv = base + 6 * TROW;
   G.etype = (unsigned int*)(base + 7 * TROW); base += 8 * TROW;
@@ -642,7 +650,23 @@ DEV void row_params(const TreeModel* tm, const float* solref_in, const float* so
   *imp = impedance(solimp, pos);
 }
 
-DEV void make_constraints(const TreeModel* tm, TreeLDS& L, const TreeScratch& G) {
+// Where the rows of THIS substep live: in LDS when they fit (nrow <= TRL; the ALOHA hand-over scenes have ~80), in the env's global scratch
+// otherwise.  Measured in round 4 (experiment build, 3 envs per CU): with Jacobian and per-row vectors in LDS the Newton stage of an env
+// takes 99 us instead of 187 - it is bound by the latency of its loads (section 8 of DESIGN.md).  The contacts' Hessian blocks stay global.
+DEV void use_row_storage(TreeLDS& L, TreeScratch& G, int nrow) {
+  if (TRL > 0 && nrow <= TRL) {
+    G.J = L.xJ;
+    G.eD = L.xv; G.eR = L.xv + TRL; G.earef = L.xv + 2 * TRL; G.efl = L.xv + 3 * TRL; G.ejar = L.xv + 4 * TRL; G.ef = L.xv + 5 * TRL; G.ejv = L.xv + 6 * TRL;
+    G.etype = (unsigned int*)(L.xv + 7 * TRL);
+  } else {
+    float* base = G.global_base;
+    G.J = base; base += TROW * TJS;
+    G.eD = base; G.eR = base + TROW; G.earef = base + 2 * TROW; G.efl = base + 3 * TROW; G.ejar = base + 4 * TROW; G.ef = base + 5 * TROW; G.ejv = base + 6 * TROW;
+    G.etype = (unsigned int*)(base + 7 * TROW);
+  }
+}
+
+DEV void make_constraints(const TreeModel* tm, TreeLDS& L, TreeScratch& G) {
   int lane = wave_lane(), nv = tm->nv, neq = tm->neq, nfric = tm->nfric, njnt = tm->njnt;
   // joint limits that are violated: (joint, side) pairs in joint order
   bool lo_on = false, hi_on = false;
@@ -666,6 +690,8 @@ DEV void make_constraints(const TreeModel* tm, TreeLDS& L, const TreeScratch& G)
   }
   if (keep < ncon) { ncon = keep; if (lane == 0) { L.flags |= 4; L.ncon = keep; } }
   if (lane == 0) { L.nrow = nrow; L.nscalar = nscalar; }
+  wave_sync();                              // (the collision stage's boxes and candidates, which the row storage may alias, are no longer read)
+  use_row_storage(L, G, nrow);
   // zero the Jacobian rows of the scalar constraints
   for (int r = 0; r < nscalar; r++) if (lane < TJS) G.J[r * TJS + lane] = 0.f;
   wave_sync();
@@ -1045,7 +1071,7 @@ DEV void solve_newton(const TreeModel* tm, TreeLDS& L, const TreeScratch& G, int
 
 // ------------------------------------------------------------------ forward dynamics and integration
 // `phases`: stage mask for timing runs (so101_tree_debug_forward with SO101_TREE_PHASES set); every caller on the step path passes all
-DEV void forward(const TreeModel* tm, const DevModel* gm, TreeLDS& L, const TreeScratch& G, int max_iter, float tolerance, int phases = 0x7f) {
+DEV void forward(const TreeModel* tm, const DevModel* gm, TreeLDS& L, TreeScratch& G, int max_iter, float tolerance, int phases = 0x7f) {
   kinematics(tm, L);
   if (phases & 2) crba(tm, L);
   if (phases & 4) rne_bias(tm, L);
@@ -1225,7 +1251,7 @@ DEV void dining_place(const TreeModel* tm, const TreeTask& T, TreeLDS& L, unsign
 
 // env.reset(): arms at the home pose, object and container placed (container by rejection, <= 20 tries), settled with the arms held
 // (aloha2_task.py:369-383, hand_over.py:208-236,340-346).  Same counter-RNG draws as the SO100 reset and the oracle.
-DEV void env_settle(const TreeModel* tm, const DevModel* gm, const TreeTask& T, TreeLDS& L, const TreeScratch& G, int e, unsigned int episode) {
+DEV void env_settle(const TreeModel* tm, const DevModel* gm, const TreeTask& T, TreeLDS& L, TreeScratch& G, int e, unsigned int episode) {
   int lane = wave_lane();
   unsigned long long env_id = T.env_id_base + (unsigned long long)e;
   if (lane < tm->nq) L.qpos[lane] = lane < tm->njnt ? T.home_qpos[lane] : 0.f;
@@ -1311,7 +1337,7 @@ DEV void write_physics_state(const TreeModel* tm, const TreeTask& T, const TreeL
 
 // env.reset(): the settled state of the episode from the store when it holds it, computed otherwise; then the episode starts -
 // delay lines padded with the reset-time value (task_suite.py:154 INITIAL_VALUE), counters cleared
-DEV void env_reset(const TreeModel* tm, const DevModel* gm, const TreeTask& T, TreeLDS& L, const TreeScratch& G, const TreeBuffers& B, const TreeEnvBuffers& E,
+DEV void env_reset(const TreeModel* tm, const DevModel* gm, const TreeTask& T, TreeLDS& L, TreeScratch& G, const TreeBuffers& B, const TreeEnvBuffers& E,
                    const TreeStore& S, int e) {
   int lane = wave_lane(), N = T.n_envs;
   unsigned int episode = (unsigned int)E.episode[e];
