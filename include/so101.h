@@ -290,7 +290,8 @@ int so101_tree_get_diag(so101_tree* sim, int32_t* out, void* hip_stream);
  * ep_return, step_count, episode.  Observation row of so101_tree_step, so101_tree_obs_dim() = 3 npos + 2 nvel floats per env:
  *   joints_pos (delayed) | joints_vel (delayed) | undelayed_joints_pos | undelayed_joints_vel | commanded_joints_pos
  * step_type 0 FIRST (the call after a LAST resets the env and ignores the action), 1 MID, 2 LAST; a physics error ends the
- * episode with reward 0 and discount 0.  Reset happens inside the step call (no prefetch yet). */
+ * episode with reward 0 and discount 0.  Reset happens inside the step call: a copy when the settled-state store or the reset prefetch
+ * (prefetch_resets) holds the episode, placement + settle in place otherwise. */
 typedef struct {
   int n_substeps;            /* physics steps per control step (10) */
   int last_step;             /* control step on which the time limit ends the episode */
@@ -305,6 +306,9 @@ typedef struct {
   int joints_delay_steps;    /* delay of joints_pos / joints_vel in CONTROL steps (joints_observation_delay_secs / control_timestep,
                                 aloha2_task.py:153-155,236-243); < 0: the reference's default 5 (0.1 s); 0: undelayed; at most 64 */
   int physics_delay_steps;   /* delay of delayed_physics_state (image_observation_delay_secs, aloha2_task.py:157-159,244-251); < 0: 15 (0.3 s) */
+  int prefetch_resets;       /* != 0: the settled initial state of every env's NEXT episode is computed on an internal low-priority stream beside
+                                the stepping kernels (library-owned cache + a second per-env scratch); a reset that finds its entry copies it, one
+                                that does not settles in place - the same bits either way.  so101_tree_configure_env / so101_tree_destroy join it */
 } so101_tree_config;
 int so101_tree_obs_dim(const so101_tree* sim);
 int so101_tree_bind_env(so101_tree* sim, float* ring_pos, float* ring_vel, float* ep_return, int32_t* step_count, int32_t* episode);

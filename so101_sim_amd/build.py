@@ -9,6 +9,7 @@ from __future__ import annotations
 import glob
 import hashlib
 import os
+import re
 import subprocess
 from concurrent.futures import ThreadPoolExecutor
 
@@ -80,9 +81,13 @@ def build(force: bool = False, verbose: bool = False, clocks: bool = False, mpr:
         flags.append("-Rpass-analysis=kernel-resource-usage")
     newest_header = max(os.path.getmtime(s) for s in sources() if not s.endswith(".hip"))
 
+    def newest_input(src):          # the file, every header, and any .hip it includes (tu_tree64.hip is tu_tree.hip under another variant)
+        included = re.findall(r'#include\s+"([^"]+\.hip)"', open(src).read())
+        return max([os.path.getmtime(src), newest_header] + [os.path.getmtime(os.path.join(os.path.dirname(src), i)) for i in included])
+
     def compile_one(src):
         obj = os.path.join(OBJ, os.path.basename(src)[:-4] + (".clk" if clocks else "") + (".mpr" if mpr else "") + ".o")
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_header):
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > newest_input(src):
             return obj
         subprocess.check_call([HIPCC, *flags, "-c", "-o", obj, src])
         return obj

@@ -1148,7 +1148,15 @@ struct TreeEnvBuffers {
 // Settled-state store (so101_tree_set_settled_store): the results of placement + settle for episodes first .. first + count - 1 of every
 // env, computed once by so101_tree_compute_settled and kept by the caller.  The settled state of an episode is a pure function of (seed,
 // global env id, episode, configuration), so a reset that finds its entry copies the same bits it would have computed.
-struct TreeStore { const float *qpos, *qvel, *warm; const int* flags; int first, count; };     // [count][nq|nv|nv][N], [count][N]
+struct TreeStore {
+  const float *qpos, *qvel, *warm; const int* flags; int first, count;     // [count][nq|nv|nv][N], [count][N]
+  // Reset prefetch (round 4; so101_tree_config.prefetch_resets): the settled state of every env's NEXT episode, computed by k_tree_prepare on a
+  // low-priority stream beside the stepping kernels into a library-owned cache [nq|nv|nv][N]; ctag[e] = 1 + the episode the entry holds
+  // (0: empty).  The producer writes the entry with agent-scope stores, drains them, then the tag; the consumer reads the tag, then the entry,
+  // with agent-scope loads (the two kernels may run on different XCDs, whose L2s are not coherent) and settles in place when the tag does not
+  // name its episode - the same bits either way, the settled state being a pure function of (seed, env id, episode, configuration).
+  float *cq, *cv, *cw; int* cf; unsigned int* ctag;
+};
 
 namespace tree {
 
@@ -1348,11 +1356,20 @@ DEV void env_reset(const TreeModel* tm, const DevModel* gm, const TreeTask& T, T
     if (lane < tm->nu) L.ctrl[lane] = T.home_ctrl[lane];
     if (lane == 0) { L.ncon = 0; L.nrow = 0; L.iters = 0; L.ncand = 0; L.flags |= S.flags[k * N + e]; }
     wave_sync();
+  } else if (S.ctag && ld_agent(&S.ctag[e]) == episode + 1u) {
+    if (lane < tm->nq) L.qpos[lane] = ld_agent(&S.cq[(size_t)lane * N + e]);
+    if (lane < tm->nv) { L.qvel[lane] = ld_agent(&S.cv[(size_t)lane * N + e]); L.warm[lane] = ld_agent(&S.cw[(size_t)lane * N + e]); L.qacc[lane] = 0.f; }
+    if (lane < tm->nu) L.ctrl[lane] = T.home_ctrl[lane];
+    if (lane == 0) { L.ncon = 0; L.nrow = 0; L.iters = 0; L.ncand = 0; L.flags |= ld_agent(&S.cf[e]); }
+    wave_sync();
   } else {
     env_settle(tm, gm, T, L, G, e, episode);
   }
   fill_delay_lines(tm, T, L, E, e);
-  if (lane == 0) { E.step_count[e] = 0; E.ep_return[e] = 0.f; E.episode[e] = (int)(episode + 1u); E.success_state[e] = T.requires_handover ? 0 : 2; }
+  // (the episode counter last, agent scope: k_tree_prepare reads it to know which episode to prepare next, and must not see the new value
+  //  before this env has finished reading its cache entry)
+  wave_sync();
+  if (lane == 0) { E.step_count[e] = 0; E.ep_return[e] = 0.f; E.success_state[e] = T.requires_handover ? 0 : 2; st_agent(&E.episode[e], (int)(episode + 1u)); }
 }
 
 // observation row: joints_pos (delayed) | joints_vel (delayed) | undelayed_joints_pos | undelayed_joints_vel | commanded_joints_pos

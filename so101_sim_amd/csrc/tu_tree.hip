@@ -117,6 +117,28 @@ __global__ void __launch_bounds__(64) k_tree_settle_table(const TreeModel* tm, c
   if (lane == 0) flags[kk * N + e] = L.flags;
 }
 
+// Reset prefetch: the settled state of the NEXT episode of every env whose cache entry does not hold it yet (TreeStore, so101_tree.hpp), into
+// the library's cache, on a low-priority stream beside the stepping kernels; its own per-env scratch (B.scratch here is the second one)
+__global__ void __launch_bounds__(64) k_tree_prepare(const TreeModel* tm, const DevModel* gm, TreeTask T, TreeBuffers B, const int* episode_of, TreeStore S) {
+  BLOCK_SHARED(TreeLDS, L);
+  int e = blockIdx.x, lane = wave_lane(), N = T.n_envs;
+  unsigned int episode = (unsigned int)ld_agent(&episode_of[e]);
+  if (ld_agent(&S.ctag[e]) == episode + 1u) return;                                      // the entry is current
+  if (S.qpos && episode - (unsigned int)S.first < (unsigned int)S.count) return;          // the caller's settled-state store covers it
+  if (lane == 0) L.flags = 0;
+  wave_sync();
+  TreeScratch G = tree::scratch_of(B, e);
+  tree::env_settle(tm, gm, T, L, G, e, episode);
+  if (lane == 0) st_agent(&S.ctag[e], 0u);                                                 // (no reader may take a half-written entry for the old episode)
+  drain_stores();
+  if (lane < tm->nq) st_agent(&S.cq[(size_t)lane * N + e], L.qpos[lane]);
+  if (lane < tm->nv) { st_agent(&S.cv[(size_t)lane * N + e], L.qvel[lane]); st_agent(&S.cw[(size_t)lane * N + e], L.warm[lane]); }
+  if (lane == 0) st_agent(&S.cf[e], L.flags);
+  drain_stores();
+  wave_sync();
+  if (lane == 0) st_agent(&S.ctag[e], episode + 1u);
+}
+
 // settle the bound state with the one-dof joints held (dm_control's PropPlacer(settle_physics=True) alone, for callers that draw the
 // placements themselves): until |qvel| < 1e-3 and |qacc| < 1e-2 over the props' dofs or the budget ends (flag 32)
 __global__ void __launch_bounds__(64) k_tree_settle(const TreeModel* tm, const DevModel* gm, TreeTask T, TreeBuffers B) {
@@ -248,6 +270,12 @@ struct TreeHandle {
   TreeEnvBuffers env{};
   TreeStore store{};
   int iterations = 0; float tolerance = 0.f;
+  // reset prefetch: second per-env scratch, low-priority stream, "previous launch still running" bookkeeping
+  float* scratch2 = nullptr;
+  float *cq = nullptr, *cv = nullptr, *cw = nullptr; int* cf = nullptr; unsigned int* ctag = nullptr;
+  hipStream_t prep_stream = nullptr;
+  hipEvent_t prep_done = nullptr, main_ev = nullptr;
+  bool prep_pending = false, prefetch = false;
   std::vector<void*> owned;
   std::string err;
 };
@@ -465,6 +493,50 @@ int tree_build(TreeHandle* s, const BlobView& b) {
 }
 }  // namespace
 
+static TreeTask task_now(TreeHandle* s) { TreeTask T = s->task; T.n_envs = s->n_envs; T.iterations = s->iterations; T.tolerance = s->tolerance; return T; }
+// the store the kernels see: the caller's settled-state tables plus, with the prefetch on, the library's cache of next-episode states
+static TreeStore store_now(TreeHandle* s) {
+  TreeStore S = s->store;
+  S.cq = S.cv = S.cw = nullptr; S.cf = nullptr; S.ctag = nullptr;
+  if (s->prefetch && s->ctag) { S.cq = s->cq; S.cv = s->cv; S.cw = s->cw; S.cf = s->cf; S.ctag = s->ctag; }
+  return S;
+}
+static bool tree_prefetch_setup(TreeHandle* s) {          // lazily: second scratch, cache, low-priority stream
+  if (s->ctag) return true;
+  size_t n = (size_t)s->n_envs;
+  auto alloc = [&](void** out, size_t bytes) {
+    void* p = nullptr;
+    if (!t_ok(s, hipMalloc(&p, bytes), "hipMalloc(prefetch)")) return false;
+    s->owned.push_back(p); *out = p;
+    return t_ok(s, hipMemset(p, 0, bytes), "hipMemset(prefetch)");
+  };
+  int lo = 0, hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+  return alloc((void**)&s->scratch2, n * T_SCRATCH * sizeof(float)) && alloc((void**)&s->cq, n * s->hm.nq * sizeof(float)) &&
+         alloc((void**)&s->cv, n * s->hm.nv * sizeof(float)) && alloc((void**)&s->cw, n * s->hm.nv * sizeof(float)) && alloc((void**)&s->cf, n * sizeof(int)) &&
+         t_ok(s, hipStreamCreateWithPriority(&s->prep_stream, hipStreamNonBlocking, lo), "hipStreamCreateWithPriority") &&
+         t_ok(s, hipEventCreateWithFlags(&s->prep_done, hipEventDisableTiming), "hipEventCreate") &&
+         t_ok(s, hipEventCreateWithFlags(&s->main_ev, hipEventDisableTiming), "hipEventCreate") && alloc((void**)&s->ctag, n * sizeof(unsigned int));
+}
+static bool drain_tree_prepare(TreeHandle* s) {
+  s->prep_pending = false;
+  return !s->prep_stream || t_ok(s, hipStreamSynchronize(s->prep_stream), "hipStreamSynchronize(prefetch)");
+}
+// k_tree_prepare behind whatever `stream` holds now, unless the previous launch is still running (it takes every env whose next episode is
+// missing, so a skipped launch only delays the refill)
+static void launch_tree_prepare(TreeHandle* s, hipStream_t stream) {
+  if (!s->prefetch || !s->ctag || s->task.settle_max == 0) return;
+  if (s->prep_pending) {
+    if (hipEventQuery(s->prep_done) != hipSuccess) { (void)hipGetLastError(); return; }
+    s->prep_pending = false;
+  }
+  if (hipEventRecord(s->main_ev, stream) != hipSuccess || hipStreamWaitEvent(s->prep_stream, s->main_ev, 0) != hipSuccess) return;
+  TreeBuffers B2 = s->buf; B2.scratch = s->scratch2;
+  hipLaunchKernelGGL(k_tree_prepare, dim3(s->n_envs), dim3(64), 0, s->prep_stream, s->dm, s->dg, task_now(s), B2, (const int*)s->env.episode, store_now(s));
+  if (hipGetLastError() == hipSuccess && hipEventRecord(s->prep_done, s->prep_stream) == hipSuccess) s->prep_pending = true;
+}
+
+
 extern "C" {
 
 int TAPI(create)(const void* blob, size_t bytes, int n_envs, int hip_device, TreeHandle** out) {
@@ -510,6 +582,9 @@ void TAPI(destroy)(TreeHandle* s) {
   {
     TreeDeviceGuard guard(s);
     (void)hipDeviceSynchronize();                 // nothing of this handle may still be running on buffers that are about to go
+    if (s->prep_stream) (void)hipStreamDestroy(s->prep_stream);
+    if (s->prep_done) (void)hipEventDestroy(s->prep_done);
+    if (s->main_ev) (void)hipEventDestroy(s->main_ev);
     for (void* p : s->owned) (void)hipFree(p);
   }
   delete s;
@@ -588,25 +663,36 @@ int TAPI(configure_env)(TreeHandle* s, const so101_tree_config* c) {
   int jd = c->joints_delay_steps < 0 ? T_RING_DEFAULT : c->joints_delay_steps, pd = c->physics_delay_steps < 0 ? T_PS_DEFAULT : c->physics_delay_steps;
   if (jd > T_DELAY_MAX || pd > T_DELAY_MAX) { s->err = "so101_tree_configure_env: observation delay above 64 control steps"; return SO101_ERR_ARG; }
   T.jdelay = jd; T.pdelay = pd;
+  // reset prefetch: whatever the cache holds was settled under the previous configuration
+  {
+    TREE_GUARD(s);
+    if (!drain_tree_prepare(s)) return SO101_ERR_HIP;
+    s->prefetch = c->prefetch_resets != 0;
+    if (s->prefetch && !tree_prefetch_setup(s)) return SO101_ERR_HIP;
+    if (s->ctag && !t_ok(s, hipMemset(s->ctag, 0, (size_t)s->n_envs * sizeof(unsigned int)), "hipMemset(prefetch)")) return SO101_ERR_HIP;
+  }
   return TAPI(configure)(s, c->solver_iterations, c->solver_tolerance);
 }
 
-static TreeTask task_now(TreeHandle* s) { TreeTask T = s->task; T.n_envs = s->n_envs; T.iterations = s->iterations; T.tolerance = s->tolerance; return T; }
 
 int TAPI(reset)(TreeHandle* s, const uint8_t* mask, void* stream) {
   if (!s) return SO101_ERR_ARG;
   if (!s->bound || !s->env_bound) { s->err = "so101_tree_reset before so101_tree_bind_state / so101_tree_bind_env"; return SO101_ERR_STATE; }
   TREE_GUARD(s);
-  hipLaunchKernelGGL(k_tree_reset, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, s->dg, task_now(s), s->buf, s->env, s->store, mask);
-  return t_ok(s, hipGetLastError(), "k_tree_reset") ? SO101_OK : SO101_ERR_HIP;
+  hipLaunchKernelGGL(k_tree_reset, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, s->dg, task_now(s), s->buf, s->env, store_now(s), mask);
+  if (!t_ok(s, hipGetLastError(), "k_tree_reset")) return SO101_ERR_HIP;
+  launch_tree_prepare(s, (hipStream_t)stream);
+  return SO101_OK;
 }
 
 int TAPI(step)(TreeHandle* s, const float* action, float* obs, float* reward, float* discount, uint8_t* step_type, void* stream) {
   if (!s || !action || !obs || !reward || !discount || !step_type) { if (s) s->err = "so101_tree_step: NULL argument"; return SO101_ERR_ARG; }
   if (!s->bound || !s->env_bound) { s->err = "so101_tree_step before so101_tree_bind_state / so101_tree_bind_env"; return SO101_ERR_STATE; }
   TREE_GUARD(s);
-  hipLaunchKernelGGL(k_tree_step, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, s->dg, task_now(s), s->buf, s->env, s->store, action, obs, reward, discount, step_type);
-  return t_ok(s, hipGetLastError(), "k_tree_step") ? SO101_OK : SO101_ERR_HIP;
+  hipLaunchKernelGGL(k_tree_step, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, s->dg, task_now(s), s->buf, s->env, store_now(s), action, obs, reward, discount, step_type);
+  if (!t_ok(s, hipGetLastError(), "k_tree_step")) return SO101_ERR_HIP;
+  launch_tree_prepare(s, (hipStream_t)stream);
+  return SO101_OK;
 }
 
 int TAPI(compute_settled)(TreeHandle* s, int first_episode, int count, float* qpos, float* qvel, float* warmstart, int32_t* flags, void* stream) {

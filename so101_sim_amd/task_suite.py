@@ -112,8 +112,7 @@ def create_task_env(
 
     task_instance = task_class(**kwargs)
     if isinstance(task_instance, _aloha.HandOverTask):
-        for k in ("solver", "prefetch_resets"):          # knobs of the SO100 kernels only
-            env_kwargs.pop(k, None)
+        env_kwargs.pop("solver", None)                    # (a knob of the SO100 kernels only)
         return _aloha.AlohaEnvironment(task_instance, n_envs=n_envs, time_limit=time_limit, random_state=random_state, **env_kwargs)
     if n_envs == 1:
         return _env.SingleEnvironment(task_instance, time_limit=time_limit, random_state=random_state, **env_kwargs)

@@ -490,6 +490,35 @@ def test_single_aloha_env_reset_is_seed_compatible_with_the_reference():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["banana", "dining"])
+def test_reset_prefetch_of_the_tree_engine_is_bit_identical(scene):
+    """so101_tree_config.prefetch_resets: the next episode's settled state computed on a low-priority stream beside the stepping kernels
+    changes WHEN a reset state is computed, never its value - rollouts across several auto-resets (short time limit, some envs ended early
+    by scripted successes are not needed: the time limit alone resets every env three times) are bit-identical with the prefetch off and on,
+    and with the prefetch on the later resets are served from the cache (the step calls that reset get short)."""
+    import time
+    import torch
+    raw32 = scenes.load_dining_blob("banana", "f32")[0] if scene == "dining" else _blobs("banana")[1]
+    n, steps = (16, 10) if scene == "dining" else (64, 13)
+    out = []
+    for prefetch in (0, 1):
+        sim = TreeArraySim(raw32, n, backend="gpu")
+        sim.enable_env(seed=5, last_step=3, settle_max_substeps=300, prefetch_resets=prefetch)
+        rng = np.random.RandomState(2)
+        trace = []
+        for k in range(steps):
+            a = np.tile(np.concatenate([scenes.ALOHA_HOME_CTRL] * 2), (n, 1)) + 0.2 * rng.normal(size=(n, 14))
+            obs, r, d, st = sim.step(a)
+            if prefetch:
+                torch.cuda.synchronize(); time.sleep(0.05)          # (let the background settle finish: the next reset then finds its entry)
+            trace.append(np.concatenate([obs.ravel(), r, d, st.astype(np.float64)] + [x.ravel() for x in sim.get_state()]))
+        out.append(trace)
+        assert np.all(sim._get(sim.episode) >= 3)
+    for k, (a, b) in enumerate(zip(*out)):
+        np.testing.assert_array_equal(a, b, err_msg=f"step {k}")
+
+
+@pytest.mark.gpu
 def test_settled_store_of_the_tree_engine_is_bit_identical():
     """compute_settled(): the settle results of the first episodes of every env, computed ahead of time; the resets that find them copy -
     the rollout across two auto-resets is bit-identical to the one that settles inside the step calls."""
