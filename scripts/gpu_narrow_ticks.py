@@ -40,3 +40,7 @@ whole = tot[0] + tot[5]
 print("narrowphase time by phase (share of fetch + narrow_pair): fetch of the work item and both geoms %.1f %% | hull vertices into registers %.1f %% | "
       "flat-face scan incl. patch pass %.1f %% | MPR %.1f %% | contact output %.1f %%" % (100 * tot[0] / whole, 100 * tot[1] / whole, 100 * tot[2] / whole,
       100 * tot[3] / whole, 100 * (tot[5] - tot[1] - tot[2] - tot[3]) / whole))
+
+fine = tk[:, 230:234].astype(np.float64).sum(0)
+print("inside the face scan (share of fetch + narrow_pair): face setup %.1f %% | first support pass %.1f %% | outline tests %.1f %% | five-sample patch pass %.1f %%"
+      % tuple(100 * fine / whole))

@@ -1307,6 +1307,11 @@ DEV bool flat_face(const GeomW& G, int axis, const float* toward, float* f, floa
   return true;
 }
 
+#ifdef SO101_DEBUG_CLOCKS
+#define QPROF(k) { unsigned long long qn_ = SO101_CLOCK(); if (prof && wave_lane() == 0) atomicAdd(&prof[k], (unsigned int)(qn_ - qp_)); qp_ = qn_; }
+#else
+#define QPROF(k)
+#endif
 struct FaceRef { float f[3], c[3], u[3], v[3], hu, hv, depth; int side; bool exact, separated; Patch5 P; };
 
 // Flat-face scan of GR (box / cylinder) against the incident geom GI, before any iterative query.  For every flat face
@@ -1319,8 +1324,11 @@ struct FaceRef { float f[3], c[3], u[3], v[3], hu, hv, depth; int side; bool exa
 //  * a0 merely inside the outline (d0 <= half thickness): a CANDIDATE; the shallowest one is kept in R and later wins
 //    over MPR's answer when it is not deeper (narrow_pair).
 template <class Cache, class GP = G64>
-DEV void scan_faces(const DevModel* m, const GeomW& GR, const GeomW& GI, const Cache& HI, int side, FaceRef& R) {
+DEV void scan_faces(const DevModel* m, const GeomW& GR, const GeomW& GI, const Cache& HI, int side, FaceRef& R, unsigned int* prof = nullptr) {
   if (GR.type != G_BOX && GR.type != G_CYLINDER) return;
+#ifdef SO101_DEBUG_CLOCKS
+  unsigned long long qp_ = SO101_CLOCK();
+#endif
   float toward[3] = {GI.c[0] - GR.c[0], GI.c[1] - GR.c[1], GI.c[2] - GR.c[2]};
   // Visiting order: increasing depth of the incident's centre below the face plane (= half extent along the axis minus
   // |centre offset along it|, a lower bound of d0), i.e. the face the incident geom sticks out of first - for a prop on
@@ -1344,7 +1352,9 @@ DEV void scan_faces(const DevModel* m, const GeomW& GR, const GeomW& GI, const C
     float cr[3] = {c[0] - GI.c[0], c[1] - GI.c[1], c[2] - GI.c[2]};
     if (dot3(cr, f) > half) continue;                  // d0 >= depth of the incident's centre > half thickness
     float nf[3] = {-f[0], -f[1], -f[2]}, a0[3];
+    QPROF(6)
     support<Cache, GP>(m, GI, nf, a0, HI);
+    QPROF(7)
     float rel[3] = {a0[0] - c[0], a0[1] - c[1], a0[2] - c[2]};
     float d0 = -dot3(rel, f);
     if (!(d0 > 0.f)) { R.separated = true; continue; }
@@ -1358,19 +1368,16 @@ DEV void scan_faces(const DevModel* m, const GeomW& GR, const GeomW& GI, const C
     // (taking them in the same pass that finds a0 for the face visited first measured no faster: 1.257 M vs 1.261 M
     // env-steps/s at 32768 envs - the passes over the hull are not what a candidate's 5-10 us go into)
     Patch5 P;
+    QPROF(8)
     support_patch<Cache, GP>(m, GI, f, u, v, P, HI);
 #pragma unroll
     for (int k = 0; k < NCPP; k++) { R.P.p[k][0] = P.p[k][0]; R.P.p[k][1] = P.p[k][1]; R.P.p[k][2] = P.p[k][2]; }
+    QPROF(9)
   }
 }
 
 // Narrowphase of one candidate pair (geom types ordered): up to NCPP contacts sharing one normal (geom1 -> geom2),
 // each with its penetration distance (< 0) and position.
-#ifdef SO101_DEBUG_CLOCKS
-#define QPROF(k) { unsigned long long qn_ = SO101_CLOCK(); if (prof && wave_lane() == 0) atomicAdd(&prof[k], (unsigned int)(qn_ - qp_)); qp_ = qn_; }
-#else
-#define QPROF(k)
-#endif
 template <class Cache, class GP = G64>
 DEV void narrow_pair(const DevModel* m, const GeomW& G1, const GeomW& G2, int g1, int g2, PairContacts& out, unsigned int* prof = nullptr) {
 #ifdef SO101_DEBUG_CLOCKS
@@ -1398,8 +1405,8 @@ DEV void narrow_pair(const DevModel* m, const GeomW& G1, const GeomW& G2, int g1
   for (int k = 0; k < 3; k++) { best.f[k] = 0.f; best.c[k] = 0.f; best.u[k] = 0.f; best.v[k] = 0.f; }
 #pragma unroll
   for (int k = 0; k < NCPP; k++) { best.P.p[k][0] = 0.f; best.P.p[k][1] = 0.f; best.P.p[k][2] = 0.f; }
-  scan_faces<Cache, GP>(m, G1, G2, H2, 0, best);
-  if (!best.separated && !best.exact) scan_faces<Cache, GP>(m, G2, G1, H1, 1, best);
+  scan_faces<Cache, GP>(m, G1, G2, H2, 0, best, prof);
+  if (!best.separated && !best.exact) scan_faces<Cache, GP>(m, G2, G1, H1, 1, best, prof);
   QPROF(2)
   if (best.separated) return;
   float depth = 0.f, nrm[3] = {0.f, 0.f, 0.f}, pos[3] = {0.f, 0.f, 0.f};
