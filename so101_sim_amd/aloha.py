@@ -132,7 +132,7 @@ def aloha_action_spec(ctrlrange: np.ndarray, waist_joint_limit: float = np.pi / 
 class AlohaEnvironment:
     def __init__(self, task: HandOverTask, n_envs: int = 1, time_limit: float = float("inf"), random_state=None, device=None,
                  env_id_base: int = 0, solver_iterations: int = 0, solver_tolerance: float = -1.0, settle_max_substeps: int = 1000,
-                 physics_state: bool | None = None, seed_compatible: bool = True, narrowphase: str = "epa", prefetch_resets: bool = True):
+                 physics_state: bool | None = None, seed_compatible: bool = True, narrowphase: str = "epa", prefetch_resets: bool = True, pipeline: bool = True):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("so101_sim_amd needs a ROCm GPU (MI355X): the step path has no CPU fallback")
@@ -196,7 +196,10 @@ class AlohaEnvironment:
                         reward_mode=task.reward_mode, reward_requires_handover=int(task.reward_requires_handover),
                         joints_delay_steps=jd, physics_delay_steps=pd,
                         # reset prefetch (batches; a seed-compatible single env draws its placements on the host: nothing to settle ahead)
-                        prefetch_resets=int(bool(prefetch_resets) and not self._seed_compatible))
+                        prefetch_resets=int(bool(prefetch_resets) and not self._seed_compatible),
+                        # the step as a launch chain (narrowphase in a launch of its own; the library falls back to the single kernel for the
+                        # contact rewards); one env is one wavefront either way and keeps the single launch
+                        pipeline=int(bool(pipeline) and self.n_envs > 1))
         # physics_state / delayed_physics_state (aloha2_task.py:244-251,441-444): qpos | qvel and its copy of `pd` control steps ago,
         # from a device-side delay line the step / reset kernels maintain.  The reference ties them to image_observation_enabled;
         # for batches they are opt-in (58 + 58 floats per env and step).

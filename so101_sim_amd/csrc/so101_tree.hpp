@@ -58,7 +58,10 @@
 #define TCAND 256
 #define TGEOM 128
 #define TJS 32
-#define TRL 96         // constraint rows kept in LDS while a substep has no more (round 4): Jacobian + per-row vectors, 15 KB aliased with CRBA / RNE / collision scratch
+#ifndef TREE_TRL32
+#define TREE_TRL32 96
+#endif
+#define TRL TREE_TRL32 // constraint rows kept in LDS while a substep has no more (round 4): Jacobian + per-row vectors, 15 KB aliased with CRBA / RNE / collision scratch
 #undef TREE_CHOL_DEV
 #define TREE_CHOL_DEV DEV
 #endif
@@ -505,7 +508,8 @@ DEV void contact_params(const TreeModel* tm, const DevModel* gm, TCon& c, int g1
   for (int k = 0; k < 5; k++) c.solimp[k] = mix * gm->geom_solimp[5 * g1 + k] + (1.f - mix) * gm->geom_solimp[5 * g2 + k];
 }
 
-DEV void collision(const TreeModel* tm, const DevModel* gm, TreeLDS& L, bool narrow = true) {      // narrow = false: timing runs (broadphase only)
+// candidate pairs of the current poses into L.cand, in pair-list order (world boxes, then the oriented-box filter); clears the contact count
+DEV int broadphase(const TreeModel* tm, const DevModel* gm, TreeLDS& L) {
   int lane = wave_lane(), ng = tm->ngeom;
   // world boxes of the geoms
   for (int g = lane; g < ng; g += WAVE) {
@@ -603,6 +607,26 @@ DEV void collision(const TreeModel* tm, const DevModel* gm, TreeLDS& L, bool nar
     wave_sync();
     ncand = nout;
   }
+  if (lane == 0) L.ncand = ncand;
+  wave_sync();
+  return ncand;
+}
+
+// one contact of the pair (g1, g2) into slot `slot` of the env's contact list (one lane)
+DEV void write_contact(const TreeModel* tm, const DevModel* gm, TCon& c, int g1, int g2, int b1, int b2, const float* nrm, float dist, const float* pos) {
+  float fr[9] = {nrm[0], nrm[1], nrm[2], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  make_frame(fr);
+#pragma unroll
+  for (int i = 0; i < 9; i++) c.frame[i] = fr[i];
+  c.pos[0] = pos[0]; c.pos[1] = pos[1]; c.pos[2] = pos[2]; c.dist = dist;
+  c.g1 = g1; c.g2 = g2; c.b1 = b1; c.b2 = b2;
+  contact_params(tm, gm, c, g1, g2);
+  if (!tm->elliptic) c.dim = 1;
+}
+
+DEV void collision(const TreeModel* tm, const DevModel* gm, TreeLDS& L, bool narrow = true) {      // narrow = false: timing runs (broadphase only)
+  int lane = wave_lane();
+  int ncand = broadphase(tm, gm, L);
   int ncon = 0;
   for (int k = 0; k < (narrow ? ncand : 0); k++) {
     unsigned int cg = L.cand[k];
@@ -618,21 +642,68 @@ DEV void collision(const TreeModel* tm, const DevModel* gm, TreeLDS& L, bool nar
     if (ncon + n > TCON) { if (lane == 0) L.flags |= 2; break; }
     if (lane < NCPP && ((valid >> lane) & 1u)) {
       int slot = ncon + __popc(valid & ((1u << lane) - 1u));
-      TCon& c = L.con[slot];
       float dist = 0.f, pos[3] = {0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < NCPP; j++) if (j == lane) { dist = pc.dist[j]; pos[0] = pc.pos[j][0]; pos[1] = pc.pos[j][1]; pos[2] = pc.pos[j][2]; }
-      float fr[9] = {pc.nrm[0], pc.nrm[1], pc.nrm[2], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      make_frame(fr);
-#pragma unroll
-      for (int i = 0; i < 9; i++) c.frame[i] = fr[i];
-      c.pos[0] = pos[0]; c.pos[1] = pos[1]; c.pos[2] = pos[2]; c.dist = dist;
-      c.g1 = g1; c.g2 = g2; c.b1 = b1; c.b2 = b2;
-      contact_params(tm, gm, c, g1, g2);
-      if (!tm->elliptic) c.dim = 1;
+      write_contact(tm, gm, L.con[slot], g1, g2, b1, b2, pc.nrm, dist, pos);
     }
     ncon += n;
     wave_sync();
+  }
+  if (lane == 0) { L.ncon = ncon; L.ncand = ncand; }
+  wave_sync();
+}
+
+// ------------------------------------------------------------------ the narrowphase in a launch of its own (round 4, tu_tree.hip: k_tree_pipe_*)
+// A control step as a launch chain: per substep one launch with a wavefront per CANDIDATE PAIR of the whole batch (persistent wavefronts
+// pulling from a work list, as k_narrow of the SO100 step) and one with a wavefront per env for everything else.  Inside k_tree_step the env's
+// wavefront walks its 18 (ALOHA) to 59 (Dining) candidates one after the other at ~12 us each while the hull caches and the EPA polytope
+// keep the kernel at one wavefront per SIMD; out of it, the pairs of all envs are balanced over the machine.  Hand-off through global
+// memory between launches of one stream: body poses and candidates out, contact records back (count, normal, then (dist, position) per
+// contact, compact, in slot order), the env's state through its home buffers.  Same functions on the same data: bit-identical to the fused step.
+#define TREC 24                  // floats per contact record
+#define TPIPE_MAXSUB 64
+struct TreePipe {
+  float* pose;                   // [N][TB][12] xpos, xmat of every body
+  unsigned int* cand;            // [N][TCAND] geom1 | geom2 << 16
+  int* ncand;                    // [N]
+  float* rec;                    // [N][TCAND][TREC]
+  unsigned int* work;            // [2][N * TCAND] env * TCAND + k, double buffered over substeps
+  int* counters;                 // [TPIPE_MAXSUB][2] work items, cursor
+  unsigned char* active;         // [N] 0 not stepping in this call (auto-reset), 1 stepping, 2 diverged
+  int* pflags;                   // [N] event flags of the step so far
+};
+
+// hands the candidates of the current poses to substep s
+DEV void publish(const TreeModel* tm, const DevModel* gm, TreeLDS& L, const TreePipe& P, int e, int N, int s) {
+  int lane = wave_lane(), nb = tm->nbody;
+  for (int i = lane; i < nb * 12; i += WAVE) {
+    int b = i / 12, j = i % 12;
+    P.pose[(size_t)e * (TB * 12) + i] = j < 3 ? L.xpos[b][j] : L.xmat[b][j - 3];
+  }
+  int ncand = broadphase(tm, gm, L);
+  int base = 0;
+  if (lane == 0) { base = ncand ? atomicAdd(&P.counters[2 * s], ncand) : 0; P.ncand[e] = ncand; }
+  base = wave_bcast_i(base, 0);
+  unsigned int* list = P.work + (size_t)(s & 1) * ((size_t)N * TCAND);
+  for (int k = lane; k < ncand; k += WAVE) { P.cand[(size_t)e * TCAND + k] = L.cand[k]; list[base + k] = (unsigned int)e * TCAND + (unsigned int)k; }
+}
+
+// the env's contacts of this substep from the records, in candidate order, truncated at TCON like the fused loop
+DEV void gather_contacts(const TreeModel* tm, const DevModel* gm, TreeLDS& L, const TreePipe& P, int e) {
+  int lane = wave_lane(), ncand = P.ncand[e], ncon = 0;
+  for (int k = 0; k < ncand; k++) {
+    const float* r = P.rec + ((size_t)e * TCAND + k) * TREC;
+    int n = (int)r[0];
+    if (n == 0) continue;
+    if (ncon + n > TCON) { if (lane == 0) L.flags |= 2; break; }
+    if (lane < n) {
+      unsigned int cg = P.cand[(size_t)e * TCAND + k];
+      int g1 = (int)(cg & 0xffffu), g2 = (int)(cg >> 16);
+      float nrm[3] = {r[1], r[2], r[3]}, pos[3] = {r[5 + 4 * lane], r[6 + 4 * lane], r[7 + 4 * lane]};
+      write_contact(tm, gm, L.con[ncon + lane], g1, g2, tm->geom_body[g1], tm->geom_body[g2], nrm, r[4 + 4 * lane], pos);
+    }
+    ncon += n;
   }
   if (lane == 0) { L.ncon = ncon; L.ncand = ncand; }
   wave_sync();
@@ -1071,6 +1142,9 @@ DEV void solve_newton(const TreeModel* tm, TreeLDS& L, const TreeScratch& G, int
 
 // ------------------------------------------------------------------ forward dynamics and integration
 // `phases`: stage mask for timing runs (so101_tree_debug_forward with SO101_TREE_PHASES set); every caller on the step path passes all
+// the two halves of forward() around the collision stage (launch chain: the contacts come from the records instead)
+DEV void forward_smooth(const TreeModel* tm, TreeLDS& L) { kinematics(tm, L); crba(tm, L); rne_bias(tm, L); smooth(tm, L); }
+DEV void forward_constrained(const TreeModel* tm, TreeLDS& L, TreeScratch& G, int max_iter, float tolerance) { make_constraints(tm, L, G); solve_newton(tm, L, G, max_iter, tolerance); }
 DEV void forward(const TreeModel* tm, const DevModel* gm, TreeLDS& L, TreeScratch& G, int max_iter, float tolerance, int phases = 0x7f) {
   kinematics(tm, L);
   if (phases & 2) crba(tm, L);

@@ -40,7 +40,12 @@
 #define TAPI_CAT(v, name) TAPI_CAT2(v, name)
 #define TAPI(name) TAPI_CAT(TREE_VARIANT, name)
 
+#ifndef TREE_SOLVE_OCC
+#define TREE_SOLVE_OCC 2
+#endif
+
 namespace TREE_NS {
+using tree::TreePipe;
 
 __global__ void __launch_bounds__(64) k_tree_physics(const TreeModel* tm, const DevModel* gm, TreeBuffers B, int N, int nsub, int iterations, float tolerance) {
   BLOCK_SHARED(TreeLDS, L);
@@ -178,44 +183,11 @@ __global__ void __launch_bounds__(64) k_tree_begin(const TreeModel* tm, TreeTask
   if (lane == 0) { E.step_count[e] = 0; E.ep_return[e] = 0.f; E.need_reset[e] = 0; E.success_state[e] = T.requires_handover ? 0 : 2; }
 }
 
-// (one wave per SIMD: 390 unified registers.  __launch_bounds__(64, 2) was measured in round 4 - 256 VGPRs, 770 spilled, 864 B of scratch per
-// lane: 171 k against 175 k env-steps/s at 4096 envs; the LDS footprint, 31 KB, would admit 5 envs per CU)
-// one control step of every env: dm_control's Environment.step - an env whose last step was LAST resets and reports FIRST
-// (the action is ignored), the others apply the action, run n_substeps and report observation, reward, discount, step type
-__global__ void __launch_bounds__(64) k_tree_step(const TreeModel* tm, const DevModel* gm, TreeTask T, TreeBuffers B, TreeEnvBuffers E, TreeStore S, const float* action,
-                                                  float* obs, float* reward, float* discount, unsigned char* step_type) {
-  BLOCK_SHARED(TreeLDS, L);
-  int e = blockIdx.x, lane = wave_lane(), N = T.n_envs;
-  if (lane == 0) L.flags = 0;
-  wave_sync();
-  TreeScratch G = tree::scratch_of(B, e);
-  if (E.need_reset[e]) {
-    tree::env_reset(tm, gm, T, L, G, B, E, S, e);
-    tree::kinematics(tm, L);
-    tree::write_obs(T, L, E, e, 0, true, obs);
-    tree::store_state(tm, L, B, e, N);
-    if (lane < tm->nu) B.ctrl[(size_t)lane * N + e] = L.ctrl[lane];
-    if (lane == 0) { reward[e] = 0.f; discount[e] = 1.f; step_type[e] = 0; E.need_reset[e] = 0; }
-    if (lane == 0 && B.diag) { int* d = B.diag + 8 * e; d[0] = L.ncon; d[1] = L.nrow; d[2] = L.iters; d[3] = L.ncand; d[4] = L.flags; }
-    return;
-  }
-  tree::load_state(tm, L, B, e, N);
-  // before_step (aloha2_task.py:316-349): joint targets as given, grippers from follower units to the sim's ctrl range; no clipping
-  if (lane < tm->nu) {
-    float a = action[(size_t)e * tm->nu + lane];
-    if (T.act_is_gripper[lane]) a = tree::convert_gripper(a, T.grip[4], T.grip[5], T.grip[2], T.grip[3]);
-    L.ctrl[lane] = a;
-  }
-  wave_sync();
-  bool diverged = false;
-  for (int s = 0; s < T.n_substeps && !diverged; s++) {
-    tree::forward(tm, gm, L, G, T.iterations, T.tolerance);
-    tree::euler(tm, L);
-    bool ok = true;
-    if (lane < tm->nq) ok = ok && fabsf(L.qpos[lane]) <= 1e10f;
-    if (lane < tm->nv) ok = ok && fabsf(L.qvel[lane]) <= 1e10f && fabsf(L.qacc[lane]) <= 1e10f;
-    diverged = wave_ballot(!ok) != 0ull;
-  }
+// end of a control step of one env (after the last substep): observation, reward / discount / termination, state and counters out
+template <bool CONTACT_REWARDS>
+__device__ __forceinline__ void tree_finish_step(const TreeModel* tm, const DevModel* gm, const TreeTask& T, TreeLDS& L, TreeScratch& G, const TreeBuffers& B,
+                                                 const TreeEnvBuffers& E, int e, bool diverged, float* obs, float* reward, float* discount, unsigned char* step_type) {
+  int lane = wave_lane(), N = T.n_envs;
   if (diverged) {         // mj_check*: the data is reset, dm_control ends the episode with reward 0 and discount 0
     if (lane < tm->nq) L.qpos[lane] = 0.f;
     if (lane < tm->nv) { L.qvel[lane] = 0.f; L.warm[lane] = 0.f; }
@@ -235,7 +207,7 @@ __global__ void __launch_bounds__(64) k_tree_step(const TreeModel* tm, const Dev
   // physics.step(), whose legacy step ends with mj_step1 - the contacts of the integrated state, recomputed here.
   float r = 0.f, r_disc = 0.f, r_term = 0.f;
   if (!diverged) {
-    if (T.reward_mode == 0) r = r_disc = r_term = tree::task_reward(tm, T, L);
+    if (!CONTACT_REWARDS || T.reward_mode == 0) r = r_disc = r_term = tree::task_reward(tm, T, L);      // (the launch chain runs reward mode 0 only)
     else if (T.reward_mode == 2) { tree::collision(tm, gm, L); r = r_disc = r_term = tree::task_reward_touching(tm, T, L); }
     else {
       tree::collision(tm, gm, L);
@@ -257,6 +229,144 @@ __global__ void __launch_bounds__(64) k_tree_step(const TreeModel* tm, const Dev
   }
 }
 
+// start of a control step of one env: an env whose last step was LAST resets and reports FIRST (returns true: done for this call);
+// the others load their state and apply the action
+__device__ __forceinline__ bool tree_begin_step(const TreeModel* tm, const DevModel* gm, const TreeTask& T, TreeLDS& L, TreeScratch& G, const TreeBuffers& B,
+                                                const TreeEnvBuffers& E, const TreeStore& S, int e, const float* action, float* obs, float* reward, float* discount,
+                                                unsigned char* step_type) {
+  int lane = wave_lane(), N = T.n_envs;
+  if (E.need_reset[e]) {
+    tree::env_reset(tm, gm, T, L, G, B, E, S, e);
+    tree::kinematics(tm, L);
+    tree::write_obs(T, L, E, e, 0, true, obs);
+    tree::store_state(tm, L, B, e, N);
+    if (lane < tm->nu) B.ctrl[(size_t)lane * N + e] = L.ctrl[lane];
+    if (lane == 0) { reward[e] = 0.f; discount[e] = 1.f; step_type[e] = 0; E.need_reset[e] = 0; }
+    if (lane == 0 && B.diag) { int* d = B.diag + 8 * e; d[0] = L.ncon; d[1] = L.nrow; d[2] = L.iters; d[3] = L.ncand; d[4] = L.flags; }
+    return true;
+  }
+  tree::load_state(tm, L, B, e, N);
+  // before_step (aloha2_task.py:316-349): joint targets as given, grippers from follower units to the sim's ctrl range; no clipping
+  if (lane < tm->nu) {
+    float a = action[(size_t)e * tm->nu + lane];
+    if (T.act_is_gripper[lane]) a = tree::convert_gripper(a, T.grip[4], T.grip[5], T.grip[2], T.grip[3]);
+    L.ctrl[lane] = a;
+  }
+  wave_sync();
+  return false;
+}
+
+// (one wave per SIMD: 390 unified registers.  __launch_bounds__(64, 2) was measured in round 4 - 256 VGPRs, 770 spilled, 864 B of scratch per
+// lane: 171 k against 175 k env-steps/s at 4096 envs; the LDS footprint, 31 KB, would admit 5 envs per CU)
+// one control step of every env: dm_control's Environment.step - an env whose last step was LAST resets and reports FIRST
+// (the action is ignored), the others apply the action, run n_substeps and report observation, reward, discount, step type
+__global__ void __launch_bounds__(64) k_tree_step(const TreeModel* tm, const DevModel* gm, TreeTask T, TreeBuffers B, TreeEnvBuffers E, TreeStore S, const float* action,
+                                                  float* obs, float* reward, float* discount, unsigned char* step_type) {
+  BLOCK_SHARED(TreeLDS, L);
+  int e = blockIdx.x, lane = wave_lane(), N = T.n_envs;
+  if (lane == 0) L.flags = 0;
+  wave_sync();
+  TreeScratch G = tree::scratch_of(B, e);
+  if (tree_begin_step(tm, gm, T, L, G, B, E, S, e, action, obs, reward, discount, step_type)) return;
+  bool diverged = false;
+  for (int s = 0; s < T.n_substeps && !diverged; s++) {
+    tree::forward(tm, gm, L, G, T.iterations, T.tolerance);
+    tree::euler(tm, L);
+    bool ok = true;
+    if (lane < tm->nq) ok = ok && fabsf(L.qpos[lane]) <= 1e10f;
+    if (lane < tm->nv) ok = ok && fabsf(L.qvel[lane]) <= 1e10f && fabsf(L.qacc[lane]) <= 1e10f;
+    diverged = wave_ballot(!ok) != 0ull;
+  }
+  tree_finish_step<true>(tm, gm, T, L, G, B, E, e, diverged, obs, reward, discount, step_type);
+}
+
+// ---- the control step as a launch chain (so101_tree.hpp, "the narrowphase in a launch of its own"): k_tree_pipe_begin, then per substep
+// k_tree_narrow and k_tree_pipe_solve.  Reward mode 0 (overlap boxes) only: the contact rewards need the contacts of the post-step state.
+__global__ void __launch_bounds__(64) k_tree_pipe_begin(const TreeModel* tm, const DevModel* gm, TreeTask T, TreeBuffers B, TreeEnvBuffers E, TreeStore S, TreePipe P,
+                                                        const float* action, float* obs, float* reward, float* discount, unsigned char* step_type) {
+  BLOCK_SHARED(TreeLDS, L);
+  int e = blockIdx.x, lane = wave_lane(), N = T.n_envs;
+  if (lane == 0) L.flags = 0;
+  wave_sync();
+  TreeScratch G = tree::scratch_of(B, e);
+  if (tree_begin_step(tm, gm, T, L, G, B, E, S, e, action, obs, reward, discount, step_type)) {
+    if (lane == 0) { P.active[e] = 0; P.ncand[e] = 0; }
+    return;
+  }
+  if (lane < tm->nu) B.ctrl[(size_t)lane * N + e] = L.ctrl[lane];
+  if (lane == 0) { P.active[e] = 1; P.pflags[e] = 0; }
+  tree::kinematics(tm, L);
+  tree::publish(tm, gm, L, P, e, N, 0);
+}
+
+// one wavefront per candidate pair of the whole batch: persistent wavefronts take two work items per fetch
+__global__ void __launch_bounds__(64, 2) k_tree_narrow(const TreeModel* tm, const DevModel* gm, TreePipe P, int N, int s) {
+  int lane = wave_lane();
+  const int nwork = ldc(&P.counters[2 * s]);
+  const unsigned int* list = P.work + (size_t)(s & 1) * ((size_t)N * TCAND);
+  for (;;) {
+    int i0 = 0;
+    if (lane == 0) i0 = atomicAdd(&P.counters[2 * s + 1], 2);
+    i0 = wave_uniform_i(i0);
+    if (i0 >= nwork) break;
+    unsigned int wl = 0, cl = 0;
+    if (lane < 2 && i0 + lane < nwork) { wl = list[i0 + lane]; cl = P.cand[wl]; }
+#pragma unroll 1
+    for (int j = 0; j < 2; j++) {
+      if (i0 + j >= nwork) break;
+      unsigned int w = (unsigned int)__builtin_amdgcn_readlane((int)wl, j), c = (unsigned int)__builtin_amdgcn_readlane((int)cl, j);
+      int e = (int)(w / TCAND), g1 = (int)(c & 0xffffu), g2 = (int)(c >> 16);
+      int b1 = wave_uniform_i(tm->geom_body[g1]), b2 = wave_uniform_i(tm->geom_body[g2]);
+      const float* p1 = P.pose + ((size_t)e * TB + b1) * 12; const float* p2 = P.pose + ((size_t)e * TB + b2) * 12;
+      GeomW G1, G2;
+      load_geom_at(gm, g1, p1, p1 + 3, G1); load_geom_at(gm, g2, p2, p2 + 3, G2);
+      PairContacts pc;
+      narrow_pair<HullCache, G64>(gm, G1, G2, g1, g2, pc);
+      if (lane == 0) {
+        float* r = P.rec + (size_t)w * TREC;
+        r[0] = (float)__popc(pc.valid); r[1] = pc.nrm[0]; r[2] = pc.nrm[1]; r[3] = pc.nrm[2];
+        int o = 4;                                     // valid slots are written compactly, in slot order
+#pragma unroll
+        for (int q = 0; q < NCPP; q++)
+          if ((pc.valid >> q) & 1u) { r[o] = pc.dist[q]; r[o + 1] = pc.pos[q][0]; r[o + 2] = pc.pos[q][1]; r[o + 3] = pc.pos[q][2]; o += 4; }
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(64, TREE_SOLVE_OCC) k_tree_pipe_solve(const TreeModel* tm, const DevModel* gm, TreeTask T, TreeBuffers B, TreeEnvBuffers E, TreePipe P, int s, int last,
+                                                                       float* obs, float* reward, float* discount, unsigned char* step_type) {
+  BLOCK_SHARED(TreeLDS, L);
+  int e = blockIdx.x, lane = wave_lane(), N = T.n_envs;
+  int act = P.active[e];
+  if (act == 0) return;
+  if (lane == 0) L.flags = P.pflags[e];
+  tree::load_state(tm, L, B, e, N);
+  TreeScratch G = tree::scratch_of(B, e);
+  bool diverged = act == 2;
+  if (!diverged) {
+    tree::forward_smooth(tm, L);
+    tree::gather_contacts(tm, gm, L, P, e);
+    tree::forward_constrained(tm, L, G, T.iterations, T.tolerance);
+    tree::euler(tm, L);
+    bool ok = true;
+    if (lane < tm->nq) ok = ok && fabsf(L.qpos[lane]) <= 1e10f;
+    if (lane < tm->nv) ok = ok && fabsf(L.qvel[lane]) <= 1e10f && fabsf(L.qacc[lane]) <= 1e10f;
+    diverged = wave_ballot(!ok) != 0ull;
+    if (diverged && lane == 0) P.active[e] = 2;
+  }
+  if (!last) {
+    if (act == 1) {
+      tree::store_state(tm, L, B, e, N);
+      if (lane == 0) P.pflags[e] = L.flags;
+      if (!diverged) { tree::kinematics(tm, L); tree::publish(tm, gm, L, P, e, N, s + 1); }
+      else if (lane == 0) P.ncand[e] = 0;
+    }
+    return;
+  }
+  tree_finish_step<false>(tm, gm, T, L, G, B, E, e, diverged, obs, reward, discount, step_type);
+}
+
 // ==================================================================================================== host side
 struct TreeHandle {
   int n_envs = 0, device = 0;
@@ -276,6 +386,9 @@ struct TreeHandle {
   hipStream_t prep_stream = nullptr;
   hipEvent_t prep_done = nullptr, main_ev = nullptr;
   bool prep_pending = false, prefetch = false;
+  // launch chain of the control step (so101_tree_config.pipeline): hand-off buffers, allocated when first asked for
+  TreePipe pipe{};
+  bool pipeline = false;
   std::vector<void*> owned;
   std::string err;
 };
@@ -518,6 +631,23 @@ static bool tree_prefetch_setup(TreeHandle* s) {          // lazily: second scra
          t_ok(s, hipEventCreateWithFlags(&s->prep_done, hipEventDisableTiming), "hipEventCreate") &&
          t_ok(s, hipEventCreateWithFlags(&s->main_ev, hipEventDisableTiming), "hipEventCreate") && alloc((void**)&s->ctag, n * sizeof(unsigned int));
 }
+static bool tree_pipe_setup(TreeHandle* s) {             // lazily: the hand-off buffers of the launch chain
+  if (s->pipe.pose) return true;
+  size_t n = (size_t)s->n_envs;
+  auto alloc = [&](void** out, size_t bytes) {
+    void* p = nullptr;
+    if (!t_ok(s, hipMalloc(&p, bytes), "hipMalloc(pipeline)")) return false;
+    s->owned.push_back(p); *out = p;
+    return t_ok(s, hipMemset(p, 0, bytes), "hipMemset(pipeline)");
+  };
+  TreePipe& P = s->pipe;
+  void* pose = nullptr;
+  bool ok = alloc((void**)&P.cand, n * TCAND * sizeof(unsigned int)) && alloc((void**)&P.ncand, n * sizeof(int)) && alloc((void**)&P.rec, n * TCAND * TREC * sizeof(float)) &&
+            alloc((void**)&P.work, 2 * n * TCAND * sizeof(unsigned int)) && alloc((void**)&P.counters, 2 * TPIPE_MAXSUB * sizeof(int)) && alloc((void**)&P.active, n) &&
+            alloc((void**)&P.pflags, n * sizeof(int)) && alloc(&pose, n * TB * 12 * sizeof(float));
+  if (ok) P.pose = (float*)pose;          // (last: marks the set as complete)
+  return ok;
+}
 static bool drain_tree_prepare(TreeHandle* s) {
   s->prep_pending = false;
   return !s->prep_stream || t_ok(s, hipStreamSynchronize(s->prep_stream), "hipStreamSynchronize(prefetch)");
@@ -669,6 +799,8 @@ int TAPI(configure_env)(TreeHandle* s, const so101_tree_config* c) {
     if (!drain_tree_prepare(s)) return SO101_ERR_HIP;
     s->prefetch = c->prefetch_resets != 0;
     if (s->prefetch && !tree_prefetch_setup(s)) return SO101_ERR_HIP;
+    s->pipeline = c->pipeline != 0;
+    if (s->pipeline && !tree_pipe_setup(s)) return SO101_ERR_HIP;
     if (s->ctag && !t_ok(s, hipMemset(s->ctag, 0, (size_t)s->n_envs * sizeof(unsigned int)), "hipMemset(prefetch)")) return SO101_ERR_HIP;
   }
   return TAPI(configure)(s, c->solver_iterations, c->solver_tolerance);
@@ -689,8 +821,23 @@ int TAPI(step)(TreeHandle* s, const float* action, float* obs, float* reward, fl
   if (!s || !action || !obs || !reward || !discount || !step_type) { if (s) s->err = "so101_tree_step: NULL argument"; return SO101_ERR_ARG; }
   if (!s->bound || !s->env_bound) { s->err = "so101_tree_step before so101_tree_bind_state / so101_tree_bind_env"; return SO101_ERR_STATE; }
   TREE_GUARD(s);
-  hipLaunchKernelGGL(k_tree_step, dim3(s->n_envs), dim3(64), 0, (hipStream_t)stream, s->dm, s->dg, task_now(s), s->buf, s->env, store_now(s), action, obs, reward, discount, step_type);
-  if (!t_ok(s, hipGetLastError(), "k_tree_step")) return SO101_ERR_HIP;
+  hipStream_t st = (hipStream_t)stream;
+  TreeTask T = task_now(s);
+  if (s->pipeline && s->pipe.pose && T.reward_mode == 0 && T.n_substeps <= TPIPE_MAXSUB) {
+    // launch chain: prologue, then per substep the narrowphase of every candidate pair of the batch and the rest of the substep per env
+    const TreePipe& P = s->pipe;
+    int nw = s->n_envs * 2; nw = nw < 4096 ? nw : 4096;
+    if (!t_ok(s, hipMemsetAsync(P.counters, 0, 2 * TPIPE_MAXSUB * sizeof(int), st), "hipMemsetAsync(pipeline)")) return SO101_ERR_HIP;
+    hipLaunchKernelGGL(k_tree_pipe_begin, dim3(s->n_envs), dim3(64), 0, st, s->dm, s->dg, T, s->buf, s->env, store_now(s), P, action, obs, reward, discount, step_type);
+    for (int k = 0; k < T.n_substeps; k++) {
+      hipLaunchKernelGGL(k_tree_narrow, dim3(nw), dim3(64), 0, st, s->dm, s->dg, P, s->n_envs, k);
+      hipLaunchKernelGGL(k_tree_pipe_solve, dim3(s->n_envs), dim3(64), 0, st, s->dm, s->dg, T, s->buf, s->env, P, k, (int)(k == T.n_substeps - 1), obs, reward, discount, step_type);
+    }
+    if (!t_ok(s, hipGetLastError(), "k_tree_pipe_solve")) return SO101_ERR_HIP;
+  } else {
+    hipLaunchKernelGGL(k_tree_step, dim3(s->n_envs), dim3(64), 0, st, s->dm, s->dg, T, s->buf, s->env, store_now(s), action, obs, reward, discount, step_type);
+    if (!t_ok(s, hipGetLastError(), "k_tree_step")) return SO101_ERR_HIP;
+  }
   launch_tree_prepare(s, (hipStream_t)stream);
   return SO101_OK;
 }

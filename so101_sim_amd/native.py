@@ -223,7 +223,7 @@ class TreeConfig(C.Structure):
     _fields_ = [("n_substeps", C.c_int), ("last_step", C.c_int), ("settle_max_substeps", C.c_int), ("terminate_on_success", C.c_int),
                 ("solver_iterations", C.c_int), ("solver_tolerance", C.c_float), ("seed", C.c_uint64), ("env_id_base", C.c_uint64),
                 ("reward_mode", C.c_int), ("reward_requires_handover", C.c_int),
-                ("joints_delay_steps", C.c_int), ("physics_delay_steps", C.c_int), ("prefetch_resets", C.c_int)]
+                ("joints_delay_steps", C.c_int), ("physics_delay_steps", C.c_int), ("prefetch_resets", C.c_int), ("pipeline", C.c_int)]
 
 
 TREE_DBG = dict(COUNTS=0, BIAS=8, QSM=40, QACC=72, XPOS=104, M=200, CON=1224, FORCE=1864, MSTRIDE=32)     # the 32-dof build; TreeSim.dbg is the handle's own
@@ -272,7 +272,7 @@ class TreeSim:
         self.obs_dim = int(L.so101_tree_obs_dim(h))
         self.cfg = TreeConfig(n_substeps=10, last_step=1 << 30, settle_max_substeps=1000, terminate_on_success=1, solver_iterations=0,
                               solver_tolerance=-1.0, seed=0, env_id_base=0, reward_mode=0, reward_requires_handover=0,
-                              joints_delay_steps=-1, physics_delay_steps=-1, prefetch_resets=0)
+                              joints_delay_steps=-1, physics_delay_steps=-1, prefetch_resets=0, pipeline=0)
 
     def close(self):
         if getattr(self, "h", None):

@@ -98,7 +98,7 @@ def create_task_env(
         )
     n_envs = int(kwargs.pop("n_envs", 1))
     env_kwargs = {k: kwargs.pop(k) for k in ("device", "solver_iterations", "solver_tolerance", "env_id_base", "settle_max_substeps", "solver",
-                                                 "prefetch_resets", "physics_state", "seed_compatible", "narrowphase")
+                                                 "prefetch_resets", "physics_state", "seed_compatible", "narrowphase", "pipeline")
                   if k in kwargs}
 
     task_class, task_kwargs = TASK_FACTORIES[task_name]

@@ -518,6 +518,38 @@ def test_reset_prefetch_of_the_tree_engine_is_bit_identical(scene):
         np.testing.assert_array_equal(a, b, err_msg=f"step {k}")
 
 
+def _launch_chain_identity(scene, backend, n, steps, n_substeps, settle, last_step=3):
+    """so101_tree_config.pipeline: the control step as a launch chain (narrowphase in a launch of its own, one wavefront per candidate pair of
+    the whole batch) against the single kernel - observations, rewards, step types, states and the per-env diagnostics (contacts, rows, solver
+    iterations, candidates, flags) of a rollout across auto-resets, bit for bit."""
+    raw32 = scenes.load_dining_blob("banana", "f32")[0] if scene == "dining" else _blobs("banana")[1]
+    out = []
+    for pipeline in (0, 1):
+        sim = TreeArraySim(raw32, n, backend=backend)
+        sim.enable_env(seed=5, last_step=last_step, settle_max_substeps=settle, pipeline=pipeline, n_substeps=n_substeps)
+        rng = np.random.RandomState(2)
+        trace = []
+        for k in range(steps):
+            a = np.tile(np.concatenate([scenes.ALOHA_HOME_CTRL] * 2), (n, 1)) + 0.2 * rng.normal(size=(n, 14))
+            obs, r, d, st = sim.step(a)
+            trace.append(np.concatenate([obs.ravel(), r, d, st.astype(np.float64)] + [x.ravel() for x in sim.get_state()] + [sim.get_diag().ravel().astype(np.float64)]))
+        out.append(trace)
+        assert np.all(sim._get(sim.episode) >= 2)
+    for k, (a, b) in enumerate(zip(*out)):
+        np.testing.assert_array_equal(a, b, err_msg=f"step {k}")
+
+
+def test_launch_chain_of_the_tree_engine_is_bit_identical_emulated():
+    _launch_chain_identity("banana", "emu", n=1, steps=4, n_substeps=2, settle=2, last_step=2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene", ["banana", "dining"])
+def test_launch_chain_of_the_tree_engine_is_bit_identical(scene):
+    n, steps = (16, 8) if scene == "dining" else (64, 9)
+    _launch_chain_identity(scene, "gpu", n=n, steps=steps, n_substeps=10, settle=300)
+
+
 @pytest.mark.gpu
 def test_settled_store_of_the_tree_engine_is_bit_identical():
     """compute_settled(): the settle results of the first episodes of every env, computed ahead of time; the resets that find them copy -
