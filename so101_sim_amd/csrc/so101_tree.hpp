@@ -668,7 +668,8 @@ struct TreePipe {
   unsigned int* cand;            // [N][TCAND] geom1 | geom2 << 16
   int* ncand;                    // [N]
   float* rec;                    // [N][TCAND][TREC]
-  unsigned int* work;            // [2][N * TCAND] env * TCAND + k, double buffered over substeps
+  unsigned int* work;            // [2][work_cap] env * TCAND + k, double buffered over substeps (per env slice)
+  unsigned int work_cap;         // envs of the slice * TCAND
   int* counters;                 // [TPIPE_MAXSUB][2] work items, cursor
   unsigned char* active;         // [N] 0 not stepping in this call (auto-reset), 1 stepping, 2 diverged
   int* pflags;                   // [N] event flags of the step so far
@@ -685,7 +686,7 @@ DEV void publish(const TreeModel* tm, const DevModel* gm, TreeLDS& L, const Tree
   int base = 0;
   if (lane == 0) { base = ncand ? atomicAdd(&P.counters[2 * s], ncand) : 0; P.ncand[e] = ncand; }
   base = wave_bcast_i(base, 0);
-  unsigned int* list = P.work + (size_t)(s & 1) * ((size_t)N * TCAND);
+  unsigned int* list = P.work + (size_t)(s & 1) * P.work_cap;
   for (int k = lane; k < ncand; k += WAVE) { P.cand[(size_t)e * TCAND + k] = L.cand[k]; list[base + k] = (unsigned int)e * TCAND + (unsigned int)k; }
 }
 

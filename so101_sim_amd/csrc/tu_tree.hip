@@ -283,9 +283,9 @@ __global__ void __launch_bounds__(64) k_tree_step(const TreeModel* tm, const Dev
 // ---- the control step as a launch chain (so101_tree.hpp, "the narrowphase in a launch of its own"): k_tree_pipe_begin, then per substep
 // k_tree_narrow and k_tree_pipe_solve.  Reward mode 0 (overlap boxes) only: the contact rewards need the contacts of the post-step state.
 __global__ void __launch_bounds__(64) k_tree_pipe_begin(const TreeModel* tm, const DevModel* gm, TreeTask T, TreeBuffers B, TreeEnvBuffers E, TreeStore S, TreePipe P,
-                                                        const float* action, float* obs, float* reward, float* discount, unsigned char* step_type) {
+                                                        const float* action, float* obs, float* reward, float* discount, unsigned char* step_type, int e0) {
   BLOCK_SHARED(TreeLDS, L);
-  int e = blockIdx.x, lane = wave_lane(), N = T.n_envs;
+  int e = e0 + blockIdx.x, lane = wave_lane(), N = T.n_envs;
   if (lane == 0) L.flags = 0;
   wave_sync();
   TreeScratch G = tree::scratch_of(B, e);
@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(64) k_tree_pipe_begin(const TreeModel* tm, con
 __global__ void __launch_bounds__(64, 2) k_tree_narrow(const TreeModel* tm, const DevModel* gm, TreePipe P, int N, int s) {
   int lane = wave_lane();
   const int nwork = ldc(&P.counters[2 * s]);
-  const unsigned int* list = P.work + (size_t)(s & 1) * ((size_t)N * TCAND);
+  const unsigned int* list = P.work + (size_t)(s & 1) * P.work_cap;
   for (;;) {
     int i0 = 0;
     if (lane == 0) i0 = atomicAdd(&P.counters[2 * s + 1], 2);
@@ -335,9 +335,9 @@ __global__ void __launch_bounds__(64, 2) k_tree_narrow(const TreeModel* tm, cons
 }
 
 __global__ void __launch_bounds__(64, TREE_SOLVE_OCC) k_tree_pipe_solve(const TreeModel* tm, const DevModel* gm, TreeTask T, TreeBuffers B, TreeEnvBuffers E, TreePipe P, int s, int last,
-                                                                       float* obs, float* reward, float* discount, unsigned char* step_type) {
+                                                                       float* obs, float* reward, float* discount, unsigned char* step_type, int e0) {
   BLOCK_SHARED(TreeLDS, L);
-  int e = blockIdx.x, lane = wave_lane(), N = T.n_envs;
+  int e = e0 + blockIdx.x, lane = wave_lane(), N = T.n_envs;
   int act = P.active[e];
   if (act == 0) return;
   if (lane == 0) L.flags = P.pflags[e];
@@ -389,6 +389,9 @@ struct TreeHandle {
   // launch chain of the control step (so101_tree_config.pipeline): hand-off buffers, allocated when first asked for
   TreePipe pipe{};
   bool pipeline = false;
+  static constexpr int MAXSLICES = 4;
+  hipStream_t slice_stream[MAXSLICES] = {};      // env slices whose chains overlap (one's narrowphase beside another's solve)
+  hipEvent_t slice_begin = nullptr, slice_done[MAXSLICES] = {};
   std::vector<void*> owned;
   std::string err;
 };
@@ -643,8 +646,12 @@ static bool tree_pipe_setup(TreeHandle* s) {             // lazily: the hand-off
   TreePipe& P = s->pipe;
   void* pose = nullptr;
   bool ok = alloc((void**)&P.cand, n * TCAND * sizeof(unsigned int)) && alloc((void**)&P.ncand, n * sizeof(int)) && alloc((void**)&P.rec, n * TCAND * TREC * sizeof(float)) &&
-            alloc((void**)&P.work, 2 * n * TCAND * sizeof(unsigned int)) && alloc((void**)&P.counters, 2 * TPIPE_MAXSUB * sizeof(int)) && alloc((void**)&P.active, n) &&
+            alloc((void**)&P.work, 2 * n * TCAND * sizeof(unsigned int)) && alloc((void**)&P.counters, TreeHandle::MAXSLICES * 2 * TPIPE_MAXSUB * sizeof(int)) && alloc((void**)&P.active, n) &&
             alloc((void**)&P.pflags, n * sizeof(int)) && alloc(&pose, n * TB * 12 * sizeof(float));
+  for (int g = 0; ok && g < TreeHandle::MAXSLICES; g++)
+    ok = t_ok(s, hipStreamCreateWithFlags(&s->slice_stream[g], hipStreamNonBlocking), "hipStreamCreate") &&
+         t_ok(s, hipEventCreateWithFlags(&s->slice_done[g], hipEventDisableTiming), "hipEventCreate");
+  ok = ok && t_ok(s, hipEventCreateWithFlags(&s->slice_begin, hipEventDisableTiming), "hipEventCreate");
   if (ok) P.pose = (float*)pose;          // (last: marks the set as complete)
   return ok;
 }
@@ -715,6 +722,8 @@ void TAPI(destroy)(TreeHandle* s) {
     if (s->prep_stream) (void)hipStreamDestroy(s->prep_stream);
     if (s->prep_done) (void)hipEventDestroy(s->prep_done);
     if (s->main_ev) (void)hipEventDestroy(s->main_ev);
+    for (int g = 0; g < TreeHandle::MAXSLICES; g++) { if (s->slice_stream[g]) (void)hipStreamDestroy(s->slice_stream[g]); if (s->slice_done[g]) (void)hipEventDestroy(s->slice_done[g]); }
+    if (s->slice_begin) (void)hipEventDestroy(s->slice_begin);
     for (void* p : s->owned) (void)hipFree(p);
   }
   delete s;
@@ -824,16 +833,31 @@ int TAPI(step)(TreeHandle* s, const float* action, float* obs, float* reward, fl
   hipStream_t st = (hipStream_t)stream;
   TreeTask T = task_now(s);
   if (s->pipeline && s->pipe.pose && T.reward_mode == 0 && T.n_substeps <= TPIPE_MAXSUB) {
-    // launch chain: prologue, then per substep the narrowphase of every candidate pair of the batch and the rest of the substep per env
-    const TreePipe& P = s->pipe;
-    int nw = s->n_envs * 2; nw = nw < 4096 ? nw : 4096;
-    if (!t_ok(s, hipMemsetAsync(P.counters, 0, 2 * TPIPE_MAXSUB * sizeof(int), st), "hipMemsetAsync(pipeline)")) return SO101_ERR_HIP;
-    hipLaunchKernelGGL(k_tree_pipe_begin, dim3(s->n_envs), dim3(64), 0, st, s->dm, s->dg, T, s->buf, s->env, store_now(s), P, action, obs, reward, discount, step_type);
-    for (int k = 0; k < T.n_substeps; k++) {
-      hipLaunchKernelGGL(k_tree_narrow, dim3(nw), dim3(64), 0, st, s->dm, s->dg, P, s->n_envs, k);
-      hipLaunchKernelGGL(k_tree_pipe_solve, dim3(s->n_envs), dim3(64), 0, st, s->dm, s->dg, T, s->buf, s->env, P, k, (int)(k == T.n_substeps - 1), obs, reward, discount, step_type);
+    // launch chain: prologue, then per substep the narrowphase of every candidate pair of the batch and the rest of the substep per env.
+    // Env slices on their own streams: the narrowphase of one (latency-bound, two wavefronts per SIMD) runs beside the solve of another
+    // (bound by the CU's LDS / L1 traffic, three envs per CU); the slices share nothing but the model.  Measured, 1 / 2 / 3 / 4 slices:
+    // ALOHA (4096 envs) 206 / 232 / 228 / 231 k, Dining (1024 envs) 33.2 / 44.6 / - / 47.0 k env-steps/s.
+    static const int slices_env = getenv("SO101_TREE_SLICES") ? atoi(getenv("SO101_TREE_SLICES")) : 0;          // (kernel experiments)
+    const int G = s->n_envs < 128 ? 1 : (slices_env >= 1 && slices_env <= TreeHandle::MAXSLICES ? slices_env : (s->n_envs < 512 ? 2 : 4));
+    if (G > 1 && !t_ok(s, hipEventRecord(s->slice_begin, st), "hipEventRecord")) return SO101_ERR_HIP;
+    for (int g = 0; g < G; g++) {
+      int e0 = (int)((long long)s->n_envs * g / G), ng = (int)((long long)s->n_envs * (g + 1) / G) - e0;
+      hipStream_t gs = G == 1 ? st : s->slice_stream[g];
+      TreePipe P = s->pipe;
+      P.counters = s->pipe.counters + 2 * TPIPE_MAXSUB * g;
+      P.work = s->pipe.work + (size_t)2 * e0 * TCAND;
+      P.work_cap = (unsigned int)ng * TCAND;
+      int nw = ng * 2; nw = nw < 4096 ? nw : 4096;
+      if (G > 1 && !t_ok(s, hipStreamWaitEvent(gs, s->slice_begin, 0), "hipStreamWaitEvent")) return SO101_ERR_HIP;
+      if (!t_ok(s, hipMemsetAsync(P.counters, 0, 2 * TPIPE_MAXSUB * sizeof(int), gs), "hipMemsetAsync(pipeline)")) return SO101_ERR_HIP;
+      hipLaunchKernelGGL(k_tree_pipe_begin, dim3(ng), dim3(64), 0, gs, s->dm, s->dg, T, s->buf, s->env, store_now(s), P, action, obs, reward, discount, step_type, e0);
+      for (int k = 0; k < T.n_substeps; k++) {
+        hipLaunchKernelGGL(k_tree_narrow, dim3(nw), dim3(64), 0, gs, s->dm, s->dg, P, s->n_envs, k);
+        hipLaunchKernelGGL(k_tree_pipe_solve, dim3(ng), dim3(64), 0, gs, s->dm, s->dg, T, s->buf, s->env, P, k, (int)(k == T.n_substeps - 1), obs, reward, discount, step_type, e0);
+      }
+      if (!t_ok(s, hipGetLastError(), "k_tree_pipe_solve")) return SO101_ERR_HIP;
+      if (G > 1 && !(t_ok(s, hipEventRecord(s->slice_done[g], gs), "hipEventRecord") && t_ok(s, hipStreamWaitEvent(st, s->slice_done[g], 0), "hipStreamWaitEvent"))) return SO101_ERR_HIP;
     }
-    if (!t_ok(s, hipGetLastError(), "k_tree_pipe_solve")) return SO101_ERR_HIP;
   } else {
     hipLaunchKernelGGL(k_tree_step, dim3(s->n_envs), dim3(64), 0, st, s->dm, s->dg, T, s->buf, s->env, store_now(s), action, obs, reward, discount, step_type);
     if (!t_ok(s, hipGetLastError(), "k_tree_step")) return SO101_ERR_HIP;
