@@ -229,7 +229,7 @@ def run_aloha(args, torch, sdist, dev, rank, world, hbm_measured):
     d = env.diagnostics().cpu().numpy()
     all_returns = sdist.all_gather_returns(env.episode_returns())
     if rank == 0:
-        # counters of exactly this build's k_tree_step at 4096 ALOHA envs, when a PMC pass of it is committed (scripts/gpu_pmc_tree.sh)
+        # counters of exactly this build's control step (the launch chain) at 4096 ALOHA envs, when a PMC pass of it is committed (scripts/gpu_pmc_tree.sh)
         tree_hash = sbuild.source_hash(mpr=args.narrowphase == "mpr")
         tree_pmc = None
         pmc_path = os.path.join(ROOT, "profiles", f"pmc_tree_{tree_hash}.json")
@@ -253,15 +253,15 @@ def run_aloha(args, torch, sdist, dev, rank, world, hbm_measured):
                        "parallelism": f"env-shard x{world}", "build": sbuild.source_hash(mpr=args.narrowphase == "mpr")},
             "roofline": {"bound": "latency/valu", "achieved": achieved, "peak": hbm_measured, "unit": "GB/s", "frac": achieved / hbm_measured if hbm_measured else None,
                          "traffic": (tree_pmc or {}).get("hbm_bytes_per_step"), "peak_spec": HBM_SPEC_GBS, "frac_of_spec": achieved / HBM_SPEC_GBS,
-                         "kernel": "k_tree_step (one launch per control step)",
-                         "kernel_ms": 1e3 * elapsed / args.steps, "launches_per_step": 1,
+                         "kernel": "launch chain per control step and env slice: k_tree_pipe_begin + 10 x (k_tree_narrow + k_tree_pipe_solve); up to four slices on their own streams",
+                         "kernel_ms": 1e3 * elapsed / args.steps, "launches_per_step": (4 if N >= 512 else 2 if N >= 128 else 1) * 21,
                          "compute": None if not tree_pmc else {
                              "valu_tflops_equiv": tree_pmc["valu_insts_per_step"] * 64 * 2 / (elapsed / args.steps) / 1e12, "peak_tflops": VALU_PEAK_TFLOPS,
                              "frac": tree_pmc["valu_insts_per_step"] * 64 * 2 / (elapsed / args.steps) / 1e12 / VALU_PEAK_TFLOPS,
                              "valu_insts_per_env_substep": tree_pmc["valu_insts_per_step"] / (N * 10.0), "active_lane_fraction": tree_pmc.get("active_lane_fraction"),
                              "wait_fraction": tree_pmc.get("wait_fraction"), "source": f"profiles/pmc_tree_{tree_hash}.json"},
-                         "note": f"algorithmic bytes {algo} B per env-step; the kernel is bound by its instruction count (profiles/r03_aloha_pmc.txt: 101 k vector "
-                                 "wave-instructions per env-substep before the oriented-box filter of round 4), not by HBM"},
+                         "note": f"algorithmic bytes {algo} B per env-step; the step is bound by its instruction count and the per-CU LDS / L1 traffic of the solver "
+                                 "(DESIGN.md section 8), not by HBM"},
             "dist": sdist.evidence(1e3 * elapsed / args.steps, dev),
             "diag_mean": {"contacts": float(d[:, 0].mean()), "constraint_rows": float(d[:, 1].mean()), "solver_iterations": float(d[:, 2].mean()),
                           "narrowphase_candidates": float(d[:, 3].mean())},

@@ -1,7 +1,6 @@
 """Throughput of the ALOHA hand-over env on the general-tree engine (run through gpurun): env-steps/s of so101_tree_step with
-uniform random joint targets around the home pose, at a few batch sizes.  First GPU path for these scenes (one wavefront per
-env, 57 KB of LDS, fused launch per control step) - a baseline for the work on it, not a tuned number.
-    python scripts/gpu_aloha_bench.py [banana|pen] > gpurun_out/r03_aloha_bench.json"""
+uniform random joint targets around the home pose, at a few batch sizes.  The env's default step path (batches: the launch chain of so101_tree.hpp).
+    python scripts/gpu_aloha_bench.py [banana|pen] [n_envs ...] > gpurun_out/r03_aloha_bench.json"""
 import json
 import sys
 import time
@@ -15,7 +14,7 @@ from so101_sim_amd.model import scenes        # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "banana"
 out = []
-for n in (256, 1024, 4096):
+for n in ([int(x) for x in sys.argv[2:]] or (256, 1024, 4096)):
     env = task_suite.create_task_env("HandOverBanana" if name == "banana" else "HandOverPen", time_limit=10.0, random_state=0, n_envs=n)
     t0 = time.time(); env.reset(); torch.cuda.synchronize(); t_reset = time.time() - t0
     home = torch.tensor(np.concatenate([scenes.ALOHA_HOME_CTRL] * 2), dtype=torch.float32, device=env.device)
