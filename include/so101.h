@@ -311,7 +311,7 @@ typedef struct {
                                 that does not settles in place - the same bits either way.  so101_tree_configure_env / so101_tree_destroy join it */
   int pipeline;              /* != 0: so101_tree_step runs as a launch chain - per substep one launch with a wavefront per candidate pair of the whole
                                 batch (the narrowphase) and one with a wavefront per env (everything else) - instead of one kernel; the same bits
-                                either way.  Reward mode 0 and at most 64 substeps; any other configuration runs the single kernel */
+                                either way (the contact rewards add one narrowphase launch on the post-step state).  At most 63 substeps; above, the single kernel */
 } so101_tree_config;
 int so101_tree_obs_dim(const so101_tree* sim);
 int so101_tree_bind_env(so101_tree* sim, float* ring_pos, float* ring_vel, float* ep_return, int32_t* step_count, int32_t* episode);

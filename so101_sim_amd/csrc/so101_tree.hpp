@@ -662,7 +662,7 @@ DEV void collision(const TreeModel* tm, const DevModel* gm, TreeLDS& L, bool nar
 // memory between launches of one stream: body poses and candidates out, contact records back (count, normal, then (dist, position) per
 // contact, compact, in slot order), the env's state through its home buffers.  Same functions on the same data: bit-identical to the fused step.
 #define TREC 24                  // floats per contact record
-#define TPIPE_MAXSUB 64
+#define TPIPE_MAXSUB 64          // work-list slots per step: the substeps, plus one for the contacts of the post-step state (contact rewards)
 struct TreePipe {
   float* pose;                   // [N][TB][12] xpos, xmat of every body
   unsigned int* cand;            // [N][TCAND] geom1 | geom2 << 16
@@ -673,6 +673,7 @@ struct TreePipe {
   int* counters;                 // [TPIPE_MAXSUB][2] work items, cursor
   unsigned char* active;         // [N] 0 not stepping in this call (auto-reset), 1 stepping, 2 diverged
   int* pflags;                   // [N] event flags of the step so far
+  int* pdiag;                    // [N][4] rows, solver iterations, contacts, candidates of the env's last substep (diagnostics of a step that ends in k_tree_pipe_finish)
 };
 
 // hands the candidates of the current poses to substep s

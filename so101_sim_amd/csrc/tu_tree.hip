@@ -184,9 +184,12 @@ __global__ void __launch_bounds__(64) k_tree_begin(const TreeModel* tm, TreeTask
 }
 
 // end of a control step of one env (after the last substep): observation, reward / discount / termination, state and counters out
-template <bool CONTACT_REWARDS>
+// CONTACTS: where the contact rewards take the contacts of the post-step state from - 0: not compiled (reward mode 0 only), 1: collision() in
+// place (single kernel), 2: gathered from the launch chain's records (k_tree_pipe_finish)
+template <int CONTACTS>
 __device__ __forceinline__ void tree_finish_step(const TreeModel* tm, const DevModel* gm, const TreeTask& T, TreeLDS& L, TreeScratch& G, const TreeBuffers& B,
-                                                 const TreeEnvBuffers& E, int e, bool diverged, float* obs, float* reward, float* discount, unsigned char* step_type) {
+                                                 const TreeEnvBuffers& E, int e, bool diverged, float* obs, float* reward, float* discount, unsigned char* step_type,
+                                                 const TreePipe* P = nullptr) {
   int lane = wave_lane(), N = T.n_envs;
   if (diverged) {         // mj_check*: the data is reset, dm_control ends the episode with reward 0 and discount 0
     if (lane < tm->nq) L.qpos[lane] = 0.f;
@@ -207,10 +210,12 @@ __device__ __forceinline__ void tree_finish_step(const TreeModel* tm, const DevM
   // physics.step(), whose legacy step ends with mj_step1 - the contacts of the integrated state, recomputed here.
   float r = 0.f, r_disc = 0.f, r_term = 0.f;
   if (!diverged) {
-    if (!CONTACT_REWARDS || T.reward_mode == 0) r = r_disc = r_term = tree::task_reward(tm, T, L);      // (the launch chain runs reward mode 0 only)
-    else if (T.reward_mode == 2) { tree::collision(tm, gm, L); r = r_disc = r_term = tree::task_reward_touching(tm, T, L); }
-    else {
-      tree::collision(tm, gm, L);
+    if (CONTACTS == 0 || T.reward_mode == 0) r = r_disc = r_term = tree::task_reward(tm, T, L);
+    else if (T.reward_mode == 2) {
+      if constexpr (CONTACTS == 2) tree::gather_contacts(tm, gm, L, *P, e); else tree::collision(tm, gm, L);
+      r = r_disc = r_term = tree::task_reward_touching(tm, T, L);
+    } else {
+      if constexpr (CONTACTS == 2) tree::gather_contacts(tm, gm, L, *P, e); else tree::collision(tm, gm, L);
       int st = E.success_state[e];
       r = tree::task_reward_contacts(tm, T, L, G, &st);
       if (T.terminate_on_success) { r_disc = tree::task_reward_contacts(tm, T, L, G, &st); r_term = tree::task_reward_contacts(tm, T, L, G, &st); }
@@ -277,7 +282,7 @@ __global__ void __launch_bounds__(64) k_tree_step(const TreeModel* tm, const Dev
     if (lane < tm->nv) ok = ok && fabsf(L.qvel[lane]) <= 1e10f && fabsf(L.qacc[lane]) <= 1e10f;
     diverged = wave_ballot(!ok) != 0ull;
   }
-  tree_finish_step<true>(tm, gm, T, L, G, B, E, e, diverged, obs, reward, discount, step_type);
+  tree_finish_step<1>(tm, gm, T, L, G, B, E, e, diverged, obs, reward, discount, step_type);
 }
 
 // ---- the control step as a launch chain (so101_tree.hpp, "the narrowphase in a launch of its own"): k_tree_pipe_begin, then per substep
@@ -358,13 +363,27 @@ __global__ void __launch_bounds__(64, TREE_SOLVE_OCC) k_tree_pipe_solve(const Tr
   if (!last) {
     if (act == 1) {
       tree::store_state(tm, L, B, e, N);
-      if (lane == 0) P.pflags[e] = L.flags;
+      if (lane == 0) { P.pflags[e] = L.flags; P.pdiag[4 * e] = L.nrow; P.pdiag[4 * e + 1] = L.iters; P.pdiag[4 * e + 2] = L.ncon; P.pdiag[4 * e + 3] = L.ncand; }
       if (!diverged) { tree::kinematics(tm, L); tree::publish(tm, gm, L, P, e, N, s + 1); }
       else if (lane == 0) P.ncand[e] = 0;
     }
     return;
   }
-  tree_finish_step<false>(tm, gm, T, L, G, B, E, e, diverged, obs, reward, discount, step_type);
+  tree_finish_step<0>(tm, gm, T, L, G, B, E, e, diverged, obs, reward, discount, step_type);
+}
+
+// end of a control step whose reward needs the contacts of the post-step state (reward modes 1 and 2): the last k_tree_pipe_solve published that
+// state's candidates like a substep's, k_tree_narrow has turned them into records
+__global__ void __launch_bounds__(64, 2) k_tree_pipe_finish(const TreeModel* tm, const DevModel* gm, TreeTask T, TreeBuffers B, TreeEnvBuffers E, TreePipe P,
+                                                            float* obs, float* reward, float* discount, unsigned char* step_type, int e0) {
+  BLOCK_SHARED(TreeLDS, L);
+  int e = e0 + blockIdx.x, lane = wave_lane(), N = T.n_envs;
+  int act = P.active[e];
+  if (act == 0) return;
+  if (lane == 0) { L.flags = P.pflags[e]; L.nrow = P.pdiag[4 * e]; L.iters = P.pdiag[4 * e + 1]; L.ncon = P.pdiag[4 * e + 2]; L.ncand = P.pdiag[4 * e + 3]; }
+  tree::load_state(tm, L, B, e, N);
+  TreeScratch G = tree::scratch_of(B, e);
+  tree_finish_step<2>(tm, gm, T, L, G, B, E, e, act == 2, obs, reward, discount, step_type, &P);
 }
 
 // ==================================================================================================== host side
@@ -647,7 +666,7 @@ static bool tree_pipe_setup(TreeHandle* s) {             // lazily: the hand-off
   void* pose = nullptr;
   bool ok = alloc((void**)&P.cand, n * TCAND * sizeof(unsigned int)) && alloc((void**)&P.ncand, n * sizeof(int)) && alloc((void**)&P.rec, n * TCAND * TREC * sizeof(float)) &&
             alloc((void**)&P.work, 2 * n * TCAND * sizeof(unsigned int)) && alloc((void**)&P.counters, TreeHandle::MAXSLICES * 2 * TPIPE_MAXSUB * sizeof(int)) && alloc((void**)&P.active, n) &&
-            alloc((void**)&P.pflags, n * sizeof(int)) && alloc(&pose, n * TB * 12 * sizeof(float));
+            alloc((void**)&P.pflags, n * sizeof(int)) && alloc((void**)&P.pdiag, 4 * n * sizeof(int)) && alloc(&pose, n * TB * 12 * sizeof(float));
   for (int g = 0; ok && g < TreeHandle::MAXSLICES; g++)
     ok = t_ok(s, hipStreamCreateWithFlags(&s->slice_stream[g], hipStreamNonBlocking), "hipStreamCreate") &&
          t_ok(s, hipEventCreateWithFlags(&s->slice_done[g], hipEventDisableTiming), "hipEventCreate");
@@ -832,7 +851,8 @@ int TAPI(step)(TreeHandle* s, const float* action, float* obs, float* reward, fl
   TREE_GUARD(s);
   hipStream_t st = (hipStream_t)stream;
   TreeTask T = task_now(s);
-  if (s->pipeline && s->pipe.pose && T.reward_mode == 0 && T.n_substeps <= TPIPE_MAXSUB) {
+  const bool post = T.reward_mode != 0;          // contact rewards: one more narrowphase launch, on the post-step state
+  if (s->pipeline && s->pipe.pose && T.n_substeps + (post ? 1 : 0) <= TPIPE_MAXSUB) {
     // launch chain: prologue, then per substep the narrowphase of every candidate pair of the batch and the rest of the substep per env.
     // Env slices on their own streams: the narrowphase of one (latency-bound, two wavefronts per SIMD) runs beside the solve of another
     // (bound by the CU's LDS / L1 traffic, three envs per CU); the slices share nothing but the model.  Measured, 1 / 2 / 3 / 4 slices:
@@ -853,7 +873,11 @@ int TAPI(step)(TreeHandle* s, const float* action, float* obs, float* reward, fl
       hipLaunchKernelGGL(k_tree_pipe_begin, dim3(ng), dim3(64), 0, gs, s->dm, s->dg, T, s->buf, s->env, store_now(s), P, action, obs, reward, discount, step_type, e0);
       for (int k = 0; k < T.n_substeps; k++) {
         hipLaunchKernelGGL(k_tree_narrow, dim3(nw), dim3(64), 0, gs, s->dm, s->dg, P, s->n_envs, k);
-        hipLaunchKernelGGL(k_tree_pipe_solve, dim3(ng), dim3(64), 0, gs, s->dm, s->dg, T, s->buf, s->env, P, k, (int)(k == T.n_substeps - 1), obs, reward, discount, step_type, e0);
+        hipLaunchKernelGGL(k_tree_pipe_solve, dim3(ng), dim3(64), 0, gs, s->dm, s->dg, T, s->buf, s->env, P, k, (int)(!post && k == T.n_substeps - 1), obs, reward, discount, step_type, e0);
+      }
+      if (post) {
+        hipLaunchKernelGGL(k_tree_narrow, dim3(nw), dim3(64), 0, gs, s->dm, s->dg, P, s->n_envs, T.n_substeps);
+        hipLaunchKernelGGL(k_tree_pipe_finish, dim3(ng), dim3(64), 0, gs, s->dm, s->dg, T, s->buf, s->env, P, obs, reward, discount, step_type, e0);
       }
       if (!t_ok(s, hipGetLastError(), "k_tree_pipe_solve")) return SO101_ERR_HIP;
       if (G > 1 && !(t_ok(s, hipEventRecord(s->slice_done[g], gs), "hipEventRecord") && t_ok(s, hipStreamWaitEvent(st, s->slice_done[g], 0), "hipStreamWaitEvent"))) return SO101_ERR_HIP;

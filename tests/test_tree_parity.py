@@ -518,15 +518,15 @@ def test_reset_prefetch_of_the_tree_engine_is_bit_identical(scene):
         np.testing.assert_array_equal(a, b, err_msg=f"step {k}")
 
 
-def _launch_chain_identity(scene, backend, n, steps, n_substeps, settle, last_step=3):
+def _launch_chain_identity(scene, backend, n, steps, n_substeps, settle, last_step=3, reward_mode=0):
     """so101_tree_config.pipeline: the control step as a launch chain (narrowphase in a launch of its own, one wavefront per candidate pair of
     the whole batch) against the single kernel - observations, rewards, step types, states and the per-env diagnostics (contacts, rows, solver
     iterations, candidates, flags) of a rollout across auto-resets, bit for bit."""
-    raw32 = scenes.load_dining_blob("banana", "f32")[0] if scene == "dining" else _blobs("banana")[1]
+    raw32 = scenes.load_dining_blob("mug" if reward_mode == 2 else "banana", "f32")[0] if scene == "dining" else _blobs("banana")[1]
     out = []
     for pipeline in (0, 1):
         sim = TreeArraySim(raw32, n, backend=backend)
-        sim.enable_env(seed=5, last_step=last_step, settle_max_substeps=settle, pipeline=pipeline, n_substeps=n_substeps)
+        sim.enable_env(seed=5, last_step=last_step, settle_max_substeps=settle, pipeline=pipeline, n_substeps=n_substeps, reward_mode=reward_mode)
         rng = np.random.RandomState(2)
         trace = []
         for k in range(steps):
@@ -544,10 +544,12 @@ def test_launch_chain_of_the_tree_engine_is_bit_identical_emulated():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("scene", ["banana", "dining"])
-def test_launch_chain_of_the_tree_engine_is_bit_identical(scene):
+@pytest.mark.parametrize("scene,reward_mode", [("banana", 0), ("dining", 0), ("banana", 1), ("dining", 2)])
+def test_launch_chain_of_the_tree_engine_is_bit_identical(scene, reward_mode):
+    """(reward modes 1 and 2 - contact sequence, object touches receptacle - end the chain with one more narrowphase launch on the post-step state
+    and k_tree_pipe_finish)"""
     n, steps = (16, 8) if scene == "dining" else (64, 9)
-    _launch_chain_identity(scene, "gpu", n=n, steps=steps, n_substeps=10, settle=300)
+    _launch_chain_identity(scene, "gpu", n=n, steps=steps, n_substeps=10, settle=300, reward_mode=reward_mode)
 
 
 @pytest.mark.gpu
