@@ -855,7 +855,7 @@ int TAPI(step)(TreeHandle* s, const float* action, float* obs, float* reward, fl
   if (s->pipeline && s->pipe.pose && T.n_substeps + (post ? 1 : 0) <= TPIPE_MAXSUB) {
     // launch chain: prologue, then per substep the narrowphase of every candidate pair of the batch and the rest of the substep per env.
     // Env slices on their own streams: the narrowphase of one (latency-bound, two wavefronts per SIMD) runs beside the solve of another
-    // (bound by the CU's LDS / L1 traffic, three envs per CU); the slices share nothing but the model.  Measured, 1 / 2 / 3 / 4 slices:
+    // (four envs per CU by its LDS footprint); the slices share nothing but the model.  Measured, 1 / 2 / 3 / 4 slices:
     // ALOHA (4096 envs) 206 / 232 / 228 / 231 k, Dining (1024 envs) 33.2 / 44.6 / - / 47.0 k env-steps/s.
     static const int slices_env = getenv("SO101_TREE_SLICES") ? atoi(getenv("SO101_TREE_SLICES")) : 0;          // (kernel experiments)
     const int G = s->n_envs < 128 ? 1 : (slices_env >= 1 && slices_env <= TreeHandle::MAXSLICES ? slices_env : (s->n_envs < 512 ? 2 : 4));
