@@ -10,7 +10,8 @@
 #include "so101_device.hpp"
 
 // Two builds of this file share one library (csrc/tu_tree.hip, csrc/tu_tree64.hip; TREE_VARIANT), each inside its own namespace:
-//   32 (ALOHA hand-over): 32 dofs, 40 positions, 128 geoms, 64 contacts, 384 rows - LDS 31 KB per env;
+//   32 (ALOHA hand-over): 32 dofs, 40 positions, 128 geoms, 64 contacts, 384 rows - LDS 40 KB per env (25 KB + the constraint
+//      rows of substeps with at most 96 of them): four envs per CU;
 //   64 (Dining, SURVEY 8f-4: two arms + six free props = 52 dofs, 240 geoms, ~105 contacts while the props land): 64 dofs, 64
 //      positions, 256 geoms, 128 contacts, 768 rows - LDS 70 KB per env, the Cholesky a call instead of inlined code.
 // so101_tree_create picks the build from the model's dimensions (csrc/tu_tree_api.hip).

@@ -261,8 +261,9 @@ __device__ __forceinline__ bool tree_begin_step(const TreeModel* tm, const DevMo
   return false;
 }
 
-// (one wave per SIMD: 390 unified registers.  __launch_bounds__(64, 2) was measured in round 4 - 256 VGPRs, 770 spilled, 864 B of scratch per
-// lane: 171 k against 175 k env-steps/s at 4096 envs; the LDS footprint, 31 KB, would admit 5 envs per CU)
+// (The single-kernel step: N = 1, steps of more than 63 substeps, and the reference the launch chain below is tested against.  One wavefront per
+// SIMD: 458 unified registers, the hull caches and the EPA polytope of the inlined narrowphase among them.  __launch_bounds__(64, 2) was measured
+// in round 4 - 256 VGPRs, 770 spilled, 864 B of scratch per lane: 171 k against 175 k env-steps/s at 4096 envs.)
 // one control step of every env: dm_control's Environment.step - an env whose last step was LAST resets and reports FIRST
 // (the action is ignored), the others apply the action, run n_substeps and report observation, reward, discount, step type
 __global__ void __launch_bounds__(64) k_tree_step(const TreeModel* tm, const DevModel* gm, TreeTask T, TreeBuffers B, TreeEnvBuffers E, TreeStore S, const float* action,
@@ -867,7 +868,8 @@ int TAPI(step)(TreeHandle* s, const float* action, float* obs, float* reward, fl
       P.counters = s->pipe.counters + 2 * TPIPE_MAXSUB * g;
       P.work = s->pipe.work + (size_t)2 * e0 * TCAND;
       P.work_cap = (unsigned int)ng * TCAND;
-      int nw = ng * 2; nw = nw < 4096 ? nw : 4096;
+      static const int nwq_env = getenv("SO101_TREE_NARROW_WAVES_Q") ? atoi(getenv("SO101_TREE_NARROW_WAVES_Q")) : 0;      // (kernel experiments: quarter waves per env)
+      int nw = (int)((long long)ng * (nwq_env > 0 ? nwq_env : 8) / 4); nw = nw < 1 ? 1 : (nw < 4096 ? nw : 4096);
       if (G > 1 && !t_ok(s, hipStreamWaitEvent(gs, s->slice_begin, 0), "hipStreamWaitEvent")) return SO101_ERR_HIP;
       if (!t_ok(s, hipMemsetAsync(P.counters, 0, 2 * TPIPE_MAXSUB * sizeof(int), gs), "hipMemsetAsync(pipeline)")) return SO101_ERR_HIP;
       hipLaunchKernelGGL(k_tree_pipe_begin, dim3(ng), dim3(64), 0, gs, s->dm, s->dg, T, s->buf, s->env, store_now(s), P, action, obs, reward, discount, step_type, e0);
