@@ -553,6 +553,14 @@ def test_launch_chain_of_the_tree_engine_is_bit_identical(scene, reward_mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scene,n", [("banana", 512), ("dining", 128)])
+def test_launch_chain_slices_are_bit_identical(scene, n):
+    """From 128 envs on the chain is cut into two env slices, from 512 into four, each on its own stream (counters and work lists per slice):
+    the same rollout across auto-resets as the single kernel, bit for bit."""
+    _launch_chain_identity(scene, "gpu", n=n, steps=6, n_substeps=10, settle=300)
+
+
+@pytest.mark.gpu
 def test_settled_store_of_the_tree_engine_is_bit_identical():
     """compute_settled(): the settle results of the first episodes of every env, computed ahead of time; the resets that find them copy -
     the rollout across two auto-resets is bit-identical to the one that settles inside the step calls."""
