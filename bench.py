@@ -228,6 +228,8 @@ def run_aloha(args, torch, sdist, dev, rank, world, hbm_measured):
     elapsed = sdist.max_over_ranks(time.perf_counter() - t0, dev)
     d = env.diagnostics().cpu().numpy()
     all_returns = sdist.all_gather_returns(env.episode_returns())
+    dist_info = sdist.evidence(1e3 * elapsed / args.steps, dev)      # a collective: every rank calls it
+    plan = env.launch_plan()
     if rank == 0:
         # counters of exactly this build's control step (the launch chain) at 4096 ALOHA envs, when a PMC pass of it is committed (scripts/gpu_pmc_tree.sh)
         tree_hash = sbuild.source_hash(mpr=args.narrowphase == "mpr")
@@ -253,8 +255,8 @@ def run_aloha(args, torch, sdist, dev, rank, world, hbm_measured):
                        "parallelism": f"env-shard x{world}", "build": sbuild.source_hash(mpr=args.narrowphase == "mpr")},
             "roofline": {"bound": "latency/valu", "achieved": achieved, "peak": hbm_measured, "unit": "GB/s", "frac": achieved / hbm_measured if hbm_measured else None,
                          "traffic": (tree_pmc or {}).get("hbm_bytes_per_step"), "peak_spec": HBM_SPEC_GBS, "frac_of_spec": achieved / HBM_SPEC_GBS,
-                         "kernel": "launch chain per control step and env slice: k_tree_pipe_begin + 10 x (k_tree_narrow + k_tree_pipe_solve); up to four slices on their own streams",
-                         "kernel_ms": 1e3 * elapsed / args.steps, "launches_per_step": (4 if N >= 512 else 2 if N >= 128 else 1) * 21,
+                         "kernel": f"{plan['path']}: {plan.get('kernels', 'k_tree_step')}; {plan['slices']} env slice(s) on their own streams",
+                         "kernel_ms": 1e3 * elapsed / args.steps, "launches_per_step": plan["kernel_launches"], "memsets_per_step": plan["memsets"],
                          "compute": None if not tree_pmc else {
                              "valu_tflops_equiv": tree_pmc["valu_insts_per_step"] * 64 * 2 / (elapsed / args.steps) / 1e12, "peak_tflops": VALU_PEAK_TFLOPS,
                              "frac": tree_pmc["valu_insts_per_step"] * 64 * 2 / (elapsed / args.steps) / 1e12 / VALU_PEAK_TFLOPS,
@@ -262,7 +264,8 @@ def run_aloha(args, torch, sdist, dev, rank, world, hbm_measured):
                              "wait_fraction": tree_pmc.get("wait_fraction"), "source": f"profiles/pmc_tree_{tree_hash}.json"},
                          "note": f"algorithmic bytes {algo} B per env-step; the step is bound by its instruction count and the per-CU LDS / L1 traffic of the solver "
                                  "(DESIGN.md section 8), not by HBM"},
-            "dist": sdist.evidence(1e3 * elapsed / args.steps, dev),
+            "dist": dist_info,
+            "windows": "first window only (the SO100 workloads report the mean of --repeats windows)",
             "diag_mean": {"contacts": float(d[:, 0].mean()), "constraint_rows": float(d[:, 1].mean()), "solver_iterations": float(d[:, 2].mean()),
                           "narrowphase_candidates": float(d[:, 3].mean())},
             "flagged_envs_last_step": int((d[:, 4] != 0).sum()),
@@ -585,8 +588,14 @@ def main():
             out["config"]["step_path"] = envs[0].sim.info()
             if path == 2:
                 out["config"]["chain_stats"] = envs[0].sim.chain_stats()
-        if not args.no_cpu_baseline and world == 1 and on_gpu:
+        if not args.no_cpu_baseline and on_gpu:
+            # world > 1 as well: rank 0 alone, after the timed region and after every collective of the run - the other
+            # ranks are not held at a barrier for it, they finalize and exit while rank 0 times the oracle on the host cores
+            if world > 1:
+                sdist.finalize()
             out["cpu_baseline"] = cpu_baseline()
+            if world > 1:
+                out["cpu_baseline"]["note_ranks"] = f"timed on rank 0 of {world} after the GPU windows, the other ranks idle or gone"
         print(json.dumps(out))
     sdist.finalize()
 

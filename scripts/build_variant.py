@@ -1,25 +1,43 @@
-"""Kernel experiments: builds the library with extra compiler flags into ab/libso101_<tag>.so (git-ignored; selected with SO101_HIP_LIB).
-    usage: python scripts/build_variant.py TAG -DNAME=VALUE ..."""
+"""Kernel experiments: build ab/lib_<name>.so = the default library with some translation units recompiled under extra -D flags.
+   python scripts/build_variant.py <name> [--tus tu_narrow,tu_pipe_solve] -- -DFOO=1 ...
+The variant is selected at run time with SO101_HIP_LIB=ab/lib_<name>.so (so101_sim_amd/native.py); ab/ is git-ignored and travels with gpurun."""
 import os, subprocess, sys
-from concurrent.futures import ThreadPoolExecutor
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-from so101_sim_amd import build as b
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from so101_sim_amd import build as B
 
-tag, extra = sys.argv[1], sys.argv[2:]
-obj_dir = f"/tmp/so101_objs_{tag}"
-os.makedirs(obj_dir, exist_ok=True)
-os.makedirs(os.path.join(ROOT, "ab"), exist_ok=True)
+def main():
+    argv = sys.argv[1:]
+    extra = []
+    if "--" in argv:
+        k = argv.index("--"); extra = argv[k + 1:]; argv = argv[:k]
+    name = argv[0]
+    tus = ["tu_narrow"]
+    if "--tus" in argv:
+        tus = argv[argv.index("--tus") + 1].split(",")
+    B.build()
+    root = os.path.dirname(B._HERE)
+    out = os.path.join(root, "ab"); os.makedirs(out, exist_ok=True)
+    objs = []
+    for src in B.translation_units():
+        base = os.path.basename(src)[:-4]
+        if base in tus or "all" in tus:
+            obj = os.path.join(out, f"{base}.{name}.o")
+            cmd = [B.HIPCC, *B.FLAGS, *extra, "-Rpass-analysis=kernel-resource-usage", "-c", "-o", obj, src]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode:
+                print(r.stderr); sys.exit(1)
+            cur = None
+            for line in r.stderr.splitlines():
+                if "Function Name" in line: cur = line.split("Function Name:")[1].split("[")[0].strip()
+                for key in ("VGPRs:", "VGPRs Spill", "ScratchSize", "Occupancy", "LDS Size"):
+                    if key in line and cur and ("k_narrow" in cur or "k_pipe_solve" in cur or "k_tree" in cur):
+                        print(f"  {cur[:40]:40s} {line.split('remark:')[1].split('[-R')[0].strip()}")
+        else:
+            obj = os.path.join(B.OBJ, base + ".o")
+        objs.append(obj)
+    lib = os.path.join(out, f"lib_{name}.so")
+    subprocess.check_call([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])
+    print(lib)
 
-
-def one(src):
-    obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
-    subprocess.check_call([b.HIPCC, *b.FLAGS, *extra, "-c", "-o", obj, src])
-    return obj
-
-
-with ThreadPoolExecutor(max_workers=8) as pool:
-    objs = list(pool.map(one, b.translation_units()))
-out = os.path.join(ROOT, "ab", f"libso101_{tag}.so")
-subprocess.check_call([b.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs])
-print(out)
+if __name__ == "__main__":
+    main()

@@ -197,9 +197,10 @@ class AlohaEnvironment:
                         joints_delay_steps=jd, physics_delay_steps=pd,
                         # reset prefetch (batches; a seed-compatible single env draws its placements on the host: nothing to settle ahead)
                         prefetch_resets=int(bool(prefetch_resets) and not self._seed_compatible),
-                        # the step as a launch chain (narrowphase in a launch of its own; the library falls back to the single kernel for the
-                        # contact rewards); one env is one wavefront either way and keeps the single launch
+                        # the step as a launch chain (narrowphase in a launch of its own; the contact rewards end the chain with one more narrowphase
+                        # launch on the post-step state + k_tree_pipe_finish); one env is one wavefront either way and keeps the single launch
                         pipeline=int(bool(pipeline) and self.n_envs > 1))
+        self._pipeline = bool(pipeline)
         # physics_state / delayed_physics_state (aloha2_task.py:244-251,441-444): qpos | qvel and its copy of `pd` control steps ago,
         # from a device-side delay line the step / reset kernels maintain.  The reference ties them to image_observation_enabled;
         # for batches they are opt-in (58 + 58 floats per env and step).
@@ -398,6 +399,21 @@ class AlohaEnvironment:
 
     def episode_returns(self):
         return self.ep_return
+
+    def launch_plan(self) -> dict:
+        """What one `step_tensor` call enqueues (the rule of `so101_tree_step`, csrc/tu_tree.hip: env slices by batch size or SO101_TREE_SLICES,
+        per slice one memset, k_tree_pipe_begin, n_substeps x (k_tree_narrow + k_tree_pipe_solve), and for the contact rewards one more
+        k_tree_narrow + k_tree_pipe_finish)."""
+        import os
+        nsub = int(round(self.task.control_timestep / PHYSICS_TIMESTEP))
+        post = self.task.reward_mode != 0
+        if not (self._pipeline and self.n_envs > 1) or nsub + int(post) > 63:
+            return {"path": "single kernel (k_tree_step)", "slices": 1, "kernel_launches": 1, "memsets": 0}
+        env_slices = int(os.environ.get("SO101_TREE_SLICES", "0") or 0)
+        g = 1 if self.n_envs < 128 else (env_slices if 1 <= env_slices <= 4 else (2 if self.n_envs < 512 else 4))
+        per_slice = 1 + 2 * nsub + (2 if post else 0)
+        return {"path": "launch chain", "slices": g, "kernel_launches": g * per_slice, "memsets": g,
+                "kernels": "k_tree_pipe_begin + %d x (k_tree_narrow + k_tree_pipe_solve)%s per slice" % (nsub, " + k_tree_narrow + k_tree_pipe_finish" if post else "")}
 
     def diagnostics(self):
         """per env: contacts, constraint rows, solver iterations, broadphase candidates, flags of the last substep"""

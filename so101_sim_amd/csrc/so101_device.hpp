@@ -533,6 +533,38 @@ DEV void hull_load(const DevModel* m, const GeomW& G, HullCache& H) {
 template <class GP = G64>
 DEV void hull_load(const DevModel*, const GeomW&, NoCache&) {}
 
+// The same cache in LDS (k_narrow, one wavefront per workgroup: round 5).  The register cache above costs 48 VGPRs for the two geoms of a
+// pair across the whole query - with the EPA polytope inlined k_narrow needed 256 + 43 spilled - while the kernel used 256 B of its 20 KB LDS
+// share.  Here the first HULL_LDS_N vertices of a hull are copied once per pair into the workgroup's LDS as x[] | y[] | z[], and a support
+// scan reads them four vertices per lane and instruction (ds_read_b128: lane l takes vertices 256 J + 4 l + 0..3, in increasing index order,
+// so "largest dot product, smallest index" picks the vertex every other variant picks).
+#define HULL_LDS_N 512
+struct HullLDS { float* p; };      // [3][HULL_LDS_N]
+DEV float* hull_lds_store() { __shared__ __attribute__((aligned(16))) float store[2 * 3 * HULL_LDS_N]; return store; }
+// uniform values parked in LDS across a phase that does not need them (k_narrow: the candidate face across the iterative query, the portal
+// across the EPA expansion): the register allocator otherwise keeps them in VGPRs, 64 copies of each, or spills them to scratch memory
+DEV float* narrow_park_store() { __shared__ __attribute__((aligned(16))) float park[128]; return park; }
+template <class GP = G64>
+DEV void hull_load(const DevModel* m, const GeomW& G, HullLDS& H) {
+  if (G.type != G_MESH) return;
+  int lane = GP::sub();
+  const float* x = ldc(&m->vx) + G.vadr; const float* y = ldc(&m->vy) + G.vadr; const float* z = ldc(&m->vz) + G.vadr;
+  float tx[HULL_LDS_N / WAVE], ty[HULL_LDS_N / WAVE], tz[HULL_LDS_N / WAVE];
+#pragma unroll
+  for (int j = 0; j < HULL_LDS_N / WAVE; j++) {
+    if (WAVE * j >= G.vnum) break;
+    int i = lane + WAVE * j;
+    bool v = i < G.vnum;
+    tx[j] = v ? x[i] : 0.f; ty[j] = v ? y[i] : 0.f; tz[j] = v ? z[i] : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < HULL_LDS_N / WAVE; j++) {
+    if (WAVE * j >= G.vnum) break;
+    int i = lane + WAVE * j;
+    H.p[i] = tx[j]; H.p[HULL_LDS_N + i] = ty[j]; H.p[2 * HULL_LDS_N + i] = tz[j];
+  }
+}
+
 DEV void select_geom(bool first, const GeomW& A, const GeomW& B, GeomW& o) {
   o.type = first ? A.type : B.type; o.vadr = first ? A.vadr : B.vadr; o.vnum = first ? A.vnum : B.vnum;
 #pragma unroll
@@ -545,6 +577,9 @@ DEV void select_hull(bool first, const HullCache& A, const HullCache& B, HullCac
   for (int j = 0; j < HULL_K; j++) { o.x[j] = first ? A.x[j] : B.x[j]; o.y[j] = first ? A.y[j] : B.y[j]; o.z[j] = first ? A.z[j] : B.z[j]; }
 }
 DEV void select_hull(bool, const NoCache&, const NoCache&, NoCache&) {}
+DEV void select_hull(bool first, const HullLDS& A, const HullLDS& B, HullLDS& o) { o.p = first ? A.p : B.p; }
+template <class C> struct is_hull_lds { static constexpr bool value = false; };
+template <> struct is_hull_lds<HullLDS> { static constexpr bool value = true; };
 
 // support point (world) of G in world direction dir; wave-parallel over hull vertices for meshes
 template <class Cache, class GP = G64>
@@ -559,7 +594,22 @@ DEV void support(const DevModel* m, const GeomW& G, const float* dir, float* out
     float best = -3.0e38f, bx = 0.f, by = 0.f, bz = 0.f; int bi = 0x7fffffff;
     const float* x = ldc(&m->vx) + G.vadr; const float* y = ldc(&m->vy) + G.vadr; const float* z = ldc(&m->vz) + G.vadr;
     int first = lane;
-    if constexpr (sizeof(Cache) >= sizeof(HullCache)) {
+    if constexpr (is_hull_lds<Cache>::value) {
+      const float4* X4 = (const float4*)H.p; const float4* Y4 = (const float4*)(H.p + HULL_LDS_N); const float4* Z4 = (const float4*)(H.p + 2 * HULL_LDS_N);
+#pragma unroll
+      for (int J = 0; J < HULL_LDS_N / (4 * WAVE); J++) {
+        if (4 * WAVE * J >= G.vnum) break;
+        float4 xv = X4[WAVE * J + lane], yv = Y4[WAVE * J + lane], zv = Z4[WAVE * J + lane];
+        float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w}, zs[4] = {zv.x, zv.y, zv.z, zv.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          int i = 4 * WAVE * J + 4 * lane + k;
+          float d = xs[k] * dl[0] + ys[k] * dl[1] + zs[k] * dl[2];
+          if (i < G.vnum && d > best) { best = d; bi = i; bx = xs[k]; by = ys[k]; bz = zs[k]; }
+        }
+      }
+      first = lane + HULL_LDS_N;
+    } else if constexpr (sizeof(Cache) >= sizeof(HullCache)) {
 #pragma unroll
       for (int j = 0; j < HULL_K; j++) {
         if (GP::N * j >= G.vnum) break;
@@ -897,7 +947,23 @@ DEV bool mpr_penetration(const DevModel* m, const GeomW& G1, const GeomW& G2, fl
       if (isz(dt) || dt > 0.f) {                                        // portal encapsules origin: start penetration phase
 #ifndef SO101_MPR     // (default; -DSO101_MPR = build.py --mpr, libso101_hip_mpr.so, keeps MPR's own answer): EPA takes over here - the tetrahedron v0 v1 v2 v3 contains the
         if constexpr (GP::N == WAVE) {          // origin from now on, and MPR's own refinement of the portal towards the surface is work EPA does anyway
+          if constexpr (is_hull_lds<Cache>::value) {
+            float* pk = narrow_park_store() + 64;
+            if (wave_lane() == 0) {
+#pragma unroll
+              for (int i = 0; i < 3; i++) { pk[i] = v0.v[i]; pk[3 + i] = v0.a[i]; pk[6 + i] = v0.b[i]; pk[9 + i] = v1.v[i]; pk[12 + i] = v1.a[i]; pk[15 + i] = v1.b[i];
+                                            pk[18 + i] = v2.v[i]; pk[21 + i] = v2.a[i]; pk[24 + i] = v2.b[i]; pk[27 + i] = v3.v[i]; pk[30 + i] = v3.a[i]; pk[33 + i] = v3.b[i]; }
+            }
+            wave_sync();
+          }
           if (epa_expand<Cache, GP>(m, G1, G2, org, v0, v1, v2, v3, mpr_tol, depth, dir, pos, H1, H2)) return true;
+          if constexpr (is_hull_lds<Cache>::value) {
+            wave_sync();
+            const float* pk = narrow_park_store() + 64;
+#pragma unroll
+            for (int i = 0; i < 3; i++) { v0.v[i] = pk[i]; v0.a[i] = pk[3 + i]; v0.b[i] = pk[6 + i]; v1.v[i] = pk[9 + i]; v1.a[i] = pk[12 + i]; v1.b[i] = pk[15 + i];
+                                          v2.v[i] = pk[18 + i]; v2.a[i] = pk[21 + i]; v2.b[i] = pk[24 + i]; v3.v[i] = pk[27 + i]; v3.a[i] = pk[30 + i]; v3.b[i] = pk[33 + i]; }
+          }
         }
 #endif
         inside = true; it = -1; continue;
@@ -1191,7 +1257,25 @@ DEV void support_patch(const DevModel* m, const GeomW& G, const float* f, const 
   int lane = GP::sub();
   const float* x = ldc(&m->vx) + G.vadr; const float* y = ldc(&m->vy) + G.vadr; const float* z = ldc(&m->vz) + G.vadr;
   int first = lane;
-  if constexpr (sizeof(Cache) >= sizeof(HullCache)) {
+  if constexpr (is_hull_lds<Cache>::value) {
+    const float4* X4 = (const float4*)H.p; const float4* Y4 = (const float4*)(H.p + HULL_LDS_N); const float4* Z4 = (const float4*)(H.p + 2 * HULL_LDS_N);
+#pragma unroll
+    for (int J = 0; J < HULL_LDS_N / (4 * WAVE); J++) {
+      if (4 * WAVE * J >= G.vnum) break;
+      float4 xv = X4[WAVE * J + lane], yv = Y4[WAVE * J + lane], zv = Z4[WAVE * J + lane];
+      float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w}, zs[4] = {zv.x, zv.y, zv.z, zv.w};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        int i = 4 * WAVE * J + 4 * lane + q;
+#pragma unroll
+        for (int k = 0; k < NCPP; k++) {
+          float s = xs[q] * dl[k][0] + ys[q] * dl[k][1] + zs[q] * dl[k][2];
+          if (i < G.vnum && s > best[k]) { best[k] = s; bi[k] = i; }
+        }
+      }
+    }
+    first = lane + HULL_LDS_N;
+  } else if constexpr (sizeof(Cache) >= sizeof(HullCache)) {
 #pragma unroll
     for (int j = 0; j < HULL_K; j++) {
       if (GP::N * j >= G.vnum) break;
@@ -1384,7 +1468,9 @@ DEV void narrow_pair(const DevModel* m, const GeomW& G1, const GeomW& G2, int g1
   unsigned long long qp_ = SO101_CLOCK();
 #endif
   Cache H1, H2;
+  if constexpr (is_hull_lds<Cache>::value) { H1.p = hull_lds_store(); H2.p = H1.p + 3 * HULL_LDS_N; wave_sync(); }      // (the previous pair's scans are done)
   hull_load<GP>(m, G1, H1); hull_load<GP>(m, G2, H2);
+  if constexpr (is_hull_lds<Cache>::value) wave_sync();
   QPROF(1)
   out.valid = 0u; out.nrm[0] = out.nrm[1] = out.nrm[2] = 0.f;
 #pragma unroll
@@ -1411,11 +1497,31 @@ DEV void narrow_pair(const DevModel* m, const GeomW& G1, const GeomW& G2, int g1
   if (best.separated) return;
   float depth = 0.f, nrm[3] = {0.f, 0.f, 0.f}, pos[3] = {0.f, 0.f, 0.f};
   if (!best.exact) {
+    if constexpr (is_hull_lds<Cache>::value) {
+      float* pk = narrow_park_store();
+      if (wave_lane() == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { pk[k] = best.f[k]; pk[3 + k] = best.c[k]; pk[6 + k] = best.u[k]; pk[9 + k] = best.v[k]; }
+        pk[12] = best.hu; pk[13] = best.hv; pk[14] = best.depth; pk[15] = __int_as_float(best.side);
+#pragma unroll
+        for (int k = 0; k < NCPP; k++) { pk[16 + 3 * k] = best.P.p[k][0]; pk[17 + 3 * k] = best.P.p[k][1]; pk[18 + 3 * k] = best.P.p[k][2]; }
+      }
+      wave_sync();
+    }
     // MPR's depth is the depth along ITS final portal normal, which for a thin plate (finger pad) against a hull can be
     // an oblique direction ten times deeper than the plate's face normal: the shallowest face candidate wins when it
     // is not deeper (1 % + 1e-6 m slack: for a face contact both are the same number)
     bool ok = mpr_penetration<Cache, GP>(m, G1, G2, &depth, nrm, pos, H1, H2);
     if (!ok || !(depth > 0.f)) return;
+    if constexpr (is_hull_lds<Cache>::value) {
+      wave_sync();
+      const float* pk = narrow_park_store();
+#pragma unroll
+      for (int k = 0; k < 3; k++) { best.f[k] = pk[k]; best.c[k] = pk[3 + k]; best.u[k] = pk[6 + k]; best.v[k] = pk[9 + k]; }
+      best.hu = pk[12]; best.hv = pk[13]; best.depth = pk[14]; best.side = __float_as_int(pk[15]);
+#pragma unroll
+      for (int k = 0; k < NCPP; k++) { best.P.p[k][0] = pk[16 + 3 * k]; best.P.p[k][1] = pk[17 + 3 * k]; best.P.p[k][2] = pk[18 + 3 * k]; }
+    }
     if (best.side >= 0 && !(best.depth <= depth * (1.f + FACE_DEPTH_REL) + FACE_DEPTH_ABS)) best.side = -1;
   }
   QPROF(3)

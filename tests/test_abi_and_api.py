@@ -60,6 +60,25 @@ def test_registry_matches_reference_names():
     assert task_suite.DEFAULT_CAMERAS == ("overhead_cam", "worms_eye_cam", "wrist_cam_left", "wrist_cam_right")
 
 
+def test_reference_import_path_works_without_an_install_call():
+    """`from so101_sim import task_suite` (run_eval.py:22, scripts/so101_lerobot_wrapper.py:12, so101_rl.ipynb) resolves to this build from a fresh
+    interpreter with the repo root on the path - no install_as_so101_sim() line - and hands out the SAME registry and factory objects."""
+    import subprocess
+    import sys
+    code = ("from so101_sim import task_suite\n"
+            "import so101_sim, so101_sim_amd.task_suite as t\n"
+            "assert task_suite.create_task_env is t.create_task_env and task_suite.TASK_FACTORIES is t.TASK_FACTORIES\n"
+            "assert so101_sim.task_suite is task_suite and len(task_suite.TASK_FACTORIES) == 22\n"
+            "assert task_suite.DEFAULT_CONTROL_TIMESTEP == 0.02 and task_suite.SO100HandOver is t.SO100HandOver\n"
+            "try:\n    task_suite.create_task_env('Nope', time_limit=1.0)\nexcept ValueError as e:\n    assert 'Unknown task_name: Nope' in str(e)\nelse:\n    raise SystemExit(3)\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, env=dict(os.environ, PYTHONPATH=ROOT))
+    assert r.returncode == 0, r.stderr
+    # nothing of the reference lives in the alias package: two short files that import so101_sim_amd
+    files = sorted(f for f in os.listdir(os.path.join(ROOT, "so101_sim")) if not f.startswith("__pycache__"))
+    assert files == ["__init__.py", "task_suite.py"]
+    assert all(len(open(os.path.join(ROOT, "so101_sim", f)).read().splitlines()) < 20 for f in files)
+
+
 def test_factory_errors_like_reference():
     from so101_sim_amd import task_suite
     with pytest.raises(ValueError, match="Unknown task_name: Nope. Available tasks:"):
