@@ -122,6 +122,10 @@ class Oracle:
         self.L.orc_set_narrowphase.argtypes = [C.c_void_p, C.c_int]
         self.L.orc_set_narrowphase(self.h, int(bool(epa)))
 
+    def set_hull_multicontact(self, on: bool):
+        self.L.orc_set_hull_multicontact.argtypes = [C.c_void_p, C.c_int]
+        self.L.orc_set_hull_multicontact(self.h, int(bool(on)))
+
     def set_solver_type(self, newton: bool):
         self.L.orc_set_solver_type(self.h, int(bool(newton)))
 

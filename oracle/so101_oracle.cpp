@@ -173,6 +173,7 @@ struct orc_sim {
   std::vector<real> J, efc_pos, efc_D, efc_R, efc_aref, efc_force, efc_floss, efc_b, AR;
   std::vector<int> efc_type, efc_id, efc_dim;
   int iterations; real tolerance; bool collide = true;
+  bool hull_multi = false;       // several contacts for hull pairs resting on flat features (hull_patch; off: the single EPA contact of rounds 1-4)
   std::vector<real> mass0, inertia0, invweight0;     // unscaled prop masses (orc_set_mass_scale)
   std::vector<Contact> injected;                      // orc_inject_contacts
   int narrow = 1;              // 1 (default, what the kernels run) = MPR portal expanded by EPA to the nearest face of the Minkowski difference (minimum translation: mujoco >= 3.3's native GJK / EPA), 0 = MPR's own depth (the -DSO101_MPR option of the kernels)
@@ -828,6 +829,64 @@ bool face_patch(const orc_sim* s, int gI, const real* f, const real* c, const re
   return true;
 }
 
+// Hull against hull (round 5).  MuJoCo's multiccd gives a mesh pair resting face on face (or face on edge) several contacts; until round 4
+// kernel and oracle kept the single EPA contact there (a mug on a plate rocked on one point per hull pair).  EPA ends on the nearest face
+// of the Minkowski difference: normal n (geom 1 -> geom 2), depth, witness midpoint pos, so w1 = pos + depth/2 n is a point of geom 1's
+// surface and w2 = pos - depth/2 n one of geom 2's.  The same tilted support samples as for box faces then take the extreme points of
+// whatever flat feature each hull presents along n:
+//   b_k = support_2(-n + eps s_k), a_k = support_1(+n + eps s_k), k = 1..4, s_k = (+-u +- v)/sqrt(2), (u, v) = make_frame(n), eps = 1e-3.
+// b_k becomes a contact when it lies below geom 1's supporting plane (through w1, normal n) and laterally inside geom 1's feature there:
+// with r the unit lateral direction from w1 to b_k, r . (b_k - w1) <= r . (support_1(n + eps r) - w1) + 1e-6 - the feature's extent in
+// that direction, again by a tilted support; a vertex or a curved patch has extent 0, so nothing beyond the EPA contact survives there.
+// a_k symmetrically against geom 2's feature at w2.  Accepted in the order b_1..b_4, a_1..a_4 behind the EPA contact (slot 0) while they are
+// farther than dup_tol from the contacts already accepted, up to NCPP in all; every contact carries the normal n, its distance is the
+// sample's signed distance to the other hull's supporting plane and its position the midpoint between sample and plane.
+void hull_patch(const orc_sim* s, int g1, int g2, const real* n, real depth, const real* pos, real dup_tol, Patch* out) {
+  out->n = 1; out->dist[0] = -depth;
+  for (int i = 0; i < 3; i++) out->pos[0][i] = pos[i];
+  real fr[9] = {n[0], n[1], n[2], 0, 0, 0, 0, 0, 0};
+  make_frame(fr);
+  const real* u = fr + 3; const real* v = fr + 6;
+  static const real su[4] = {1, -1, -1, 1}, sv[4] = {1, 1, -1, -1};
+  real w[2][3];
+  for (int i = 0; i < 3; i++) { w[0][i] = pos[i] + 0.5 * depth * n[i]; w[1][i] = pos[i] - 0.5 * depth * n[i]; }
+  for (int side = 0; side < 2; side++) {              // side 0: samples of geom 2 against geom 1's feature; side 1: the other way round
+    int gs = side == 0 ? g2 : g1, go = side == 0 ? g1 : g2;
+    real sg = side == 0 ? -1.0 : 1.0;                // the sampled hull is probed towards the other one: -n for geom 2, +n for geom 1
+    const real* wo = w[side];                         // surface point of the OTHER hull (the plane the sample is measured against)
+    for (int k = 0; k < 4; k++) {
+      if (out->n >= NCPP) return;
+      real d[3];
+      for (int i = 0; i < 3; i++) d[i] = sg * n[i] + PATCH_EPS * (su[k] * u[i] + sv[k] * v[i]) * 0.70710678118654752440;
+      normalize3(d);
+      real p[3]; support(s, gs, d, p);
+      real rel[3] = {p[0] - wo[0], p[1] - wo[1], p[2] - wo[2]};
+      real dist = -sg * dot3(rel, n);                 // geom 2's sample: (p - w1) . n;  geom 1's sample: -(p - w2) . n
+      if (!(dist < 0)) continue;
+      real h = dot3(rel, n), r[3] = {rel[0] - h * n[0], rel[1] - h * n[1], rel[2] - h * n[2]};
+      real rl = normalize3(r);
+      if (rl > 1e-9) {
+        real de[3], e[3];
+        for (int i = 0; i < 3; i++) de[i] = -sg * n[i] + PATCH_EPS * r[i];
+        normalize3(de);
+        support(s, go, de, e);
+        real ext = r[0] * (e[0] - wo[0]) + r[1] * (e[1] - wo[1]) + r[2] * (e[2] - wo[2]);
+        if (!(rl <= ext + 1e-6)) continue;
+      }
+      real cp[3] = {p[0] + sg * 0.5 * dist * n[0], p[1] + sg * 0.5 * dist * n[1], p[2] + sg * 0.5 * dist * n[2]};
+      bool ok = true;
+      for (int j = 0; j < out->n && ok; j++) {
+        real dd[3] = {cp[0] - out->pos[j][0], cp[1] - out->pos[j][1], cp[2] - out->pos[j][2]};
+        if (norm3(dd) < dup_tol) ok = false;
+      }
+      if (!ok) continue;
+      int q = out->n++;
+      for (int i = 0; i < 3; i++) out->pos[q][i] = cp[i];
+      out->dist[q] = dist;
+    }
+  }
+}
+
 // flat face number `axis` (box: 0..2 = local x/y/z on the side facing `toward`; cylinder: only axis 2 = the cap) of
 // geom g: outward normal f, centre c, in-plane axes u/v with half extents (hv < 0: disc of radius hu).  Returns the
 // cosine between f and `toward` (unit, world); the face is a candidate when that exceeds FACE_MIN_COS.
@@ -939,6 +998,8 @@ void collision(orc_sim* s) {
         if (exact) continue;
         pt.n = 1; pt.dist[0] = -depth;
         for (int k = 0; k < 3; k++) { pt.nrm[k] = dir[k]; pt.pos[0][k] = pos[k]; }
+        if (s->hull_multi && m.geom_type[g1] == G_MESH && m.geom_type[g2] == G_MESH)
+          hull_patch(s, g1, g2, dir, depth, pos, PATCH_DUP * std::min(m.geom_rbound[g1], m.geom_rbound[g2]), &pt);
       }
     }
     for (int j = 0; j < pt.n; j++) {
@@ -1736,6 +1797,7 @@ void orc_set_mass_scale(orc_sim* s, const double* scale) {
 }
 void orc_set_solver_type(orc_sim* s, int t) { s->solver = t; }
 void orc_set_narrowphase(orc_sim* s, int mode) { s->narrow = mode; }
+void orc_set_hull_multicontact(orc_sim* s, int on) { s->hull_multi = on != 0; }
 int orc_epa_iterations(const orc_sim* s) { return s->epa_iters; }
 int orc_ls_evals(const orc_sim* s) { return s->ls_evals; }
 void orc_set_state(orc_sim* s, const double* q, const double* v, const double* w) {

@@ -60,6 +60,9 @@ void orc_set_solver_type(orc_sim*, int type);
 // face of the Minkowski difference (the minimum translation, as mujoco >= 3.3's native GJK / EPA reports it); 0 = MPR's own portal depth
 // (the -DSO101_MPR option of the kernels)
 void orc_set_narrowphase(orc_sim*, int mode);
+// hull against hull: 1 (default; what the kernels run) = up to NCPP contacts on flat features (hull_patch in so101_oracle.cpp), 0 = the single
+// EPA contact of rounds 1-4
+void orc_set_hull_multicontact(orc_sim*, int on);
 int orc_epa_iterations(const orc_sim*);
 int orc_ls_evals(const orc_sim*);
 

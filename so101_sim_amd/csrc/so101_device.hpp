@@ -535,35 +535,48 @@ DEV void hull_load(const DevModel*, const GeomW&, NoCache&) {}
 
 // The same cache in LDS (k_narrow, one wavefront per workgroup: round 5).  The register cache above costs 48 VGPRs for the two geoms of a
 // pair across the whole query - with the EPA polytope inlined k_narrow needed 256 + 43 spilled - while the kernel used 256 B of its 20 KB LDS
-// share.  Here the first HULL_LDS_N vertices of a hull are copied once per pair into the workgroup's LDS as x[] | y[] | z[], and a support
-// scan reads them four vertices per lane and instruction (ds_read_b128: lane l takes vertices 256 J + 4 l + 0..3, in increasing index order,
-// so "largest dot product, smallest index" picks the vertex every other variant picks).
-#define HULL_LDS_N 512
-struct HullLDS { float* p; };      // [3][HULL_LDS_N]
-DEV float* hull_lds_store() { __shared__ __attribute__((aligned(16))) float store[2 * 3 * HULL_LDS_N]; return store; }
+// share.  Here the first HULL_LDS_MAX vertices of a hull are staged by the kernel (so101_narrow.hpp: all hulls of a work-item chunk at once,
+// behind ONE memory round trip) as x[n] | y[n] | z[n] with n = 256 or 512 slots, and a support scan reads them four vertices per lane and
+// instruction (ds_read_b128: lane l takes vertices 256 J + 4 l + 0..3, in increasing index order, so "largest dot product, smallest index"
+// picks the vertex every other variant picks).
+#define HULL_LDS_MAX 512
+struct HullLDS { float* p; int n; };      // p: [3][n] floats in LDS (16-byte aligned), n: slots per coordinate (0: nothing staged)
+DEV int hull_lds_slots(int type, int vnum) { return type != G_MESH ? 0 : (vnum <= 256 ? 256 : HULL_LDS_MAX); }
+// the loads of one hull (issued, not waited for) and their LDS stores: split so that a caller can issue the loads of several hulls first
+template <int NJ> struct HullStage { float x[NJ], y[NJ], z[NJ]; };
+template <int NJ>
+DEV void hull_stage_issue(const DevModel* m, int vadr, int vnum, int j0, HullStage<NJ>& T) {
+  int lane = wave_lane();
+  const float* x = ldc(&m->vx) + vadr; const float* y = ldc(&m->vy) + vadr; const float* z = ldc(&m->vz) + vadr;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    int i = lane + WAVE * (j0 + j);
+    bool v = i < vnum;
+    T.x[j] = v ? x[i] : 0.f; T.y[j] = v ? y[i] : 0.f; T.z[j] = v ? z[i] : 0.f;
+  }
+}
+template <int NJ>
+DEV void hull_stage_store(const HullLDS& H, int vnum, int j0, const HullStage<NJ>& T) {
+  int lane = wave_lane();
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    int i = lane + WAVE * (j0 + j);
+    if (WAVE * (j0 + j) < H.n) { H.p[i] = T.x[j]; H.p[H.n + i] = T.y[j]; H.p[2 * H.n + i] = T.z[j]; }
+  }
+}
+// one hull into its LDS slots (loads of a 256-slot block in flight together)
+DEV void hull_stage(const DevModel* m, int vadr, int vnum, const HullLDS& H) {
+  for (int j0 = 0; WAVE * j0 < H.n; j0 += 4) {
+    HullStage<4> T;
+    hull_stage_issue<4>(m, vadr, vnum, j0, T);
+    hull_stage_store<4>(H, vnum, j0, T);
+  }
+}
+template <class GP = G64>
+DEV void hull_load(const DevModel* m, const GeomW& G, HullLDS& H) { if (H.n) hull_stage(m, G.vadr, G.vnum, H); }
 // uniform values parked in LDS across a phase that does not need them (k_narrow: the candidate face across the iterative query, the portal
 // across the EPA expansion): the register allocator otherwise keeps them in VGPRs, 64 copies of each, or spills them to scratch memory
 DEV float* narrow_park_store() { __shared__ __attribute__((aligned(16))) float park[128]; return park; }
-template <class GP = G64>
-DEV void hull_load(const DevModel* m, const GeomW& G, HullLDS& H) {
-  if (G.type != G_MESH) return;
-  int lane = GP::sub();
-  const float* x = ldc(&m->vx) + G.vadr; const float* y = ldc(&m->vy) + G.vadr; const float* z = ldc(&m->vz) + G.vadr;
-  float tx[HULL_LDS_N / WAVE], ty[HULL_LDS_N / WAVE], tz[HULL_LDS_N / WAVE];
-#pragma unroll
-  for (int j = 0; j < HULL_LDS_N / WAVE; j++) {
-    if (WAVE * j >= G.vnum) break;
-    int i = lane + WAVE * j;
-    bool v = i < G.vnum;
-    tx[j] = v ? x[i] : 0.f; ty[j] = v ? y[i] : 0.f; tz[j] = v ? z[i] : 0.f;
-  }
-#pragma unroll
-  for (int j = 0; j < HULL_LDS_N / WAVE; j++) {
-    if (WAVE * j >= G.vnum) break;
-    int i = lane + WAVE * j;
-    H.p[i] = tx[j]; H.p[HULL_LDS_N + i] = ty[j]; H.p[2 * HULL_LDS_N + i] = tz[j];
-  }
-}
 
 DEV void select_geom(bool first, const GeomW& A, const GeomW& B, GeomW& o) {
   o.type = first ? A.type : B.type; o.vadr = first ? A.vadr : B.vadr; o.vnum = first ? A.vnum : B.vnum;
@@ -577,7 +590,7 @@ DEV void select_hull(bool first, const HullCache& A, const HullCache& B, HullCac
   for (int j = 0; j < HULL_K; j++) { o.x[j] = first ? A.x[j] : B.x[j]; o.y[j] = first ? A.y[j] : B.y[j]; o.z[j] = first ? A.z[j] : B.z[j]; }
 }
 DEV void select_hull(bool, const NoCache&, const NoCache&, NoCache&) {}
-DEV void select_hull(bool first, const HullLDS& A, const HullLDS& B, HullLDS& o) { o.p = first ? A.p : B.p; }
+DEV void select_hull(bool first, const HullLDS& A, const HullLDS& B, HullLDS& o) { o.p = first ? A.p : B.p; o.n = first ? A.n : B.n; }
 template <class C> struct is_hull_lds { static constexpr bool value = false; };
 template <> struct is_hull_lds<HullLDS> { static constexpr bool value = true; };
 
@@ -595,10 +608,10 @@ DEV void support(const DevModel* m, const GeomW& G, const float* dir, float* out
     const float* x = ldc(&m->vx) + G.vadr; const float* y = ldc(&m->vy) + G.vadr; const float* z = ldc(&m->vz) + G.vadr;
     int first = lane;
     if constexpr (is_hull_lds<Cache>::value) {
-      const float4* X4 = (const float4*)H.p; const float4* Y4 = (const float4*)(H.p + HULL_LDS_N); const float4* Z4 = (const float4*)(H.p + 2 * HULL_LDS_N);
+      const float4* X4 = (const float4*)H.p; const float4* Y4 = (const float4*)(H.p + H.n); const float4* Z4 = (const float4*)(H.p + 2 * H.n);
 #pragma unroll
-      for (int J = 0; J < HULL_LDS_N / (4 * WAVE); J++) {
-        if (4 * WAVE * J >= G.vnum) break;
+      for (int J = 0; J < HULL_LDS_MAX / (4 * WAVE); J++) {
+        if (4 * WAVE * J >= G.vnum || 4 * WAVE * J >= H.n) break;
         float4 xv = X4[WAVE * J + lane], yv = Y4[WAVE * J + lane], zv = Z4[WAVE * J + lane];
         float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w}, zs[4] = {zv.x, zv.y, zv.z, zv.w};
 #pragma unroll
@@ -608,7 +621,7 @@ DEV void support(const DevModel* m, const GeomW& G, const float* dir, float* out
           if (i < G.vnum && d > best) { best = d; bi = i; bx = xs[k]; by = ys[k]; bz = zs[k]; }
         }
       }
-      first = lane + HULL_LDS_N;
+      first = lane + H.n;
     } else if constexpr (sizeof(Cache) >= sizeof(HullCache)) {
 #pragma unroll
       for (int j = 0; j < HULL_K; j++) {
@@ -1258,10 +1271,10 @@ DEV void support_patch(const DevModel* m, const GeomW& G, const float* f, const 
   const float* x = ldc(&m->vx) + G.vadr; const float* y = ldc(&m->vy) + G.vadr; const float* z = ldc(&m->vz) + G.vadr;
   int first = lane;
   if constexpr (is_hull_lds<Cache>::value) {
-    const float4* X4 = (const float4*)H.p; const float4* Y4 = (const float4*)(H.p + HULL_LDS_N); const float4* Z4 = (const float4*)(H.p + 2 * HULL_LDS_N);
+    const float4* X4 = (const float4*)H.p; const float4* Y4 = (const float4*)(H.p + H.n); const float4* Z4 = (const float4*)(H.p + 2 * H.n);
 #pragma unroll
-    for (int J = 0; J < HULL_LDS_N / (4 * WAVE); J++) {
-      if (4 * WAVE * J >= G.vnum) break;
+    for (int J = 0; J < HULL_LDS_MAX / (4 * WAVE); J++) {
+      if (4 * WAVE * J >= G.vnum || 4 * WAVE * J >= H.n) break;
       float4 xv = X4[WAVE * J + lane], yv = Y4[WAVE * J + lane], zv = Z4[WAVE * J + lane];
       float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w}, zs[4] = {zv.x, zv.y, zv.z, zv.w};
 #pragma unroll
@@ -1274,7 +1287,7 @@ DEV void support_patch(const DevModel* m, const GeomW& G, const float* f, const 
         }
       }
     }
-    first = lane + HULL_LDS_N;
+    first = lane + H.n;
   } else if constexpr (sizeof(Cache) >= sizeof(HullCache)) {
 #pragma unroll
     for (int j = 0; j < HULL_K; j++) {
@@ -1306,6 +1319,9 @@ DEV void support_patch(const DevModel* m, const GeomW& G, const float* f, const 
 #pragma unroll
   for (int k = 0; k < NCPP; k++) {
     int w = (unsigned int)bi[k] < (unsigned int)G.vnum ? bi[k] : 0;       // (a non-finite direction selects nothing)
+    if constexpr (is_hull_lds<Cache>::value) {
+      if (w < H.n) { loc[k][0] = H.p[w]; loc[k][1] = H.p[H.n + w]; loc[k][2] = H.p[2 * H.n + w]; continue; }      // (the staged copy: same floats)
+    }
     loc[k][0] = x[w]; loc[k][1] = y[w]; loc[k][2] = z[w];
   }
 #pragma unroll
@@ -1462,20 +1478,16 @@ DEV void scan_faces(const DevModel* m, const GeomW& GR, const GeomW& GI, const C
 
 // Narrowphase of one candidate pair (geom types ordered): up to NCPP contacts sharing one normal (geom1 -> geom2),
 // each with its penetration distance (< 0) and position.
+// narrow_pair_cached: the caches H1 / H2 are ready (k_narrow stages them in LDS), rb1 / rb2 = the geoms' bounding radii
 template <class Cache, class GP = G64>
-DEV void narrow_pair(const DevModel* m, const GeomW& G1, const GeomW& G2, int g1, int g2, PairContacts& out, unsigned int* prof = nullptr) {
+DEV void narrow_pair_cached(const DevModel* m, const GeomW& G1, const GeomW& G2, float rb1, float rb2, const Cache& H1, const Cache& H2, PairContacts& out,
+                            unsigned int* prof = nullptr) {
 #ifdef SO101_DEBUG_CLOCKS
   unsigned long long qp_ = SO101_CLOCK();
 #endif
-  Cache H1, H2;
-  if constexpr (is_hull_lds<Cache>::value) { H1.p = hull_lds_store(); H2.p = H1.p + 3 * HULL_LDS_N; wave_sync(); }      // (the previous pair's scans are done)
-  hull_load<GP>(m, G1, H1); hull_load<GP>(m, G2, H2);
-  if constexpr (is_hull_lds<Cache>::value) wave_sync();
-  QPROF(1)
   out.valid = 0u; out.nrm[0] = out.nrm[1] = out.nrm[2] = 0.f;
 #pragma unroll
   for (int j = 0; j < NCPP; j++) { out.dist[j] = 0.f; out.pos[j][0] = out.pos[j][1] = out.pos[j][2] = 0.f; }
-  float rb1 = GP::ld(ldc(&m->geom_rbound) + g1), rb2 = GP::ld(ldc(&m->geom_rbound) + g2);
   if (G1.type == G_PLANE) {
     float fr[9] = {G1.R[2], G1.R[5], G1.R[8], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     make_frame(fr);
@@ -1539,6 +1551,19 @@ DEV void narrow_pair(const DevModel* m, const GeomW& G1, const GeomW& G2, int g1
 #pragma unroll
     for (int k = 0; k < 3; k++) { out.nrm[k] = nrm[k]; out.pos[0][k] = pos[k]; }
   }
+}
+
+template <class Cache, class GP = G64>
+DEV void narrow_pair(const DevModel* m, const GeomW& G1, const GeomW& G2, int g1, int g2, PairContacts& out, unsigned int* prof = nullptr) {
+  static_assert(!is_hull_lds<Cache>::value, "the LDS cache is staged by its kernel: narrow_pair_cached");
+#ifdef SO101_DEBUG_CLOCKS
+  unsigned long long qp_ = SO101_CLOCK();
+#endif
+  Cache H1, H2;
+  hull_load<GP>(m, G1, H1); hull_load<GP>(m, G2, H2);
+  QPROF(1)
+  float rb1 = GP::ld(ldc(&m->geom_rbound) + g1), rb2 = GP::ld(ldc(&m->geom_rbound) + g2);
+  narrow_pair_cached<Cache, GP>(m, G1, G2, rb1, rb2, H1, H2, out, prof);
 }
 
 // Contact record of an accepted pair (one lane): frame, body indices, mixed friction / solref / solimp
@@ -1639,6 +1664,17 @@ DEV void arm_jac_row(const EnvLDS& L, int link, const float* p, const float* u, 
   }
 }
 
+// row j (0-2 translational, 3-5 rotational, along the contact frame's axes) of an arm-link contact's Jacobian in the six arm dofs:
+// J(link of geom2) - J(link of geom1); either side may be static or a free body (link -1: a zero row)
+DEV void arm_contact_row(const EnvLDS& L, const Contact& c, int j, float* Jd) {
+  int l1 = (c.d1 >= 0 && c.d1 < NARM) ? c.d1 : -1, l2 = (c.d2 >= 0 && c.d2 < NARM) ? c.d2 : -1;
+  float Jr[NARM], J1[NARM];
+  arm_jac_row(L, l2, c.pos, &c.frame[3 * (j % 3)], j >= 3, Jr);
+  arm_jac_row(L, l1, c.pos, &c.frame[3 * (j % 3)], j >= 3, J1);
+#pragma unroll
+  for (int q = 0; q < NARM; q++) Jd[q] = Jr[q] - J1[q];
+}
+
 // Constraint rows of the current contacts: scalar rows (dof frictionloss, joint limits), and per contact the
 // regularisers R, the cone parameter mu, the reference accelerations and - for contacts that touch an arm link - the
 // joint-space Jacobian rows in the LDS pool.  What only PGS needs (the diagonal blocks of A) is built by solve_pgs().
@@ -1685,13 +1721,16 @@ DEV void make_constraints(const DevModel* m, EnvLDS& L) {
     unsigned long long amask = wave_ballot(arm);
     if (arm) {
       int slot = wave_prefix(amask);
-      L.con[lane].armslot = slot < MAXARMCON ? slot : -2;      // pool exhausted: the contact is dropped below
+      // slots beyond the LDS pool keep their number: such a contact's Jacobian is not parked in the pool but computed again by the lane
+      // that owns the contact when the Newton solver loads it (conreg_load: the same lane, the same expressions, the same bits), so NO arm
+      // contact is ever dropped (round 5; until round 4 the tail of the pool was cut off and counted).  The PGS kernels stop at 32 contacts
+      // and never get here.
+      L.con[lane].armslot = slot;
     }
     int narm = __popcll(amask);
     if (lane == 0) {
       L.nrow = __popcll(mask);
       L.narmcon = narm < MAXARMCON ? narm : MAXARMCON;
-      if (narm > MAXARMCON) L.overflow |= 4;
     }
   }
   wave_sync();
@@ -1712,7 +1751,6 @@ DEV void make_constraints(const DevModel* m, EnvLDS& L) {
     c.R[2] = fmaxf(MINVAL_F, R1 * mu0 * mu0 / (c.fric[1] * c.fric[1]));
     c.R[3] = fmaxf(MINVAL_F, R1 * mu0 * mu0 / (c.fric[2] * c.fric[2]));
     c.mu = mu0 * sqrtf(R1 / R0);
-    if (c.armslot == -2) c.dim = 0;
     // row velocities J qvel: translational rows j<3 use frame[j] at the contact point, rotational rows frame[j-3]
     float vel[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1732,16 +1770,15 @@ DEV void make_constraints(const DevModel* m, EnvLDS& L) {
       // Arm part, ONCE per contact: J = J(link of geom2) - J(link of geom1) in the 6 arm dofs (either side may
       // be static or a free body; for arm-arm self-collision both contribute), kept dof-major in this contact's
       // slot of the LDS pool.
-      ArmCon& ac = L.armcon[c.armslot];
-      int l1 = (c.d1 >= 0 && c.d1 < NARM) ? c.d1 : -1, l2 = (c.d2 >= 0 && c.d2 < NARM) ? c.d2 : -1;
+      const bool pooled = c.armslot < MAXARMCON;
+      ArmCon& ac = L.armcon[pooled ? c.armslot : 0];
 #pragma unroll
       for (int j = 0; j < 6; j++) {
-        float Jr[NARM], J1[NARM];
-        arm_jac_row(L, l2, c.pos, &c.frame[3 * (j % 3)], j >= 3, Jr);      // link -1 gives a zero row
-        arm_jac_row(L, l1, c.pos, &c.frame[3 * (j % 3)], j >= 3, J1);
+        float Jd[NARM];
+        arm_contact_row(L, c, j, Jd);
         float vj = 0.f;
 #pragma unroll
-        for (int q = 0; q < NARM; q++) { float e = Jr[q] - J1[q]; ac.Jt[q][j] = e; vj += e * L.qvel[q]; }
+        for (int q = 0; q < NARM; q++) { if (pooled) ac.Jt[q][j] = Jd[q]; vj += Jd[q] * L.qvel[q]; }
         vel[j] += vj;
       }
     }

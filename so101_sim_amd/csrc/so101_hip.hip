@@ -400,7 +400,7 @@ int so101_create(const void* blob, size_t bytes, int n_envs, int device, uint64_
   if (rc == SO101_OK) {
     PipeBuffers& W = s->pipe;
     bool ok = dev_alloc(s, &W.pose, NDYN * 12 * n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.cand, MAXCAND * n, 0, "hipMalloc(pipe)") &&
-              dev_alloc(s, &W.ncand, n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.work, 2 * MAXCAND * n, 0, "hipMalloc(pipe)") &&
+              dev_alloc(s, &W.ncand, n, 0, "hipMalloc(pipe)") && dev_alloc(s, &W.items, ITEM_WORDS * (CONRES_PER_ENV * n + (size_t)MAXCAND * so101_sim::MAXGROUPS), 0, "hipMalloc(pipe)") &&
               dev_alloc(s, &W.counters, (size_t)4 * MAXSUB * so101_sim::MAXGROUPS, 0, "hipMalloc(pipe)") &&
               dev_alloc(s, &W.conres, CONRES_DIM * (CONRES_PER_ENV * n + (size_t)MAXCAND * so101_sim::MAXGROUPS), 0, "hipMalloc(pipe)") && dev_alloc(s, &W.cbase, n, 0, "hipMalloc(pipe)") &&
               dev_alloc(s, &W.active, n, 0, "hipMalloc(pipe)") &&
@@ -420,7 +420,6 @@ int so101_create(const void* blob, size_t bytes, int n_envs, int device, uint64_
     s->chain.role_mode = getenv("SO101_CHAIN_ROLE") ? atoi(getenv("SO101_CHAIN_ROLE")) : 0;
     // (the queues of pipelines 2 and 3 and their full-size contact-record array are allocated when such a step is first asked
     // for: ensure_experimental_buffers())
-    W.work_cap = 0u;
     for (int g = 0; g < so101_sim::MAXGROUPS && ok; g++)
       ok = hip_ok(s, hipStreamCreateWithFlags(&s->group_stream[g], hipStreamNonBlocking), "hipStreamCreate") &&
            hip_ok(s, hipEventCreateWithFlags(&s->group_done[g], hipEventDisableTiming), "hipEventCreate");
@@ -602,13 +601,12 @@ static int enqueue_pipelined(so101_sim* s, hipStream_t st, const so101::StepIO& 
     hipStream_t gs = G == 1 ? st : s->group_stream[g];
     PipeBuffers W = s->pipe;
     W.counters = s->pipe.counters + 4 * MAXSUB * g;      // [MAXSUB][2] work items / cursor, then [MAXSUB][2] heavy / light items (so101_pipeline.hpp)
-    W.work = s->pipe.work + (size_t)2 * MAXCAND * e0;
-    W.work_cap = (unsigned int)ng * MAXCAND;
     // the slice's pool of contact records: CONRES_PER_ENV per env plus a floor of MAXCAND, so that ONE env can always place every
     // candidate the broadphase may hand over (a single env or a small batch is not cut off at 48 records; which env would lose
     // records depended on the arrival order of the atomics in publish_candidates)
     W.conres = s->pipe.conres + ((size_t)e0 * CONRES_PER_ENV + (size_t)g * MAXCAND) * CONRES_DIM;
     W.conres_cap = (unsigned int)ng * CONRES_PER_ENV + MAXCAND;
+    W.items = s->pipe.items + ((size_t)e0 * CONRES_PER_ENV + (size_t)g * MAXCAND) * ITEM_WORDS;      // one work item per record position of the slice
     static const int chunk_env = getenv("SO101_NARROW_CHUNK") ? atoi(getenv("SO101_NARROW_CHUNK")) : 0;          // (kernel experiments)
     static const int chunk_env_l = getenv("SO101_NARROW_CHUNK_LIGHT") ? atoi(getenv("SO101_NARROW_CHUNK_LIGHT")) : 0;
     // measured at 4096 envs (heavy / light pairs per fetch -> env-steps/s): 3/3 707 k, 1/3 684 k, 2/3 712 k, 2/4 720 k, 1/4 692 k, 2/2 679 k

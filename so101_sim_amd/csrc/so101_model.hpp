@@ -179,12 +179,25 @@ struct EventBuffers {
 #define CONRES_DIM (4 + 4 * NCPP)
 #define CONRES_PER_ENV 48       // compact contact-record pool: records per env of a slice (mean use 12) + MAXCAND per slice (one env can always place all its candidates); overflow drops candidates and is counted
 
+// work items of the narrowphase launches (so101_pipeline.hpp, publish_candidates): word offsets
+#define ITEM_WORDS 48            // 192 bytes: rec, env * MAXCAND + k, geom 1 at word ITEM_GEOM0, geom 2 at ITEM_GEOM1
+#define ITEM_GEOM0 2
+#define ITEM_GEOM1 24
+#define ITEM_G_TYPE 0
+#define ITEM_G_VADR 1
+#define ITEM_G_VNUM 2
+#define ITEM_G_SIZE 3
+#define ITEM_G_R 6
+#define ITEM_G_P 15
+#define ITEM_G_C 18
+#define ITEM_G_RBOUND 21
+
 // Scratch of the pipelined step (so101_pipeline.hpp)
 struct PipeBuffers {
   float* pose;            // [N][NDYN][12] xpos, xmat of the dynamic bodies
   unsigned int* cand;     // [N][MAXCAND]  geom1 | geom2 << 16, in pair-list order
   int* ncand;             // [N]           count | broadphase overflow flag << 16
-  unsigned int* work;     // [2][work_cap] env * MAXCAND + k, double buffered over substeps (per env group)
+  unsigned int* items;    // [conres_cap][ITEM_WORDS] work items of the current substep's narrowphase launch, per env slice (so101_pipeline.hpp)
   int* counters;          // [MAXSUB][2]   work items, cursor
   float* conres;          // narrowphase results: count, normal, NCPP x (dist, position) per candidate.  Launch chains: one record
                           // per work-list position of the current substep, [conres_cap][CONRES_DIM] per env slice (an env's
@@ -196,7 +209,6 @@ struct PipeBuffers {
   unsigned int* stage;    // [N][8] k_pipe_solve stage clocks of the last substep (10 ns ticks; SO101_DEBUG_CLOCKS builds)
   unsigned int* cost;     // [N] solver time of the env in its last substep (ticks): scheduling hint only
   int* order;             // [N] per group: env indices sorted by decreasing cost, see k_order
-  unsigned int work_cap;  // capacity of one work list = envs of the group * MAXCAND
   unsigned int* ticks;    // [N][MAXCAND] narrowphase time of each candidate (10 ns ticks; SO101_DEBUG_CLOCKS builds)
   // merged launches (pipeline = 3, so101_chain.hpp): the chain's chunk queue and per-launch counters
   unsigned int* mq_ctl;   // [64] head, avail, tail (QC_*)

@@ -135,11 +135,26 @@ DEV void conreg_load(const EnvLDS& L, const Contact& c, ConReg& r) {
   for (int s = 0; s < (SINGLE ? 1 : 2); s++) {
     int g = s == 0 ? r.g0 : r.g1;
     if (g == 0) {
-      const ArmCon& ac = L.armcon[c.armslot];
+      if (c.armslot < MAXARMCON) {
+        const ArmCon& ac = L.armcon[c.armslot];
 #pragma unroll
-      for (int q = 0; q < 6; q++)
+        for (int q = 0; q < 6; q++)
 #pragma unroll
-        for (int j = 0; j < 6; j++) r.J[6 * s + q][j] = ac.Jt[q][j];
+          for (int j = 0; j < 6; j++) r.J[6 * s + q][j] = ac.Jt[q][j];
+      } else {
+        // beyond the LDS pool (more than MAXARMCON arm-link contacts in this env: props wedged under the arm): the rows again, by the
+        // expressions make_constraints() used for this contact's reference accelerations
+#pragma unroll 1
+        for (int j = 0; j < 6; j++) {
+          float Jd[NARM];
+          arm_contact_row(L, c, j, Jd);
+#pragma unroll
+          for (int q = 0; q < 6; q++) {
+#pragma unroll
+            for (int jj = 0; jj < 6; jj++) if (jj == j) r.J[6 * s + q][jj] = Jd[q];
+          }
+        }
+      }
     } else if (g > 0) {
       int d = NARM + g - 1;
       float sgn = (c.d2 == d) ? 1.f : -1.f;

@@ -53,51 +53,78 @@ DEV void load_state_aos(EnvLDS& L, const DevBuffers& B, const PipeBuffers& W, in
   wave_sync();
 }
 
-// hands the candidates in L.cand (and the poses the narrowphase needs) to substep s.
+// Hands the candidates in L.cand to the narrowphase launch of substep s as self-contained WORK ITEMS (round 5).
+//
+// Until round 4 the work list held one word per candidate and k_narrow followed it: list -> W.cand -> geom_dyn -> the geom tables and the
+// body pose -> the hull.  Every arrow is a dependent memory round trip (0.4 - 0.8 us each on this machine), five to seven of them per
+// candidate pair in front of 6 - 11 us of work; the counters said the wavefronts of k_narrow spent half their cycles parked on them.  Now the
+// wavefront that HAS the env's poses in LDS (k_pipe_begin / k_pipe_solve, right after the broadphase) writes, lane = candidate, everything a
+// pair's query needs into ONE 192-byte item - the record position of the result, and both geoms in world coordinates (type, hull address and
+// size, sizes, orientation, position, centre, bounding radius: load_geom_at(), the same expressions on the same numbers as the fused path) -
+// and k_narrow reads its items with one coalesced load per item: atomic -> items -> hulls -> work.
+//
 // Two orders.  RECORDS: the contact record of candidate k of env e lives at position cbase[e] + k of the slice's pool (contiguous per env, in
-// candidate order: gather_contacts reads them like that).  WORK LIST (launch chains, round 4): longest-processing-time first - pairs without a
-// box or the plane (hull against hull / capsule / cylinder: MPR + EPA, 13-48 us) fill the list from its front, the others (a flat face against
-// a hull: closed form, 6-11 us) from its end, and k_narrow walks front first; a launch of persistent wavefronts then ends on cheap items
-// instead of on an EPA chunk taken last.  The order only changes WHEN a pair is processed, never its result.
+// candidate order: gather_contacts reads them like that).  ITEMS: longest-processing-time first (round 4) - pairs without a box or the plane
+// (hull against hull / capsule / cylinder: MPR + EPA, 13-48 us) fill the item array from its front, the others (a flat face against a hull:
+// closed form, 6-11 us) from its end, and k_narrow walks front first; a launch of persistent wavefronts then ends on cheap items instead of
+// on an EPA chunk taken last.  The order only changes WHEN a pair is processed, never its result.  The item array has the capacity of the
+// record pool (W.conres_cap): a candidate without a record has no item either (dropped from the solve, counted as a candidate overflow).
 DEV bool heavy_pair(const DevModel* m, int g1, int g2) {
   int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
   return t1 != G_PLANE && t1 != G_BOX && t2 != G_PLANE && t2 != G_BOX;
 }
+// one geom of an item (one lane): world-frame GeomW by load_geom_at() with per-lane loads (policy G16: plain loads, no uniformity claims)
+DEV void item_put_geom(const DevModel* m, const EnvLDS& L, int g, unsigned int* it) {
+  int d = m->geom_dyn[g];
+  GeomW G;
+  load_geom_at<G16>(m, g, L.xpos[d < 0 ? 0 : d], L.xmat[d < 0 ? 0 : d], G);
+  it[ITEM_G_TYPE] = (unsigned int)G.type; it[ITEM_G_VADR] = (unsigned int)G.vadr; it[ITEM_G_VNUM] = (unsigned int)G.vnum;
+#pragma unroll
+  for (int i = 0; i < 3; i++) { it[ITEM_G_SIZE + i] = __float_as_uint(G.size[i]); it[ITEM_G_P + i] = __float_as_uint(G.p[i]); it[ITEM_G_C + i] = __float_as_uint(G.c[i]); }
+#pragma unroll
+  for (int i = 0; i < 9; i++) it[ITEM_G_R + i] = __float_as_uint(G.R[i]);
+  it[ITEM_G_RBOUND] = __float_as_uint(m->geom_rbound[g]);
+}
 DEV void publish_candidates(const DevModel* m, const EnvLDS& L, const PipeBuffers& W, int e, int N, int s) {
   int lane = wave_lane(), ncand = L.ncand;
-  for (int i = lane; i < NDYN * 12; i += WAVE) {
+  for (int i = lane; i < NDYN * 12; i += WAVE) {          // (the poses: k_pipe_solve's kinematics_from_pose reads them back)
     int b = i / 12, j = i % 12;
     W.pose[(size_t)e * (NDYN * 12) + i] = j < 3 ? L.xpos[b][j] : L.xmat[b][j - 3];
   }
-  bool lpt = W.conres_cap != 0u;                       // (the queue-fed step paths keep the plain order)
+  int base = 0;
+  if (lane == 0) base = ncand ? atomicAdd(&W.counters[2 * s], ncand) : 0;
+  base = wave_bcast_i(base, 0);
+  // the contact records of this substep live at the candidates' record positions: what does not fit the slice's pool is dropped from
+  // the solve (no item is written for it) and counted as a candidate overflow
+  int room = (int)W.conres_cap - base, keep = ncand < room ? ncand : (room > 0 ? room : 0);
   int nheavy = 0;
-  if (lpt) for (int k0 = 0; k0 < ncand; k0 += WAVE) { int k = k0 + lane; nheavy += __popcll(wave_ballot(k < ncand && heavy_pair(m, L.cand[k][0], L.cand[k][1]))); }
-  int base = 0, hb = 0, lb = 0;
+  for (int k0 = 0; k0 < keep; k0 += WAVE) { int k = k0 + lane; nheavy += __popcll(wave_ballot(k < keep && heavy_pair(m, L.cand[k][0], L.cand[k][1]))); }
+  int hb = 0, lb = 0;
   if (lane == 0) {
-    base = ncand ? atomicAdd(&W.counters[2 * s], ncand) : 0;
-    // the contact records of this substep live at the candidates' record positions: what does not fit the slice's pool is
-    // dropped from the solve (k_narrow skips those positions) and counted as a candidate overflow
-    int room = (int)W.conres_cap - base, keep = ncand < room ? ncand : (room > 0 ? room : 0);
     W.cbase[e] = base;
     W.ncand[e] = keep | (((L.overflow & 1) | (keep < ncand ? 1 : 0)) << 16);
-    if (lpt) {
-      hb = nheavy ? atomicAdd(&W.counters[2 * MAXSUB + 2 * s], nheavy) : 0;
-      lb = ncand - nheavy ? atomicAdd(&W.counters[2 * MAXSUB + 2 * s + 1], ncand - nheavy) : 0;
-    }
+    hb = nheavy ? atomicAdd(&W.counters[2 * MAXSUB + 2 * s], nheavy) : 0;
+    lb = keep - nheavy ? atomicAdd(&W.counters[2 * MAXSUB + 2 * s + 1], keep - nheavy) : 0;
   }
-  base = wave_bcast_i(base, 0); hb = wave_bcast_i(hb, 0); lb = wave_bcast_i(lb, 0);
-  unsigned int* list = W.work + (size_t)(s & 1) * W.work_cap;
+  hb = wave_bcast_i(hb, 0); lb = wave_bcast_i(lb, 0);
   int hseen = 0, lseen = 0;
-  for (int k0 = 0; k0 < ncand; k0 += WAVE) {
+  for (int k0 = 0; k0 < keep; k0 += WAVE) {
     int k = k0 + lane;
-    bool in = k < ncand, heavy = in && lpt && heavy_pair(m, L.cand[in ? k : 0][0], L.cand[in ? k : 0][1]);
+    bool in = k < keep;
+    int g1 = L.cand[in ? k : 0][0], g2 = L.cand[in ? k : 0][1];
+    bool heavy = in && heavy_pair(m, g1, g2);
     unsigned long long mh = wave_ballot(heavy), ml = wave_ballot(in && !heavy);
     if (in) {
       unsigned int w = (unsigned int)e * MAXCAND + k;
-      W.cand[w] = (unsigned int)L.cand[k][0] | ((unsigned int)L.cand[k][1] << 16);
-      if (!lpt) list[base + k] = w;
-      else if (heavy) list[hb + hseen + wave_prefix(mh)] = w;
-      else list[W.work_cap - 1u - (unsigned int)(lb + lseen + wave_prefix(ml))] = w;
+      W.cand[w] = (unsigned int)g1 | ((unsigned int)g2 << 16);
+      unsigned int pos = heavy ? (unsigned int)(hb + hseen + wave_prefix(mh)) : W.conres_cap - 1u - (unsigned int)(lb + lseen + wave_prefix(ml));
+      unsigned int it[ITEM_WORDS];
+      it[0] = (unsigned int)(base + k); it[1] = w;
+      item_put_geom(m, L, g1, it + ITEM_GEOM0); item_put_geom(m, L, g2, it + ITEM_GEOM1);
+      it[46] = 0u; it[47] = 0u;
+      uint4* dst = (uint4*)(W.items + (size_t)pos * ITEM_WORDS);
+#pragma unroll
+      for (int q = 0; q < ITEM_WORDS / 4; q++) dst[q] = make_uint4(it[4 * q], it[4 * q + 1], it[4 * q + 2], it[4 * q + 3]);
     }
     hseen += __popcll(mh); lseen += __popcll(ml);
   }

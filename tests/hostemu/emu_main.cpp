@@ -9,6 +9,7 @@ thread_local EmuBlock* emu_blk;
 #include "../../so101_sim_amd/csrc/tu_misc.hip"
 #include "../../so101_sim_amd/csrc/tu_pipe_begin.hip"
 #include "../../so101_sim_amd/csrc/tu_pipe_solve.hip"
+#include "../../so101_sim_amd/csrc/tu_narrow.hip"
 #include "../../so101_sim_amd/csrc/tu_chain.hip"
 #include "../../so101_sim_amd/csrc/tu_pipe_merged.hip"
 #include "../../so101_sim_amd/csrc/tu_pgs_a.hip"

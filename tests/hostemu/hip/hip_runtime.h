@@ -90,6 +90,14 @@ inline unsigned long long wall_clock64() {        // 100 MHz like the device's s
   timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
   return (unsigned long long)ts.tv_sec * 100000000ull + (unsigned long long)ts.tv_nsec / 10ull;
 }
+// vector types and bit casts the kernels use
+struct float4 { float x, y, z, w; };
+struct uint4 { unsigned int x, y, z, w; };
+inline uint4 make_uint4(unsigned int x, unsigned int y, unsigned int z, unsigned int w) { return uint4{x, y, z, w}; }
+inline unsigned int __float_as_uint(float f) { unsigned int u; memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(unsigned int u) { float f; memcpy(&f, &u, 4); return f; }
+inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
+inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
 // v_readlane: value of lane `l`
 inline int __builtin_amdgcn_readlane(int v, int l) { emu_xchg_i[threadIdx.x] = v; __syncthreads(); int r = emu_xchg_i[l]; __syncthreads(); return r; }
 inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
