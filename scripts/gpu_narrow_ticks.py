@@ -44,3 +44,8 @@ print("narrowphase time by phase (share of fetch + narrow_pair): fetch of the wo
 fine = tk[:, 230:234].astype(np.float64).sum(0)
 print("inside the face scan (share of fetch + narrow_pair): face setup %.1f %% | first support pass %.1f %% | outline tests %.1f %% | five-sample patch pass %.1f %%"
       % tuple(100 * fine / whole))
+
+rp = tk[:, 234:237].astype(np.float64).sum(0)
+if rp[1] > 0:
+    print("row pass (light region, four pairs per wavefront): %.0f rows attempted, %.1f %% settled, %.2f us per pass-row (%.1f ms in all = %.1f %% of fetch + narrow_pair)"
+          % (rp[1], 100 * rp[2] / rp[1], rp[0] * 1e-2 / rp[1], rp[0] * 1e-5, 100 * rp[0] / whole))

@@ -576,7 +576,8 @@ template <class GP = G64>
 DEV void hull_load(const DevModel* m, const GeomW& G, HullLDS& H) { if (H.n) hull_stage(m, G.vadr, G.vnum, H); }
 // uniform values parked in LDS across a phase that does not need them (k_narrow: the candidate face across the iterative query, the portal
 // across the EPA expansion): the register allocator otherwise keeps them in VGPRs, 64 copies of each, or spills them to scratch memory
-DEV float* narrow_park_store() { __shared__ __attribute__((aligned(16))) float park[128]; return park; }
+#define NARROW_PARK_WORDS 192
+DEV float* narrow_park_store() { __shared__ __attribute__((aligned(16))) float park[NARROW_PARK_WORDS]; return park; }
 
 DEV void select_geom(bool first, const GeomW& A, const GeomW& B, GeomW& o) {
   o.type = first ? A.type : B.type; o.vadr = first ? A.vadr : B.vadr; o.vnum = first ? A.vnum : B.vnum;
@@ -609,17 +610,27 @@ DEV void support(const DevModel* m, const GeomW& G, const float* dir, float* out
     int first = lane;
     if constexpr (is_hull_lds<Cache>::value) {
       const float4* X4 = (const float4*)H.p; const float4* Y4 = (const float4*)(H.p + H.n); const float4* Z4 = (const float4*)(H.p + 2 * H.n);
-#pragma unroll
-      for (int J = 0; J < HULL_LDS_MAX / (4 * WAVE); J++) {
-        if (4 * WAVE * J >= G.vnum || 4 * WAVE * J >= H.n) break;
-        float4 xv = X4[WAVE * J + lane], yv = Y4[WAVE * J + lane], zv = Z4[WAVE * J + lane];
+      auto block = [&](int J) {
+        float4 xv = X4[GP::N * J + lane], yv = Y4[GP::N * J + lane], zv = Z4[GP::N * J + lane];
         float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w}, zs[4] = {zv.x, zv.y, zv.z, zv.w};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          int i = 4 * WAVE * J + 4 * lane + k;
+          int i = 4 * GP::N * J + 4 * lane + k;
           float d = xs[k] * dl[0] + ys[k] * dl[1] + zs[k] * dl[2];
           if (i < G.vnum && d > best) { best = d; bi = i; bx = xs[k]; by = ys[k]; bz = zs[k]; }
         }
+      };
+      if constexpr (GP::N == WAVE) {
+#pragma unroll
+        for (int J = 0; J < HULL_LDS_MAX / (4 * WAVE); J++) {
+          if (4 * WAVE * J >= G.vnum || 4 * WAVE * J >= H.n) break;
+          block(J);
+        }
+      } else {
+        // a row of 16 lanes per pair (k_narrow's row pass): 64 vertices per step, trip count per row
+        const int lim = G.vnum < H.n ? G.vnum : H.n;
+#pragma unroll 1
+        for (int J = 0; 4 * GP::N * J < lim; J++) block(J);
       }
       first = lane + H.n;
     } else if constexpr (sizeof(Cache) >= sizeof(HullCache)) {
@@ -1272,20 +1283,29 @@ DEV void support_patch(const DevModel* m, const GeomW& G, const float* f, const 
   int first = lane;
   if constexpr (is_hull_lds<Cache>::value) {
     const float4* X4 = (const float4*)H.p; const float4* Y4 = (const float4*)(H.p + H.n); const float4* Z4 = (const float4*)(H.p + 2 * H.n);
-#pragma unroll
-    for (int J = 0; J < HULL_LDS_MAX / (4 * WAVE); J++) {
-      if (4 * WAVE * J >= G.vnum || 4 * WAVE * J >= H.n) break;
-      float4 xv = X4[WAVE * J + lane], yv = Y4[WAVE * J + lane], zv = Z4[WAVE * J + lane];
+    auto block = [&](int J) {
+      float4 xv = X4[GP::N * J + lane], yv = Y4[GP::N * J + lane], zv = Z4[GP::N * J + lane];
       float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w}, zs[4] = {zv.x, zv.y, zv.z, zv.w};
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        int i = 4 * WAVE * J + 4 * lane + q;
+        int i = 4 * GP::N * J + 4 * lane + q;
 #pragma unroll
         for (int k = 0; k < NCPP; k++) {
           float s = xs[q] * dl[k][0] + ys[q] * dl[k][1] + zs[q] * dl[k][2];
           if (i < G.vnum && s > best[k]) { best[k] = s; bi[k] = i; }
         }
       }
+    };
+    if constexpr (GP::N == WAVE) {
+#pragma unroll
+      for (int J = 0; J < HULL_LDS_MAX / (4 * WAVE); J++) {
+        if (4 * WAVE * J >= G.vnum || 4 * WAVE * J >= H.n) break;
+        block(J);
+      }
+    } else {
+      const int lim = G.vnum < H.n ? G.vnum : H.n;
+#pragma unroll 1
+      for (int J = 0; 4 * GP::N * J < lim; J++) block(J);
     }
     first = lane + H.n;
   } else if constexpr (sizeof(Cache) >= sizeof(HullCache)) {
@@ -1479,8 +1499,10 @@ DEV void scan_faces(const DevModel* m, const GeomW& GR, const GeomW& GI, const C
 // Narrowphase of one candidate pair (geom types ordered): up to NCPP contacts sharing one normal (geom1 -> geom2),
 // each with its penetration distance (< 0) and position.
 // narrow_pair_cached: the caches H1 / H2 are ready (k_narrow stages them in LDS), rb1 / rb2 = the geoms' bounding radii
-template <class Cache, class GP = G64>
-DEV void narrow_pair_cached(const DevModel* m, const GeomW& G1, const GeomW& G2, float rb1, float rb2, const Cache& H1, const Cache& H2, PairContacts& out,
+// FACES_ONLY (k_narrow's row pass, policy G16: four pairs per wavefront, one per DPP row): the plane and flat-face closed forms only; returns
+// false when the pair needs the iterative query (MPR / EPA), which the caller then runs with the whole wavefront.  Otherwise returns true.
+template <class Cache, class GP = G64, bool FACES_ONLY = false>
+DEV bool narrow_pair_cached(const DevModel* m, const GeomW& G1, const GeomW& G2, float rb1, float rb2, const Cache& H1, const Cache& H2, PairContacts& out,
                             unsigned int* prof = nullptr) {
 #ifdef SO101_DEBUG_CLOCKS
   unsigned long long qp_ = SO101_CLOCK();
@@ -1495,7 +1517,7 @@ DEV void narrow_pair_cached(const DevModel* m, const GeomW& G1, const GeomW& G2,
     support_patch<Cache, GP>(m, G2, fr, fr + 3, fr + 6, P, H2);
     face_patch(P, fr, G1.p, fr + 3, fr + 6, -1.f, -1.f, PATCH_DUP * rb2, out);
     out.nrm[0] = fr[0]; out.nrm[1] = fr[1]; out.nrm[2] = fr[2];
-    return;
+    return true;
   }
   FaceRef best;
   best.depth = 3.0e38f; best.side = -1; best.hu = 0.f; best.hv = 0.f; best.exact = false; best.separated = false;
@@ -1506,9 +1528,10 @@ DEV void narrow_pair_cached(const DevModel* m, const GeomW& G1, const GeomW& G2,
   scan_faces<Cache, GP>(m, G1, G2, H2, 0, best, prof);
   if (!best.separated && !best.exact) scan_faces<Cache, GP>(m, G2, G1, H1, 1, best, prof);
   QPROF(2)
-  if (best.separated) return;
+  if (best.separated) return true;
   float depth = 0.f, nrm[3] = {0.f, 0.f, 0.f}, pos[3] = {0.f, 0.f, 0.f};
-  if (!best.exact) {
+  if constexpr (FACES_ONLY) { if (!best.exact) return false; }
+  else if (!best.exact) {
     if constexpr (is_hull_lds<Cache>::value) {
       float* pk = narrow_park_store();
       if (wave_lane() == 0) {
@@ -1524,7 +1547,7 @@ DEV void narrow_pair_cached(const DevModel* m, const GeomW& G1, const GeomW& G2,
     // an oblique direction ten times deeper than the plate's face normal: the shallowest face candidate wins when it
     // is not deeper (1 % + 1e-6 m slack: for a face contact both are the same number)
     bool ok = mpr_penetration<Cache, GP>(m, G1, G2, &depth, nrm, pos, H1, H2);
-    if (!ok || !(depth > 0.f)) return;
+    if (!ok || !(depth > 0.f)) return true;
     if constexpr (is_hull_lds<Cache>::value) {
       wave_sync();
       const float* pk = narrow_park_store();
@@ -1551,6 +1574,7 @@ DEV void narrow_pair_cached(const DevModel* m, const GeomW& G1, const GeomW& G2,
 #pragma unroll
     for (int k = 0; k < 3; k++) { out.nrm[k] = nrm[k]; out.pos[0][k] = pos[k]; }
   }
+  return true;
 }
 
 template <class Cache, class GP = G64>

@@ -611,8 +611,16 @@ static int enqueue_pipelined(so101_sim* s, hipStream_t st, const so101::StepIO& 
     static const int chunk_env_l = getenv("SO101_NARROW_CHUNK_LIGHT") ? atoi(getenv("SO101_NARROW_CHUNK_LIGHT")) : 0;
     // measured at 4096 envs (heavy / light pairs per fetch -> env-steps/s): 3/3 707 k, 1/3 684 k, 2/3 712 k, 2/4 720 k, 1/4 692 k, 2/2 679 k
     int ch = chunk_env >= 1 && chunk_env <= NARROW_CHUNK ? chunk_env : (n <= 8192 ? 2 : NARROW_CHUNK);
-    int cl = chunk_env_l >= 1 && chunk_env_l <= NARROW_CHUNK ? chunk_env_l : NARROW_CHUNK;
-    W.narrow_chunk = (unsigned int)ch | ((unsigned int)cl << 4);        // heavy region | light region
+    // (round 5, work items + LDS hull pool of 1024 slots: light pairs per fetch 4 / 3 / 2 / 1 -> 718 / 736 / 740 / 604 k env-steps/s at 4096 envs - four
+    //  light pairs with a 512-slot hull among them overflow the pool and stage late -; 32 768 envs, row-pass instance: 4 -> 1078 k, 2 -> 938 k)
+    int cl = chunk_env_l >= 1 && chunk_env_l <= NARROW_CHUNK ? chunk_env_l : (n <= 8192 ? 2 : NARROW_CHUNK);
+    // bit 8: the row pass (four light pairs per wavefront, one per DPP row; so101 tu_narrow.hip).  Measured, round 5: 32 768 envs 996 k -> 1 067 k
+    // env-steps/s (first window 1.21 -> 1.35 M); 4096 envs 715 k -> 710 k (there the step follows the critical path of its slowest slice -
+    // heavy pairs, long Newton solves -, not the light pairs' instruction count), so it is on above 8192 envs
+    const char* rows_var = getenv("SO101_NARROW_ROWS");            // (tests and kernel experiments: read when the step is enqueued / captured, so a handle created after a change sees it)
+    const int rows_env = rows_var ? atoi(rows_var) : -1;
+    const bool rows = rows_env >= 0 ? rows_env != 0 : n > 8192;
+    W.narrow_chunk = (unsigned int)ch | ((unsigned int)cl << 4) | (rows ? 256u : 0u);        // heavy region | light region | row pass
     // persistent narrowphase waves (they pull work items until the list is empty): 1.5 - 2 per env of the slice, at
     // most what fills 256 CUs - a smaller narrowphase grid leaves slots to the other chains' solve kernels
     // (round 4, with the heavy-first work list: 1.5 waves per env 725 k, 2 per env 718 k, 2.5 per env 697 k env-steps/s at 4096 envs)

@@ -1,4 +1,7 @@
 // Translation unit: the narrowphase kernel of the pipelined control step (see so101_pipeline.hpp).
+// (everything derived from the lane index is loop invariant in a persistent kernel; LLVM hoists it in front of the work loop and keeps it
+// live across everything: see wave.hpp.  With the opaque lane index k_narrow needs 212 VGPRs instead of 246 at two waves per SIMD.)
+#define SO101_OPAQUE_LANE
 #include "so101_pipeline.hpp"
 #include "so101_launch.hpp"
 
@@ -18,12 +21,11 @@
 // Measured alternative (kept as policy G16, bit-identical results): one pair per DPP row of 16 lanes, four pairs per
 // wavefront.  It is SLOWER (4096-env bench 490-509 k against 635 k env-steps/s): ~70 % of a query's instructions are
 // the lane-parallel hull scans, not the uniform portal math.
-#ifndef NARROW_WAVES
-#define NARROW_WAVES 2
-#endif
-#ifndef HULL_POOL
-#define HULL_POOL 1536           // vertex slots of the LDS hull pool (18 KB): three 512-slot or six 256-slot hulls
-#endif
+// Two instances.  ROWS = false (batches up to 8192 envs): three wavefronts per SIMD - 168 VGPRs, 13.3 KB of LDS, a pool of 1024 vertex slots.
+// ROWS = true (larger batches): with the row pass for the light region of the list (below), which needs the registers of two wavefronts per
+// SIMD; pool of 1536 slots.  Measured, round 5, env-steps/s at 4096 / 32768 envs: two waves, 1536 slots, no row pass 714 k / 996 k; with the
+// row pass 710 k / 1067 k; three waves, 1024 slots, no row pass 727 k / 1075 k; the register-cache kernel of round 4 727 k / 1038 k.
+template <bool ROWS> struct NarrowCfg { static constexpr int waves = ROWS ? 2 : 3, pool = ROWS ? 1536 : 1024; };
 
 DEV float item_f(unsigned int word, int i) { return __uint_as_float((unsigned int)__builtin_amdgcn_readlane((int)word, i)); }
 DEV int item_i(unsigned int word, int i) { return __builtin_amdgcn_readlane((int)word, i); }
@@ -36,8 +38,15 @@ DEV void item_geom(unsigned int word, int o, GeomW& G, float& rbound) {
   rbound = item_f(word, o + ITEM_G_RBOUND);
 }
 
-__global__ void __launch_bounds__(64, NARROW_WAVES) k_narrow(const DevModel* m, int N, PipeBuffers W, int s) {
+template <bool ROWS>
+__global__ void __launch_bounds__(64, NarrowCfg<ROWS>::waves) k_narrow(const DevModel* m, int N, PipeBuffers W, int s) {
+  constexpr int HULL_POOL = NarrowCfg<ROWS>::pool;          // vertex slots of the LDS hull pool: 256 or 512 per staged hull
   __shared__ __attribute__((aligned(16))) float pool[3 * HULL_POOL];
+  // the row pass: every row reads its own item.  (Shares its storage with the values the full-wave query parks across MPR / EPA -
+  // narrow_park_store() of so101_device.hpp -: the row pass runs the closed forms only and parks nothing, and its items are dead before
+  // the full-wave loop starts.)
+  unsigned int* row_items = (unsigned int*)narrow_park_store();
+  static_assert(NARROW_CHUNK * ITEM_WORDS <= NARROW_PARK_WORDS, "the row items must fit the park area");
   int lane = wave_lane();
   // Scalar loads on purpose.  The counts share their cache line with the cursor every wave of this launch does atomics on; when the
   // compiler picked a plain vector load here the whole launch ran 26 % longer at an identical instruction count (round 3); a scalar or a
@@ -51,7 +60,7 @@ __global__ void __launch_bounds__(64, NARROW_WAVES) k_narrow(const DevModel* m, 
     // work items per fetch: launch-time numbers (W.narrow_chunk, at most NARROW_CHUNK each).  Smaller chunks balance the tail of a launch
     // (a chunk of four EPA pairs is 45-190 us against a launch of ~100 us alone), larger ones save atomics.  Two sizes: W.narrow_chunk & 15
     // pairs per fetch while this wavefront's LAST fetch started in the heavy region, W.narrow_chunk >> 4 once it has seen the light region.
-    const int chunk = last_i0 < nheavy ? (int)(W.narrow_chunk & 15u) : (int)(W.narrow_chunk >> 4);
+    const int chunk = last_i0 < nheavy ? (int)(W.narrow_chunk & 15u) : (int)((W.narrow_chunk >> 4) & 15u);
     if (lane == 0) i0 = atomicAdd(&W.counters[2 * s + 1], chunk);
     i0 = wave_uniform_i(i0);
     if (i0 >= nwork) break;
@@ -104,10 +113,68 @@ __global__ void __launch_bounds__(64, NARROW_WAVES) k_narrow(const DevModel* m, 
       for (int u = 0; u < 3; u++)
         if (b0 + u < nb) { HullLDS H{pool + __builtin_amdgcn_readlane(tdst, b0 + u), __builtin_amdgcn_readlane(tn, b0 + u)}; hull_stage_store<4>(H, 0, 0, T[u]); }
     }
+    // ---- ROW PASS (light region of the list: a flat face - the plane, a box - against anything): four pairs at once, one per DPP row of 16
+    // lanes (policy G16), closed forms only.  The wavefront is issue-bound (doubling the queries of every pair lengthened the control step by
+    // 48 %; a third wavefront per SIMD changed nothing), and two thirds of a light pair's instructions are wave-uniform arithmetic issued
+    // for 64 lanes on one pair's numbers: here one instruction stream serves four pairs, the hull scans cost the same per pair (16 lanes x
+    // four times the steps), the reductions stay inside a row (four DPP steps, no v_readlane).  Rows whose pair needs the iterative query
+    // (no exact face: ~10 %) report it and are served by the whole wavefront below.  Same vertices, same arithmetic: same contacts.
+    unsigned int todo = (1u << cnt) - 1u;              // pairs the full-wave loop below still has to do
+    if constexpr (ROWS) if (i0 >= nheavy) {
+      unsigned long long tr0 = SO101_CLOCK();
+#pragma unroll
+      for (int j = 0; j < NARROW_CHUNK; j++) if (lane < ITEM_WORDS) row_items[j * ITEM_WORDS + lane] = it[j];
+      wave_sync();
+      const int row = lane >> 4;
+      bool settled = false;
+      if (row < cnt) {
+        const unsigned int* I = row_items + row * ITEM_WORDS;
+        GeomW G1, G2;
+        auto geom = [&](int o, GeomW& G) {
+          G.type = (int)I[o + ITEM_G_TYPE]; G.vadr = (int)I[o + ITEM_G_VADR]; G.vnum = (int)I[o + ITEM_G_VNUM];
+#pragma unroll
+          for (int i = 0; i < 3; i++) { G.size[i] = __uint_as_float(I[o + ITEM_G_SIZE + i]); G.p[i] = __uint_as_float(I[o + ITEM_G_P + i]); G.c[i] = __uint_as_float(I[o + ITEM_G_C + i]); }
+#pragma unroll
+          for (int i = 0; i < 9; i++) G.R[i] = __uint_as_float(I[o + ITEM_G_R + i]);
+        };
+        geom(ITEM_GEOM0, G1); geom(ITEM_GEOM1, G2);
+        float rb1 = __uint_as_float(I[ITEM_GEOM0 + ITEM_G_RBOUND]), rb2 = __uint_as_float(I[ITEM_GEOM1 + ITEM_G_RBOUND]);
+        int o1 = off[0], o2 = off[1];
+#pragma unroll
+        for (int q = 1; q < NARROW_CHUNK; q++) if (row == q) { o1 = off[2 * q]; o2 = off[2 * q + 1]; }
+        int n1 = hull_lds_slots(G1.type, G1.vnum), n2 = hull_lds_slots(G2.type, G2.vnum);
+        // (a hull that found no room in the pool is scanned in memory by its row: n = 0)
+        HullLDS H1{pool + 3 * (o1 < 0 ? 0 : o1), o1 < 0 ? 0 : n1}, H2{pool + 3 * (o2 < 0 ? 0 : o2), o2 < 0 ? 0 : n2};
+        PairContacts pc;
+        settled = narrow_pair_cached<HullLDS, G16, true>(m, G1, G2, rb1, rb2, H1, H2, pc);
+        if (settled && (lane & 15) == 0) {
+          float* r = W.conres + (size_t)I[0] * CONRES_DIM;
+          r[0] = (float)__popc(pc.valid); r[1] = pc.nrm[0]; r[2] = pc.nrm[1]; r[3] = pc.nrm[2];
+          int o = 4;
+#pragma unroll
+          for (int q = 0; q < NCPP; q++)
+            if ((pc.valid >> q) & 1u) { r[o] = pc.dist[q]; r[o + 1] = pc.pos[q][0]; r[o + 2] = pc.pos[q][1]; r[o + 3] = pc.pos[q][2]; o += 4; }
+        }
+      }
+      unsigned long long sm = wave_ballot(settled);
+#ifdef SO101_EMU_ROWSTATS
+      if (lane == 0) fprintf(stderr, "row pass: cnt %d settled mask %llx i0 %d nheavy %d nwork %d\n", cnt, sm, i0, nheavy, nwork);
+#endif
+      todo = 0u;
+#pragma unroll
+      for (int j = 0; j < NARROW_CHUNK; j++) if (j < cnt && !((sm >> (16 * j)) & 1ull)) todo |= 1u << j;
+#ifdef SO101_DEBUG_CLOCKS
+      if (lane == 0) {          // per-env sums (scripts/gpu_narrow_ticks.py): [10] row-pass ticks, [11] rows attempted, [12] rows settled
+        unsigned int* rp = W.ticks + (size_t)(item_i(it[0], 1) / MAXCAND) * MAXCAND + 224;
+        atomicAdd(&rp[10], (unsigned int)(SO101_CLOCK() - tr0)); atomicAdd(&rp[11], (unsigned int)cnt); atomicAdd(&rp[12], (unsigned int)(cnt - __popc(todo)));
+      }
+#endif
+    }
     wave_sync();
     // not unrolled: four inlined copies of the query are ~130 KB of code, more than the instruction cache holds
 #pragma unroll 1
     for (int j = 0; j < cnt; j++) {
+      if (!((todo >> j) & 1u)) continue;
       unsigned long long t0 = SO101_CLOCK();
       unsigned int word = it[0]; int o1 = off[0], o2 = off[1];
 #pragma unroll
@@ -160,6 +227,8 @@ __global__ void __launch_bounds__(64, NARROW_WAVES) k_narrow(const DevModel* m, 
 
 namespace so101 {
 void launch_narrow(int waves, hipStream_t st, const DevModel* m, int n_envs, const PipeBuffers& W, int substep) {
-  hipLaunchKernelGGL(k_narrow, dim3(waves), dim3(64), 0, st, m, n_envs, W, substep);
+  // W.narrow_chunk bit 8: the instance with the row pass (large batches; set by the host, so101_hip.hip)
+  if (W.narrow_chunk & 256u) hipLaunchKernelGGL(k_narrow<true>, dim3(waves), dim3(64), 0, st, m, n_envs, W, substep);
+  else hipLaunchKernelGGL(k_narrow<false>, dim3(waves), dim3(64), 0, st, m, n_envs, W, substep);
 }
 }  // namespace so101

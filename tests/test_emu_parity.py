@@ -63,6 +63,12 @@ def test_pipelined_step_matches_fused(make_sim, golden):
     pc.check_pipeline_identical(make_sim, golden, n=1, steps=1, settle=1, pipelines=(0, 1), first_state=9)
 
 
+def test_row_pass_of_the_narrowphase_matches_fused(make_sim, golden, monkeypatch):
+    """the k_narrow instance of large batches (row pass: four light pairs per wavefront), forced on for one env"""
+    monkeypatch.setenv("SO101_NARROW_ROWS", "1")
+    pc.check_pipeline_identical(make_sim, golden, n=1, steps=1, settle=1, pipelines=(0, 1), first_state=9)
+
+
 @SLOW
 def test_chained_and_merged_steps_match_fused(make_sim, golden):
     # two envs on concurrently alive emulated wavefronts: every queue hand-off of so101_chain.hpp (pipeline 2: persistent k_chain)

@@ -87,6 +87,15 @@ def test_pipelined_step_matches_fused(make_sim, golden):
     pc.check_pipeline_identical(make_sim, golden, n=8, steps=6)
 
 
+@pytest.mark.parametrize("n,steps", [(8, 6), (512, 4)])
+def test_row_pass_of_the_narrowphase_matches_fused(make_sim, golden, monkeypatch, n, steps):
+    """k_narrow<ROWS> - the instance large batches run: four light pairs per wavefront, one per DPP row, closed forms only, the rest by the
+    whole wavefront - forced on for a small batch (SO101_NARROW_ROWS is read when a handle enqueues its step): against the fused step,
+    bit for bit, on the contact-rich states."""
+    monkeypatch.setenv("SO101_NARROW_ROWS", "1")
+    pc.check_pipeline_identical(make_sim, golden, n=n, steps=steps, seed=11, all_reset_last=(n == 8), pipelines=(0, 1))
+
+
 def test_four_launch_chains_match_fused_at_512_envs(make_sim, golden):
     """512 envs: four slices on four streams, across an auto-reset, against the fused step, bit for bit."""
     pc.check_pipeline_identical(make_sim, golden, n=512, steps=5, seed=13, all_reset_last=False, pipelines=(0, 1))
