@@ -201,7 +201,8 @@ int so101_get_diag(so101_sim* sim, int32_t* out, void* hip_stream);
 /* Event counters since so101_create (or the last call with clear != 0): out is a DEVICE pointer to
  * SO101_NEVENTS uint64.  Counter b counts env-steps (b <= 3) or env-resets (b = 4, 5) on which flag b was raised:
  *   0 broadphase candidate list overflowed (candidates dropped)      1 contact list overflowed (contacts dropped)
- *   2 arm-contact Jacobian pool overflowed (contacts dropped)        3 physics diverged: NaN or |x| > 1e10 in the
+ *   2 (retired in round 5, always 0: arm-link contacts beyond the LDS pool recompute their Jacobian instead of being dropped)
+ *                                                                     3 physics diverged: NaN or |x| > 1e10 in the
  *     state (mj_checkPos/Vel/Acc); the episode ends with reward 0 / discount 0 like a dm_control PhysicsError
  *     (task_suite.py:153 raise_exception_on_physics_error=False)
  *   4 reset: the container placer's 20 attempts all collided (dm_control's PropPlacer raises RuntimeError there;
@@ -209,6 +210,8 @@ int so101_get_diag(so101_sim* sim, int32_t* out, void* hip_stream);
  *     settle_max_substeps (dm_control warns, examples/so101_rl_breakdown.ipynb:50-55)
  *   6 chained steps (pipeline = 2) ended by the watchdog (scheduler protocol error).  The abort is sticky: that step's results and
  *     those of EVERY later chained step of the handle are invalid - each counts here - until so101_configure selects another step path
+ *   7 more than so101_max_contacts() contacts in a substep: the env kept ONE contact per touching geom pair (the first of its patch) for
+ *     that substep instead of cutting the list; counter 1 then only counts substeps whose touching PAIRS alone exceeded the limit
  * The same bits appear per env in diag word 4 for the most recent substep. */
 #define SO101_NEVENTS 8
 int so101_get_events(so101_sim* sim, uint64_t* out, int clear, void* hip_stream);

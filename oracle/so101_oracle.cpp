@@ -173,7 +173,7 @@ struct orc_sim {
   std::vector<real> J, efc_pos, efc_D, efc_R, efc_aref, efc_force, efc_floss, efc_b, AR;
   std::vector<int> efc_type, efc_id, efc_dim;
   int iterations; real tolerance; bool collide = true;
-  bool hull_multi = false;       // several contacts for hull pairs resting on flat features (hull_patch; off: the single EPA contact of rounds 1-4)
+  bool hull_multi = true;        // several contacts for hull pairs resting on flat features (hull_patch; off: the single EPA contact of rounds 1-4)
   std::vector<real> mass0, inertia0, invweight0;     // unscaled prop masses (orc_set_mass_scale)
   std::vector<Contact> injected;                      // orc_inject_contacts
   int narrow = 1;              // 1 (default, what the kernels run) = MPR portal expanded by EPA to the nearest face of the Minkowski difference (minimum translation: mujoco >= 3.3's native GJK / EPA), 0 = MPR's own depth (the -DSO101_MPR option of the kernels)
@@ -838,6 +838,7 @@ bool face_patch(const orc_sim* s, int gI, const real* f, const real* c, const re
 // b_k becomes a contact when it lies below geom 1's supporting plane (through w1, normal n) and laterally inside geom 1's feature there:
 // with r the unit lateral direction from w1 to b_k, r . (b_k - w1) <= r . (support_1(n + eps r) - w1) + 1e-6 - the feature's extent in
 // that direction, again by a tilted support; a vertex or a curved patch has extent 0, so nothing beyond the EPA contact survives there.
+// Samples laterally closer than dup_tol to w1 are skipped (they would only repeat the EPA contact).
 // a_k symmetrically against geom 2's feature at w2.  Accepted in the order b_1..b_4, a_1..a_4 behind the EPA contact (slot 0) while they are
 // farther than dup_tol from the contacts already accepted, up to NCPP in all; every contact carries the normal n, its distance is the
 // sample's signed distance to the other hull's supporting plane and its position the midpoint between sample and plane.
@@ -865,7 +866,8 @@ void hull_patch(const orc_sim* s, int g1, int g2, const real* n, real depth, con
       if (!(dist < 0)) continue;
       real h = dot3(rel, n), r[3] = {rel[0] - h * n[0], rel[1] - h * n[1], rel[2] - h * n[2]};
       real rl = normalize3(r);
-      if (rl > 1e-9) {
+      if (rl < dup_tol) continue;                     // laterally at the EPA witness: would repeat the EPA contact
+      {
         real de[3], e[3];
         for (int i = 0; i < 3; i++) de[i] = -sg * n[i] + PATCH_EPS * r[i];
         normalize3(de);
@@ -998,7 +1000,7 @@ void collision(orc_sim* s) {
         if (exact) continue;
         pt.n = 1; pt.dist[0] = -depth;
         for (int k = 0; k < 3; k++) { pt.nrm[k] = dir[k]; pt.pos[0][k] = pos[k]; }
-        if (s->hull_multi && m.geom_type[g1] == G_MESH && m.geom_type[g2] == G_MESH)
+        if (s->hull_multi && s->narrow == 1 && m.geom_type[g1] == G_MESH && m.geom_type[g2] == G_MESH)       // (EPA only: MPR's portal normal is no face normal)
           hull_patch(s, g1, g2, dir, depth, pos, PATCH_DUP * std::min(m.geom_rbound[g1], m.geom_rbound[g2]), &pt);
       }
     }

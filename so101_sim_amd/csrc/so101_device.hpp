@@ -1258,6 +1258,10 @@ DEV void broadphase(const DevModel* m, EnvLDS& L) {
 // index - the same vertex support() would return) are fetched afterwards.
 struct Patch5 { float p[NCPP][3]; };
 
+// support points of G in NCPP world directions d[k] (unit), one pass over the hull
+template <class Cache, class GP = G64>
+DEV void support_multi(const DevModel* m, const GeomW& G, const float (*d)[3], Patch5& P, const Cache& H);
+
 template <class Cache, class GP = G64>
 DEV void support_patch(const DevModel* m, const GeomW& G, const float* f, const float* u, const float* v, Patch5& P, const Cache& H) {
   float d[NCPP][3];
@@ -1269,6 +1273,11 @@ DEV void support_patch(const DevModel* m, const GeomW& G, const float* f, const 
     for (int i = 0; i < 3; i++) d[k][i] = -f[i] + e * (su * u[i] + sv * v[i]);
     normalize3(d[k]);
   }
+  support_multi<Cache, GP>(m, G, d, P, H);
+}
+
+template <class Cache, class GP>
+DEV void support_multi(const DevModel* m, const GeomW& G, const float (*d)[3], Patch5& P, const Cache& H) {
   if (G.type != G_MESH) {
 #pragma unroll
     for (int k = 0; k < NCPP; k++) support<Cache, GP>(m, G, d[k], P.p[k], H);
@@ -1496,6 +1505,91 @@ DEV void scan_faces(const DevModel* m, const GeomW& GR, const GeomW& GI, const C
   }
 }
 
+// Hull against hull (round 5; the reference runs with multiccd, so100_task.py:151, aloha2_task.py:197): behind the EPA contact (slot 0) the
+// extreme points of whatever flat feature each hull presents along the contact normal n (geom 1 -> geom 2).  With w1 = pos + depth/2 n on
+// geom 1's surface and w2 = pos - depth/2 n on geom 2's:
+//   b_k = support_2(-n + eps s_k), a_k = support_1(+n + eps s_k), k = 1..4 (the tilted samples of support_patch);
+//   b_k is a contact when it lies below geom 1's supporting plane (through w1) and, with r the unit lateral direction from w1 to b_k,
+//   r . (b_k - w1) <= r . (support_1(n + eps r) - w1) + 1e-6 - inside the extent of geom 1's feature in that direction, again by a tilted
+//   support (a vertex or a curved patch has extent 0: nothing beyond the EPA contact survives); samples laterally closer than dup_tol to
+//   w1 are skipped (they would repeat the EPA contact); a_k likewise against geom 2 at w2.
+// Accepted in the order b_1..b_4, a_1..a_4 while farther than dup_tol from those already accepted, NCPP in all; normal n for all, distance
+// = the sample's signed distance to the other hull's plane, position = the midpoint.  Four more passes over the hulls (two of samples, two
+// of extents), only for mesh pairs that EPA found in contact.  (The test suite holds an fp64 restatement of the rule.)
+template <class Cache, class GP = G64>
+DEV void hull_patch(const DevModel* m, const GeomW& G1, const GeomW& G2, const Cache& H1, const Cache& H2, const float* n, float depth, const float* pos,
+                    float dup_tol, PairContacts& out) {
+  float fr[9] = {n[0], n[1], n[2], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  make_frame(fr);
+  const float* u = fr + 3; const float* v = fr + 6;
+  float nn[3] = {-n[0], -n[1], -n[2]};
+  float w1[3], w2[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) { w1[i] = pos[i] + 0.5f * depth * n[i]; w2[i] = pos[i] - 0.5f * depth * n[i]; }
+  int count = 1;                                       // (slot 0: the EPA contact, already in `out`)
+#pragma unroll 1
+  for (int side = 0; side < 2; side++) {
+    if (count >= NCPP) break;
+    const float sg = side == 0 ? -1.f : 1.f;
+    GeomW GS, GO; Cache HS, HO;
+    select_geom(side == 0, G2, G1, GS); select_geom(side == 0, G1, G2, GO);
+    select_hull(side == 0, H2, H1, HS); select_hull(side == 0, H1, H2, HO);
+    float wo[3] = {side == 0 ? w1[0] : w2[0], side == 0 ? w1[1] : w2[1], side == 0 ? w1[2] : w2[2]};
+    Patch5 S;
+    support_patch<Cache, GP>(m, GS, side == 0 ? n : nn, u, v, S, HS);        // slots 1..4: support(sg n + eps s_k)
+    float dist[4], rl[4], de[NCPP][3], r[4][3];
+    bool cand[4];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const float* p = S.p[k + 1];
+      float rel[3] = {p[0] - wo[0], p[1] - wo[1], p[2] - wo[2]};
+      float h = dot3(rel, n);
+      dist[k] = -sg * h;
+      cand[k] = dist[k] < 0.f;
+      r[k][0] = rel[0] - h * n[0]; r[k][1] = rel[1] - h * n[1]; r[k][2] = rel[2] - h * n[2];
+      rl[k] = normalize3(r[k]);
+      // (a sample laterally closer than dup_tol to the EPA witness would only repeat the EPA contact: a vertex or an edge end - skipped
+      //  before the extent pass, which is then not run at all for a hull that presents a vertex)
+      cand[k] = cand[k] && rl[k] >= dup_tol;
+      bool ext = cand[k];
+      any = any || ext;
+#pragma unroll
+      for (int i = 0; i < 3; i++) de[k + 1][i] = ext ? -sg * n[i] + PATCH_EPS * r[k][i] : -sg * n[i];
+      normalize3(de[k + 1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) de[0][i] = -sg * n[i];
+    Patch5 E;
+#pragma unroll
+    for (int k = 0; k < NCPP; k++) { E.p[k][0] = wo[0]; E.p[k][1] = wo[1]; E.p[k][2] = wo[2]; }
+    if (any) support_multi<Cache, GP>(m, GO, de, E, HO);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      bool ok = cand[k] && count < NCPP;
+      if (ok) {
+        const float* e = E.p[k + 1];
+        float ext = r[k][0] * (e[0] - wo[0]) + r[k][1] * (e[1] - wo[1]) + r[k][2] * (e[2] - wo[2]);
+        ok = rl[k] <= ext + 1e-6f;
+      }
+      const float* p = S.p[k + 1];
+      float cp[3] = {p[0] + sg * 0.5f * dist[k] * n[0], p[1] + sg * 0.5f * dist[k] * n[1], p[2] + sg * 0.5f * dist[k] * n[2]};
+#pragma unroll
+      for (int j = 0; j < NCPP; j++) {
+        float dd[3] = {cp[0] - out.pos[j][0], cp[1] - out.pos[j][1], cp[2] - out.pos[j][2]};
+        if (((out.valid >> j) & 1u) && sqrtf(dot3(dd, dd)) < dup_tol) ok = false;
+      }
+      if (ok) {
+#pragma unroll
+        for (int t = 1; t < NCPP; t++)                 // (slot = count: selects instead of a dynamic register index)
+          if (count == t) { out.dist[t] = dist[k]; out.pos[t][0] = cp[0]; out.pos[t][1] = cp[1]; out.pos[t][2] = cp[2]; }
+        out.valid |= 1u << count;
+        count++;
+      }
+    }
+  }
+}
+
 // Narrowphase of one candidate pair (geom types ordered): up to NCPP contacts sharing one normal (geom1 -> geom2),
 // each with its penetration distance (< 0) and position.
 // narrow_pair_cached: the caches H1 / H2 are ready (k_narrow stages them in LDS), rb1 / rb2 = the geoms' bounding radii
@@ -1573,6 +1667,14 @@ DEV bool narrow_pair_cached(const DevModel* m, const GeomW& G1, const GeomW& G2,
     out.valid = 1u; out.dist[0] = -depth;
 #pragma unroll
     for (int k = 0; k < 3; k++) { out.nrm[k] = nrm[k]; out.pos[0][k] = pos[k]; }
+#if !defined(SO101_NO_HULL_PATCH) && !defined(SO101_MPR)      // (the MPR option keeps the single contact: its portal normal is no face normal of the Minkowski difference; NO_HULL_PATCH: kernel experiments)
+    if constexpr (!FACES_ONLY) {
+      // (inlined.  Measured in k_narrow, round 5, env-steps/s at 4096 envs: at three wavefronts per SIMD the patch code costs 96 more spilled
+      //  VGPRs on the common path - 656 k against 738 k without it -, out of line behind a call with its arguments in LDS 537 k; at two
+      //  wavefronts per SIMD nothing spills: 730 k)
+      if (G1.type == G_MESH && G2.type == G_MESH) hull_patch<Cache, GP>(m, G1, G2, H1, H2, nrm, depth, pos, PATCH_DUP * fminf(rb1, rb2), out);
+    }
+#endif
   }
   return true;
 }
@@ -1614,22 +1716,47 @@ DEV void contact_init(const DevModel* m, Contact& c, int g1, int g2, float dist,
 
 // Fused collision stage: the wave walks its own candidate list.  (The pipelined step hands the candidates to
 // k_narrow instead, one wavefront per candidate.)
+// More contacts than MAXCON (round 5; until round 4 the tail of the list was cut off): the env goes over to ONE contact per geom pair - the
+// first of each pair's patch: the deepest point of a flat patch, the EPA contact of a hull pair - for this substep, so that no touching pair
+// loses its contact; flag 128 (event 7, "contacts_reduced").  Only when the touching PAIRS alone exceed MAXCON is the list cut (flag 2,
+// "contact_overflow").  The launch chains' gather_contacts() applies the same rule from the pairs' counts, so both step paths keep the
+// same contacts in the same order.
+DEV int reduce_contacts(EnvLDS& L, int ncon) {
+  int lane = wave_lane(), out = 0;
+  wave_sync();
+  for (int j = 0; j < ncon; j++) {
+    bool first = j == 0 || L.con[j].g1 != L.con[j - 1].g1 || L.con[j].g2 != L.con[j - 1].g2;      // (a pair's contacts are consecutive)
+    if (first) {
+      if (out != j && lane < (int)(sizeof(Contact) / 4)) ((int*)&L.con[out])[lane] = ((const int*)&L.con[j])[lane];
+      out++;
+    }
+    wave_sync();
+  }
+  return out;
+}
 DEV void collision(const DevModel* m, EnvLDS& L) {
   int lane = wave_lane();
   broadphase(m, L);
   int ncand = L.ncand, ncon = 0;
-  bool full = false;
+  bool full = false, reduced = false;
   for (int k = 0; k < ncand && !full; k++) {
     int g1 = L.cand[k][0], g2 = L.cand[k][1];
     GeomW G1, G2;
     load_geom(m, L, g1, G1); load_geom(m, L, g2, G2);
     PairContacts pc;
     narrow_pair<NoCache>(m, G1, G2, g1, g2, pc);
+    int cnt = __popc(pc.valid);
+    if (!reduced && ncon + cnt > MAXCON) {
+      if (lane == 0) L.overflow |= 128;
+      ncon = reduce_contacts(L, ncon);
+      reduced = true;
+    }
+    bool taken = false;                                // (reduced: the pair's first contact only)
 #pragma unroll
     for (int j = 0; j < NCPP; j++) {
-      if (((pc.valid >> j) & 1u) && !full) {
+      if (((pc.valid >> j) & 1u) && !full && !(reduced && taken)) {
         if (ncon >= MAXCON) { if (lane == 0) L.overflow |= 2; full = true; }
-        else { if (lane == 0) contact_init(m, L.con[ncon], g1, g2, pc.dist[j], pc.nrm, pc.pos[j]); ncon++; }
+        else { if (lane == 0) contact_init(m, L.con[ncon], g1, g2, pc.dist[j], pc.nrm, pc.pos[j]); ncon++; taken = true; }
       }
     }
   }

@@ -136,11 +136,23 @@ template <bool AG = false>
 DEV void gather_contacts(const DevModel* m, EnvLDS& L, const PipeBuffers& W, int e) {
   int lane = wave_lane();
   int info = pld<AG>(&W.ncand[e]), ncand = info & 0xffff, ncon = 0;
+  // more contacts than MAXCON: one contact per pair (the first of its patch) for this substep, as collision() does in the fused step
+  int total = 0;
   for (int k0 = 0; k0 < ncand; k0 += WAVE) {
     int k = k0 + lane;
     size_t w = (size_t)e * MAXCAND + k;
     const float* r = W.conres + (W.conres_cap ? (size_t)(W.cbase[e] + k) : w) * CONRES_DIM;
     int cnt = k < ncand ? (int)pld<AG>(&r[0]) : 0;
+#pragma unroll
+    for (int b = 0; b < 3; b++) total += __popcll(wave_ballot((cnt >> b) & 1)) << b;
+  }
+  const bool reduced = total > MAXCON;
+  for (int k0 = 0; k0 < ncand; k0 += WAVE) {
+    int k = k0 + lane;
+    size_t w = (size_t)e * MAXCAND + k;
+    const float* r = W.conres + (W.conres_cap ? (size_t)(W.cbase[e] + k) : w) * CONRES_DIM;
+    int cnt = k < ncand ? (int)pld<AG>(&r[0]) : 0;
+    if (reduced && cnt > 1) cnt = 1;
     // exclusive prefix of the per-candidate contact counts (at most NCPP each): one ballot per possible count bit
     int idx = ncon, total = 0;
 #pragma unroll
@@ -164,6 +176,7 @@ DEV void gather_contacts(const DevModel* m, EnvLDS& L, const PipeBuffers& W, int
   if (lane == 0) {
     L.ncand = ncand; L.narmcon = 0;
     L.overflow |= info >> 16;
+    if (reduced) L.overflow |= 128;
     if (ncon > MAXCON) L.overflow |= 2;
     L.ncon = ncon > MAXCON ? MAXCON : ncon;
   }

@@ -21,11 +21,15 @@
 // Measured alternative (kept as policy G16, bit-identical results): one pair per DPP row of 16 lanes, four pairs per
 // wavefront.  It is SLOWER (4096-env bench 490-509 k against 635 k env-steps/s): ~70 % of a query's instructions are
 // the lane-parallel hull scans, not the uniform portal math.
-// Two instances.  ROWS = false (batches up to 8192 envs): three wavefronts per SIMD - 168 VGPRs, 13.3 KB of LDS, a pool of 1024 vertex slots.
-// ROWS = true (larger batches): with the row pass for the light region of the list (below), which needs the registers of two wavefronts per
-// SIMD; pool of 1536 slots.  Measured, round 5, env-steps/s at 4096 / 32768 envs: two waves, 1536 slots, no row pass 714 k / 996 k; with the
-// row pass 710 k / 1067 k; three waves, 1024 slots, no row pass 727 k / 1075 k; the register-cache kernel of round 4 727 k / 1038 k.
-template <bool ROWS> struct NarrowCfg { static constexpr int waves = ROWS ? 2 : 3, pool = ROWS ? 1536 : 1024; };
+// Two instances, both at two wavefronts per SIMD (no scratch, a pool of 1536 vertex slots): ROWS = false for batches up to 8192 envs, ROWS =
+// true - with the row pass for the light region of the list, below - for larger ones.  Measured, round 5, env-steps/s at 4096 / 32768 envs:
+// no row pass 737 k (light pairs two per fetch) / 996 k; row pass 722 k / 1078 k; the register-cache kernel of round 4: 727 k / 1038 k.  Three
+// wavefronts per SIMD (168 VGPRs, 1024 slots) gave 738 k at 4096 envs before the hull-against-hull patches existed and 656 k with them (137
+// spilled VGPRs instead of 41); NARROW_WAVES_SMALL = 3 builds that instance.
+#ifndef NARROW_WAVES_SMALL
+#define NARROW_WAVES_SMALL 2
+#endif
+template <bool ROWS> struct NarrowCfg { static constexpr int waves = ROWS ? 2 : NARROW_WAVES_SMALL, pool = (ROWS || NARROW_WAVES_SMALL == 2) ? 1536 : 1024; };
 
 DEV float item_f(unsigned int word, int i) { return __uint_as_float((unsigned int)__builtin_amdgcn_readlane((int)word, i)); }
 DEV int item_i(unsigned int word, int i) { return __builtin_amdgcn_readlane((int)word, i); }

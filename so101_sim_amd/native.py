@@ -19,7 +19,7 @@ DIAG_DIM = 8
 PS_DIM, PS_DELAY = 38, 15
 NEVENTS = 8
 EVENT_NAMES = ("candidate_overflow", "contact_overflow", "arm_pool_overflow", "diverged", "placement_rejected",
-               "settle_not_converged", "scheduler_abort")
+               "settle_not_converged", "scheduler_abort", "contacts_reduced")
 INFO = dict(graph_active=0, step_path=1, chains=2, hw_queues=3, scheduler_aborts=4, scratch_bytes=5)
 DEBUG_DIM = 2048
 MAXCON = 64

