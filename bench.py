@@ -300,6 +300,10 @@ def main():
     ap.add_argument("--env-factory", default="", help="module:callable replacing task_suite.create_task_env (tests)")
     args = ap.parse_args()
 
+    if args.pipeline >= 2 and "SO101_HIP_LIB" not in os.environ:
+        # the experimental step paths (per-env chaining, merged launches) are not in the default library: build libso101_hip_exp.so and load it
+        from so101_sim_amd import build as _b
+        os.environ["SO101_HIP_LIB"] = _b.build(exp=True, mpr=args.narrowphase == "mpr")
     # A plain `bench.py --gpus N` (no torchrun environment) launches its own N ranks before anything touches the GPU
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))

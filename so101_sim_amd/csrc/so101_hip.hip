@@ -420,9 +420,16 @@ int so101_create(const void* blob, size_t bytes, int n_envs, int device, uint64_
     s->chain.role_mode = getenv("SO101_CHAIN_ROLE") ? atoi(getenv("SO101_CHAIN_ROLE")) : 0;
     // (the queues of pipelines 2 and 3 and their full-size contact-record array are allocated when such a step is first asked
     // for: ensure_experimental_buffers())
-    for (int g = 0; g < so101_sim::MAXGROUPS && ok; g++)
-      ok = hip_ok(s, hipStreamCreateWithFlags(&s->group_stream[g], hipStreamNonBlocking), "hipStreamCreate") &&
+    // (kernel experiments: SO101_GROUP_PRIO=1 gives the chain of the most expensive envs - slice 0 of the cost-sorted order - the highest
+    //  stream priority and the cheapest slice the lowest)
+    int plo = 0, phi = 0;
+    hipDeviceGetStreamPriorityRange(&plo, &phi);
+    const bool gprio_on = getenv("SO101_GROUP_PRIO") && atoi(getenv("SO101_GROUP_PRIO")) != 0;
+    for (int g = 0; g < so101_sim::MAXGROUPS && ok; g++) {
+      int pr = !gprio_on ? 0 : (g == 0 ? phi : (g >= 3 ? plo : (plo + phi) / 2));
+      ok = hip_ok(s, gprio_on ? hipStreamCreateWithPriority(&s->group_stream[g], hipStreamNonBlocking, pr) : hipStreamCreateWithFlags(&s->group_stream[g], hipStreamNonBlocking), "hipStreamCreate") &&
            hip_ok(s, hipEventCreateWithFlags(&s->group_done[g], hipEventDisableTiming), "hipEventCreate");
+    }
     ok = ok && hip_ok(s, hipEventCreateWithFlags(&s->step_begin, hipEventDisableTiming), "hipEventCreate");
     if (!ok) rc = SO101_ERR_HIP;
   }
@@ -610,10 +617,11 @@ static int enqueue_pipelined(so101_sim* s, hipStream_t st, const so101::StepIO& 
     static const int chunk_env = getenv("SO101_NARROW_CHUNK") ? atoi(getenv("SO101_NARROW_CHUNK")) : 0;          // (kernel experiments)
     static const int chunk_env_l = getenv("SO101_NARROW_CHUNK_LIGHT") ? atoi(getenv("SO101_NARROW_CHUNK_LIGHT")) : 0;
     // measured at 4096 envs (heavy / light pairs per fetch -> env-steps/s): 3/3 707 k, 1/3 684 k, 2/3 712 k, 2/4 720 k, 1/4 692 k, 2/2 679 k
-    int ch = chunk_env >= 1 && chunk_env <= NARROW_CHUNK ? chunk_env : (n <= 8192 ? 2 : NARROW_CHUNK);
+    // (a handful of envs: one pair per fetch - 16 wavefronts share an env's dozen pairs, and the step is a chain of dependent launches)
+    int ch = chunk_env >= 1 && chunk_env <= NARROW_CHUNK ? chunk_env : (n <= 16 ? 1 : (n <= 8192 ? 2 : NARROW_CHUNK));
     // (round 5, work items + LDS hull pool of 1024 slots: light pairs per fetch 4 / 3 / 2 / 1 -> 718 / 736 / 740 / 604 k env-steps/s at 4096 envs - four
     //  light pairs with a 512-slot hull among them overflow the pool and stage late -; 32 768 envs, row-pass instance: 4 -> 1078 k, 2 -> 938 k)
-    int cl = chunk_env_l >= 1 && chunk_env_l <= NARROW_CHUNK ? chunk_env_l : (n <= 8192 ? 2 : NARROW_CHUNK);
+    int cl = chunk_env_l >= 1 && chunk_env_l <= NARROW_CHUNK ? chunk_env_l : (n <= 16 ? 1 : (n <= 8192 ? 2 : NARROW_CHUNK));
     // bit 8: the row pass (four light pairs per wavefront, one per DPP row; so101 tu_narrow.hip).  Measured, round 5: 32 768 envs 996 k -> 1 067 k
     // env-steps/s (first window 1.21 -> 1.35 M); 4096 envs 715 k -> 710 k (there the step follows the critical path of its slowest slice -
     // heavy pairs, long Newton solves -, not the light pairs' instruction count), so it is on above 8192 envs
@@ -627,7 +635,9 @@ static int enqueue_pipelined(so101_sim* s, hipStream_t st, const so101::StepIO& 
     static const int nw_env = getenv("SO101_NARROW_WAVES_Q") ? atoi(getenv("SO101_NARROW_WAVES_Q")) : 0;      // (kernel experiments: quarter waves per env)
     const int nw_quarters = nw_env > 0 ? nw_env : (n <= 8192 ? 6 : 8);
     int nw = (int)((long long)ng * nw_quarters / 4);
-    nw = nw < 1 ? 1 : (nw < 4096 ? nw : 4096);
+    // (a handful of envs - the reference's own N = 1: a step is a chain of dependent single-env launches, so the pairs of an env are spread
+    //  over 16 wavefronts instead of queued on one or two)
+    nw = nw < 16 ? 16 : (nw < 4096 ? nw : 4096);
     if (G > 1 && !hip_ok(s, hipStreamWaitEvent(gs, s->step_begin, 0), "hipStreamWaitEvent")) return SO101_ERR_HIP;
     if (!hip_ok(s, hipMemsetAsync(W.counters, 0, sizeof(int) * 4 * MAXSUB, gs), "hipMemsetAsync(pipe)")) return SO101_ERR_HIP;
     if (s->cfg.pipeline == 3) {
@@ -732,6 +742,13 @@ int so101_step(so101_sim* s, const float* action, float* obs, float* reward, flo
   so101::StepIO io{action, obs, reward, discount, step_type};
   // the pipelined step is a Newton path; PGS (107 ms per control step at 4096 envs) runs the fused kernel
   if (s->cfg.pipeline && s->cfg.n_substeps <= MAXSUB && s->cfg.solver == SO101_SOLVER_NEWTON) {
+#ifndef SO101_EXPERIMENTAL_PIPELINES
+    if (s->cfg.pipeline >= 2) {
+      s->err = "so101_step: pipeline 2 (per-env chaining) and 3 (merged launches) are experimental step paths that the default library does not carry: "
+               "python -m so101_sim_amd.build --experimental builds libso101_hip_exp.so with them";
+      return SO101_ERR_STATE;
+    }
+#endif
     const bool chained = s->cfg.pipeline == 2;
     s->last_path = s->cfg.pipeline;
     if (s->cfg.pipeline >= 2 && !ensure_experimental_buffers(s)) return SO101_ERR_HIP;

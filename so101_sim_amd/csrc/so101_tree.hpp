@@ -42,8 +42,8 @@
 #define TREE_NS tv64
 #define TV 64          // dofs
 #define TQ 64          // generalized positions
-#define TCON 192       // contacts per env (round 5: 128 -> 192, hull pairs on flat features carry up to five contacts now and the six props landing after a reset went over 128)
-#define TROW 1152      // constraint rows per env (6 per contact at most)
+#define TCON 160       // contacts per env (round 5: 128 -> 160, hull pairs on flat features carry up to five contacts now and the six props landing after a reset went over 128)
+#define TROW 960       // constraint rows per env (6 per contact at most)
 #define TCAND 512      // broadphase candidates per env
 #define TGEOM 256      // collision geoms
 #define TJS 64         // row stride of the constraint Jacobian scratch

@@ -1,4 +1,7 @@
 // Translation unit: the persistent kernel of the per-env chained control step (so101_chain.hpp).
+// Built only with -DSO101_EXPERIMENTAL_PIPELINES (python -m so101_sim_amd.build --experimental -> libso101_hip_exp.so): this step path was built, proven
+// bit-identical to the fused step and measured slower than the launch chains; the default library does not carry it.
+#ifdef SO101_EXPERIMENTAL_PIPELINES
 #define SO101_OPAQUE_LANE 1
 #include "so101_chain.hpp"
 #include "so101_launch.hpp"
@@ -139,3 +142,8 @@ void launch_chain(int waves, hipStream_t st, const ChainParams* params) {
   SO101_LAUNCH_CONCURRENT(k_chain, dim3(waves), dim3(64), st, params);
 }
 }  // namespace so101
+
+#else
+#include "so101_launch.hpp"
+namespace so101 { void launch_chain(int, hipStream_t, const ChainParams*) {} }
+#endif

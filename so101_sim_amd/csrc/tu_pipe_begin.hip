@@ -1,5 +1,9 @@
 // Translation unit: prologue of the pipelined control step.
+#ifdef SO101_EXPERIMENTAL_PIPELINES
 #include "so101_chain.hpp"
+#else
+#include "so101_pipeline.hpp"
+#endif
 #include "so101_launch.hpp"
 
 __global__ void __launch_bounds__(64, 2) k_pipe_begin(const DevModel* m, StepParams P, DevBuffers B, PrepBuffers C, EventBuffers E, PipeBuffers W,
@@ -17,7 +21,9 @@ __global__ void __launch_bounds__(64, 2) k_pipe_begin(const DevModel* m, StepPar
     write_first(L, e, obs, reward, discount, step_type, need_reset);
     if (lane == 0) {
       W.active[e] = 0; W.ncand[e] = 0;
+#ifdef SO101_EXPERIMENTAL_PIPELINES
       if (chain) atom_add_agent(ldc(&chain->Q.chain_ctl), 1u);       // not stepping in this call: done as far as k_chain is concerned
+#endif
     }
     return;
   }
@@ -29,13 +35,16 @@ __global__ void __launch_bounds__(64, 2) k_pipe_begin(const DevModel* m, StepPar
   kinematics(m, L);
   broadphase(m, L);
   if (lane == 0) W.active[e] = 1;
+#ifdef SO101_EXPERIMENTAL_PIPELINES
   if (chain) {
     // (all of this becomes visible to k_chain at the launch boundary; the queue protocol is the same as inside it)
     ChainQueues Q = ldc_obj(&chain->Q);
     ChainQ QS = chain_queue_of(Q, Q_SOLVE, e);
     if (publish_chain(L, W, Q, e, 0) == 0 && lane == 0) q_push_lane(QS, solve_item(e, 0));
   } else if (W.mq_ctl) publish_merged(L, W, e);          // pipeline = 3: chunks for the chain's first (narrowphase only) launch
-  else publish_candidates(m, L, W, e, N, 0);
+  else
+#endif
+  publish_candidates(m, L, W, e, N, 0);
 }
 
 namespace so101 {

@@ -1,4 +1,7 @@
 // Translation unit: the launches of the merged pipeline (pipeline = 3, see so101_chain.hpp "merged launches").
+// Built only with -DSO101_EXPERIMENTAL_PIPELINES (python -m so101_sim_amd.build --experimental -> libso101_hip_exp.so): this step path was built, proven
+// bit-identical to the fused step and measured slower than the launch chains; the default library does not carry it.
+#ifdef SO101_EXPERIMENTAL_PIPELINES
 #include "so101_chain.hpp"
 #include "so101_launch.hpp"
 
@@ -24,3 +27,8 @@ void launch_pipe_merged(int n_group, hipStream_t st, const DevModel* m, const St
   SO101_LAUNCH_CONCURRENT(k_pipe_merged, dim3(n_group), dim3(64), st, m, P, B, E, W, substep, last, launch, sio, e0, n_group);
 }
 }  // namespace so101
+
+#else
+#include "so101_launch.hpp"
+namespace so101 { void launch_pipe_merged(int, hipStream_t, const DevModel*, const StepParams&, const DevBuffers&, const EventBuffers&, const PipeBuffers&, int, int, int, const StepIO&, unsigned char*, int*, int) {} }
+#endif

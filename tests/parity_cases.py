@@ -235,13 +235,29 @@ def check_env_semantics(make_sim, blobs, n=2, settle=30, steps=8, last_step=7, s
         at_rest = abs(qo[8] - rest_z) < 2e-4 and np.abs(vo[6:]).max() < 2e-3
         # (the settle is a dynamic transient of drops/impacts: fp32 vs fp64 drift of up to 2 mm over hundreds of substeps
         # while the props still move; once at rest the poses agree to 1e-4 - measured 5e-7 .. 1.1e-4 on MI355X)
-        tol = 0.2 if ejected else (5e-4 if at_rest else 5e-3)
-        assert np.abs(q0[:, e] - qo).max() < tol, (e, np.abs(q0[:, e] - qo).max())
+        if ejected:
+            # (round 5, VERDICT r4 item 6: no blanket 0.2 m.)  The ejection itself is chaotic - WHERE the prop lands differs - but not WHAT happens:
+            # both copies are settled on (400 more substeps on copies of the two states, arm held by its actuators) and must then lie at rest on
+            # the same surface: heights within 2 mm of each other, speeds below 5e-2, and still within 0.2 m horizontally
+            s2 = make_sim(1, seed=seed, solver_iterations=iterations)
+            s2.set_state(q0[:, e:e + 1], v0[:, e:e + 1], np.zeros((6, 1)), np.zeros((18, 1)))
+            s2.physics(400)
+            qk, vk, _ = s2.get_state()
+            o2 = Oracle(blobs["f64"]); o2.set_solver(iterations, -1.0)
+            o2.set_state(qo, vo, np.zeros(18)); o2.set_ctrl(np.zeros(6)); o2.substeps(400)
+            qe, ve, _ = o2.get_state()
+            for b in (6, 13):          # object, container: x y z at qpos[b .. b + 2]
+                assert abs(qk[b + 2, 0] - qe[b + 2]) < 2e-3 and np.abs(qk[b:b + 2, 0] - qe[b:b + 2]).max() < 0.2, (e, b, qk[b:b + 3, 0], qe[b:b + 3])
+            assert np.abs(vk[6:, 0]).max() < 5e-2 and np.abs(ve[6:]).max() < 5e-2, (np.abs(vk[6:, 0]).max(), np.abs(ve[6:]).max())
+        else:
+            tol = 5e-4 if at_rest else 5e-3
+            assert np.abs(q0[:, e] - qo).max() < tol, (e, np.abs(q0[:, e] - qo).max())
         assert np.all(q0[:6, e] == 0)
         oracles.append(o)
     rng = np.random.RandomState(seed)
     undelayed_hist = []
     touched, deep = [False] * n, [False] * n          # the arm has been in (deep) contact during this episode
+    resynced = [0] * n                                # control step at which the oracle was put back on the kernel's state after a deep contact
     for t in range(1, steps + 1):
         act = rng.uniform(-0.4, 0.4, size=(n, 6)).astype(np.float32)
         obs, rew, disc, st = sim.step(act)
@@ -256,14 +272,23 @@ def check_env_semantics(make_sim, blobs, n=2, settle=30, steps=8, last_step=7, s
                 # A jaw driven > 1 cm into the 4 cm table slab sits near the slab's mid-plane, where the penetration
                 # direction flips from "up" to "down" (tunnelling): a discontinuity of any min-depth contact model, and
                 # fp32 / fp64 take different sides.  Joint trajectories are not compared for the rest of such an episode.
-                deep[e] = deep[e] or any(c["dist"] < -1e-2 for c in arm_con)
+                deep_now = any(c["dist"] < -1e-2 for c in arm_con)
+                if deep[e] and not deep_now:
+                    # (round 5) the deep contact is gone: the oracle continues from the KERNEL's state and the joint
+                    # comparison resumes - the delayed joints one delay line (5 control steps) later, the undelayed ones at once
+                    qk, vk, wk = sim.get_state()
+                    o.set_state(qk[:, e].astype(np.float64), vk[:, e].astype(np.float64), wk[:, e].astype(np.float64))
+                    deep[e], resynced[e] = False, t
+                    continue
+                deep[e] = deep[e] or deep_now
                 if deep[e]:
                     continue
                 # free-space arm: fp32 vs fp64 round-off only.  Once the arm pushes against the table or a prop, the
                 # joint trajectory depends on the contact phase (same bound as check_control_step)
                 tol = 5e-3 if touched[e] else 5e-5
                 np.testing.assert_allclose(obs[e, 6:12], oo[6:12], atol=tol)
-                np.testing.assert_allclose(obs[e, 0:6], oo[0:6], atol=tol)
+                if not resynced[e] or t > resynced[e] + 5:
+                    np.testing.assert_allclose(obs[e, 0:6], oo[0:6], atol=tol)
         undelayed_hist.append(obs[:, 6:12].copy())
         if t <= last_step:
             assert np.all(st == (2 if t == last_step else 1))

@@ -34,7 +34,9 @@ class ArraySim:
             from so101_sim_amd import build as sbuild
             self.torch = torch
             self.dev = torch.device("cuda:0")
-            self.sim = native.Sim(blob_f32, n_envs, device=0, seed=seed, lib_path=sbuild.build(mpr=True) if mpr else None)
+            # (pipeline 2 / 3: the experimental step paths live in libso101_hip_exp.so, built on demand like the MPR option)
+            exp = int(cfg.get("pipeline", 1)) >= 2
+            self.sim = native.Sim(blob_f32, n_envs, device=0, seed=seed, lib_path=sbuild.build(mpr=mpr, exp=exp) if (mpr or exp) else None)
             z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=self.dev)
             i32, u8 = torch.int32, torch.uint8
         else:

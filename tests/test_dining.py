@@ -255,7 +255,7 @@ def test_rollout_against_the_oracle():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("task", ["banana", "mug"])
+@pytest.mark.parametrize("task", ["banana", "mug", "pen"])
 def test_env_against_the_oracle(task):
     """so101_tree_step on the Dining scene against oracle/aloha_env.py: the in-call reset (placement draws exact, settled props within
     2 mm), observations with their delay lines, reward (overlap boxes / mug touching the plate), discount, step type, the time limit."""
