@@ -370,6 +370,11 @@ __global__ void __launch_bounds__(64, TREE_SOLVE_OCC) k_tree_pipe_solve(const Tr
     }
     return;
   }
+  if (act == 2) {
+    // diverged in an earlier substep: this launch computed nothing, the diagnostics are those of the last substep that was
+    if (lane == 0) { L.nrow = P.pdiag[4 * e]; L.iters = P.pdiag[4 * e + 1]; L.ncon = P.pdiag[4 * e + 2]; L.ncand = P.pdiag[4 * e + 3]; }
+    wave_sync();
+  }
   tree_finish_step<0>(tm, gm, T, L, G, B, E, e, diverged, obs, reward, discount, step_type);
 }
 

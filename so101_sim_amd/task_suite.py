@@ -114,6 +114,7 @@ def create_task_env(
     if isinstance(task_instance, _aloha.HandOverTask):
         env_kwargs.pop("solver", None)                    # (a knob of the SO100 kernels only)
         return _aloha.AlohaEnvironment(task_instance, n_envs=n_envs, time_limit=time_limit, random_state=random_state, **env_kwargs)
+    env_kwargs.pop("pipeline", None)                   # (a knob of the general-tree engine's env; the SO100 step path is chosen with env.sim.configure(pipeline=...))
     if n_envs == 1:
         return _env.SingleEnvironment(task_instance, time_limit=time_limit, random_state=random_state, **env_kwargs)
     env_kwargs.pop("seed_compatible", None)            # (single envs only: batches key the kernels' counter RNG)
