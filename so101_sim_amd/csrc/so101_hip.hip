@@ -58,6 +58,7 @@ struct so101_sim {
   // reset prefetch: cache of settled initial states, filled by k_prepare on a low-priority side stream
   PrepBuffers prep{};
   hipStream_t prep_stream = nullptr;
+  int prep_scan = 0;                       // next slice of the second look-ahead (launch_prepare)
   hipEvent_t prep_done = nullptr, main_ev = nullptr;
   bool prep_pending = false;
   int prep_waves = 0;
@@ -319,7 +320,15 @@ void launch_prepare(so101_sim* s, hipStream_t stream, bool wide = false) {
   // env - at the width of the machine (0.8 s for 4096 envs) instead of 256 wavefronts beside the first ~600 control steps, during
   // which every env whose physics diverged had to settle inside the step call (130 ms for the whole batch each time)
   int waves = wide ? (s->n_envs < 2048 ? s->n_envs : 2048) : s->prep_waves;
-  so101::launch_prepare(waves, s->prep_stream, s->dm, make_params(s), s->buf, s->prep);
+  // (the second look-ahead in slices - PrepBuffers::scan_first / scan_count, SO101_PREP_SLICE=<envs> - was measured in round 5: it removes the
+  //  ~2 s that a device-wide synchronise right after a mass reset waits for the refill - `bench.py --steps 500` reads 388 k on the host clock
+  //  against 666 k on the device's - but four or eight launches with their own tails do not finish the refill of 4096 envs within an episode
+  //  beside the steps, and envs then settle inside step calls: 1500 steps 627 k -> 590 k (1024-env slices) / 503 k (512).  One launch stays.)
+  PrepBuffers C = s->prep;
+  static const int prep_slice = getenv("SO101_PREP_SLICE") ? atoi(getenv("SO101_PREP_SLICE")) : 0;
+  if (!wide && prep_slice > 0 && s->n_envs > prep_slice) { C.scan_first = s->prep_scan; C.scan_count = prep_slice; s->prep_scan = (s->prep_scan + prep_slice) % s->n_envs; }
+  else { C.scan_first = 0; C.scan_count = 0; }
+  so101::launch_prepare(waves, s->prep_stream, s->dm, make_params(s), s->buf, C);
   if (hipEventRecord(s->prep_done, s->prep_stream) == hipSuccess) s->prep_pending = true;
 }
 

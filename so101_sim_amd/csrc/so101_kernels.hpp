@@ -17,7 +17,8 @@ __global__ void __launch_bounds__(64, 2) k_prepare(const DevModel* m, StepParams
     int e = 0;
     if (lane == 0) e = atomicAdd(C.cursor + ahead, 1);
     e = wave_uniform_i(e);
-    if (e >= N) break;
+    if (ahead == 0 || C.scan_count <= 0) { if (e >= N) break; }
+    else { if (e >= C.scan_count) break; e = (int)(((unsigned int)C.scan_first + (unsigned int)e) % (unsigned int)N); }
     // an entry is only overwritten when its episode lies behind the env's counter, i.e. after env_reset() has consumed it
     // (the counter is bumped after the entry has been read)
     int next = __atomic_load_n(&B.episode[e], __ATOMIC_ACQUIRE);

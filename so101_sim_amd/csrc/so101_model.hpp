@@ -162,6 +162,9 @@ struct PrepBuffers {
   const float *store_qpos, *store_qvel, *store_warm;   // [store_count][NQ|NV|NV][n_envs]
   const int* store_flags;                               // [store_count][n_envs]
   int store_first, store_count;
+  // k_prepare, second look-ahead (the episode after the next one): envs scan_first .. scan_first + scan_count - 1 (mod n_envs) of this launch;
+  // scan_count = 0: all envs (the default: slices were measured slower, so101_hip.hip launch_prepare)
+  int scan_first, scan_count;
 };
 
 // Event accounting (so101_get_events): flags[e] ORs the per-substep flag words of env e within one control step;

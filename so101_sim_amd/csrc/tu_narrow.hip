@@ -69,6 +69,9 @@ __global__ void __launch_bounds__(64, NarrowCfg<ROWS>::waves) k_narrow(const Dev
     i0 = wave_uniform_i(i0);
     if (i0 >= nwork) break;
     last_i0 = i0;
+#ifdef SO101_PRIO_EXP      // (kernel experiment: heavy pairs issue ahead of the SIMD's other wavefront)
+    if (i0 < nheavy) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+#endif
     const int cnt = nwork - i0 < chunk ? nwork - i0 : chunk;
     // ---- the items: word `lane` of item j in it[j]
     unsigned int it[NARROW_CHUNK];

@@ -33,6 +33,9 @@ __global__ void __launch_bounds__(64, 2) k_pipe_solve(const DevModel* m, StepPar
                                                    unsigned char* need_reset, int* diag, int e0) {
   __shared__ EnvLDS L;
   int e = wave_uniform_i(W.order[e0 + blockIdx.x]);
+#ifdef SO101_PRIO_EXP      // (kernel experiment: the envs that were expensive in the previous step - first in the launch order - issue ahead of their SIMD's other wavefront)
+  if (blockIdx.x < gridDim.x / SO101_PRIO_EXP) __builtin_amdgcn_s_setprio(3);
+#endif
   int act = W.active[e];
   if (act == 0) return;
   SolveIO io{obs, reward, discount, step_type, need_reset, diag};
