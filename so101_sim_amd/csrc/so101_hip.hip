@@ -436,16 +436,8 @@ int so101_create(const void* blob, size_t bytes, int n_envs, int device, uint64_
     const bool gprio_on = getenv("SO101_GROUP_PRIO") && atoi(getenv("SO101_GROUP_PRIO")) != 0;
     for (int g = 0; g < so101_sim::MAXGROUPS && ok; g++) {
       int pr = !gprio_on ? 0 : (g == 0 ? phi : (g >= 3 ? plo : (plo + phi) / 2));
-      // (kernel experiments: SO101_GROUP_CUMASK=<CUs per chain> pins chain g to CUs [g * k, (g + 1) * k) - kernels of different chains then never share a
-      //  CU or its instruction cache; plain launches only, a graph replay does not keep the masks)
-      const int cumask = getenv("SO101_GROUP_CUMASK") ? atoi(getenv("SO101_GROUP_CUMASK")) : 0;
-      if (cumask > 0 && g < 4) {
-        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int c = g * cumask; c < (g + 1) * cumask && c < 256; c++) mask[c / 32] |= 1u << (c % 32);
-        ok = hip_ok(s, hipExtStreamCreateWithCUMask(&s->group_stream[g], 8, mask), "hipExtStreamCreateWithCUMask") &&
-             hip_ok(s, hipEventCreateWithFlags(&s->group_done[g], hipEventDisableTiming), "hipEventCreate");
-        continue;
-      }
+      // (measured in round 5 and removed again: the chains pinned to disjoint sets of 64 CUs by hipExtStreamCreateWithCUMask - kernels of different
+      //  chains then never share a CU or its instruction cache - ran at 459 k against 666 k env-steps/s without graph replay; 48 and 32 CUs 283 / 281 k)
       ok = hip_ok(s, gprio_on ? hipStreamCreateWithPriority(&s->group_stream[g], hipStreamNonBlocking, pr) : hipStreamCreateWithFlags(&s->group_stream[g], hipStreamNonBlocking), "hipStreamCreate") &&
            hip_ok(s, hipEventCreateWithFlags(&s->group_done[g], hipEventDisableTiming), "hipEventCreate");
     }

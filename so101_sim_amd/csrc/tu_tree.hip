@@ -306,7 +306,10 @@ __global__ void __launch_bounds__(64) k_tree_pipe_begin(const TreeModel* tm, con
 }
 
 // one wavefront per candidate pair of the whole batch: persistent wavefronts take two work items per fetch
+// (round 5: the hulls of a pair are staged in LDS - so101_device.hpp, HullLDS - instead of held in 48 VGPRs; with the hull patches inlined the register
+//  cache left this kernel 55 spilled VGPRs and 184 B of scratch per lane)
 __global__ void __launch_bounds__(64, 2) k_tree_narrow(const TreeModel* tm, const DevModel* gm, TreePipe P, int N, int s) {
+  __shared__ __attribute__((aligned(16))) float pool[3 * 2 * HULL_LDS_MAX];
   int lane = wave_lane();
   const int nwork = ldc(&P.counters[2 * s]);
   const unsigned int* list = P.work + (size_t)(s & 1) * P.work_cap;
@@ -327,7 +330,11 @@ __global__ void __launch_bounds__(64, 2) k_tree_narrow(const TreeModel* tm, cons
       GeomW G1, G2;
       load_geom_at(gm, g1, p1, p1 + 3, G1); load_geom_at(gm, g2, p2, p2 + 3, G2);
       PairContacts pc;
-      narrow_pair<HullCache, G64>(gm, G1, G2, g1, g2, pc);
+      HullLDS H1{pool, hull_lds_slots(G1.type, G1.vnum)}, H2{pool + 3 * HULL_LDS_MAX, hull_lds_slots(G2.type, G2.vnum)};
+      wave_sync();                                     // (the scans of the previous pair are done)
+      hull_load(gm, G1, H1); hull_load(gm, G2, H2);
+      wave_sync();
+      narrow_pair_cached<HullLDS, G64>(gm, G1, G2, ldc(ldc(&gm->geom_rbound) + g1), ldc(ldc(&gm->geom_rbound) + g2), H1, H2, pc);
       if (lane == 0) {
         float* r = P.rec + (size_t)w * TREC;
         r[0] = (float)__popc(pc.valid); r[1] = pc.nrm[0]; r[2] = pc.nrm[1]; r[3] = pc.nrm[2];
