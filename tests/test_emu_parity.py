@@ -37,7 +37,7 @@ def test_reward_bitexact(make_sim, blobs):
 
 
 def test_env_semantics(make_sim, blobs):
-    pc.check_env_semantics(make_sim, blobs, n=1, settle=6, steps=4, last_step=3, iterations=10)     # full delay-line wrap: GPU suite
+    pc.check_env_semantics(make_sim, blobs, n=1, settle=6, steps=4, last_step=3, iterations=10, eject_substeps=0)     # full delay-line wrap: GPU suite
 
 
 @SLOW
