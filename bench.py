@@ -205,8 +205,13 @@ def run_aloha(args, torch, sdist, dev, rank, world, hbm_measured):
     dining = args.workload == "dining"
     N = args.envs_per_gpu or (1024 if dining else 4096)
     task_name = "DiningPlaceBananaInBowl" if dining else "HandOverBanana"
-    env = task_suite.create_task_env(task_name, time_limit=10.0, random_state=0, n_envs=N, device=dev, narrowphase=args.narrowphase,
-                                     env_id_base=sdist.shard_base(rank, N), solver_iterations=args.solver_iterations, solver_tolerance=args.solver_tolerance)
+    on_gpu = args.device == "cuda"
+    sync = (lambda: torch.cuda.synchronize(dev)) if on_gpu else (lambda: None)
+    if args.env_factory:            # tests: a stub env (tests/bench_stub.py) in place of the GPU env, gloo ranks on CPU
+        env = resolve_factory(args.env_factory)(task_name, N, sdist.shard_base(rank, N), dev, workload=args.workload)
+    else:
+        env = task_suite.create_task_env(task_name, time_limit=10.0, random_state=0, n_envs=N, device=dev, narrowphase=args.narrowphase,
+                                         env_id_base=sdist.shard_base(rank, N), solver_iterations=args.solver_iterations, solver_tolerance=args.solver_tolerance)
     if args.settled_store:          # placement + settle of the episodes the run will start, done once before anything is timed
         t_store = time.perf_counter(); env.compute_settled(2 + (args.warmup + args.steps) // 500); t_store = time.perf_counter() - t_store
     env.reset()
@@ -218,13 +223,13 @@ def run_aloha(args, torch, sdist, dev, rank, world, hbm_measured):
     tape = torch.clamp(home + 0.5 * (torch.rand(total, N, 14, device=dev, generator=gen) - 0.5), lo, hi)     # actions resident in HBM
     for k in range(args.warmup):
         env.step_tensor(tape[k])
-    sdist.barrier(); torch.cuda.synchronize(dev)
+    sdist.barrier(); sync()
     t0 = time.perf_counter()
     reward_sum = torch.zeros((), device=dev)
     for k in range(args.steps):
         _, r, _, _ = env.step_tensor(tape[args.warmup + k])
         reward_sum += r.sum()
-    sdist.barrier(); torch.cuda.synchronize(dev)
+    sdist.barrier(); sync()
     elapsed = sdist.max_over_ranks(time.perf_counter() - t0, dev)
     d = env.diagnostics().cpu().numpy()
     all_returns = sdist.all_gather_returns(env.episode_returns())

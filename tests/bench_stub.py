@@ -49,5 +49,39 @@ class StubEnv:
         return self.ret.clone()
 
 
+class _TreeSim:
+    nq, nv, build = 30, 28, 32
+
+
+class TreeStubEnv(StubEnv):
+    """stands in for AlohaEnvironment (`bench.py --workload aloha | dining`): 14 action dimensions, step_tensor returns the four outputs"""
+    def __init__(self, name, n_envs, env_id_base, device, **kw):
+        super().__init__(name, n_envs, env_id_base, device, **kw)
+        self.sim = _TreeSim()
+
+    def action_spec(self):
+        class S:
+            minimum = -np.ones(14, np.float32) * 3.0
+            maximum = np.ones(14, np.float32) * 3.0
+        return S()
+
+    def reset(self):
+        self.ret.zero_()
+
+    def step_tensor(self, act):
+        assert act.shape == (self.n_envs, 14)
+        time.sleep(self.delay)
+        self.ret += self.ids
+        return self.obs, self.reward, torch.ones(self.n_envs), self.step_type
+
+    def launch_plan(self):
+        return {"path": "stub", "slices": 1, "kernel_launches": 1, "memsets": 0}
+
+    def close(self):
+        pass
+
+
 def make(name, n_envs, env_id_base, device, **kw):
+    if kw.get("workload") in ("aloha", "dining"):
+        return TreeStubEnv(name, n_envs, env_id_base, device, **kw)
     return StubEnv(name, n_envs, env_id_base, device, **kw)

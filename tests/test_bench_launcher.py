@@ -54,3 +54,18 @@ def test_single_rank_line_has_the_contract_keys():
         assert k in out
     assert out["dist"] == {"backend": None, "world_size": 1, "ranks_reporting": 1, "ranks": [0], "per_rank": out["dist"]["per_rank"]}
     assert out["n_gpus"] == 1 and out["vs_baseline"] is None and out["scaling"] == "weak"
+
+
+def test_tree_workload_with_two_ranks_prints_its_line():
+    """`bench.py --workload aloha --gpus 2` (the process-group evidence is a collective and was called by rank 0 only - rank 0 then hung):
+    the real run_aloha with two gloo ranks and a stub env; one line, both ranks in `dist`, the whole-job value from the slower rank's time."""
+    r = _run(["--workload", "aloha", "--gpus", "2", "--steps", "3", "--warmup", "1", "--envs-per-gpu", "8"], timeout=180)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(line) == 1, r.stdout
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_envs"] == 16 and out["ms_per_step"] >= 30.0 * 0.9
+    d = out["dist"]
+    assert d["backend"] == "gloo" and d["world_size"] == 2 and d["ranks"] == [0, 1] and len(d["per_rank"]) == 2
+    assert abs(out["value"] - 16 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    assert abs(out["mean_episode_return"] - 4 * 7.5) < 1e-4
