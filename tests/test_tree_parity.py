@@ -385,6 +385,10 @@ def _scripted_states(raw64, which, n):
     return np.array(Q).T, np.array(V).T
 
 
+MAX_END_GAP = 0          # control steps between the kernel's and the oracle's episode end: the SAME step since hull pairs carry patches (round 5; measured 0 on all eight drops; 3 until round 4)
+END_GAPS = []            # ... as measured by the last calls (printed by the GPU test)
+
+
 def check_contact_reward(backend, which, requires_handover, n, steps, n_substeps=10):
     from oracle.aloha_env import AlohaOracleEnv
     from so101_sim_amd.model import blob as blobfmt
@@ -406,9 +410,9 @@ def check_contact_reward(backend, which, requires_handover, n, steps, n_substeps
     a = np.tile(np.concatenate([scenes.ALOHA_HOME_CTRL] * 2), (n, 1))
     a[:, 6] = a[:, 13] = -0.06135                            # grippers closed (FOLLOWER_GRIPPER_CLOSE)
     # Step by step (reward, discount, step type) and the state of the sequence must be EQUAL while both episodes run.  The success itself
-    # is gated by "linear velocity < 1e-3" and by a hull-on-hull touch that comes and goes while the object finishes settling (single
-    # contact points per hull pair): fp32 and fp64 may pass that gate a few control steps apart - the episode must end on both sides with
-    # the same reward, discount and step type, at most 3 control steps apart.
+    # is gated by "linear velocity < 1e-3" and by the object touching the container.  Until round 4 (one contact point per hull pair: a touch that
+    # came and went while the object finished settling) fp32 and fp64 passed that gate up to three control steps apart; with the hull pairs'
+    # patches the episode ends on the same control step on both sides, with the same reward, discount and step type (MAX_END_GAP).
     k_last, o_last = np.full(n, -1), np.full(n, -1)
     k_out, o_out = [None] * n, [None] * n
     seen_states, rewards = set(), np.zeros(n)
@@ -433,8 +437,9 @@ def check_contact_reward(backend, which, requires_handover, n, steps, n_substeps
     for e in range(n):
         assert (k_last[e] >= 0) == (o_last[e] >= 0) or steps - 1 - max(k_last[e], o_last[e]) < 3, (e, k_last[e], o_last[e])
         if k_last[e] >= 0 and o_last[e] >= 0:
-            assert abs(k_last[e] - o_last[e]) <= 3 and k_out[e] == o_out[e], (e, k_last[e], o_last[e], k_out[e], o_out[e])
+            assert abs(k_last[e] - o_last[e]) <= MAX_END_GAP and k_out[e] == o_out[e], (e, k_last[e], o_last[e], k_out[e], o_out[e])
     done = k_last >= 0
+    END_GAPS.extend(int(abs(k_last[e] - o_last[e])) for e in range(n) if k_last[e] >= 0 and o_last[e] >= 0)
     return seen_states, rewards, done
 
 
@@ -449,6 +454,7 @@ def test_contact_sequence_reward_against_the_oracle():
     # the object dropped into the bowl: the default sequence (starting in its last state) pays once the object rests there
     seen, rewards, done = check_contact_reward("gpu", "in_bowl", False, 8, 120)
     assert seen == {2} and done.sum() >= 6 and np.all(rewards[done] == 1.0), (seen, rewards, done)
+    print("contact-sequence reward, episode ends kernel vs oracle (control steps apart):", END_GAPS)
     # the same with reward_requires_handover: no gripper ever touches the object, the sequence stays in state 0 and nothing is paid
     seen, rewards, done = check_contact_reward("gpu", "in_bowl", True, 4, 60)
     assert seen == {0} and rewards.sum() == 0 and not done.any()
