@@ -610,7 +610,10 @@ static int enqueue_pipelined(so101_sim* s, hipStream_t st, const so101::StepIO& 
     bounds[++G] = n;
   }
 #endif
-  so101::launch_order(st, s->pipe.cost, s->pipe.order, s->chain_cls, n);
+  // (equal slices - four chains - get the sorted envs dealt out, tu_pipe_solve.hip k_order; the three unequal slices keep the plain sorted order)
+  bool equal_slices = G > 1;
+  for (int g = 0; g < G && equal_slices; g++) equal_slices = bounds[g + 1] - bounds[g] == n / G;
+  so101::launch_order(st, s->pipe.cost, s->pipe.order, s->chain_cls, n, equal_slices && n % G == 0 ? G : 1);
   LAUNCH_CHECK(s, "k_order");
   if (G > 1 && !hip_ok(s, hipEventRecord(s->step_begin, st), "hipEventRecord")) return SO101_ERR_HIP;
   for (int g = 0; g < G; g++) {

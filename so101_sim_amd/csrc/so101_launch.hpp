@@ -27,7 +27,7 @@ void launch_begin(int n_envs, hipStream_t st, const DevModel* m, const StepParam
 void launch_reward(int n_envs, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B, float* reward);
 
 // pipelined step (Newton) -----------------------------------------------------------------------------------------
-void launch_order(hipStream_t st, const unsigned int* cost, int* order, unsigned char* cls, int n_envs);
+void launch_order(hipStream_t st, const unsigned int* cost, int* order, unsigned char* cls, int n_envs, int deal = 1);   // deal: equal slices the sorted envs are dealt to (1 = plain sorted order)
 void launch_pipe_begin(int n_group, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B, const PrepBuffers& C,
                        const EventBuffers& E, const PipeBuffers& W, const StepIO& io, unsigned char* need_reset, int* diag, int e0,
                        const ChainParams* chain = nullptr);

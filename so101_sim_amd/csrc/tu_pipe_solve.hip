@@ -6,7 +6,7 @@
 // counts: mean 2.7, max ~19) and workgroups are dispatched in index order, so envs that were expensive in the
 // previous control step go first: counting sort of the group's envs by log2(cost), descending.  The order only
 // changes WHEN an env is processed, never its result.  One workgroup for the whole batch.
-__global__ void __launch_bounds__(1024) k_order(const unsigned int* cost, int* order, unsigned char* cls, int e0, int ng) {   // e0 = 0, ng = N
+__global__ void __launch_bounds__(1024) k_order(const unsigned int* cost, int* order, unsigned char* cls, int e0, int ng, int deal) {   // e0 = 0, ng = N
   __shared__ int hist[32], start[32];
   int t = threadIdx.x;
   if (t < 32) hist[t] = 0;
@@ -23,7 +23,11 @@ __global__ void __launch_bounds__(1024) k_order(const unsigned int* cost, int* o
     unsigned int c = cost[e0 + i];
     int b = c ? __clz((int)c) : 31;
     int pos = atomicAdd(&start[b], 1);
-    order[e0 + pos] = e0 + i;
+    // deal > 1 (round 5): the sorted envs are DEALT to `deal` equal slices - sorted position p goes to slice p % deal, place p / deal - so that every
+    // launch chain gets the same mix of expensive and cheap envs, each slice still most expensive first.  With the sorted order cut into
+    // contiguous quarters one chain held all the long Newton solves and heavy pairs: 729 -> 738 k env-steps/s at 4096 envs (first window
+    // 779 -> 800 k; 1500 steps 627 -> 634 k on the device clock; 32 768 envs unchanged)
+    order[e0 + (deal > 1 ? (pos % deal) * (ng / deal) + pos / deal : pos)] = e0 + i;
     cls[e0 + i] = pos < ng / 8 ? 1 : 0;        // the expensive eighth: served first by the chained step (so101_chain.hpp)
   }
 }
@@ -49,8 +53,8 @@ __global__ void __launch_bounds__(64, 2) k_pipe_solve(const DevModel* m, StepPar
 }
 
 namespace so101 {
-void launch_order(hipStream_t st, const unsigned int* cost, int* order, unsigned char* cls, int n_envs) {
-  hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, cost, order, cls, 0, n_envs);
+void launch_order(hipStream_t st, const unsigned int* cost, int* order, unsigned char* cls, int n_envs, int deal) {
+  hipLaunchKernelGGL(k_order, dim3(1), dim3(1024), 0, st, cost, order, cls, 0, n_envs, deal);
 }
 void launch_pipe_solve(int n_group, hipStream_t st, const DevModel* m, const StepParams& P, const DevBuffers& B, const EventBuffers& E,
                        const PipeBuffers& W, int substep, int last, const StepIO& io, unsigned char* need_reset, int* diag, int e0) {
