@@ -5,7 +5,7 @@ import numpy as np, torch
 from so101_sim_amd.model import scenes
 from tests.simharness import ArraySim
 raw32, meta = scenes.load_blob("banana", "f32")
-N = 4096
+N = int(os.environ.get("STAGES_N", "4096"))
 s = ArraySim(raw32, N, backend="gpu", seed=0, settle_max_substeps=300, last_step=100000, prefetch_resets=0)
 s.reset()
 lo = np.array([-np.pi, -3.14158, -3.14158, -3.14158, -3.14158, 0.0], dtype=np.float32)

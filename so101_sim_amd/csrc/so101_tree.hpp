@@ -67,6 +67,10 @@
 #define TREE_CHOL_DEV DEV
 #endif
 
+#ifndef TREE_DIM_T
+#define TREE_DIM_T unsigned char     // per-contact row counts (0-6) in LDS
+#endif
+
 namespace TREE_NS {
 
 enum { TJ_NONE = 0, TJ_HINGE = 1, TJ_FREE = 2, TJ_SLIDE = 3 };
@@ -99,9 +103,15 @@ struct TreeBuffers { float *qpos, *qvel, *ctrl, *warm; float* scratch; int* diag
 // Per-env working set that does not fit the LDS budget (occupancy is bounded by LDS here): the constraint Jacobian, the per-row
 // vectors of the solver and the contacts' Hessian blocks.  Written and read by the env's own wavefront only (through the CU's L1).
 #define T_SCRATCH (TROW * TJS + 8 * TROW + TCON * 36)       // floats per env
+// Row stride of the Jacobian rows kept in LDS: TJS + 1.  The passes with lane = row (residuals J x, J search, reference accelerations) read column d
+// of 64 different rows at once; with a stride of TJS = 32 words all of them fall on ONE bank (64-way conflict, 64 cycles per ds_read), with 33 they
+// spread over all 32 (round 5).  Rows in the global scratch keep TJS (whole 128 / 256-byte lines per row).
+#undef TJL
+#define TJL (TJS + 1)
 struct TreeScratch {
   float* global_base;              // the env's slice of the global scratch (the pointers below may point into LDS instead, see use_row_storage)
-  float* J;                        // [TROW][TJS]
+  float* J;                        // [TROW][js]
+  int js;                          // row stride of J: TJS in the global scratch, TJL in LDS
   float *eD, *eR, *earef, *efl, *ejar, *ef, *ejv;   // [TROW] each
   unsigned int* etype;             // [TROW]
   float (*Hc)[36];                 // [TCON]
@@ -122,18 +132,27 @@ struct TreeLDS {
       float rw[TB][3], ral[TB][3], rao[TB][3], rf[TB][3], rn[TB][3];      // RNE
     };
     struct { float aabb[6][TGEOM]; unsigned int cand[TCAND]; };   // collision: world boxes of the geoms, candidate pairs
-    struct { float xJ[(TRL ? TRL : 1) * TJS]; float xv[8 * (TRL ? TRL : 1)]; };      // constraints + solver: the rows' Jacobian and per-row vectors (nrow <= TRL)
+    struct { float xJ[(TRL ? TRL : 1) * TJL]; float xv[8 * (TRL ? TRL : 1)]; };      // constraints + solver: the rows' Jacobian (row stride TJL) and per-row vectors (nrow <= TRL)
   };
   float M[TV][TV + 1];
   union { float L[TV][TV + 1]; float H[TV][TV + 1]; };  // factor of M (until qacc_smooth is known), then the Newton Hessian / M + h D
   TCon con[TCON];
-  float hJ[6][TV], hT[6][TV];       // Hessian assembly: one contact's Jacobian columns compacted to the dofs it touches, and Hc J
-  int hdl[TV];                      // ... the dof of each compacted slot
-  float x[TV], grad[TV], search[TV], Ma[TV], Mv[TV], tmp[TV], xs[TV];
-  int cdim[TCON + 1];
-  int hdim[TCON];                  // Newton: rows of the contact's Hessian block, 0 when the block is inactive
+  unsigned long long bdofs[TB];     // tm->body_dofs, copied by make_constraints(): the per-contact loops index it by the contact's bodies (round 5: a global load per contact before)
+  float x[TV], grad[TV], search[TV], Ma[TV], tmp[TV];
+  TREE_DIM_T cdim[TCON + 1];
+  TREE_DIM_T hdim[TCON];           // Newton: rows of the contact's Hessian block, 0 when the block is inactive
   int ncand, ncon, nrow, nscalar, iters, flags;
+#ifdef TREE_PROF
+  unsigned int prof[32];            // (profiling variant, scripts/gpu_tree_prof.py: phase clocks of a substep, 10 ns ticks)
+#endif
 };
+#ifdef TREE_PROF
+#define TPROF_T0() unsigned long long tp_ = wall_clock64()
+#define TPROF(k) { unsigned long long tn_ = wall_clock64(); if (wave_lane() == 0) L.prof[k] += (unsigned int)(tn_ - tp_); tp_ = tn_; }
+#else
+#define TPROF_T0()
+#define TPROF(k)
+#endif
 
 namespace tree {
 
@@ -141,7 +160,7 @@ DEV TreeScratch scratch_of(const TreeBuffers& B, int e) {
   float* base = B.scratch + (size_t)e * T_SCRATCH;
   TreeScratch G;
   G.global_base = base;
-  G.J = base; base += TROW * TJS;
+  G.J = base; G.js = TJS; base += TROW * TJS;
   G.eD = base; G.eR = base + TROW; G.earef = base + 2 * TROW; G.efl = base + 3 * TROW; G.ejar = base + 4 * TROW; G.ef = base + 5 * TROW; G.ejv = base + 6 * TROW;
   G.etype = (unsigned int*)(base + 7 * TROW); base += 8 * TROW;
   G.Hc = (float (*)[36])base;
@@ -174,20 +193,33 @@ DEV void kinematics(const TreeModel* tm, TreeLDS& L) {
     L.xipos[0][0] = L.xipos[0][1] = L.xipos[0][2] = 0.f;
   }
   wave_sync();
-  for (int level = 1; level <= tm->maxdepth; level++) {
-    if (lane > 0 && lane < nb && tm->body_depth[lane] == level) {
-      int b = lane, p = tm->body_parent[b], jt = tm->body_jnttype[b], qa = tm->body_qposadr[b];
+  // the body's constants once, in front of the level loop (round 5: inside it every level began with a round trip to the model tables)
+  const bool has = lane > 0 && lane < nb;
+  const int b = has ? lane : 0;
+  const int depth = has ? tm->body_depth[b] : -1, p = tm->body_parent[b], jt = tm->body_jnttype[b], qa = tm->body_qposadr[b];
+  float bpos[3], bquat[4], bipos[3], im[9], ax[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 3; i++) { bpos[i] = tm->body_pos[b][i]; bipos[i] = tm->body_ipos[b][i]; }
+#pragma unroll
+  for (int i = 0; i < 4; i++) bquat[i] = tm->body_quat[b][i];
+  quat2mat(im, tm->body_iquat[b]);
+  if (jt == TJ_HINGE || jt == TJ_SLIDE) {
+    const float* a = tm->jnt_axis[tm->body_jnt[b]];
+    ax[0] = a[0]; ax[1] = a[1]; ax[2] = a[2];
+  }
+  const int maxdepth = tm->maxdepth;
+  for (int level = 1; level <= maxdepth; level++) {
+    if (depth == level) {
       float xp[3], xq[4];
       if (jt == TJ_FREE) {
         xp[0] = L.qpos[qa]; xp[1] = L.qpos[qa + 1]; xp[2] = L.qpos[qa + 2];
         xq[0] = L.qpos[qa + 3]; xq[1] = L.qpos[qa + 4]; xq[2] = L.qpos[qa + 5]; xq[3] = L.qpos[qa + 6];
         normquat(xq);
       } else {
-        float t[3]; matvec3(t, L.xmat[p], tm->body_pos[b]);
+        float t[3]; matvec3(t, L.xmat[p], bpos);
         xp[0] = L.xpos[p][0] + t[0]; xp[1] = L.xpos[p][1] + t[1]; xp[2] = L.xpos[p][2] + t[2];
-        mulquat(xq, L.xquat[p], tm->body_quat[b]);
+        mulquat(xq, L.xquat[p], bquat);
         if (jt == TJ_HINGE) {
-          const float* ax = tm->jnt_axis[tm->body_jnt[b]];
           float sn, cs; sincos_f(0.5f * L.qpos[qa], &sn, &cs);
           float jq[4] = {cs, ax[0] * sn, ax[1] * sn, ax[2] * sn}, o[4];
           mulquat(o, xq, jq);
@@ -195,14 +227,14 @@ DEV void kinematics(const TreeModel* tm, TreeLDS& L) {
         }
         normquat(xq);
         if (jt == TJ_SLIDE) {
-          float a[3]; rotvecquat(a, tm->jnt_axis[tm->body_jnt[b]], xq);
+          float a[3]; rotvecquat(a, ax, xq);
           float q = L.qpos[qa];
           xp[0] += a[0] * q; xp[1] += a[1] * q; xp[2] += a[2] * q;
         }
       }
       float xm[9]; quat2mat(xm, xq);
-      float t[3]; matvec3(t, xm, tm->body_ipos[b]);
-      float im[9], xim[9]; quat2mat(im, tm->body_iquat[b]); matmul3(xim, xm, im);
+      float t[3]; matvec3(t, xm, bipos);
+      float xim[9]; matmul3(xim, xm, im);
 #pragma unroll
       for (int i = 0; i < 3; i++) { L.xpos[b][i] = xp[i]; L.xipos[b][i] = xp[i] + t[i]; }
 #pragma unroll
@@ -273,17 +305,22 @@ TREE_CHOL_DEV void chol_solve(float (*A)[TV + 1], int n, float* x) {
 #pragma unroll
   for (int k = 0; k < TV; k++) { a[k] = A[row][k]; t[k] = A[k][row]; }       // (row stride TV + 1: both reads are conflict-free)
   float y = lane < n ? x[row] : 0.f;
+  // 1 / L[lane][lane], one division per lane (round 5; before: two divisions of broadcast values per column, 2 x TV in all)
+  float dg = 1.f;
+#pragma unroll
+  for (int k = 0; k < TV; k++) dg = (row == k) ? a[k] : dg;
+  const float inv = 1.f / dg;
 #pragma unroll
   for (int j = 0; j < TV; j++) {
     if (j < n) {
-      float yj = wave_get_f(y, j) / wave_get_f(a[j], j);
+      float yj = wave_get_f(y, j) * wave_get_f(inv, j);
       if (lane == j) y = yj; else if (lane > j) y -= a[j] * yj;
     }
   }
 #pragma unroll
   for (int j = TV - 1; j >= 0; j--) {
     if (j < n) {
-      float xj = wave_get_f(y, j) / wave_get_f(a[j], j);
+      float xj = wave_get_f(y, j) * wave_get_f(inv, j);
       if (lane == j) y = xj; else if (lane < j) y -= t[j] * xj;
     }
   }
@@ -526,31 +563,46 @@ DEV int broadphase(const TreeModel* tm, const DevModel* gm, TreeLDS& L) {
   }
   if (lane == 0) { L.ncand = 0; L.ncon = 0; }
   wave_sync();
-  // candidate pairs in pair-list order
+  // candidate pairs in pair-list order.  Four blocks of 64 pairs per trip (round 5): their pair words are four loads in flight and their box
+  // reads overlap; one block per trip paid a round trip to the pair list each (360 trips for the 23 016 pairs of the Dining scenes: 197 us of the
+  // 720 us an env-substep took).  The ballots run block by block, so the candidate order is the list's.
   int base = 0;
-  for (int p0 = 0; p0 < tm->npair; p0 += WAVE) {
-    int p = p0 + lane;
-    bool hit = false;
-    int g1 = 0, g2 = 0;
-    if (p < tm->npair) {
-      unsigned int pk = gm->pair_packed[p];          // geom1 | geom2 << 8 | plane flag << 16, types ordered
-      g1 = (int)(pk & 0xffu); g2 = (int)((pk >> 8) & 0xffu);
-      if ((pk >> 16) & 1u) {
-        float pp[3], R[9]; geom_pose(tm, gm, L, g1, pp, R);
-        float nrm[3] = {R[2], R[5], R[8]}, lowest = 0.f;
+  const int npair = tm->npair;
+  for (int p0 = 0; p0 < npair; p0 += 4 * WAVE) {
+    unsigned int pk[4];
 #pragma unroll
-        for (int k = 0; k < 3; k++) lowest += nrm[k] * ((nrm[k] >= 0.f ? L.aabb[k][g2] : L.aabb[3 + k][g2]) - pp[k]);
-        hit = !(lowest > 0.f);
-      } else {
-        hit = true;
+    for (int u = 0; u < 4; u++) { int p = p0 + u * WAVE + lane; pk[u] = p < npair ? gm->pair_packed[p] : 0xffffffffu; }   // geom1 | geom2 << 8 | plane flag << 16, types ordered
+    bool hit[4];
 #pragma unroll
-        for (int k = 0; k < 3; k++) if (L.aabb[k][g1] > L.aabb[3 + k][g2] || L.aabb[k][g2] > L.aabb[3 + k][g1]) hit = false;
+    for (int u = 0; u < 4; u++) {
+      int g1 = (int)(pk[u] & 0xffu), g2 = (int)((pk[u] >> 8) & 0xffu);
+      hit[u] = false;
+      if (pk[u] != 0xffffffffu) {
+        if ((pk[u] >> 16) & 1u) {
+          float pp[3], R[9]; geom_pose(tm, gm, L, g1, pp, R);
+          float nrm[3] = {R[2], R[5], R[8]}, lowest = 0.f;
+#pragma unroll
+          for (int k = 0; k < 3; k++) lowest += nrm[k] * ((nrm[k] >= 0.f ? L.aabb[k][g2] : L.aabb[3 + k][g2]) - pp[k]);
+          hit[u] = !(lowest > 0.f);
+        } else {
+          // (all twelve box reads first, then one combined test: with `||` inside the loop every axis was its own LDS round trip behind a branch)
+          float lo1[3], hi1[3], lo2[3], hi2[3];
+#pragma unroll
+          for (int k = 0; k < 3; k++) { lo1[k] = L.aabb[k][g1]; hi1[k] = L.aabb[3 + k][g1]; lo2[k] = L.aabb[k][g2]; hi2[k] = L.aabb[3 + k][g2]; }
+          bool sep = false;
+#pragma unroll
+          for (int k = 0; k < 3; k++) sep = sep | (lo1[k] > hi2[k]) | (lo2[k] > hi1[k]);
+          hit[u] = !sep;
+        }
       }
     }
-    unsigned long long mask = wave_ballot(hit);
-    int idx = base + wave_prefix(mask);
-    if (hit && idx < TCAND) L.cand[idx] = (unsigned int)g1 | ((unsigned int)g2 << 16);
-    base += __popcll(mask);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      unsigned long long mask = wave_ballot(hit[u]);
+      int idx = base + wave_prefix(mask);
+      if (hit[u] && idx < TCAND) L.cand[idx] = (pk[u] & 0xffu) | (((pk[u] >> 8) & 0xffu) << 16);
+      base += __popcll(mask);
+    }
   }
   wave_sync();
   int ncand = base;
@@ -694,19 +746,40 @@ DEV void publish(const TreeModel* tm, const DevModel* gm, TreeLDS& L, const Tree
 
 // the env's contacts of this substep from the records, in candidate order, truncated at TCON like the fused loop
 DEV void gather_contacts(const TreeModel* tm, const DevModel* gm, TreeLDS& L, const TreePipe& P, int e) {
+  // Round 5: the pairs' counts are read by lane = candidate and scanned with three ballots (a count has three bits), which gives every pair its first
+  // slot at once; only the pairs that HAVE contacts are then visited one after the other, lane j writing contact j as collision() does.  Before, one
+  // wavefront walked all candidates and waited for a record's count from global memory before it looked at the next (18-59 round trips per
+  // env-substep: 16 / 40 us on the hand-over / Dining scenes).  (The records are written lane = contact, not lane = pair: with the pair's lane writing
+  // all of its contacts the inlined copy of write_contact() rounded the tangent frames differently from collision()'s copy - last bit, every contact
+  // that is not axis-aligned - and the chain stopped being bit-identical to the fused step.)
   int lane = wave_lane(), ncand = P.ncand[e], ncon = 0;
-  for (int k = 0; k < ncand; k++) {
-    const float* r = P.rec + ((size_t)e * TCAND + k) * TREC;
-    int n = (int)r[0];
-    if (n == 0) continue;
-    if (ncon + n > TCON) { if (lane == 0) L.flags |= 2; break; }
-    if (lane < n) {
-      unsigned int cg = P.cand[(size_t)e * TCAND + k];
-      int g1 = (int)(cg & 0xffffu), g2 = (int)(cg >> 16);
-      float nrm[3] = {r[1], r[2], r[3]}, pos[3] = {r[5 + 4 * lane], r[6 + 4 * lane], r[7 + 4 * lane]};
-      write_contact(tm, gm, L.con[ncon + lane], g1, g2, tm->geom_body[g1], tm->geom_body[g2], nrm, r[4 + 4 * lane], pos);
+  bool full = false;
+  for (int k0 = 0; k0 < ncand && !full; k0 += WAVE) {
+    int k = k0 + lane;
+    int n = k < ncand ? (int)P.rec[((size_t)e * TCAND + k) * TREC] : 0;
+    unsigned long long b0 = wave_ballot((n & 1) != 0), b1 = wave_ballot((n & 2) != 0), b2 = wave_ballot((n & 4) != 0);
+    int slot = ncon + wave_prefix(b0) + 2 * wave_prefix(b1) + 4 * wave_prefix(b2);
+    unsigned long long over = wave_ballot(n > 0 && slot + n > TCON);       // the first pair that does not fit ends the list (flag 2), as in collision()
+    unsigned long long todo = wave_ballot(n > 0);
+    if (over) {
+      int first = (int)__builtin_ctzll(over);
+      todo &= (1ull << first) - 1ull;
+      ncon = wave_bcast_i(slot, first);
+      full = true;
+      if (lane == 0) L.flags |= 2;
+    } else ncon += __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+    while (todo) {
+      int l = (int)__builtin_ctzll(todo);
+      todo &= todo - 1ull;
+      int kk = k0 + l, nn = wave_bcast_i(n, l), ss = wave_bcast_i(slot, l);
+      const float* r = P.rec + ((size_t)e * TCAND + kk) * TREC;
+      if (lane < nn) {
+        unsigned int cg = P.cand[(size_t)e * TCAND + kk];
+        int g1 = (int)(cg & 0xffffu), g2 = (int)(cg >> 16);
+        float nrm[3] = {r[1], r[2], r[3]}, pos[3] = {r[5 + 4 * lane], r[6 + 4 * lane], r[7 + 4 * lane]};
+        write_contact(tm, gm, L.con[ss + lane], g1, g2, tm->geom_body[g1], tm->geom_body[g2], nrm, r[4 + 4 * lane], pos);
+      }
     }
-    ncon += n;
   }
   if (lane == 0) { L.ncon = ncon; L.ncand = ncand; }
   wave_sync();
@@ -729,15 +802,35 @@ DEV void row_params(const TreeModel* tm, const float* solref_in, const float* so
 // takes 99 us instead of 187 - it is bound by the latency of its loads (section 8 of DESIGN.md).  The contacts' Hessian blocks stay global.
 DEV void use_row_storage(TreeLDS& L, TreeScratch& G, int nrow) {
   if (TRL > 0 && nrow <= TRL) {
-    G.J = L.xJ;
+    G.J = L.xJ; G.js = TJL;
     G.eD = L.xv; G.eR = L.xv + TRL; G.earef = L.xv + 2 * TRL; G.efl = L.xv + 3 * TRL; G.ejar = L.xv + 4 * TRL; G.ef = L.xv + 5 * TRL; G.ejv = L.xv + 6 * TRL;
     G.etype = (unsigned int*)(L.xv + 7 * TRL);
   } else {
     float* base = G.global_base;
-    G.J = base; base += TROW * TJS;
+    G.J = base; G.js = TJS; base += TROW * TJS;
     G.eD = base; G.eR = base + TROW; G.earef = base + 2 * TROW; G.efl = base + 3 * TROW; G.ejar = base + 4 * TROW; G.ef = base + 5 * TROW; G.ejv = base + 6 * TROW;
     G.etype = (unsigned int*)(base + 7 * TROW);
   }
+}
+
+// init + (Jacobian row r) . v for a vector v in LDS, one row per lane.  Rows in the global scratch are fetched as float4 (row stride TJS: 16-byte
+// aligned; a quarter of the load instructions, each of which touches 64 different lines); rows in LDS have the conflict-free stride TJL.
+DEV float row_dot(const TreeScratch& G, int r, const float* v, int nv, float init) {
+  float s = init;
+  if (TRL == 0 || G.js == TJS) {
+    const float4* p = (const float4*)(G.J + (size_t)r * TJS);
+    for (int d = 0; d < nv; d += 4) {
+      float4 a = p[d >> 2];
+      s += a.x * v[d];
+      if (d + 1 < nv) s += a.y * v[d + 1];
+      if (d + 2 < nv) s += a.z * v[d + 2];
+      if (d + 3 < nv) s += a.w * v[d + 3];
+    }
+  } else {
+    const float* p = G.J + r * G.js;
+    for (int d = 0; d < nv; d++) s += p[d] * v[d];
+  }
+  return s;
 }
 
 DEV void make_constraints(const TreeModel* tm, TreeLDS& L, TreeScratch& G) {
@@ -753,6 +846,7 @@ DEV void make_constraints(const TreeModel* tm, TreeLDS& L, TreeScratch& G) {
   int nlim = __popcll(mlo) + __popcll(mhi);
   int nscalar = neq + nfric + nlim;
   int ncon = L.ncon;
+  if (lane < TB) L.bdofs[lane] = lane < tm->nbody ? tm->body_dofs[lane] : 0ull;
   // first row of every contact
   for (int c = lane; c < ncon; c += WAVE) L.cdim[c] = L.con[c].dim;
   wave_sync();
@@ -767,7 +861,7 @@ DEV void make_constraints(const TreeModel* tm, TreeLDS& L, TreeScratch& G) {
   wave_sync();                              // (the collision stage's boxes and candidates, which the row storage may alias, are no longer read)
   use_row_storage(L, G, nrow);
   // zero the Jacobian rows of the scalar constraints
-  for (int r = 0; r < nscalar; r++) if (lane < TJS) G.J[r * TJS + lane] = 0.f;
+  for (int r = 0; r < nscalar; r++) if (lane < TJS) G.J[r * G.js + lane] = 0.f;
   wave_sync();
   // ---- scalar rows: one lane each
   {
@@ -800,8 +894,8 @@ DEV void make_constraints(const TreeModel* tm, TreeLDS& L, TreeScratch& G) {
       float imp, K, Bc; row_params(tm, solref, solimp, pos, &imp, &K, &Bc);
       float R = fmaxf(MINVAL_F, (1.f - imp) * diag / imp);
       float vel = j1 * L.qvel[d1] + (d2 >= 0 ? j2 * L.qvel[d2] : 0.f);
-      G.J[r * TJS + d1] = j1; if (d2 >= 0) G.J[r * TJS + d2] = j2;
-      G.etype[r] = (unsigned int)type; G.eR[r] = R; G.eD[r] = 1.f / R; G.efl[r] = floss;
+      G.J[r * G.js + d1] = j1; if (d2 >= 0) G.J[r * G.js + d2] = j2;
+      G.etype[r] = (unsigned int)type | ((unsigned int)d1 << 8) | ((unsigned int)(d2 >= 0 ? d2 : 0xff) << 16); G.eR[r] = R; G.eD[r] = 1.f / R; G.efl[r] = floss;
       G.earef[r] = -Bc * vel - (type == TR_FRICTION ? 0.f : K * imp * pos);
     }
   }
@@ -817,8 +911,8 @@ DEV void make_constraints(const TreeModel* tm, TreeLDS& L, TreeScratch& G) {
       float pos = side == 0 ? q_j - tm->jnt_range[j][0] : tm->jnt_range[j][1] - q_j, sg = side == 0 ? 1.f : -1.f;
       float imp, K, Bc; row_params(tm, solref, solimp, pos, &imp, &K, &Bc);
       float R = fmaxf(MINVAL_F, (1.f - imp) * tm->dof_invweight0[d] / imp);
-      G.J[r * TJS + d] = sg;
-      G.etype[r] = TR_LIMIT; G.eR[r] = R; G.eD[r] = 1.f / R; G.efl[r] = 0.f;
+      G.J[r * G.js + d] = sg;
+      G.etype[r] = TR_LIMIT | ((unsigned int)d << 8) | (0xffu << 16); G.eR[r] = R; G.eD[r] = 1.f / R; G.efl[r] = 0.f;
       G.earef[r] = -Bc * sg * L.qvel[d] - K * imp * pos;
     }
   }
@@ -830,7 +924,7 @@ DEV void make_constraints(const TreeModel* tm, TreeLDS& L, TreeScratch& G) {
       int d = lane;
       float jp[3] = {0.f, 0.f, 0.f}, jr[3] = {0.f, 0.f, 0.f};
       if (d < nv) {
-        bool in1 = (tm->body_dofs[b1] >> d) & 1ull, in2 = (tm->body_dofs[b2] >> d) & 1ull;
+        bool in1 = (L.bdofs[b1] >> d) & 1ull, in2 = (L.bdofs[b2] >> d) & 1ull;
         float sgn = (in2 ? 1.f : 0.f) - (in1 ? 1.f : 0.f);
         if (sgn != 0.f) {
           float t[3]; cross3(t, L.S[d], C.pos);
@@ -840,7 +934,7 @@ DEV void make_constraints(const TreeModel* tm, TreeLDS& L, TreeScratch& G) {
       }
       for (int j = 0; j < dim; j++) {
         const float* ax = &C.frame[3 * (j < 3 ? j : j - 3)];
-        G.J[(row + j) * TJS + d] = j < 3 ? dot3(ax, jp) : dot3(ax, jr);
+        G.J[(row + j) * G.js + d] = j < 3 ? dot3(ax, jp) : dot3(ax, jr);
       }
     }
   }
@@ -866,8 +960,7 @@ DEV void make_constraints(const TreeModel* tm, TreeLDS& L, TreeScratch& G) {
   wave_sync();
   // reference acceleration of the contact rows: aref = -B (J qvel) - K imp pos; lane = row
   for (int r = nscalar + lane; r < nrow; r += WAVE) {
-    float vel = 0.f;
-    for (int d = 0; d < nv; d++) vel += G.J[r * TJS + d] * L.qvel[d];
+    float vel = row_dot(G, r, L.qvel, nv, 0.f);
     G.earef[r] = -G.ejar[r] * vel - G.ejv[r];
   }
   wave_sync();
@@ -964,6 +1057,7 @@ DEV float scalar_block(int type, float D, float R, float fl, float r, float* for
 DEV float total_cost(const TreeModel* tm, TreeLDS& L, const TreeScratch& G, bool want) {
   int lane = wave_lane(), nv = tm->nv, nrow = L.nrow, nscalar = L.nscalar, ncon = L.ncon;
   float part = 0.f;
+  TPROF_T0();
   if (lane < nv) {
     float v = 0.f;
     for (int c = 0; c < nv; c++) v += L.M[lane][c] * L.x[c];
@@ -971,14 +1065,13 @@ DEV float total_cost(const TreeModel* tm, TreeLDS& L, const TreeScratch& G, bool
     part = 0.5f * (v - L.qfrc[lane]) * (L.x[lane] - L.qsm[lane]);
   }
   for (int r = lane; r < nrow; r += WAVE) {
-    float v = -G.earef[r];
-    for (int d = 0; d < nv; d++) v += G.J[r * TJS + d] * L.x[d];
-    G.ejar[r] = v;
+    G.ejar[r] = row_dot(G, r, L.x, nv, -G.earef[r]);
   }
   wave_sync();
+  TPROF(0)
   for (int r = lane; r < nscalar; r += WAVE) {
     float f, h;
-    part += scalar_block(G.etype[r], G.eD[r], G.eR[r], G.efl[r], G.ejar[r], &f, &h);
+    part += scalar_block((int)(G.etype[r] & 0xffu), G.eD[r], G.eR[r], G.efl[r], G.ejar[r], &f, &h);
     G.ef[r] = f; G.ejv[r] = h;        // (ejv doubles as the scalar rows' second derivative until the line search fills it)
   }
   for (int ci = lane; ci < ncon; ci += WAVE) {         // (one pass with at most 64 contacts; the 64-dof build holds up to 128)
@@ -999,70 +1092,122 @@ DEV float total_cost(const TreeModel* tm, TreeLDS& L, const TreeScratch& G, bool
   }
   float cost = wave_sum_f(part);
   wave_sync();
+  TPROF(1)
   if (!want) return cost;
   // gradient: Ma - qfrc_smooth - J' force; lane = dof
   if (lane < nv) {
     float g = L.Ma[lane] - L.qfrc[lane];
-    for (int r = 0; r < nrow; r++) g -= G.J[r * TJS + lane] * G.ef[r];
+    const int js = G.js;
+    int r = 0;
+    for (; r + 8 <= nrow; r += 8) {                       // (eight rows' loads in flight; the subtractions keep their order)
+      float a[8], f[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { a[u] = G.J[(r + u) * js + lane]; f[u] = G.ef[r + u]; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) g -= a[u] * f[u];
+    }
+    for (; r < nrow; r++) g -= G.J[r * js + lane] * G.ef[r];
     L.grad[lane] = g;
   }
+  TPROF(2)
   // Hessian: M + sum J' Hc J, assembled in LDS (L.H) over the dofs each row TOUCHES (round 4; before, lane = column accumulated every
   // contact's 6 x nv product in registers: 36 + 6 TV multiply-adds per lane and contact, two barriers, although a prop-on-table contact
   // moves 6 of the 28 / 52 dofs - 480 instructions per contact against 60-150 here).
-  for (int i = lane; i < nv * nv; i += WAVE) { int r = i / nv, c = i - r * nv; L.H[r][c] = L.M[r][c]; }
+  for (int i = lane; i < nv * (TV + 1); i += WAVE) (&L.H[0][0])[i] = (&L.M[0][0])[i];       // (same layout: rows 0 .. nv-1 with their padding word)
   wave_sync();
-  // scalar rows (equality, dof friction, limits): one or two non-zero columns.  Entry [a][b] is always written by lane a, so two rows
-  // that meet on one entry (a limit and a friction row of one dof) are ordered by that lane's own program order
-  for (int r = 0; r < nscalar; r++) {
-    float h = G.ejv[r];
-    if (h == 0.f) continue;
-    float jd = lane < nv ? G.J[r * TJS + lane] : 0.f;
-    unsigned long long nz = wave_ballot(jd != 0.f);
-    if (nz == 0ull) continue;
-    int d1 = (int)__builtin_ctzll(nz);
-    unsigned long long rest = nz & (nz - 1ull);
-    int d2 = rest ? (int)__builtin_ctzll(rest) : -1;
-    float j1 = wave_bcast_f(jd, d1), j2 = d2 >= 0 ? wave_bcast_f(jd, d2) : 0.f;
-    if (lane == d1) { L.H[d1][d1] += h * j1 * j1; if (d2 >= 0) L.H[d1][d2] += h * j1 * j2; }
-    if (lane == d2) { L.H[d2][d2] += h * j2 * j2; L.H[d2][d1] += h * j1 * j2; }
-  }
-  wave_sync();
-  for (int c = 0; c < ncon; c++) {
-    int dim = L.hdim[c];
-    if (dim == 0) continue;
-    const TCon& C = L.con[c];
-    int row = C.row;
-    unsigned long long mask = tm->body_dofs[C.b1] | tm->body_dofs[C.b2];     // wave-uniform: the dofs that move either body
-    int nd = __popcll(mask);
-    // (i) compact the contact's Jacobian columns: the lane of dof d takes slot rank(d)
-    if (lane < nv && ((mask >> lane) & 1ull)) {
-      int k = __popcll(mask & ((1ull << lane) - 1ull));
-      L.hdl[k] = lane;
+  TPROF(3)
+  // Round 5: the constraint part  sum_rows J' Hc J  on the matrix cores, as in the SO100 solver (so101_newton.hpp).  With the constraint rows as the K
+  // dimension the sum is  J' T,  T = blockdiag(Hc) J:  v_mfma_f32_32x32x2_f32 takes two rows per instruction - lane l supplies column l % 32 of row
+  // l / 32 of both factors - and the 32 x 32 accumulator tile(s) hold H's constraint part until the end; no LDS exchange, no barrier.  Before, every
+  // active contact was compacted to the dofs it touches and multiplied through LDS (three exchanges per contact, ~1.5 us each on a wavefront that has
+  // its SIMD to itself: 40 of the 115 us of a hand-over env's Newton solve, 98 of 300 on the Dining scenes), the scalar rows one after the other.
+  {
+    constexpr int NT = (TV + 31) / 32;                      // tiles per dimension: 1 (32-dof build) or 2
+    const int col = lane & 31, kk = lane >> 5;
+    const int js = G.js;
+    mfma_acc16 acc[NT][NT];
 #pragma unroll
-      for (int j = 0; j < 6; j++) L.hJ[j][k] = j < dim ? G.J[(row + j) * TJS + lane] : 0.f;
+    for (int ti = 0; ti < NT; ti++)
+#pragma unroll
+      for (int tj = 0; tj < NT; tj++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[ti][tj][r] = 0.f;
+    // scalar rows (equality, dof friction, limits; Hc = the row's second derivative, 0 outside its quadratic zone): two per instruction
+#pragma unroll 4
+    for (int r0 = 0; r0 < nscalar; r0 += 2) {
+      int r = r0 + kk;
+      bool on = r < nscalar;
+      float h = on ? G.ejv[r] : 0.f, jv[NT];
+#pragma unroll
+      for (int t = 0; t < NT; t++) jv[t] = on ? G.J[r * js + 32 * t + col] : 0.f;
+#pragma unroll
+      for (int ti = 0; ti < NT; ti++)
+#pragma unroll
+        for (int tj = 0; tj < NT; tj++) acc[ti][tj] = mfma_32x32x2(jv[ti], h * jv[tj], acc[ti][tj]);
     }
-    wave_sync();
-    // (ii) T = Hc J (6 x nd), lane = (row j, slot k)
-    for (int i = lane; i < 6 * nd; i += WAVE) {
-      int j = i / nd, k = i - j * nd;
-      float v = 0.f;
-      if (j < dim) {
+    TPROF(4)
+    // contact blocks, the active ones; the 6 x 6 block and the Jacobian columns of the NEXT one are fetched while this one is multiplied
+    auto next_active = [&](int c) -> int { c++; while (c < ncon && L.hdim[c] == 0) c++; return c; };
+    float4 hn[9]; float jn[NT][6];
+    auto fetch = [&](int cc) {
+      int dim = L.hdim[cc], row = L.con[cc].row;
+      const float4* hp = (const float4*)G.Hc[cc];
 #pragma unroll
-        for (int l = 0; l < 6; l++) v += G.Hc[c][j * 6 + l] * L.hJ[l][k];
+      for (int q = 0; q < 9; q++) hn[q] = hp[q];
+#pragma unroll
+      for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) jn[t][j] = j < dim ? G.J[(row + j) * js + 32 * t + col] : 0.f;
+    };
+    int c = next_active(-1);
+    if (c < ncon) fetch(c);
+    while (c < ncon) {
+      const int dim = L.hdim[c];
+      float hc[36], jc[NT][6], tv[NT][6];
+#pragma unroll
+      for (int q = 0; q < 9; q++) { hc[4 * q] = hn[q].x; hc[4 * q + 1] = hn[q].y; hc[4 * q + 2] = hn[q].z; hc[4 * q + 3] = hn[q].w; }
+#pragma unroll
+      for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) jc[t][j] = jn[t][j];
+      int cn = next_active(c);
+      if (cn < ncon) fetch(cn);
+#pragma unroll
+      for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int j = 0; j < 6; j++) {                          // T = Hc J, this lane's column(s)
+          float v = 0.f;
+#pragma unroll
+          for (int l = 0; l < 6; l++) v += hc[j * 6 + l] * jc[t][l];
+          tv[t][j] = v;
+        }
+#pragma unroll
+      for (int s2 = 0; s2 < 3; s2++) {
+        if (2 * s2 < dim) {
+          float a[NT], b[NT];
+#pragma unroll
+          for (int t = 0; t < NT; t++) { a[t] = kk ? jc[t][2 * s2 + 1] : jc[t][2 * s2]; b[t] = kk ? tv[t][2 * s2 + 1] : tv[t][2 * s2]; }
+#pragma unroll
+          for (int ti = 0; ti < NT; ti++)
+#pragma unroll
+            for (int tj = 0; tj < NT; tj++) acc[ti][tj] = mfma_32x32x2(a[ti], b[tj], acc[ti][tj]);
+        }
       }
-      L.hT[j][k] = v;
+      c = cn;
     }
-    wave_sync();
-    // (iii) H[dof a][dof b] += sum_j J[j][a] T[j][b], lane = (slot a, slot b)
-    for (int i = lane; i < nd * nd; i += WAVE) {
-      int ka = i / nd, kb = i - ka * nd;
-      float v = 0.f;
+    // the accumulators into H: lane l holds column l % 32, rows 8 (r / 4) + 4 (l / 32) + r % 4 of each tile
 #pragma unroll
-      for (int j = 0; j < 6; j++) v += L.hJ[j][ka] * L.hT[j][kb];
-      L.H[L.hdl[ka]][L.hdl[kb]] += v;
-    }
-    wave_sync();
+    for (int ti = 0; ti < NT; ti++)
+#pragma unroll
+      for (int tj = 0; tj < NT; tj++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          int hr = 32 * ti + 8 * (r / 4) + 4 * kk + (r % 4), hcol = 32 * tj + col;
+          if (hr < nv && hcol < nv) L.H[hr][hcol] += acc[ti][tj][r];
+        }
   }
+  wave_sync();
+  TPROF(5)
   return cost;
 }
 
@@ -1082,16 +1227,18 @@ DEV void solve_newton(const TreeModel* tm, TreeLDS& L, const TreeScratch& G, int
   float scale = 1.f / (tm->meaninertia * (float)(nv > 1 ? nv : 1));
   float cost = total_cost(tm, L, G, true);
   int it = 0;
+  TPROF_T0();
   for (; it < max_iter; ) {
+    TPROF(15)
     chol_factor(L.H, nv);
+    TPROF(6)
     if (lane < nv) L.search[lane] = -L.grad[lane];
     wave_sync();
     chol_solve(L.H, nv, L.search);
+    TPROF(7)
     // line search on phi(alpha) = cost(x + alpha search): safeguarded Newton on phi'
     for (int r = lane; r < nrow; r += WAVE) {
-      float v = 0.f;
-      for (int d = 0; d < nv; d++) v += G.J[r * TJS + d] * L.search[d];
-      G.ejv[r] = v;
+      G.ejv[r] = row_dot(G, r, L.search, nv, 0.f);
     }
     float p1 = 0.f, p2 = 0.f;
     if (lane < nv) {
@@ -1101,12 +1248,13 @@ DEV void solve_newton(const TreeModel* tm, TreeLDS& L, const TreeScratch& G, int
     }
     float q1 = wave_sum_f(p1), q2 = wave_sum_f(p2);
     wave_sync();
+    TPROF(8)
     float alpha = 0.f, lo = 0.f, hi = -1.f, d10 = 0.f;
     for (int ls = 0; ls < 24; ls++) {
       float a1 = 0.f, a2 = 0.f;
       for (int r = lane; r < nscalar; r += WAVE) {
         float f, h, jv = G.ejv[r];
-        scalar_block(G.etype[r], G.eD[r], G.eR[r], G.efl[r], G.ejar[r] + alpha * jv, &f, &h);
+        scalar_block((int)(G.etype[r] & 0xffu), G.eD[r], G.eR[r], G.efl[r], G.ejar[r] + alpha * jv, &f, &h);
         a1 -= f * jv; a2 += jv * h * jv;
       }
       for (int ci = lane; ci < ncon; ci += WAVE) {
@@ -1130,6 +1278,7 @@ DEV void solve_newton(const TreeModel* tm, TreeLDS& L, const TreeScratch& G, int
     }
     if (lane < nv) L.x[lane] += alpha * L.search[lane];
     wave_sync();
+    TPROF(9)
     float newcost = total_cost(tm, L, G, true);
     float improvement = scale * (cost - newcost);
     float gn = wave_sum_f(lane < nv ? L.grad[lane] * L.grad[lane] : 0.f);
@@ -1146,16 +1295,35 @@ DEV void solve_newton(const TreeModel* tm, TreeLDS& L, const TreeScratch& G, int
 // ------------------------------------------------------------------ forward dynamics and integration
 // `phases`: stage mask for timing runs (so101_tree_debug_forward with SO101_TREE_PHASES set); every caller on the step path passes all
 // the two halves of forward() around the collision stage (launch chain: the contacts come from the records instead)
-DEV void forward_smooth(const TreeModel* tm, TreeLDS& L) { kinematics(tm, L); crba(tm, L); rne_bias(tm, L); smooth(tm, L); }
-DEV void forward_constrained(const TreeModel* tm, TreeLDS& L, TreeScratch& G, int max_iter, float tolerance) { make_constraints(tm, L, G); solve_newton(tm, L, G, max_iter, tolerance); }
+DEV void forward_smooth(const TreeModel* tm, TreeLDS& L) {
+  TPROF_T0();
+  kinematics(tm, L);
+  TPROF(17)
+  crba(tm, L);
+  TPROF(18)
+  rne_bias(tm, L);
+  TPROF(19)
+  smooth(tm, L);
+  TPROF(20)
+}
+DEV void forward_constrained(const TreeModel* tm, TreeLDS& L, TreeScratch& G, int max_iter, float tolerance) {
+  TPROF_T0();
+  make_constraints(tm, L, G);
+  TPROF(10)
+  solve_newton(tm, L, G, max_iter, tolerance);
+  TPROF(11)
+}
 DEV void forward(const TreeModel* tm, const DevModel* gm, TreeLDS& L, TreeScratch& G, int max_iter, float tolerance, int phases = 0x7f) {
   kinematics(tm, L);
   if (phases & 2) crba(tm, L);
   if (phases & 4) rne_bias(tm, L);
   if (phases & 8) smooth(tm, L);
   if (phases & 16) collision(tm, gm, L, !(phases & 128)); else { if (wave_lane() == 0) { L.ncon = 0; L.ncand = 0; } wave_sync(); }
+  TPROF_T0();
   if (phases & 32) make_constraints(tm, L, G); else { if (wave_lane() == 0) { L.nrow = 0; L.nscalar = 0; } wave_sync(); }
+  TPROF(10)
   if (phases & 64) solve_newton(tm, L, G, max_iter, tolerance);
+  TPROF(11)
 }
 
 DEV void euler(const TreeModel* tm, TreeLDS& L) {

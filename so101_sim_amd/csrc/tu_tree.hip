@@ -41,7 +41,11 @@
 #define TAPI(name) TAPI_CAT(TREE_VARIANT, name)
 
 #ifndef TREE_SOLVE_OCC
+#if TREE_VARIANT == 64
+#define TREE_SOLVE_OCC 1     // (LDS allows two envs per CU: registers are free; the Hessian's four accumulator tiles want them)
+#else
 #define TREE_SOLVE_OCC 2
+#endif
 #endif
 
 namespace TREE_NS {
@@ -72,6 +76,9 @@ __global__ void __launch_bounds__(64) k_tree_forward(const TreeModel* tm, const 
   BLOCK_SHARED(TreeLDS, L);
   int e = blockIdx.x, lane = wave_lane();
   if (lane == 0) L.flags = 0;
+#ifdef TREE_PROF
+  if (lane < 32) L.prof[lane] = 0u;
+#endif
   tree::load_state(tm, L, B, e, N);
   TreeScratch G = tree::scratch_of(B, e);
   tree::forward(tm, gm, L, G, iterations, tolerance, phases);
@@ -83,6 +90,10 @@ __global__ void __launch_bounds__(64) k_tree_forward(const TreeModel* tm, const 
     for (int r = 0; r < nv; r++) o[TDBG_M + r * TV + lane] = L.M[r][lane];
   }
   if (lane < nb) for (int k = 0; k < 3; k++) o[TDBG_XPOS + 3 * lane + k] = L.xpos[lane][k];
+#ifdef TREE_PROF
+  wave_sync();
+  if (lane < 16) o[TDBG_M + lane] = (float)L.prof[lane];         // (profiling variant: the phase clocks take the first slots of the mass-matrix dump)
+#endif
   for (int ci = lane; ci < L.ncon; ci += WAVE) {
     const TCon& c = L.con[ci];
     float* q = o + TDBG_CON + 10 * ci;
@@ -286,6 +297,9 @@ __global__ void __launch_bounds__(64) k_tree_step(const TreeModel* tm, const Dev
   tree_finish_step<1>(tm, gm, T, L, G, B, E, e, diverged, obs, reward, discount, step_type);
 }
 
+#ifdef TREE_PROF
+__device__ unsigned long long g_tprof[33];     // (profiling variant: phase clocks of k_tree_pipe_solve summed over env-substeps, printed by destroy)
+#endif
 // ---- the control step as a launch chain (so101_tree.hpp, "the narrowphase in a launch of its own"): k_tree_pipe_begin, then per substep
 // k_tree_narrow and k_tree_pipe_solve.  Reward mode 0 (overlap boxes) only: the contact rewards need the contacts of the post-step state.
 __global__ void __launch_bounds__(64) k_tree_pipe_begin(const TreeModel* tm, const DevModel* gm, TreeTask T, TreeBuffers B, TreeEnvBuffers E, TreeStore S, TreePipe P,
@@ -354,27 +368,48 @@ __global__ void __launch_bounds__(64, TREE_SOLVE_OCC) k_tree_pipe_solve(const Tr
   int act = P.active[e];
   if (act == 0) return;
   if (lane == 0) L.flags = P.pflags[e];
+#ifdef TREE_PROF
+  if (lane < 32) L.prof[lane] = 0u;
+  wave_sync();
+#endif
+  TPROF_T0();
   tree::load_state(tm, L, B, e, N);
+  TPROF(16)
   TreeScratch G = tree::scratch_of(B, e);
   bool diverged = act == 2;
   if (!diverged) {
     tree::forward_smooth(tm, L);
+    TPROF(12)
     tree::gather_contacts(tm, gm, L, P, e);
+    TPROF(21)
     tree::forward_constrained(tm, L, G, T.iterations, T.tolerance);
+    TPROF(13)
     tree::euler(tm, L);
     bool ok = true;
     if (lane < tm->nq) ok = ok && fabsf(L.qpos[lane]) <= 1e10f;
     if (lane < tm->nv) ok = ok && fabsf(L.qvel[lane]) <= 1e10f && fabsf(L.qacc[lane]) <= 1e10f;
     diverged = wave_ballot(!ok) != 0ull;
     if (diverged && lane == 0) P.active[e] = 2;
+    TPROF(22)
   }
   if (!last) {
     if (act == 1) {
       tree::store_state(tm, L, B, e, N);
       if (lane == 0) { P.pflags[e] = L.flags; P.pdiag[4 * e] = L.nrow; P.pdiag[4 * e + 1] = L.iters; P.pdiag[4 * e + 2] = L.ncon; P.pdiag[4 * e + 3] = L.ncand; }
-      if (!diverged) { tree::kinematics(tm, L); tree::publish(tm, gm, L, P, e, N, s + 1); }
+      TPROF(23)
+      if (!diverged) {
+        tree::kinematics(tm, L);
+        TPROF(24)
+        tree::publish(tm, gm, L, P, e, N, s + 1);
+        TPROF(25)
+      }
       else if (lane == 0) P.ncand[e] = 0;
     }
+#ifdef TREE_PROF
+    wave_sync();
+    if (lane < 32) atomicAdd(&g_tprof[lane], (unsigned long long)L.prof[lane]);
+    if (lane == 0) atomicAdd(&g_tprof[32], 1ull);
+#endif
     return;
   }
   if (act == 2) {
@@ -751,6 +786,20 @@ void TAPI(destroy)(TreeHandle* s) {
   {
     TreeDeviceGuard guard(s);
     (void)hipDeviceSynchronize();                 // nothing of this handle may still be running on buffers that are about to go
+#ifdef TREE_PROF
+    {
+      unsigned long long h[33] = {};
+      (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tprof), sizeof(h));
+      if (h[32]) {
+        static const char* nm[32] = {"cost: M x + jar", "cost: blocks", "cost: gradient", "cost: H = M", "cost: H scalar rows", "cost: H contacts", "chol factor", "chol solve",
+                                     "ls setup (J search)", "line search", "make_constraints", "newton total", "SMOOTH HALF", "CONSTRAINED HALF", "", "newton loop top (incl. cost)",
+                                     "load_state", "kinematics", "crba + factor", "rne", "smooth", "gather_contacts", "euler + check", "store_state", "kinematics (next)", "publish (next broadphase)",
+                                     "", "", "", "", "", ""};
+        fprintf(stderr, "TREE_PROF k_tree_pipe_solve, %llu env-substeps, mean us each:\n", h[32]);
+        for (int k = 0; k < 32; k++) if (nm[k][0]) fprintf(stderr, "  %-30s %8.2f\n", nm[k], (double)h[k] * 1e-2 / (double)h[32]);
+      }
+    }
+#endif
     if (s->prep_stream) (void)hipStreamDestroy(s->prep_stream);
     if (s->prep_done) (void)hipEventDestroy(s->prep_done);
     if (s->main_ev) (void)hipEventDestroy(s->main_ev);

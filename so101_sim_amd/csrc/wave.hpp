@@ -27,6 +27,11 @@ __device__ __forceinline__ int wave_lane() {
 #endif
 }
 __device__ __forceinline__ void wave_sync() { __syncthreads(); }
+// Exchange through LDS only, inside the one wavefront of the workgroup: a wavefront's LDS instructions execute in order, so a ds_read behind a
+// ds_write sees it; what is needed is that the compiler keeps that order.  Unlike wave_sync() (fence + s_barrier: s_waitcnt vmcnt(0)) this does not
+// wait for global loads that are still in flight - the point of it (software-pipelined fetches in so101_tree.hpp).  NOT for data handed over through
+// global memory.
+__device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
 // DPP controls (GFX9 encoding)
 #define DPP_QUAD_XOR1 0xB1        // quad_perm [1,0,3,2]

@@ -13,6 +13,7 @@
 #define BLOCK_SHARED(T, name) static_assert(sizeof(T) <= sizeof(EmuBlock::lds), "LDS"); T& name = *reinterpret_cast<T*>(emu_blk->lds)
 inline int wave_lane() { return threadIdx.x; }
 inline void wave_sync() { __syncthreads(); }
+inline void wave_lds_sync() { __syncthreads(); }
 inline float wave_max_f(float v) {
   emu_xchg_f[threadIdx.x] = v; __syncthreads();
   float m = emu_xchg_f[0]; for (int i = 1; i < 64; i++) m = std::fmax(m, emu_xchg_f[i]);
