@@ -747,7 +747,7 @@ DEV void publish(const TreeModel* tm, const DevModel* gm, TreeLDS& L, const Tree
 // the env's contacts of this substep from the records, in candidate order, truncated at TCON like the fused loop
 DEV void gather_contacts(const TreeModel* tm, const DevModel* gm, TreeLDS& L, const TreePipe& P, int e) {
   // Round 5: the pairs' counts are read by lane = candidate and scanned with three ballots (a count has three bits), which gives every pair its first
-  // slot at once; only the pairs that HAVE contacts are then visited one after the other, lane j writing contact j as collision() does.  Before, one
+  // slot at once; only the pairs that HAVE contacts are then visited, eight per trip, one lane per contact as in collision().  Before, one
   // wavefront walked all candidates and waited for a record's count from global memory before it looked at the next (18-59 round trips per
   // env-substep: 16 / 40 us on the hand-over / Dining scenes).  (The records are written lane = contact, not lane = pair: with the pair's lane writing
   // all of its contacts the inlined copy of write_contact() rounded the tangent frames differently from collision()'s copy - last bit, every contact
@@ -769,15 +769,23 @@ DEV void gather_contacts(const TreeModel* tm, const DevModel* gm, TreeLDS& L, co
       if (lane == 0) L.flags |= 2;
     } else ncon += __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
     while (todo) {
-      int l = (int)__builtin_ctzll(todo);
-      todo &= todo - 1ull;
-      int kk = k0 + l, nn = wave_bcast_i(n, l), ss = wave_bcast_i(slot, l);
-      const float* r = P.rec + ((size_t)e * TCAND + kk) * TREC;
-      if (lane < nn) {
+      // up to eight pairs with contacts per trip: lane = (pair of the trip, contact of the pair)
+      const int p = lane >> 3, j = lane & 7;
+      int l = -1;
+      unsigned long long t = todo;
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        if (t) { if (q == p) l = (int)__builtin_ctzll(t); t &= t - 1ull; }
+      }
+      todo = t;
+      int nn = wave_bcast_i(n, l < 0 ? 0 : l), ss = wave_bcast_i(slot, l < 0 ? 0 : l);
+      if (l >= 0 && j < nn) {
+        int kk = k0 + l;
+        const float* r = P.rec + ((size_t)e * TCAND + kk) * TREC;
         unsigned int cg = P.cand[(size_t)e * TCAND + kk];
         int g1 = (int)(cg & 0xffffu), g2 = (int)(cg >> 16);
-        float nrm[3] = {r[1], r[2], r[3]}, pos[3] = {r[5 + 4 * lane], r[6 + 4 * lane], r[7 + 4 * lane]};
-        write_contact(tm, gm, L.con[ss + lane], g1, g2, tm->geom_body[g1], tm->geom_body[g2], nrm, r[4 + 4 * lane], pos);
+        float nrm[3] = {r[1], r[2], r[3]}, pos[3] = {r[5 + 4 * j], r[6 + 4 * j], r[7 + 4 * j]};
+        write_contact(tm, gm, L.con[ss + j], g1, g2, tm->geom_body[g1], tm->geom_body[g2], nrm, r[4 + 4 * j], pos);
       }
     }
   }
@@ -1146,39 +1154,32 @@ DEV float total_cost(const TreeModel* tm, TreeLDS& L, const TreeScratch& G, bool
         for (int tj = 0; tj < NT; tj++) acc[ti][tj] = mfma_32x32x2(jv[ti], h * jv[tj], acc[ti][tj]);
     }
     TPROF(4)
-    // contact blocks, the active ones; the 6 x 6 block and the Jacobian columns of the NEXT one are fetched while this one is multiplied
+    // contact blocks, the active ones; the 6 x 6 block and the Jacobian columns of the NEXT one (the next TWO on the 64-dof build, whose rows live in
+    // the global scratch: one contact's arithmetic does not cover a round trip there) are fetched while this one is multiplied
     auto next_active = [&](int c) -> int { c++; while (c < ncon && L.hdim[c] == 0) c++; return c; };
-    float4 hn[9]; float jn[NT][6];
-    auto fetch = [&](int cc) {
+    struct Fetched { float4 h[9]; float j[NT][6]; };
+    auto fetch = [&](int cc, Fetched& F) {
       int dim = L.hdim[cc], row = L.con[cc].row;
       const float4* hp = (const float4*)G.Hc[cc];
 #pragma unroll
-      for (int q = 0; q < 9; q++) hn[q] = hp[q];
+      for (int q = 0; q < 9; q++) F.h[q] = hp[q];
 #pragma unroll
       for (int t = 0; t < NT; t++)
 #pragma unroll
-        for (int j = 0; j < 6; j++) jn[t][j] = j < dim ? G.J[(row + j) * js + 32 * t + col] : 0.f;
+        for (int j = 0; j < 6; j++) F.j[t][j] = j < dim ? G.J[(row + j) * js + 32 * t + col] : 0.f;
     };
-    int c = next_active(-1);
-    if (c < ncon) fetch(c);
-    while (c < ncon) {
-      const int dim = L.hdim[c];
-      float hc[36], jc[NT][6], tv[NT][6];
+    auto multiply = [&](int cc, const Fetched& F) {
+      const int dim = L.hdim[cc];
+      float hc[36], tv[NT][6];
 #pragma unroll
-      for (int q = 0; q < 9; q++) { hc[4 * q] = hn[q].x; hc[4 * q + 1] = hn[q].y; hc[4 * q + 2] = hn[q].z; hc[4 * q + 3] = hn[q].w; }
-#pragma unroll
-      for (int t = 0; t < NT; t++)
-#pragma unroll
-        for (int j = 0; j < 6; j++) jc[t][j] = jn[t][j];
-      int cn = next_active(c);
-      if (cn < ncon) fetch(cn);
+      for (int q = 0; q < 9; q++) { hc[4 * q] = F.h[q].x; hc[4 * q + 1] = F.h[q].y; hc[4 * q + 2] = F.h[q].z; hc[4 * q + 3] = F.h[q].w; }
 #pragma unroll
       for (int t = 0; t < NT; t++)
 #pragma unroll
         for (int j = 0; j < 6; j++) {                          // T = Hc J, this lane's column(s)
           float v = 0.f;
 #pragma unroll
-          for (int l = 0; l < 6; l++) v += hc[j * 6 + l] * jc[t][l];
+          for (int l = 0; l < 6; l++) v += hc[j * 6 + l] * F.j[t][l];
           tv[t][j] = v;
         }
 #pragma unroll
@@ -1186,14 +1187,42 @@ DEV float total_cost(const TreeModel* tm, TreeLDS& L, const TreeScratch& G, bool
         if (2 * s2 < dim) {
           float a[NT], b[NT];
 #pragma unroll
-          for (int t = 0; t < NT; t++) { a[t] = kk ? jc[t][2 * s2 + 1] : jc[t][2 * s2]; b[t] = kk ? tv[t][2 * s2 + 1] : tv[t][2 * s2]; }
+          for (int t = 0; t < NT; t++) { a[t] = kk ? F.j[t][2 * s2 + 1] : F.j[t][2 * s2]; b[t] = kk ? tv[t][2 * s2 + 1] : tv[t][2 * s2]; }
 #pragma unroll
           for (int ti = 0; ti < NT; ti++)
 #pragma unroll
             for (int tj = 0; tj < NT; tj++) acc[ti][tj] = mfma_32x32x2(a[ti], b[tj], acc[ti][tj]);
         }
       }
-      c = cn;
+    };
+    if constexpr (TRL == 0) {
+      Fetched A, B, cur;
+      int c0 = next_active(-1), c1 = c0 < ncon ? next_active(c0) : ncon;
+      if (c0 < ncon) fetch(c0, A);
+      if (c1 < ncon) fetch(c1, B);
+      while (c0 < ncon) {
+        cur = A;
+        int c2 = c1 < ncon ? next_active(c1) : ncon;
+        if (c2 < ncon) fetch(c2, A);
+        multiply(c0, cur);
+        if (c1 >= ncon) break;
+        cur = B;
+        int c3 = c2 < ncon ? next_active(c2) : ncon;
+        if (c3 < ncon) fetch(c3, B);
+        multiply(c1, cur);
+        c0 = c2; c1 = c3;
+      }
+    } else {
+      Fetched N, cur;
+      int c = next_active(-1);
+      if (c < ncon) fetch(c, N);
+      while (c < ncon) {
+        cur = N;
+        int cn = next_active(c);
+        if (cn < ncon) fetch(cn, N);
+        multiply(c, cur);
+        c = cn;
+      }
     }
     // the accumulators into H: lane l holds column l % 32, rows 8 (r / 4) + 4 (l / 32) + r % 4 of each tile
 #pragma unroll
