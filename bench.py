@@ -423,6 +423,12 @@ def main():
                 hold[k] = env.obs[:, 12:18].clone()
     sync()
 
+    # the path's one exchange step (SURVEY 8e, configs[4]): every 100 control steps the episode returns of every rank are all-gathered for
+    # logging, on a side stream behind a snapshot - inside the timed region whenever a window is that long (the driver's 20-step windows
+    # never reach it; `--steps 500` does five)
+    returns_log = sdist.PeriodicReturnsGather(interval=100, device=dev)
+    steps_done = [0]
+
     def one_step(i, timed, sample=None):
         # `i` indexes the action tape (warm-up part, then one K-step slice per timed window).  `sample`: read the per-env diagnostics after this step.  The first warm-up
         # step does it too (result discarded), so that every torch kernel the sampling needs is loaded before the timed
@@ -450,6 +456,12 @@ def main():
                     stats[k]["ncand"] += d[:, 3].sum()
         if sample:
             samples[0] += sum(e.n_envs for e in envs)
+        if timed:
+            with on_stream(streams[0]):
+                if len(envs) > 1:
+                    streams[0].wait_stream(streams[1])
+                returns_log.maybe(steps_done[0], lambda: torch.cat([env.episode_returns() for env in envs]))
+            steps_done[0] += 1
 
     for i in range(args.warmup):
         one_step(i, False, sample=(i == 0))
@@ -478,16 +490,23 @@ def main():
                     ticks[k].append(Tick(s))
         for k, s in enumerate(streams):
             ticks[k].append(Tick(s))
+        # the K steps are complete when their launch streams are (what a caller that joins ITS stream waits for) ...
+        for s in streams:
+            s.synchronize()
+        joined = time.perf_counter() - t0
+        # ... and the contract's device-wide synchronize also waits for work the steps started for FUTURE episodes: the reset prefetch
+        # that the last mass reset of a long window kicked off on the library's low-priority stream (up to ~2 s on 256 wavefronts)
         sync()
         own = time.perf_counter() - t0             # this rank's own time, before it waits for the others
         sdist.barrier()
         host = time.perf_counter() - t0
         dev_ms = max(t[0].ms_until(t[-1]) for t in ticks) / args.steps
         segs = [max(t[j].ms_until(t[j + 1]) for t in ticks) for j in range(len(ticks[0]) - 1)] if segment else []
-        return host, dev_ms, segs, own
+        return host, dev_ms, segs, own, joined
 
-    elapsed_local, kernel_ms, segments, own_local = timed_window(segment=100 if args.steps >= 500 else 0)
+    elapsed_local, kernel_ms, segments, own_local, joined_local = timed_window(segment=100 if args.steps >= 500 else 0)
     elapsed = sdist.max_over_ranks(elapsed_local, dev)
+    joined = sdist.max_over_ranks(joined_local, dev)
     events_first = {}
     for env in envs:
         for k, v in env.events().items():
@@ -516,6 +535,9 @@ def main():
 
     # what the process group itself reports (backend, world size, which ranks answered) + every rank's own ms per step of the first window
     dist_info = sdist.evidence(1e3 * own_local / args.steps, dev)
+    logged = returns_log.latest()
+    dist_info["periodic_returns_gather"] = {"interval_steps": returns_log.interval, "collectives": returns_log.count,
+                                            "last": None if logged is None else {"timed_step": logged[0], "envs": int(logged[1].numel()), "mean_return": float(logged[1].float().mean())}}
     # logging-only exchange: episode returns all-gathered over RCCL/xGMI (not in the timed region)
     returns = torch.cat([env.episode_returns() for env in envs])
     all_returns = sdist.all_gather_returns(returns)
@@ -525,7 +547,7 @@ def main():
 
     path = 0 if args.fused else (args.pipeline if args.pipeline >= 0 else 1)
     if rank == 0:
-        build_hash = sbuild.source_hash(mpr=args.narrowphase == "mpr")
+        build_hash = sbuild.source_hash(mpr=args.narrowphase == "mpr", exp=args.pipeline >= 2)      # (the library that ran: pipeline 2 / 3 live in the exp build)
         # `value` = the MEAN over all timed windows (each EXACTLY --steps steps; the first one host-clocked between barrier +
         # synchronize, the others back to back behind it, cut with device events), not the first - and usually best - window alone
         rep_values = [world * n_local * args.steps / e for e in rep_elapsed]
@@ -585,14 +607,20 @@ def main():
         if segments:
             seg_rates = [n_local * 100 / (ms * 1e-3) for ms in segments]
             out["sustained"] = {"steps": args.steps, "env_steps_per_s": value,
+                                "host_env_steps_per_s": n_local * world * args.steps / joined,
                                 "device_env_steps_per_s": n_local * world * args.steps / (1e-3 * sum(segments)),
+                                "prefetch_drain_s": elapsed - joined,
                                 "per_100_steps_env_steps_per_s": seg_rates,
                                 "min": min(seg_rates), "max": max(seg_rates),
                                 "note": "one window long enough for every env to pass its time limit (auto-reset inside); device time "
                                         "of each 100-step slice on rank 0, the way the reference logs its step time (run_eval.py:103-124). "
-                                        "`env_steps_per_s` = `value` (host clock, device-wide synchronize: it also waits for the reset "
-                                        "prefetch of FUTURE episodes that the last mass reset started, up to 1.6 s of background work); "
-                                        "`device_env_steps_per_s` = the same steps over the device time of the launch streams"}
+                                        "`host_env_steps_per_s` = host clock from the barrier to the moment the launch streams are "
+                                        "joined (stream.synchronize(): the K steps are complete - what a caller that synchronises its own "
+                                        "stream measures, max over ranks); `env_steps_per_s` = `value` = host clock to the contract's "
+                                        "device-wide synchronize, `prefetch_drain_s` later: it also waits for the reset prefetch of FUTURE "
+                                        "episodes that the last mass reset started on the library's low-priority stream (in a longer run that "
+                                        "work overlaps the next episode's steps - the dips of `per_100_steps` - instead of standing alone at the "
+                                        "end); `device_env_steps_per_s` = the same steps over the device time of the launch streams"}
         if hasattr(envs[0], "sim") and hasattr(envs[0].sim, "info"):
             out["config"]["step_path"] = envs[0].sim.info()
             if path == 2:

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SO101_ABI_VERSION 9      /* 9: so101_tree_config gains the observation delays, so101_tree_bind_physics_state; 8: the general-tree engine (so101_tree_*) */
+#define SO101_ABI_VERSION 10     /* 10: so101_tree_last_plan; 9: so101_tree_config gains the observation delays, so101_tree_bind_physics_state; 8: the general-tree engine (so101_tree_*) */
 #define SO101_OBS_DIM 18      /* joints_pos(6, delayed) | undelayed_joints_pos(6) | commanded_joints_pos(6) */
 #define SO101_ACT_DIM 6
 #define SO101_SOLVER_PGS 0
@@ -269,6 +269,9 @@ void so101_tree_destroy(so101_tree* sim);
  * matrix - and the build itself (32 or 64: so101_tree_create takes the 32-dof / 128-geom / 64-contact build whenever the model fits it,
  * otherwise the 64-dof / 256-geom / 128-contact one of the Dining scenes) */
 int so101_tree_dims(const so101_tree* sim, int* dims);
+/* What the last so101_tree_step of this handle enqueued, as the library counted it (not a host-side copy of the rule): out[4] = env slices,
+ * kernel launches, memsets, path (0: no step yet, 1: the single kernel k_tree_step, 2: the launch chain).  bench.py reports it as evidence. */
+int so101_tree_last_plan(const so101_tree* sim, int* out);
 int so101_tree_bind_state(so101_tree* sim, float* qpos, float* qvel, float* ctrl, float* warmstart);
 /* solver_iterations <= 0 / solver_tolerance < 0 keep the model's (100, 1e-8) */
 int so101_tree_configure(so101_tree* sim, int solver_iterations, float solver_tolerance);

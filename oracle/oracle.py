@@ -126,6 +126,17 @@ class Oracle:
         self.L.orc_set_hull_multicontact.argtypes = [C.c_void_p, C.c_int]
         self.L.orc_set_hull_multicontact(self.h, int(bool(on)))
 
+    def set_contact_capacity(self, capacity: int):
+        """Mirror the kernels' contact capacity (native so101_max_contacts()): a substep with more contacts keeps ONE per touching geom pair.
+        0 (the default) = no limit, like MuJoCo."""
+        self.L.orc_set_contact_capacity.argtypes = [C.c_void_p, C.c_int]
+        self.L.orc_set_contact_capacity(self.h, int(capacity))
+
+    def contacts_reduced(self) -> int:
+        self.L.orc_contacts_reduced.argtypes = [C.c_void_p]
+        self.L.orc_contacts_reduced.restype = C.c_int
+        return int(self.L.orc_contacts_reduced(self.h))
+
     def set_solver_type(self, newton: bool):
         self.L.orc_set_solver_type(self.h, int(bool(newton)))
 

@@ -173,6 +173,9 @@ struct orc_sim {
   std::vector<real> J, efc_pos, efc_D, efc_R, efc_aref, efc_force, efc_floss, efc_b, AR;
   std::vector<int> efc_type, efc_id, efc_dim;
   int iterations; real tolerance; bool collide = true;
+  int contact_capacity = 0;      // > 0: the kernels' capacity rule (csrc/so101_device.hpp reduce_contacts / gather_contacts): a substep with more contacts keeps ONE per touching geom
+                                 // pair - the first of its patch -, and the list is cut only when the touching pairs alone exceed it.  0 (default): no limit, like MuJoCo
+  bool contacts_reduced = false, contacts_cut = false;
   bool hull_multi = true;        // several contacts for hull pairs resting on flat features (hull_patch; off: the single EPA contact of rounds 1-4)
   std::vector<real> mass0, inertia0, invweight0;     // unscaled prop masses (orc_set_mass_scale)
   std::vector<Contact> injected;                      // orc_inject_contacts
@@ -1014,6 +1017,16 @@ void collision(orc_sim* s) {
       s->con.push_back(c);
     }
   }
+  // the kernels' capacity rule, mirrored on request (orc_set_contact_capacity): one lane per contact in the Newton solver = 64 slots per env
+  s->contacts_reduced = s->contacts_cut = false;
+  if (s->contact_capacity > 0 && (int)s->con.size() > s->contact_capacity) {
+    std::vector<Contact> kept;
+    for (size_t j = 0; j < s->con.size(); j++)
+      if (j == 0 || s->con[j].g1 != s->con[j - 1].g1 || s->con[j].g2 != s->con[j - 1].g2) kept.push_back(s->con[j]);      // (a pair's contacts are consecutive)
+    s->contacts_reduced = true;
+    if ((int)kept.size() > s->contact_capacity) { kept.resize(s->contact_capacity); s->contacts_cut = true; }
+    s->con.swap(kept);
+  }
 }
 
 // ================================================================ constraints
@@ -1800,6 +1813,8 @@ void orc_set_mass_scale(orc_sim* s, const double* scale) {
 void orc_set_solver_type(orc_sim* s, int t) { s->solver = t; }
 void orc_set_narrowphase(orc_sim* s, int mode) { s->narrow = mode; }
 void orc_set_hull_multicontact(orc_sim* s, int on) { s->hull_multi = on != 0; }
+void orc_set_contact_capacity(orc_sim* s, int cap) { s->contact_capacity = cap; }
+int orc_contacts_reduced(const orc_sim* s) { return (s->contacts_reduced ? 1 : 0) | (s->contacts_cut ? 2 : 0); }
 int orc_epa_iterations(const orc_sim* s) { return s->epa_iters; }
 int orc_ls_evals(const orc_sim* s) { return s->ls_evals; }
 void orc_set_state(orc_sim* s, const double* q, const double* v, const double* w) {

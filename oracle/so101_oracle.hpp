@@ -63,6 +63,9 @@ void orc_set_narrowphase(orc_sim*, int mode);
 // hull against hull: 1 (default; what the kernels run) = up to NCPP contacts on flat features (hull_patch in so101_oracle.cpp), 0 = the single
 // EPA contact of rounds 1-4
 void orc_set_hull_multicontact(orc_sim*, int on);
+/* the kernels' contact capacity (so101_max_contacts()) mirrored: a substep with more contacts keeps one per touching geom pair; 0 = no limit (default) */
+void orc_set_contact_capacity(orc_sim*, int capacity);
+int orc_contacts_reduced(const orc_sim*);      /* bit 0: the last collision pass reduced the list, bit 1: it was cut as well */
 int orc_epa_iterations(const orc_sim*);
 int orc_ls_evals(const orc_sim*);
 

@@ -9,6 +9,7 @@ for n in default "$@"; do
   if [ "$n" = default ]; then unset SO101_HIP_LIB; else export SO101_HIP_LIB=$R/ab/lib_$n.so; fi
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$n -- python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline $BENCH_ARGS > $O/${TAG}_kstats_$n.log 2>&1
   f=$(find /tmp/ks_$n -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] || { echo "== $n: no kernel_stats.csv (the profiler run failed)"; continue; }
   cp $f $O/${TAG}_kstats_$n.csv
   echo "== $n"; python3 - $f <<'PY'
 import csv, sys

@@ -1,10 +1,11 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT}; cd /tmp; export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd /tmp; export TMPDIR=/tmp
 for n in default r04; do
   if [ "$n" = default ]; then unset SO101_HIP_LIB; else export SO101_HIP_LIB=$R/ab/lib_$n.so; fi
   rm -rf /tmp/pt_$n
   rocprofv3 --kernel-trace --output-format csv -d /tmp/pt_$n -- python3 $R/bench.py --steps 500 --warmup 10 --repeats 1 --no-cpu-baseline > /dev/null 2>&1
   f=$(find /tmp/pt_$n -name "*kernel_trace.csv" | head -1)
+  [ -n "$f" ] || { echo "$n: no kernel_trace.csv (the profiler run failed)"; continue; }
   python3 - $f $n <<'PY'
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]

@@ -401,18 +401,18 @@ class AlohaEnvironment:
         return self.ep_return
 
     def launch_plan(self) -> dict:
-        """What one `step_tensor` call enqueues (the rule of `so101_tree_step`, csrc/tu_tree.hip: env slices by batch size or SO101_TREE_SLICES,
-        per slice one memset, k_tree_pipe_begin, n_substeps x (k_tree_narrow + k_tree_pipe_solve), and for the contact rewards one more
-        k_tree_narrow + k_tree_pipe_finish)."""
-        import os
+        """What the last `step_tensor` call enqueued, as the LIBRARY counted it (`so101_tree_last_plan`; round 5 re-implemented the slicing rule
+        of csrc/tu_tree.hip here, which a change over there or a late SO101_TREE_SLICES would silently falsify - ADVICE r5).  Launch chain:
+        per env slice one memset, k_tree_pipe_begin, n_substeps x (k_tree_narrow + k_tree_pipe_solve), and for the contact rewards one more
+        k_tree_narrow + k_tree_pipe_finish."""
+        slices, launches, memsets, path = self.sim.last_plan()
+        if path == 0:
+            return {"path": "no step yet", "slices": 0, "kernel_launches": 0, "memsets": 0}
+        if path == 1:
+            return {"path": "single kernel (k_tree_step)", "slices": 1, "kernel_launches": launches, "memsets": memsets}
         nsub = int(round(self.task.control_timestep / PHYSICS_TIMESTEP))
         post = self.task.reward_mode != 0
-        if not (self._pipeline and self.n_envs > 1) or nsub + int(post) > 63:
-            return {"path": "single kernel (k_tree_step)", "slices": 1, "kernel_launches": 1, "memsets": 0}
-        env_slices = int(os.environ.get("SO101_TREE_SLICES", "0") or 0)
-        g = 1 if self.n_envs < 128 else (env_slices if 1 <= env_slices <= 4 else (2 if self.n_envs < 512 else 4))
-        per_slice = 1 + 2 * nsub + (2 if post else 0)
-        return {"path": "launch chain", "slices": g, "kernel_launches": g * per_slice, "memsets": g,
+        return {"path": "launch chain", "slices": slices, "kernel_launches": launches, "memsets": memsets,
                 "kernels": "k_tree_pipe_begin + %d x (k_tree_narrow + k_tree_pipe_solve)%s per slice" % (nsub, " + k_tree_narrow + k_tree_pipe_finish" if post else "")}
 
     def diagnostics(self):

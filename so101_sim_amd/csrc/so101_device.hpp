@@ -915,7 +915,14 @@ DEV bool mpr_penetration(const DevModel* m, const GeomW& G1, const GeomW& G2, fl
   if (isz(dt) || dt < 0.f) return false;
   cross3(d, v0.v, v1.v);
   float dn = sqrtf(dot3(d, d));
-  if (isz(dn)) {
+  // "origin on the v0-v1 segment": v0 and v1 collinear.  libccd's absolute test |v0 x v1| < eps, with the fp32 epsilon 1.2e-7, fires far from
+  // collinearity when the vectors are short - the nudged ray of two coinciding interior points is 1e-5 long, so any support point within 9
+  // degrees of it passed for "on the ray" and the pair got the distance to that support point as its depth: a wrist hull whose centre lies
+  // inside the static puck reported 76 mm sideways where the minimum translation (and the fp64 oracle, whose epsilon is 1e-10 as in MuJoCo's
+  // double-precision build of libccd) says 45 mm through the cap (round 6: seed 3 of test_failure_rates_on_the_headline_workload, env 23;
+  // tests/golden/probe_outlier_states.json).  Hence also a RELATIVE bound, sin(angle) < 1e-4 - an order of magnitude above what fp32 support
+  // points resolve for centimetre-sized vectors; for |v0| |v1| >= 1.2e-3 m^2 the absolute test is the tighter one and decides as before.
+  if (dn < fminf(EPS_F, 1e-4f * sqrtf(dot3(v0.v, v0.v) * dot3(v1.v, v1.v)))) {
     if (isz(v1.v[0]) && isz(v1.v[1]) && isz(v1.v[2])) {     // touching contact
       *depth = 0.f; dir[0] = dir[1] = dir[2] = 0.f;
 #pragma unroll

@@ -459,6 +459,7 @@ struct TreeHandle {
   static constexpr int MAXSLICES = 4;
   hipStream_t slice_stream[MAXSLICES] = {};      // env slices whose chains overlap (one's narrowphase beside another's solve)
   hipEvent_t slice_begin = nullptr, slice_done[MAXSLICES] = {};
+  int plan[4] = {0, 0, 0, 0};          // what the last so101_tree_step enqueued: env slices, kernel launches, memsets, path (0 none yet, 1 single kernel, 2 launch chain)
   std::vector<void*> owned;
   std::string err;
 };
@@ -819,6 +820,12 @@ int TAPI(dims)(const TreeHandle* s, int* dims /* [16]: nq nv nu nbody ngeom debu
   return SO101_OK;
 }
 
+int TAPI(last_plan)(const TreeHandle* s, int* out /* [4] */) {
+  if (!s || !out) return SO101_ERR_ARG;
+  for (int i = 0; i < 4; i++) out[i] = s->plan[i];
+  return SO101_OK;
+}
+
 int TAPI(bind_state)(TreeHandle* s, float* qpos, float* qvel, float* ctrl, float* warmstart) {
   if (!s || !qpos || !qvel || !ctrl || !warmstart) { if (s) s->err = "so101_tree_bind_state: NULL buffer"; return SO101_ERR_ARG; }
   s->buf.qpos = qpos; s->buf.qvel = qvel; s->buf.ctrl = ctrl; s->buf.warm = warmstart;
@@ -922,6 +929,7 @@ int TAPI(step)(TreeHandle* s, const float* action, float* obs, float* reward, fl
     static const int slices_env = getenv("SO101_TREE_SLICES") ? atoi(getenv("SO101_TREE_SLICES")) : 0;          // (kernel experiments)
     const int G = s->n_envs < 128 ? 1 : (slices_env >= 1 && slices_env <= TreeHandle::MAXSLICES ? slices_env : (s->n_envs < 512 ? 2 : 4));
     if (G > 1 && !t_ok(s, hipEventRecord(s->slice_begin, st), "hipEventRecord")) return SO101_ERR_HIP;
+    s->plan[0] = G; s->plan[1] = G * (1 + 2 * T.n_substeps + (post ? 2 : 0)); s->plan[2] = G; s->plan[3] = 2;
     for (int g = 0; g < G; g++) {
       int e0 = (int)((long long)s->n_envs * g / G), ng = (int)((long long)s->n_envs * (g + 1) / G) - e0;
       hipStream_t gs = G == 1 ? st : s->slice_stream[g];
@@ -946,6 +954,7 @@ int TAPI(step)(TreeHandle* s, const float* action, float* obs, float* reward, fl
       if (G > 1 && !(t_ok(s, hipEventRecord(s->slice_done[g], gs), "hipEventRecord") && t_ok(s, hipStreamWaitEvent(st, s->slice_done[g], 0), "hipStreamWaitEvent"))) return SO101_ERR_HIP;
     }
   } else {
+    s->plan[0] = 1; s->plan[1] = 1; s->plan[2] = 0; s->plan[3] = 1;
     hipLaunchKernelGGL(k_tree_step, dim3(s->n_envs), dim3(64), 0, st, s->dm, s->dg, T, s->buf, s->env, store_now(s), action, obs, reward, discount, step_type);
     if (!t_ok(s, hipGetLastError(), "k_tree_step")) return SO101_ERR_HIP;
   }

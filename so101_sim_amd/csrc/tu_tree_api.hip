@@ -12,6 +12,7 @@
   void so101_tree##V##_destroy(void*);                                                                                                        \
   const char* so101_tree##V##_last_error(const void*);                                                                                        \
   int so101_tree##V##_dims(const void*, int*);                                                                                                \
+  int so101_tree##V##_last_plan(const void*, int*);                                                                                            \
   int so101_tree##V##_bind_state(void*, float*, float*, float*, float*);                                                                      \
   int so101_tree##V##_configure(void*, int, float);                                                                                           \
   int so101_tree##V##_physics(void*, int, void*);                                                                                             \
@@ -73,6 +74,7 @@ const char* so101_tree_last_error(const so101_tree* s) {
 }
 
 int so101_tree_dims(const so101_tree* s, int* dims) { return s ? FWD(dims, dims) : SO101_ERR_ARG; }
+int so101_tree_last_plan(const so101_tree* s, int* out) { return s ? FWD(last_plan, out) : SO101_ERR_ARG; }
 int so101_tree_bind_state(so101_tree* s, float* qpos, float* qvel, float* ctrl, float* warmstart) { return s ? FWD(bind_state, qpos, qvel, ctrl, warmstart) : SO101_ERR_ARG; }
 int so101_tree_configure(so101_tree* s, int solver_iterations, float solver_tolerance) { return s ? FWD(configure, solver_iterations, solver_tolerance) : SO101_ERR_ARG; }
 int so101_tree_physics(so101_tree* s, int n_substeps, void* stream) { return s ? FWD(physics, n_substeps, stream) : SO101_ERR_ARG; }

@@ -128,7 +128,11 @@ class BatchedEnvironment:
                 raise ValueError(f"narrowphase must be 'mpr' or 'epa', got {narrowphase!r}")
             from . import build as _build
             self.narrowphase = narrowphase
-            self.sim = native.Sim(blob, self.n_envs, device=dev_index, seed=seed, lib_path=_build.build(mpr=True) if narrowphase == "mpr" else None)
+            # (SO101_HIP_LIB - kernel experiments, bench.py --pipeline 2|3 - names the library whatever the narrowphase: whoever sets it
+            #  built the variant it wants, e.g. build(exp=True, mpr=True); an explicit lib_path here used to override it)
+            import os as _os
+            lib = None if (_os.environ.get("SO101_HIP_LIB") or narrowphase != "mpr") else _build.build(mpr=True)
+            self.sim = native.Sim(blob, self.n_envs, device=dev_index, seed=seed, lib_path=lib)
         N = self.n_envs
         z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=self.device)
         self.qpos, self.qvel, self.ctrl, self.warm = z(20, N), z(18, N), z(6, N), z(18, N)
@@ -346,6 +350,13 @@ class BatchedEnvironment:
         self.sim.get_diag(d.data_ptr(), self._stream())
         return d
 
+    def synchronize(self):
+        """Wait until everything this env was asked to do on the caller's current stream is done (steps, resets, reads).  Cheaper than
+        `torch.cuda.synchronize()` right after a mass reset: a device-wide synchronise also waits for the library's background reset
+        prefetch - settled initial states of FUTURE episodes, up to ~2 s of low-priority work on 256 wavefronts for 4096 envs - which no
+        result of the calls made so far depends on (bench.py reports both clocks, `sustained.host_env_steps_per_s` / `env_steps_per_s`)."""
+        self.torch.cuda.current_stream(self.device).synchronize()
+
     def close(self):
         self.sim.close()
 
@@ -385,6 +396,16 @@ class SingleEnvironment(BatchedEnvironment):
         self._dbg = self.torch.zeros(1, native.DEBUG_DIM, device=self.device)
         # a stream of its own: the library replays the step's launch chain as a captured HIP graph on any stream but the legacy null stream
         self._own = self.torch.cuda.Stream(device=self.device)
+
+    def _join_caller(self):
+        """Order the env's own stream behind the caller's current stream: the constructor's fills, `bind` / `configure`, and every
+        inherited mutator (`set_mass_scale`, `set_reset_pool`, `begin_episode`, `step_tensor`, `compute_settled`) are enqueued on the stream
+        that is current when they are called, and torch creates `_own` non-blocking - without this edge `env.set_mass_scale(t); env.reset()`
+        would race on qpos / mass_scale / the record.  The other direction needs no event: `_fetch()` synchronises `_own` on the host
+        before reset() / step() return, so whatever the caller enqueues afterwards starts after this env's work."""
+        cur = self.torch.cuda.current_stream(self.device)
+        if cur != self._own:
+            self._own.wait_stream(cur)
 
     def _fetch(self):
         """the 256-byte state + output record of the last call -> pinned host memory, one copy, one synchronisation; returns the numpy view"""
@@ -457,6 +478,7 @@ class SingleEnvironment(BatchedEnvironment):
         return o
 
     def reset(self) -> TimeStep:
+        self._join_caller()
         with self.torch.cuda.stream(self._own):
             if self._seed_compatible and self._pool is None:
                 self._reset_seed_compatible()
@@ -471,6 +493,7 @@ class SingleEnvironment(BatchedEnvironment):
             raise ValueError(f"Expected 6 joint positions, got {len(a)}")
         if self._pending_first:            # the step after LAST restarts the episode and reports FIRST (dm_control)
             return self.reset()
+        self._join_caller()
         with self.torch.cuda.stream(self._own):
             self._act_host[0] = self.torch.from_numpy(a)
             self._action.copy_(self._act_host, non_blocking=True)

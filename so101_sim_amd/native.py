@@ -32,7 +32,7 @@ EXPORTS = (
     "so101_version", "so101_max_contacts", "so101_create", "so101_destroy", "so101_default_config",
     "so101_configure", "so101_bind_state", "so101_bind_physics_state", "so101_set_reset_pool", "so101_compute_settled", "so101_set_settled_store", "so101_reset", "so101_settle", "so101_begin_episode", "so101_step", "so101_physics", "so101_reward",
     "so101_get_returns", "so101_get_diag", "so101_get_events", "so101_debug_forward", "so101_debug_candidates", "so101_debug_stages", "so101_get_info", "so101_debug_chain_stats", "so101_last_error",
-    "so101_tree_create", "so101_tree_destroy", "so101_tree_dims", "so101_tree_bind_state", "so101_tree_configure", "so101_tree_physics",
+    "so101_tree_create", "so101_tree_destroy", "so101_tree_dims", "so101_tree_last_plan", "so101_tree_bind_state", "so101_tree_configure", "so101_tree_physics",
     "so101_tree_debug_forward", "so101_tree_get_diag", "so101_tree_last_error", "so101_tree_obs_dim", "so101_tree_bind_env",
     "so101_tree_configure_env", "so101_tree_bind_physics_state", "so101_tree_reset", "so101_tree_step", "so101_tree_begin_episode", "so101_tree_settle", "so101_tree_compute_settled", "so101_tree_set_settled_store",
 )
@@ -240,6 +240,7 @@ class TreeSim:
         L.so101_tree_destroy.argtypes = [C.c_void_p]
         L.so101_tree_destroy.restype = None
         L.so101_tree_dims.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.so101_tree_last_plan.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.so101_tree_bind_state.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         L.so101_tree_configure.argtypes = [C.c_void_p, C.c_int, C.c_float]
         L.so101_tree_physics.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -322,6 +323,12 @@ class TreeSim:
 
     def reset(self, mask=None, stream: int = 0):
         self._check(self.L.so101_tree_reset(self.h, mask, stream), "so101_tree_reset")
+
+    def last_plan(self):
+        """(env slices, kernel launches, memsets, path) of the last so101_tree_step as the library enqueued it; path 0 = no step yet"""
+        d = (C.c_int * 4)()
+        self._check(self.L.so101_tree_last_plan(self.h, d), "so101_tree_last_plan")
+        return tuple(d)
 
     def step(self, action, obs, reward, discount, step_type, stream: int = 0):
         self._check(self.L.so101_tree_step(self.h, action, obs, reward, discount, step_type, stream), "so101_tree_step")

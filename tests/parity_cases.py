@@ -390,9 +390,7 @@ def check_single_env_many_candidates(make_sim, n=1):
     the oriented-box filter, 52 contacts; found by a search over 4096 random poses, scripts/_many_gpu.py of round 4).  The slice's
     pool has a floor of MAXCAND records, so nothing is dropped: no candidate overflow, and the launch chains equal the fused step
     bit for bit."""
-    q = np.array([-1.0634258785616666, -0.5545677729900828, 1.211987612465097, 1.5106441037491418, 0.2955641252246174, 0.45852864142397015,
-                  -0.21614169879288164, -0.07840607080687334, 0.45169759366551465, 0.04017006147253602, -0.9923465397604655, 0.06079185274871466,
-                  -0.09969484352814978, -0.217988678, -0.0396717335, 0.422621829, 0.999999456, -0.000582714664, -0.000865621822, -8.25292623e-06])
+    q = MANY_CONTACTS_QPOS
     Q = np.tile(q[:, None], (1, n))
     out = []
     for pipeline in (0, 1):
@@ -413,6 +411,50 @@ def check_single_env_many_candidates(make_sim, n=1):
         out.append(trace)
     for a, b in zip(*out):
         np.testing.assert_array_equal(a, b)
+
+
+MANY_CONTACTS_QPOS = np.array([-1.0634258785616666, -0.5545677729900828, 1.211987612465097, 1.5106441037491418, 0.2955641252246174, 0.45852864142397015,
+                               -0.21614169879288164, -0.07840607080687334, 0.45169759366551465, 0.04017006147253602, -0.9923465397604655, 0.06079185274871466,
+                               -0.09969484352814978, -0.217988678, -0.0396717335, 0.422621829, 0.999999456, -0.000582714664, -0.000865621822, -8.25292623e-06])
+
+
+def check_contact_capacity_mirrored(make_sim, blobs, max_contacts=64):
+    """More contacts than the kernels' capacity (one lane per contact in the Newton solver: so101_max_contacts() = 64): the env keeps ONE
+    contact per touching geom pair for that substep (event 7, `contacts_reduced`; MuJoCo has no such limit - a documented deviation,
+    DESIGN.md section 4).  The oracle mirrors the rule on request (Oracle.set_contact_capacity): on the state of
+    check_single_env_many_candidates (the banana standing inside the bowl, the gripper reaching into it: > 64 contacts with the hull
+    patches) kernel and oracle must then keep the SAME contacts - pair by pair, in order, depth and normal of each - and the same
+    constrained acceleration on the kernel's list; the unlimited oracle on the same state has more contacts than the capacity."""
+    from oracle.oracle import Oracle
+    q = MANY_CONTACTS_QPOS
+    sim = make_sim(1, prefetch_resets=0, solver_iterations=50)
+    sim.set_state(q[:, None], np.zeros((18, 1)), np.zeros((6, 1)), np.zeros((18, 1)))
+    d = sim.debug_forward()[0]
+    assert d["overflow"] & 128, ("the state must exceed the capacity", d["overflow"], len(d["contacts"]))
+    assert not d["overflow"] & 2, "more touching PAIRS than contact slots: not the case this state is meant to be"
+    o = Oracle(blobs["f64"])
+    o.set_solver(50, -1.0)
+    o.set_state(q, np.zeros(18), np.zeros(18))
+    o.set_ctrl(np.zeros(6))
+    o.forward()
+    unlimited = o.contacts()
+    assert len(unlimited) > max_contacts and o.contacts_reduced() == 0, len(unlimited)
+    o.set_contact_capacity(max_contacts)
+    o.forward()
+    ref = o.contacts()
+    assert o.contacts_reduced() == 1
+    pairs = [(c["geom1"], c["geom2"]) for c in ref]
+    assert len(set(pairs)) == len(pairs) == len(set((c["geom1"], c["geom2"]) for c in unlimited)), "one contact for every touching pair, none lost"
+    assert len(d["contacts"]) == len(ref), (len(d["contacts"]), len(ref))
+    problems, total, loose, witness = _compare_contact_lists(d["contacts"], ref)
+    assert not problems, problems
+    assert loose <= max(1, 0.05 * total) and witness <= max(2, 0.1 * total), (loose, witness, total)
+    o.inject_contacts(d["contacts"])
+    o.forward()
+    a = o.qacc()[0]
+    err = np.abs(d["qacc"] - a).max() / np.abs(a).max()
+    assert err <= 1e-3, err
+    return len(unlimited), len(ref), err
 
 
 def _compare_contact_lists(mine_list, ref_list):
@@ -500,6 +542,30 @@ def check_contact_rich(make_sim, blobs, golden, count=4, verbose=False):
     assert loose <= 0.02 * total, (loose, total)
     assert witness <= 0.05 * total, (witness, total)
     return worst, (total, loose, witness)
+
+
+def check_probe_outliers(make_sim, blobs, golden, which=None):
+    """States behind the one-step parity outliers of the random-action rollout (tests/golden/probe_outlier_states.json, captured by
+    scripts/gpu_probe_outlier.py): at each of them kernel and oracle must build the SAME contact list (pairs, counts, depth and normal of
+    every contact: _compare_contact_lists) and the same constrained acceleration on the kernel's own list (1e-3).  State 1 is the regression
+    of round 6: the wrist hull whose centre lies inside the static puck - the fp32 MPR took its 1e-5 m origin ray for collinear with the
+    first support point and reported 76 mm sideways; the minimum translation is 45 mm through the cap."""
+    states = golden["probe_outlier_states"]["states"]
+    idx = list(range(len(states))) if which is None else list(which)
+    for i in idx:
+        st = states[i]
+        q, v, w, a = (np.array(st[k], dtype=np.float64) for k in ("qpos", "qvel", "warm", "action"))
+        sim = make_sim(1, prefetch_resets=0)
+        sim.set_state(q[:, None], v[:, None], a[:, None], w[:, None])
+        d = sim.debug_forward()[0]
+        o = Oracle(blobs["f64"])
+        o.set_state(q, v, w); o.set_ctrl(a); o.forward()
+        problems, total, loose, witness = _compare_contact_lists(d["contacts"], o.contacts())
+        assert not problems, (i, problems)
+        o.inject_contacts(d["contacts"]); o.forward()
+        acc = o.qacc()[0]
+        err = np.abs(d["qacc"] - acc).max() / np.abs(acc).max()
+        assert err <= 1e-3, (i, err)
 
 
 def check_divergence_handling(make_sim, blobs):

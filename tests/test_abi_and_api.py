@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     lib = native.load_library()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.so101_version() == 9 and lib.so101_max_contacts() >= 16
+    assert lib.so101_version() == 10 and lib.so101_max_contacts() >= 16
 
 
 def test_create_rejects_bad_blobs_without_gpu(hip_lib, blobs):

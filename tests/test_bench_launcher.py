@@ -40,6 +40,17 @@ def test_gpus_2_spawns_two_ranks_and_reports_the_whole_job():
     assert abs(out["mean_episode_return"] - 9 * 7.5) < 1e-4
 
 
+def test_periodic_all_gather_of_returns_inside_a_long_window():
+    """SURVEY 8e / BASELINE configs[4]: every 100 control steps the ranks all-gather their episode returns (logging only, on a side stream on
+    the GPU).  One 100-step window with two gloo ranks: exactly one collective, taken after timed step 99, holding all 8 envs of the job."""
+    r = _run(["--gpus", "2", "--steps", "100", "--warmup", "0", "--envs-per-gpu", "4", "--repeats", "1"], timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][0])
+    g = out["dist"]["periodic_returns_gather"]
+    assert g["interval_steps"] == 100 and g["collectives"] == 1
+    assert g["last"]["timed_step"] == 99 and g["last"]["envs"] == 8 and abs(g["last"]["mean_return"] - 100 * 3.5) < 1e-3
+
+
 def test_world_size_mismatch_is_refused():
     r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
@@ -52,7 +63,8 @@ def test_single_rank_line_has_the_contract_keys():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "repeats", "first_window", "dist"):
         assert k in out
-    assert out["dist"] == {"backend": None, "world_size": 1, "ranks_reporting": 1, "ranks": [0], "per_rank": out["dist"]["per_rank"]}
+    assert out["dist"] == {"backend": None, "world_size": 1, "ranks_reporting": 1, "ranks": [0], "per_rank": out["dist"]["per_rank"],
+                           "periodic_returns_gather": {"interval_steps": 100, "collectives": 0, "last": None}}
     assert out["n_gpus"] == 1 and out["vs_baseline"] is None and out["scaling"] == "weak"
 
 

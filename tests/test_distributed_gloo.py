@@ -51,6 +51,16 @@ def _worker(rank, world, port, n_global, out):
     calls = []
     pool = sd.build_on_rank0(lambda: (calls.append(rank), (torch.arange(6, dtype=torch.float32).reshape(2, 3) + 100 * rank, torch.tensor([7 + rank], dtype=torch.int32)))[1])
     assert calls == ([0] if rank == 0 else []) and pool[0].tolist() == [[0.0, 1.0, 2.0], [3.0, 4.0, 5.0]] and pool[1].tolist() == [7] and pool[1].dtype == torch.int32
+    # the periodic logging exchange of configs[4]: every 2 steps here; the gather of step 3 holds both ranks' returns of THAT step
+    log = sd.PeriodicReturnsGather(interval=2, device=torch.device("cpu"))
+    env = _StubEnv(sd.shard_base(rank, per_rank), per_rank)
+    fired = []
+    for i in range(5):
+        env.step(i, 0.0)
+        fired.append(log.maybe(i, env.episode_returns))
+    assert fired == [False, True, False, True, False] and log.count == 2
+    lstep, lret = log.latest()
+    assert lstep == 3 and lret.tolist() == [0.5 * 4 * k for k in range(world * per_rank)]
     if rank == 0:
         out.put((g.numpy(), value, elapsed, rets.numpy(), tmax))
     sd.finalize()

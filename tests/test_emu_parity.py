@@ -40,6 +40,15 @@ def test_env_semantics(make_sim, blobs):
     pc.check_env_semantics(make_sim, blobs, n=1, settle=6, steps=4, last_step=3, iterations=10, eject_substeps=0)     # full delay-line wrap: GPU suite
 
 
+def test_probe_outlier_state_of_round_6(make_sim, blobs, golden):
+    pc.check_probe_outliers(make_sim, blobs, golden, which=[1])
+
+
+@SLOW
+def test_contact_capacity_rule_is_mirrored_by_the_oracle(make_sim, blobs):
+    pc.check_contact_capacity_mirrored(make_sim, blobs)
+
+
 @SLOW
 def test_divergence_handling(make_sim, blobs):
     pc.check_divergence_handling(make_sim, blobs)

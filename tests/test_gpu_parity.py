@@ -20,7 +20,7 @@ def test_native_library_is_the_hip_build():
     import os
     from so101_sim_amd import native
     assert os.path.exists(native.LIB_PATH)
-    assert native.load_library().so101_version() == 9
+    assert native.load_library().so101_version() == 10
 
 
 def test_forward_stages(make_sim, blobs):
@@ -113,6 +113,18 @@ def test_mpr_option_pipelined_step_matches_fused(blobs, golden):
 def test_single_env_with_more_candidates_than_pool_records(make_sim):
     pc.check_single_env_many_candidates(make_sim, n=1)
     pc.check_single_env_many_candidates(make_sim, n=3)
+
+
+def test_more_contacts_than_the_solver_has_lanes_matches_the_oracle_under_the_same_rule(make_sim, blobs):
+    """the 64-contact capacity is a deviation MuJoCo does not have; with the rule mirrored in the oracle
+    (Oracle.set_contact_capacity) a state above the capacity is compared contact by contact, and the unlimited oracle shows what was given up."""
+    from so101_sim_amd import native
+    unlimited, kept, err = pc.check_contact_capacity_mirrored(make_sim, blobs, max_contacts=native.load_library().so101_max_contacts())
+    assert unlimited > 64 >= kept and err <= 1e-3
+
+
+def test_probe_outlier_states_of_round_6(make_sim, blobs, golden):
+    pc.check_probe_outliers(make_sim, blobs, golden)
 
 
 def test_three_launch_chains_match_fused(make_sim, golden):

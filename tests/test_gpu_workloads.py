@@ -374,9 +374,9 @@ def test_mixed_suite_at_full_size_with_oracle_slices(blobs, blobs_pen):
         env.close()
 
 
-@pytest.mark.parametrize("seed", [1, 7])
+@pytest.mark.parametrize("seed", [1, 7, 3])
 def test_failure_rates_on_the_headline_workload(seed):
-    """4096 envs x 500 control steps of uniform random actions over the action spec (two seeds): how often the physics diverge
+    """4096 envs x 500 control steps of uniform random actions over the action spec (three seeds): how often the physics diverge
     (the episode then ends like a dm_control PhysicsError), how often contacts are DROPPED - round 5: never for arm-link contacts (the
     Jacobian pool's tail is recomputed, event 2 is retired), and for the contact list only when the touching geom pairs alone exceed 64; an
     env with more than 64 contacts keeps one contact per pair for that substep (event 7, `contacts_reduced`, bounded here) -, and that
@@ -420,11 +420,11 @@ def test_failure_rates_on_the_headline_workload(seed):
             qo, vo, _ = o.get_state()
             err.append((np.abs(q1[:, e].cpu().numpy() - qo).max(), np.abs(v1[:, e].cpu().numpy() - vo).max()))
     err = np.array(err)
-    # bar: >= 95 % inside 2e-3 rad / 0.1 rad/s, worst <= 2e-2 rad / 5 rad/s (round 3 under MPR: median 7e-7 / 4e-5, 90 %, worst 0.012 / 1.8)
+    # bar: >= 95 % inside 2e-3 rad / 0.1 rad/s, worst <= 2e-2 rad / 3 rad/s (round 5: 5 rad/s; round 3 under MPR: median 7e-7 / 4e-5, 90 %, worst 0.012 / 1.8)
     assert len(err) >= 100
     assert np.median(err[:, 0]) <= 2e-5 and np.median(err[:, 1]) <= 2e-3, (np.median(err[:, 0]), np.median(err[:, 1]))
     # (seed 1: 99 % inside, worst 1.3e-3 rad / 0.18 rad/s; seed 7, added in round 5: 98 %, worst 2.1e-3 rad / 2.6 rad/s - one probe with the arm pressing a prop)
-    assert np.mean((err[:, 0] <= 2e-3) & (err[:, 1] <= 0.1)) >= 0.95 and err[:, 0].max() <= 2e-2 and err[:, 1].max() <= 5.0, (
+    assert np.mean((err[:, 0] <= 2e-3) & (err[:, 1] <= 0.1)) >= 0.95 and err[:, 0].max() <= 2e-2 and err[:, 1].max() <= 3.0, (
         np.mean((err[:, 0] <= 2e-3) & (err[:, 1] <= 0.1)), err[:, 0].max(), err[:, 1].max())
     ev = env.events()
     per = {k: v / (n * steps) for k, v in ev.items()}
@@ -511,6 +511,42 @@ def test_batched_physics_state_and_its_15_step_delay():
             lines[e].append(cur[e])
             assert torch.equal(env.delayed_physics_state[e], expect), (t, e)
     assert firsts >= 6
+    env.close()
+
+
+def test_single_env_orders_its_own_stream_behind_the_callers():
+    """SingleEnvironment steps on a private non-blocking stream; a mutator enqueued on the CALLER's stream right before reset()
+    must be seen by that reset.  Here the reset pool (the state an episode starts from) only comes into existence on a side stream behind
+    tens of milliseconds of matrix products; reset() is called at once, from that stream.  Without the stream edge the reset kernel reads
+    the pool's memory before it is written."""
+    import os
+    import torch
+    from so101_sim_amd import task_suite
+    cwd = os.getcwd()
+    os.chdir("/tmp")
+    try:
+        env = task_suite.create_task_env("SO100HandOverBanana", time_limit=10.0, random_state=5)
+    finally:
+        os.chdir(cwd)
+    dev = env.device
+    ts = env.reset()
+    q = torch.tensor(ts.observation["physics_state"][:20], dtype=torch.float32, device=dev)
+    arm = torch.tensor([0.1, -1.2, 1.3, 0.4, -0.2, 0.03], device=dev)
+    q[:6] = arm
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    for trial in range(3):
+        with torch.cuda.stream(side):
+            big = torch.randn(4096, 4096, device=dev)
+            for _ in range(20):
+                big = (big @ big) * 1e-3
+            late = 0.0 * big[0, :1].nan_to_num()                  # (exists only once the products are done)
+            qpos = torch.full((20, 1), 7.0, device=dev)           # fresh memory, wrong contents until the line below has run
+            qpos.copy_((q + late).unsqueeze(1))
+            env.set_reset_pool(qpos, torch.zeros(18, 1, device=dev), arm.unsqueeze(1).clone())
+            ts = env.reset()
+        np.testing.assert_allclose(ts.observation["joints_pos"], arm.cpu().numpy(), atol=1e-6, err_msg=f"trial {trial}")
+        env.set_reset_pool(None)
     env.close()
 
 
