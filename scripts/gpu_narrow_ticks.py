@@ -51,3 +51,6 @@ rp = tk[:, 234:237].astype(np.float64).sum(0)
 if rp[1] > 0:
     print("row pass (light region, four pairs per wavefront): %.0f rows attempted, %.1f %% settled, %.2f us per pass-row (%.1f ms in all = %.1f %% of fetch + narrow_pair)"
           % (rp[1], 100 * rp[2] / rp[1], rp[0] * 1e-2 / rp[1], rp[0] * 1e-5, 100 * rp[0] / whole))
+
+ex = tk[:, 237:240].astype(np.float64).sum(0)
+print("after the query (share of fetch + narrow_pair): face_patch (five samples -> contacts, wave-uniform arithmetic) %.1f %% | hull-against-hull patches %.1f %%" % (100 * ex[0] / whole, 100 * ex[1] / whole))

@@ -12,7 +12,7 @@ from tests import parity_cases as pc
 from tests.test_gpu_workloads import _batched_env
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-n, steps, k = 4096, 500, 24
+n, steps, k = 4096, 500, int(os.environ.get("PROBE_ENVS", "24"))
 env = _batched_env("SO100HandOverBanana", n)
 spec = env.action_spec()
 lo = torch.tensor(spec.minimum, device=env.device); hi = torch.tensor(spec.maximum, device=env.device)
@@ -21,12 +21,13 @@ st = torch.cuda.Stream()
 raw64, meta = scenes.load_blob("banana", "f64")
 raw32, _ = scenes.load_blob("banana", "f32")
 gn = meta["geom_names"]
+PROBE_STEPS = tuple(int(x) for x in os.environ.get("PROBE_STEPS", "60,180,300,420,480").split(","))
 checks = []
 with torch.cuda.stream(st):
     env.reset_all()
     for t in range(steps):
         act = lo + (hi - lo) * torch.rand(n, 6, device=env.device, generator=gen)
-        probe = t in (60, 180, 300, 420, 480)
+        probe = t in PROBE_STEPS
         if probe:
             before = [x[:, :k].clone() for x in (env.qpos, env.qvel, env.warm)]
         env.step_tensor(act)

@@ -1664,6 +1664,7 @@ DEV bool narrow_pair_cached(const DevModel* m, const GeomW& G1, const GeomW& G2,
   int ref = best.side;
   bool patched = false;
   if (ref >= 0) patched = face_patch(best.P, best.f, best.c, best.u, best.v, best.hu, best.hv, PATCH_DUP * fminf(rb1, rb2), out);
+  QPROF(13)
   const float* f = best.f;
   if (patched) {
     float sg = ref == 0 ? 1.f : -1.f;
@@ -1683,6 +1684,7 @@ DEV bool narrow_pair_cached(const DevModel* m, const GeomW& G1, const GeomW& G2,
     }
 #endif
   }
+  QPROF(14)
   return true;
 }
 
