@@ -38,6 +38,11 @@ timeout 600 python scripts/gpu_tree_phases.py 2>/dev/null | grep mask > $O/${TAG
 ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_aloha && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_aloha -- python3 $R/scripts/gpu_aloha_bench.py banana > /dev/null 2>&1; find /tmp/prof_aloha -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_aloha_kernel_stats.csv \; )
 rocm-smi --showclocks 2>/dev/null | grep -E "sclk|mclk" | head -4 > $O/${TAG}_clocks_after.txt
 bash $R/scripts/gpu_profile.sh $TAG > $O/${TAG}_profile.log 2>&1
+# round 6: instruction-cache counters of the step's kernels, the general-tree engine's PMC pass, the narrowphase phase clocks (profiling build)
+bash $R/scripts/gpu_pmc_icache.sh > $O/${TAG}_icache.txt 2>&1
+bash $R/scripts/gpu_pmc_tree.sh > $O/${TAG}_aloha_pmc.txt 2>&1
+[ -f $R/so101_sim_amd/csrc/libso101_hip_clocks.so ] && SO101_HIP_LIB=$R/so101_sim_amd/csrc/libso101_hip_clocks.so TICKS_STEPS=60 timeout 600 python scripts/gpu_narrow_ticks.py > $O/${TAG}_narrow_ticks.txt 2>&1
+[ -f $R/so101_sim_amd/csrc/libso101_hip_clocks.so ] && SO101_HIP_LIB=$R/so101_sim_amd/csrc/libso101_hip_clocks.so timeout 600 python scripts/gpu_solve_stages.py > $O/${TAG}_solve_stages.txt 2>&1
 for f in $O/${TAG}_pytest_gpu.txt $O/${TAG}_smoke.txt $O/${TAG}_reset_cost.txt; do echo "== $f"; cat $f; done
 for f in $O/${TAG}_bench_*.json; do echo "== $(basename $f): $(cut -c1-110 $f)"; done
 tail -8 $O/${TAG}_profile.log
