@@ -656,9 +656,10 @@ def test_config0_single_env_500_random_steps(blobs):
     success, discount 0) and auto-reset.
     ALL 500 steps are also checked one by one: a second oracle is put on the state the step started from (qpos, qvel, warm start)
     and makes the same ten substeps - free trajectories separate chaotically once the arm hits something, single steps do not.
-    Without arm contact (147 steps): at least 99 % inside 2e-5 rad / 2e-2 rad/s (measured 8e-6 / 4e-3 on all but one), every step inside
-    5e-4 / 0.5 (1.1e-4 / 0.09 on the one step in which a prop-on-table contact opens and closes: its ten substeps agree to 4e-5 rad/s each when
-    re-started from the kernel's state, scripts/gpu_config0_debug.py); with arm contact: median below 1e-5 rad (3e-7), at least 97 % inside
+    Without arm contact (147 steps): EVERY step during which the set of touching pairs does not change inside 2e-5 rad / 2e-2 rad/s (measured
+    8e-6 / 4e-3), the steps in which a pair starts or stops touching - detected from the oracle's substeps (round 6): about a third of them, marginal
+    pieces of a resting prop at depth ~ 0; the one outlier of round 5 is among them: 1.1e-4 / 0.09, its ten substeps agree to 4e-5 rad/s each when re-started from the kernel's state, scripts/gpu_config0_debug.py -
+    inside 5e-4 / 0.5; with arm contact: median below 1e-5 rad (3e-7), at least 97 % inside
     2e-3 rad / 0.1 rad/s (99.8 %), every step inside 2e-2 / 1 (1.3e-3 / 0.18; the bound was 5e-2 / 20 until round 4)."""
     from so101_sim_amd import task_suite
     cwd = os.getcwd()
@@ -690,10 +691,16 @@ def test_config0_single_env_500_random_steps(blobs):
         if not ts.last():
             o1.set_state(*before)
             o1.set_ctrl(a.astype(np.float64))
-            o1.substeps(10)
+            # substep by substep: a step during which the SET of touching pairs changes (a prop-on-table contact that opens and closes) is a
+            # discrete event that fp32 and fp64 may take one substep apart - told apart here instead of hidden in a quantile
+            sigs, arm = [], False
+            for _ in range(10):
+                o1.substeps(1)
+                cs = o1.contacts()
+                sigs.append(tuple(sorted(set((c["geom1"], c["geom2"]) for c in cs))))
+                arm = arm or any(pc._arm_geom(c["geom1"]) or pc._arm_geom(c["geom2"]) for c in cs)
             q1, v1, _ = o1.get_state()
-            arm = any(pc._arm_geom(c["geom1"]) or pc._arm_geom(c["geom2"]) for c in o1.contacts())
-            one_step.append((np.abs(ob["physics_state"][:20] - q1).max(), np.abs(ob["physics_state"][20:] - v1).max(), arm))
+            one_step.append((np.abs(ob["physics_state"][:20] - q1).max(), np.abs(ob["physics_state"][20:] - v1).max(), arm, len(set(sigs)) > 1))
         assert ob["joints_pos"].shape == (6,) and ob["joints_vel"].shape == (0,) and ob["physics_state"].shape == (38,)
         assert np.all(np.isfinite(ob["physics_state"])) and ts.reward in (0.0, 1.0)
         np.testing.assert_array_equal(ob["commanded_joints_pos"], a.astype(np.float64))        # unclamped ctrl, zero offsets
@@ -718,8 +725,14 @@ def test_config0_single_env_500_random_steps(blobs):
     r = np.array(one_step, dtype=np.float64)
     free, arm = r[r[:, 2] == 0], r[r[:, 2] == 1]
     assert len(r) >= 400 and len(arm) >= 100, (len(r), len(arm))
-    assert np.mean((free[:, 0] <= 2e-5) & (free[:, 1] <= 2e-2)) >= 0.99 and free[:, 0].max() <= 5e-4 and free[:, 1].max() <= 0.5, (
-        np.mean((free[:, 0] <= 2e-5) & (free[:, 1] <= 2e-2)), free[:, 0].max(), free[:, 1].max())
+    # without arm contact: EVERY step whose set of touching pairs stays what it is inside 2e-5 rad / 2e-2 rad/s (the hard bound of round 4); the
+    # steps in which a pair starts or stops touching (round 5: one of 147) inside 5e-4 / 0.5
+    steady, switching = free[free[:, 3] == 0], free[free[:, 3] == 1]
+    # (a resting prop's marginal pieces touch at depth ~ 0 and come and go: about a third of the free steps see the set change somewhere)
+    assert len(steady) >= 0.5 * len(free), (len(steady), len(free))
+    assert steady[:, 0].max() <= 2e-5 and steady[:, 1].max() <= 2e-2, (steady[:, 0].max(), steady[:, 1].max(), len(steady))
+    assert len(switching) == 0 or (switching[:, 0].max() <= 5e-4 and switching[:, 1].max() <= 0.5), (switching[:, 0].max(), switching[:, 1].max(), len(switching))
+    assert np.mean((free[:, 0] <= 2e-5) & (free[:, 1] <= 2e-2)) >= 0.99, np.mean((free[:, 0] <= 2e-5) & (free[:, 1] <= 2e-2))
     assert np.median(arm[:, 0]) <= 1e-5 and arm[:, 0].max() <= 2e-2 and arm[:, 1].max() <= 1.0, (np.median(arm[:, 0]), arm[:, 0].max(), arm[:, 1].max())
     assert np.mean((arm[:, 0] <= 2e-3) & (arm[:, 1] <= 0.1)) >= 0.97, np.mean((arm[:, 0] <= 2e-3) & (arm[:, 1] <= 0.1))
     assert ended is not None and (ended == 500 or ts.discount == 0.0), (ended, ts.discount)
