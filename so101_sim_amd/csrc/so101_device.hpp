@@ -1079,6 +1079,98 @@ DEV void geom_obb(const DevModel* m, const EnvLDS& L, int g, float* R, float* c,
   for (int i = 0; i < 3; i++) { c[i] = p[i] + cw[i]; h[i] = ab[3 + i]; }
 }
 
+// Upper bound of a hull's support function h(dl) = max_v v . dl (dl: unit direction in the geom frame) from its support-bound table
+// (so101_model.hpp DevModel::hull_sbt): bilinear over the four grid points around dl / |dl|_inf on the cube face, times |dl|_inf.
+DEV float sbt_bound(const float* T, const float* dl) {
+  float a0 = fabsf(dl[0]), a1 = fabsf(dl[1]), a2 = fabsf(dl[2]);
+  int ax = a0 >= a1 ? (a0 >= a2 ? 0 : 2) : (a1 >= a2 ? 1 : 2);
+  float dm = ax == 0 ? dl[0] : (ax == 1 ? dl[1] : dl[2]);
+  float du = ax == 0 ? dl[1] : (ax == 1 ? dl[2] : dl[0]);
+  float dv = ax == 0 ? dl[2] : (ax == 1 ? dl[0] : dl[1]);
+  float mm = fmaxf(fabsf(dm), 1e-20f), inv = 1.f / mm;
+  const float gs = 0.5f * (float)(SBT_GRID - 1);
+  float gu = fminf(fmaxf((du * inv + 1.f) * gs, 0.f), (float)(SBT_GRID - 1)), gv = fminf(fmaxf((dv * inv + 1.f) * gs, 0.f), (float)(SBT_GRID - 1));
+  int iu = (int)gu; iu = iu > SBT_GRID - 2 ? SBT_GRID - 2 : iu;
+  int iv = (int)gv; iv = iv > SBT_GRID - 2 ? SBT_GRID - 2 : iv;
+  float fu = gu - (float)iu, fv = gv - (float)iv;
+  const float* F = T + ((2 * ax + (dm < 0.f ? 1 : 0)) * SBT_GRID + iu) * SBT_GRID + iv;
+  float h = (1.f - fu) * ((1.f - fv) * F[0] + fv * F[1]) + fu * ((1.f - fv) * F[SBT_GRID] + fv * F[SBT_GRID + 1]);
+  return h * mm;
+}
+// lowest extent of mesh geom g (world rotation R, world origin p) along the world unit direction f, from below: min_x (x . f) >= this
+DEV float sbt_lowest(const DevModel* m, int g, const float* R, const float* p, const float* f) {
+  float dl[3] = {-(R[0] * f[0] + R[3] * f[1] + R[6] * f[2]), -(R[1] * f[0] + R[4] * f[1] + R[7] * f[2]), -(R[2] * f[0] + R[5] * f[1] + R[8] * f[2])};
+  return dot3(p, f) - sbt_bound(m->hull_sbt + (size_t)g * SBT_DIM, dl) - 2e-6f;
+}
+
+// Round 6: separating directions beyond the oriented boxes' fifteen, for a pair (g1, g2 = a hull) that passed them.  A: world rotation of g1, ca /
+// a: centre and half extents of its oriented box, B / cb: the hull's, t = A' (cb - ca).  A third of the candidates that reached the narrowphase
+// ended in "no intersection" (3-8 us of a wavefront each): a hull whose ORIENTED BOX dips below a box face although no vertex does, the static puck
+// and capsule of the scene under the props' pieces, arm links near props.  The hull's extent along a direction comes from its support-bound
+// table - a few per cent of its size above the truth instead of the box's tens of per cent.  Conservative: a pair dropped here has a separating
+// plane, so no contact changes (rollouts are bit-identical with and without the tables: scripts/gpu_sbt_ab.py).
+DEV bool sbt_separated(const DevModel* m, int g1, int g2, const float* A, const float* ca, const float* a, const float* B, const float* cb, const float* t) {
+  const float gap = 1e-6f;
+  const int t1 = m->geom_type[g1];
+  const float* lc2 = m->geom_aabb + 6 * g2;
+  float pb[3];                                 // the hull's geom origin: its box centre minus the rotated local centre
+#pragma unroll
+  for (int i = 0; i < 3; i++) pb[i] = cb[i] - (B[3 * i] * lc2[0] + B[3 * i + 1] * lc2[1] + B[3 * i + 2] * lc2[2]);
+  bool sep = false;
+  if (t1 == G_BOX) {
+    // the three box faces on the hull's side: the hull's lowest point along the face normal against the face
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      float sg = t[i] >= 0.f ? 1.f : -1.f;
+      float f[3] = {sg * A[i], sg * A[3 + i], sg * A[6 + i]};
+      sep = sep || sbt_lowest(m, g2, B, pb, f) - dot3(ca, f) > a[i] + gap;
+    }
+    return sep;
+  }
+  // a sphere / capsule / cylinder / another hull: the centre-to-centre direction, the primitive's axis and the radial direction from that axis
+  // as candidate separating directions - the primitive's extent in closed form, a hull's from its table
+  const float* lc1 = m->geom_aabb + 6 * g1;
+  float pa[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) pa[i] = ca[i] - (A[3 * i] * lc1[0] + A[3 * i + 1] * lc1[1] + A[3 * i + 2] * lc1[2]);
+  const float r1 = m->geom_size[3 * g1], hl1 = m->geom_size[3 * g1 + 1];
+  float az[3] = {A[2], A[5], A[8]};                     // the primitive's axis (capsule, cylinder)
+  // highest extent of geom 1 along the unit direction d (world): max_x x . d <= this
+  auto top1 = [&](const float* d) -> float {
+    float along = fabsf(dot3(az, d));
+    if (t1 == G_SPHERE) return dot3(pa, d) + r1;
+    if (t1 == G_CAPSULE) return dot3(pa, d) + r1 + hl1 * along;
+    if (t1 == G_CYLINDER) return dot3(pa, d) + r1 * sqrtf(fmaxf(1.f - along * along, 0.f)) + hl1 * along;
+    float nd[3] = {-d[0], -d[1], -d[2]};
+    return -sbt_lowest(m, g1, A, pa, nd);               // (a hull: max x . d = - min x . (-d))
+  };
+  float dirs[3][3]; int nd_ = 1;
+  { float w[3] = {cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2]}; float n = sqrtf(dot3(w, w)); float inv = n > 1e-9f ? 1.f / n : 0.f; dirs[0][0] = w[0] * inv; dirs[0][1] = w[1] * inv; dirs[0][2] = w[2] * inv; if (!(n > 1e-9f)) nd_ = 0; }
+#pragma unroll
+  for (int q = 1; q < 3; q++) { dirs[q][0] = 0.f; dirs[q][1] = 0.f; dirs[q][2] = 0.f; }
+  bool has[3] = {nd_ == 1, false, false};
+  if (t1 == G_CAPSULE || t1 == G_CYLINDER) {
+    float w[3] = {cb[0] - pa[0], cb[1] - pa[1], cb[2] - pa[2]};
+    float s_ = dot3(w, az), sg = s_ >= 0.f ? 1.f : -1.f;
+    dirs[1][0] = sg * az[0]; dirs[1][1] = sg * az[1]; dirs[1][2] = sg * az[2];
+    float rr[3] = {w[0] - s_ * az[0], w[1] - s_ * az[1], w[2] - s_ * az[2]}; float n = sqrtf(dot3(rr, rr)); float inv = n > 1e-9f ? 1.f / n : 0.f;
+    dirs[2][0] = rr[0] * inv; dirs[2][1] = rr[1] * inv; dirs[2][2] = rr[2] * inv;
+    has[1] = true; has[2] = n > 1e-9f;
+  }
+#pragma unroll
+  for (int q = 0; q < 3; q++)
+    if (has[q]) sep = sep || sbt_lowest(m, g2, B, pb, dirs[q]) - top1(dirs[q]) > gap + 2e-6f;
+  return sep;
+}
+// the plane (point pp, unit normal n) against a hull (world rotation B, box centre cb): its lowest point along the normal is above the plane
+DEV bool sbt_plane_separated(const DevModel* m, int g2, const float* pp, const float* n, const float* B, const float* cb) {
+  const float* lc = m->geom_aabb + 6 * g2;
+  float pb[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) pb[i] = cb[i] - (B[3 * i] * lc[0] + B[3 * i + 1] * lc[1] + B[3 * i + 2] * lc[2]);
+  return sbt_lowest(m, g2, B, pb, n) - dot3(pp, n) > 1e-6f;
+}
+
 // Second broadphase pass, lane = candidate: separating-axis test of the two geoms' ORIENTED boxes (15 axes).  The world
 // axis-aligned box of a long tilted link overlaps many hulls it is nowhere near; the oriented box is tight.  A pair whose
 // oriented boxes are more than 1e-6 m apart cannot touch, so dropping it here changes no contact - it only spares the
@@ -1123,6 +1215,14 @@ DEV void obb_filter(const DevModel* m, EnvLDS& L) {
             sep = sep || fabsf(t[i2] * Rm[i1][j] - t[i1] * Rm[i2][j]) > ra + rb + gap;
           }
         keep = !sep;
+        if (keep && m->hull_sbt && m->geom_type[g2] == G_MESH) keep = !sbt_separated(m, g1, g2, A, ca, a, B, cb, t);
+      } else if (m->hull_sbt && m->geom_type[g2] == G_MESH) {
+        // the plane against a hull: the same bound along the plane's normal
+        float A[9], ca[3], a[3], B[9], cb[3], b[3];
+        geom_obb(m, L, g1, A, ca, a); geom_obb(m, L, g2, B, cb, b);
+        float pp[3] = {ca[0], ca[1], ca[2]}, n[3] = {A[2], A[5], A[8]};
+        if (m->geom_dyn[g1] < 0) { pp[0] = m->geom_pos[3 * g1]; pp[1] = m->geom_pos[3 * g1 + 1]; pp[2] = m->geom_pos[3 * g1 + 2]; }
+        keep = !sbt_plane_separated(m, g2, pp, n, B, cb);
       }
     }
     unsigned long long mask = wave_ballot(keep);

@@ -5,6 +5,7 @@
 #include "../../include/so101.h"
 #include "so101_launch.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -287,7 +288,28 @@ int build_model(so101_sim* s, const BlobView& b) {
     if (gtype[g1] > gtype[g2]) std::swap(g1, g2);
     packed[k] = (unsigned int)g1 | ((unsigned int)g2 << 8) | ((gtype[g1] == G_PLANE ? 1u : 0u) << 16);
   }
-  bool ok = upload(s, gtype, &M.geom_type) && upload(s, gdyn, &M.geom_dyn) && upload(s, gcondim, &M.geom_condim) &&
+  // support-bound tables of the hulls (so101_model.hpp DevModel::hull_sbt, obb_filter): in double, rounded up to float
+  std::vector<float> sbt((size_t)ngeom * SBT_DIM, 0.f);
+  for (int g = 0; g < ngeom; g++) {
+    if (gtype[g] != G_MESH) continue;
+    for (int face = 0; face < 6; face++) {
+      int ax = face / 2; double sg = (face & 1) ? -1.0 : 1.0;
+      for (int iu = 0; iu < SBT_GRID; iu++)
+        for (int iv = 0; iv < SBT_GRID; iv++) {
+          const double step = 2.0 / (SBT_GRID - 1);
+          double c[3]; c[ax] = sg; c[(ax + 1) % 3] = -1.0 + step * iu; c[(ax + 2) % 3] = -1.0 + step * iv;
+          double best = -1e300;
+          for (int k = gva[g]; k < gva[g] + gvn[g]; k++) best = std::max(best, (double)mv[3 * k] * c[0] + (double)mv[3 * k + 1] * c[1] + (double)mv[3 * k + 2] * c[2]);
+          float f = (float)best;
+          if ((double)f < best) f = std::nextafterf(f, 3.0e38f);
+          sbt[(size_t)g * SBT_DIM + (face * SBT_GRID + iu) * SBT_GRID + iv] = f;
+        }
+    }
+  }
+  const bool sbt_off = getenv("SO101_NO_SBT") != nullptr;          // (tests and kernel experiments, read at every so101_create: the oriented-box filter alone, as until round 5)
+  M.hull_sbt = nullptr;
+  bool ok = (sbt_off || upload(s, sbt, &M.hull_sbt)) &&
+            upload(s, gtype, &M.geom_type) && upload(s, gdyn, &M.geom_dyn) && upload(s, gcondim, &M.geom_condim) &&
             upload(s, gva, &M.geom_vertadr) && upload(s, gvn, &M.geom_vertnum) && upload(s, gp, &M.geom_pos) &&
             upload(s, gm, &M.geom_mat) && upload(s, gsize, &M.geom_size) && upload(s, gfr, &M.geom_friction) &&
             upload(s, gsr, &M.geom_solref) && upload(s, gsi, &M.geom_solimp) && upload(s, gctr, &M.geom_center) &&

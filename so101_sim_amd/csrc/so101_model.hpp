@@ -64,7 +64,17 @@ struct DevModel {
   const float* vz;
   const int* pair;            // [npair][2] statically filtered candidate geom pairs, sorted
   const unsigned int* pair_packed;   // [npair] geom1 | geom2 << 8 | plane flag << 16 (types ordered), same order
+  // support-bound tables of the mesh geoms (round 6; NULL: none): hull_sbt[g][SBT_DIM] = max over the hull's vertices of v . c for the 6 x 5 x 5
+  // grid points c of the cube [-1, 1]^3's faces (face 2 a + (sign < 0), u and v in steps of 0.5 along axes a + 1, a + 2), rounded up.  The support
+  // function is convex and positively homogeneous, so for any direction d the bilinear interpolation over the four grid points around
+  // d / |d|_inf, times |d|_inf, is an UPPER bound of h(d) - a few per cent of the hull's size above it, against the tens of per cent of an
+  // oriented box around a curved shell piece.  Built at so101_create from the blob's vertices (so101_hip.hip); used by obb_filter.
+  const float* hull_sbt;
 };
+#ifndef SBT_GRID
+#define SBT_GRID 5
+#endif
+#define SBT_DIM (6 * SBT_GRID * SBT_GRID)
 
 // Per-env launch parameters that are not part of the model.
 struct StepParams {

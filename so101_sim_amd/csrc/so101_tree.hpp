@@ -649,6 +649,19 @@ DEV int broadphase(const TreeModel* tm, const DevModel* gm, TreeLDS& L) {
               sep = sep || fabsf(t[i2] * Rm[i1][j] - t[i1] * Rm[i2][j]) > ra + rb + gap;
             }
           keep = !sep;
+          // round 6: further separating directions from the hulls' support-bound tables (so101_device.hpp sbt_separated)
+          if (keep && gm->hull_sbt && gm->geom_type[g2] == G_MESH) {
+            float cwa[3] = {pa[0] + ca[0], pa[1] + ca[1], pa[2] + ca[2]}, cwb[3] = {pb[0] + cb[0], pb[1] + cb[1], pb[2] + cb[2]};
+            keep = !sbt_separated(gm, g1, g2, A, cwa, a, Bm, cwb, t);
+          }
+        } else if (gm->hull_sbt && gm->geom_type[g2] == G_MESH) {
+          float A[9], pa[3], Bm[9], pb[3];
+          geom_pose(tm, gm, L, g1, pa, A); geom_pose(tm, gm, L, g2, pb, Bm);
+          const float* ab = gm->geom_aabb + 6 * g2;
+          float lb[3] = {ab[0], ab[1], ab[2]}, cb[3];
+          matvec3(cb, Bm, lb);
+          float cwb[3] = {pb[0] + cb[0], pb[1] + cb[1], pb[2] + cb[2]}, n[3] = {A[2], A[5], A[8]};
+          keep = !sbt_plane_separated(gm, g2, pa, n, Bm, cwb);
         }
       }
       unsigned long long mask = wave_ballot(keep);

@@ -5,6 +5,7 @@
 #include "../../include/so101.h"
 #include "so101_tree.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <string>
@@ -614,7 +615,27 @@ int tree_build(TreeHandle* s, const BlobView& b) {
     if (gtype[g1] > gtype[g2]) std::swap(g1, g2);
     packed[p] = (unsigned)g1 | ((unsigned)g2 << 8) | (gtype[g1] == G_PLANE ? 1u << 16 : 0u);
   }
-  bool ok = t_upload(s, gtype, &G.geom_type) && t_upload(s, b.I("geom_body"), &G.geom_dyn) && t_upload(s, b.I("geom_condim"), &G.geom_condim) &&
+  // support-bound tables of the hulls (so101_model.hpp DevModel::hull_sbt): in double, rounded up to float
+  std::vector<float> sbt((size_t)ng * SBT_DIM, 0.f);
+  for (size_t g = 0; g < ng; g++) {
+    if (gtype[g] != G_MESH) continue;
+    for (int face = 0; face < 6; face++) {
+      int ax = face / 2; double sg = (face & 1) ? -1.0 : 1.0;
+      for (int iu = 0; iu < SBT_GRID; iu++)
+        for (int iv = 0; iv < SBT_GRID; iv++) {
+          const double step = 2.0 / (SBT_GRID - 1);
+          double c[3]; c[ax] = sg; c[(ax + 1) % 3] = -1.0 + step * iu; c[(ax + 2) % 3] = -1.0 + step * iv;
+          double best = -1e300;
+          for (int k = gva[g]; k < gva[g] + gvn[g]; k++) best = std::max(best, (double)mv[3 * k] * c[0] + (double)mv[3 * k + 1] * c[1] + (double)mv[3 * k + 2] * c[2]);
+          float f = (float)best;
+          if ((double)f < best) f = std::nextafterf(f, 3.0e38f);
+          sbt[g * SBT_DIM + (face * SBT_GRID + iu) * SBT_GRID + iv] = f;
+        }
+    }
+  }
+  G.hull_sbt = nullptr;
+  bool ok = (getenv("SO101_NO_SBT") != nullptr || t_upload(s, sbt, &G.hull_sbt)) &&
+            t_upload(s, gtype, &G.geom_type) && t_upload(s, b.I("geom_body"), &G.geom_dyn) && t_upload(s, b.I("geom_condim"), &G.geom_condim) &&
             t_upload(s, gva, &G.geom_vertadr) && t_upload(s, gvn, &G.geom_vertnum) && t_upload(s, b.F("geom_pos"), &G.geom_pos) && t_upload(s, gmat, &G.geom_mat) &&
             t_upload(s, b.F("geom_size"), &G.geom_size) && t_upload(s, b.F("geom_friction"), &G.geom_friction) && t_upload(s, b.F("geom_solref"), &G.geom_solref) &&
             t_upload(s, b.F("geom_solimp"), &G.geom_solimp) && t_upload(s, b.F("geom_center"), &G.geom_center) && t_upload(s, b.F("geom_aabb"), &G.geom_aabb) &&

@@ -127,6 +127,38 @@ def test_probe_outlier_states_of_round_6(make_sim, blobs, golden):
     pc.check_probe_outliers(make_sim, blobs, golden)
 
 
+def test_support_bound_tables_change_no_contact(blobs):
+    """Round 6: the broadphase drops a candidate pair when a hull's support-bound table (DevModel::hull_sbt) proves a separating plane beyond the
+    oriented boxes' fifteen axes.  A dropped pair would have ended in "no intersection", so nothing downstream may change: two handles, one
+    created with SO101_NO_SBT=1 (no tables), the same seed and random actions across a time limit - states and task outputs bit for bit,
+    fewer candidates with the tables."""
+    import os
+    n, steps = 512, 30
+    rng = np.random.RandomState(4)
+    lo = np.array([-np.pi, -3.14158, -3.14158, -3.14158, -3.14158, 0.0], dtype=np.float32)
+    hi = np.array([np.pi, 3.14158, 3.14158, 3.14158, 3.14158, 0.08], dtype=np.float32)
+    acts = rng.uniform(lo, hi, size=(steps, n, 6)).astype(np.float32)
+    traces, cands = [], []
+    for off in (False, True):
+        if off:
+            os.environ["SO101_NO_SBT"] = "1"
+        try:
+            sim = ArraySim(blobs["f32"], n, backend="gpu", seed=3, last_step=12, settle_max_substeps=200)
+        finally:
+            os.environ.pop("SO101_NO_SBT", None)
+        sim.reset()
+        tr, nc = [], 0.0
+        for t in range(steps):
+            obs, rew, disc, st = sim.step(acts[t])
+            tr.append(np.concatenate([obs.ravel(), rew, disc, st.astype(np.float32)] + [a.ravel() for a in sim.get_state()]))
+            nc += float(sim.get_diag()[:, 3].mean())
+        traces.append(tr); cands.append(nc / steps)
+    for t, (a, b) in enumerate(zip(*traces)):
+        assert np.all(np.isfinite(a))
+        np.testing.assert_array_equal(a, b, err_msg=f"step {t}")
+    assert cands[0] < 0.95 * cands[1], cands
+
+
 def test_three_launch_chains_match_fused(make_sim, golden):
     """n >= 64: so101_step cuts the cost-sorted envs into three slices on separate streams; still bit-identical to the
     fused single-launch step (different random actions per env, so the slices really differ in cost)."""
