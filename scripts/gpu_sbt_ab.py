@@ -1,5 +1,6 @@
-"""Support-bound tables in the broadphase (round 6): bit-identity of a 4096-env rollout with and without them (SO101_NO_SBT=1 uploads no tables at
-so101_create), the candidate counts, and the throughput of the driver's command both ways."""
+"""Support-bound tables in the broadphase / support-vertex lists in the narrowphase (round 6): bit-identity of a 4096-env rollout with and without
+them (SO101_NO_SBT=1 / SO101_NO_HL=1 upload no tables at so101_create; argv[1] of the top-level call names the variable, default SO101_NO_SBT),
+the candidate counts, and the throughput of the driver's command both ways."""
 import os, sys, subprocess, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,18 +26,19 @@ if len(sys.argv) > 1 and sys.argv[1] == "state":
     np.save(sys.argv[3], np.concatenate(acc)); json.dump(ncand, open(sys.argv[3] + ".json", "w"))
     sys.exit(0)
 import numpy as np
+VAR = sys.argv[1] if len(sys.argv) > 1 else "SO101_NO_SBT"
 outs, nc = [], []
 for off in (0, 1):
-    env = dict(os.environ); env.pop("SO101_NO_SBT", None)
-    if off: env["SO101_NO_SBT"] = "1"
+    env = dict(os.environ); env.pop(VAR, None)
+    if off: env[VAR] = "1"
     f = "/tmp/sbt_%d.npy" % off
     subprocess.check_call([sys.executable, os.path.abspath(__file__), "state", "120", f], env=env)
     outs.append(np.load(f)); nc.append(json.load(open(f + ".json")))
 print("120 control steps of 4096 envs across two time limits (random actions, resets with the prefetch): with and without the tables bit-identical:", bool(np.array_equal(outs[0], outs[1])), "(", outs[0].size, "numbers, all finite )")
 print("mean narrowphase candidates / contacts per env at steps 10, 60, 120:  with", [tuple(round(x, 2) for x in nc[0][i]) for i in (0, 5, 11)], " without", [tuple(round(x, 2) for x in nc[1][i]) for i in (0, 5, 11)])
 for off in (0, 1, 0, 1):
-    env = dict(os.environ); env.pop("SO101_NO_SBT", None)
-    if off: env["SO101_NO_SBT"] = "1"
+    env = dict(os.environ); env.pop(VAR, None)
+    if off: env[VAR] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline"], env=env, capture_output=True, text=True)
     d = json.loads(r.stdout.strip().splitlines()[-1])
-    print("support-bound tables %-3s  %8.1f k env-steps/s  windows %s  candidates per env %.2f" % ("off" if off else "on", d["value"] / 1e3, [round(v / 1e3) for v in d["repeats"]["values"]], d["diag_mean"]["narrowphase_candidates"]))
+    print(VAR + " %-3s  %8.1f k env-steps/s  windows %s  candidates per env %.2f" % ("set" if off else "-", d["value"] / 1e3, [round(v / 1e3) for v in d["repeats"]["values"]], d["diag_mean"]["narrowphase_candidates"]))

@@ -595,6 +595,30 @@ DEV void select_hull(bool first, const HullCache& A, const HullCache& B, HullCac
 }
 DEV void select_hull(bool, const NoCache&, const NoCache&, NoCache&) {}
 DEV void select_hull(bool first, const HullLDS& A, const HullLDS& B, HullLDS& o) { o.p = first ? A.p : B.p; o.n = first ? A.n : B.n; }
+// A SUBSET of a hull in registers (round 6, k_narrow's fast path for a flat face against a hull): the entries of one cell of the hull's
+// support-vertex lists (DevModel::hl_entry), two per lane at most, in increasing index order (entry l, then entry l + 64); slots beyond the
+// list carry the index 0x7fffffff.  Valid for the directions of that cell (widened by 4e-3 rad) only: there the largest dot product over the
+// subset is the largest over the hull, attained by the same vertices - support() and support_multi() return the same point bit for bit.
+struct HullSub { float x[2], y[2], z[2]; int i[2]; };
+template <class C> struct is_hull_sub { static constexpr bool value = false; };
+template <> struct is_hull_sub<HullSub> { static constexpr bool value = true; };
+DEV void select_hull(bool first, const HullSub& A, const HullSub& B, HullSub& o) {
+#pragma unroll
+  for (int j = 0; j < 2; j++) { o.x[j] = first ? A.x[j] : B.x[j]; o.y[j] = first ? A.y[j] : B.y[j]; o.z[j] = first ? A.z[j] : B.z[j]; o.i[j] = first ? A.i[j] : B.i[j]; }
+}
+// cell of the cube map a direction (any length, geom frame) falls into: face 2 a + (negative), then HL_GRID x HL_GRID along the axes a + 1, a + 2
+DEV int hl_cell(const float* dl) {
+  float a0 = fabsf(dl[0]), a1 = fabsf(dl[1]), a2 = fabsf(dl[2]);
+  int ax = a0 >= a1 ? (a0 >= a2 ? 0 : 2) : (a1 >= a2 ? 1 : 2);
+  float dm = ax == 0 ? dl[0] : (ax == 1 ? dl[1] : dl[2]);
+  float du = ax == 0 ? dl[1] : (ax == 1 ? dl[2] : dl[0]);
+  float dv = ax == 0 ? dl[2] : (ax == 1 ? dl[0] : dl[1]);
+  float inv = 1.f / fmaxf(fabsf(dm), 1e-20f);
+  float gu = fminf(fmaxf((du * inv + 1.f) * (0.5f * HL_GRID), 0.f), (float)HL_GRID), gv = fminf(fmaxf((dv * inv + 1.f) * (0.5f * HL_GRID), 0.f), (float)HL_GRID);
+  int iu = (int)gu; iu = iu > HL_GRID - 1 ? HL_GRID - 1 : iu;
+  int iv = (int)gv; iv = iv > HL_GRID - 1 ? HL_GRID - 1 : iv;
+  return ((2 * ax + (dm < 0.f ? 1 : 0)) * HL_GRID + iu) * HL_GRID + iv;
+}
 template <class C> struct is_hull_lds { static constexpr bool value = false; };
 template <> struct is_hull_lds<HullLDS> { static constexpr bool value = true; };
 
@@ -611,7 +635,15 @@ DEV void support(const DevModel* m, const GeomW& G, const float* dir, float* out
     float best = -3.0e38f, bx = 0.f, by = 0.f, bz = 0.f; int bi = 0x7fffffff;
     const float* x = ldc(&m->vx) + G.vadr; const float* y = ldc(&m->vy) + G.vadr; const float* z = ldc(&m->vz) + G.vadr;
     int first = lane;
-    if constexpr (is_hull_lds<Cache>::value) {
+    if constexpr (is_hull_sub<Cache>::value) {
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        int i = H.i[k];
+        float d = H.x[k] * dl[0] + H.y[k] * dl[1] + H.z[k] * dl[2];
+        if (i < G.vnum && d > best) { best = d; bi = i; bx = H.x[k]; by = H.y[k]; bz = H.z[k]; }
+      }
+      first = G.vnum;                                  // (nothing else to scan)
+    } else if constexpr (is_hull_lds<Cache>::value) {
       const float4* X4 = (const float4*)H.p; const float4* Y4 = (const float4*)(H.p + H.n); const float4* Z4 = (const float4*)(H.p + 2 * H.n);
       auto block = [&](int J) {
         float4 xv = X4[GP::N * J + lane], yv = Y4[GP::N * J + lane], zv = Z4[GP::N * J + lane];
@@ -1402,7 +1434,18 @@ DEV void support_multi(const DevModel* m, const GeomW& G, const float (*d)[3], P
   int lane = GP::sub();
   const float* x = ldc(&m->vx) + G.vadr; const float* y = ldc(&m->vy) + G.vadr; const float* z = ldc(&m->vz) + G.vadr;
   int first = lane;
-  if constexpr (is_hull_lds<Cache>::value) {
+  if constexpr (is_hull_sub<Cache>::value) {
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      int i = H.i[q];
+#pragma unroll
+      for (int k = 0; k < NCPP; k++) {
+        float s = H.x[q] * dl[k][0] + H.y[q] * dl[k][1] + H.z[q] * dl[k][2];
+        if (i < G.vnum && s > best[k]) { best[k] = s; bi[k] = i; }
+      }
+    }
+    first = G.vnum;
+  } else if constexpr (is_hull_lds<Cache>::value) {
     const float4* X4 = (const float4*)H.p; const float4* Y4 = (const float4*)(H.p + H.n); const float4* Z4 = (const float4*)(H.p + 2 * H.n);
     auto block = [&](int J) {
       float4 xv = X4[GP::N * J + lane], yv = Y4[GP::N * J + lane], zv = Z4[GP::N * J + lane];
@@ -1548,6 +1591,32 @@ DEV bool flat_face(const GeomW& G, int axis, const float* toward, float* f, floa
   return true;
 }
 
+// The direction (world, not normalised) of the FIRST support query that narrow_pair_cached() makes on the hull G2 of a light pair - the plane's normal
+// negated, or the outward normal, negated, of the box face scan_faces() visits first (same expressions as there) - and the cell of G2's support-vertex
+// lists it falls into.  Shared by the wavefront that writes the work item and the one that serves it.  -1: no such query (not a plane / box against a hull).
+DEV int light_first_cell(const GeomW& G1, const GeomW& G2) {
+  if (G2.type != G_MESH) return -1;
+  float f[3];
+  if (G1.type == G_PLANE) { f[0] = G1.R[2]; f[1] = G1.R[5]; f[2] = G1.R[8]; }
+  else if (G1.type == G_BOX) {
+    float toward[3] = {G2.c[0] - G1.c[0], G2.c[1] - G1.c[1], G2.c[2] - G1.c[2]};
+    float loc[3]; matTvec3(loc, G1.R, toward);
+    float lb0 = G1.size[0] - fabsf(loc[0]), lb1 = G1.size[1] - fabsf(loc[1]), lb2 = G1.size[2] - fabsf(loc[2]);
+    int axis = 0; float bl = lb0;
+    if (lb1 < bl) { axis = 1; bl = lb1; }
+    if (lb2 < bl) { axis = 2; bl = lb2; }
+    if (!(bl < 3.0e38f)) return -1;                      // (non-finite bounds: the full query)
+    float w0 = axis == 0 ? 1.f : 0.f, w1 = axis == 1 ? 1.f : 0.f, w2 = axis == 2 ? 1.f : 0.f;
+    float li = w0 * loc[0] + w1 * loc[1] + w2 * loc[2], sg = li >= 0.f ? 1.f : -1.f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) f[k] = sg * (w0 * G1.R[3 * k] + w1 * G1.R[3 * k + 1] + w2 * G1.R[3 * k + 2]);
+  } else return -1;
+  float nf[3] = {-f[0], -f[1], -f[2]}, dl[3];
+  matTvec3(dl, G2.R, nf);
+  if (!(fabsf(dl[0]) + fabsf(dl[1]) + fabsf(dl[2]) > 0.5f)) return -1;      // (a diverged pose)
+  return hl_cell(dl);
+}
+
 #ifdef SO101_DEBUG_CLOCKS
 #define QPROF(k) { unsigned long long qn_ = SO101_CLOCK(); if (prof && wave_lane() == 0) atomicAdd(&prof[k], (unsigned int)(qn_ - qp_)); qp_ = qn_; }
 #else
@@ -1564,7 +1633,9 @@ struct FaceRef { float f[3], c[3], u[3], v[3], hu, hv, depth; int side; bool exa
 //    iterative query is needed (R.exact: props resting on the table top, finger pads, the static puck);
 //  * a0 merely inside the outline (d0 <= half thickness): a CANDIDATE; the shallowest one is kept in R and later wins
 //    over MPR's answer when it is not deeper (narrow_pair).
-template <class Cache, class GP = G64>
+// ONE_FACE (k_narrow's fast path, HullSub): only the face visited first - the incident hull's subset is valid for that face's normal alone;
+// a pair that face does not settle (neither separated nor exact) is handed back to the full query.
+template <class Cache, class GP = G64, bool ONE_FACE = false>
 DEV void scan_faces(const DevModel* m, const GeomW& GR, const GeomW& GI, const Cache& HI, int side, FaceRef& R, unsigned int* prof = nullptr) {
   if (GR.type != G_BOX && GR.type != G_CYLINDER) return;
 #ifdef SO101_DEBUG_CLOCKS
@@ -1580,7 +1651,7 @@ DEV void scan_faces(const DevModel* m, const GeomW& GR, const GeomW& GI, const C
   float lb0 = GR.size[0] - fabsf(loc[0]), lb1 = GR.size[1] - fabsf(loc[1]), lb2 = GR.size[2] - fabsf(loc[2]);
   unsigned int done = 0u;
 #pragma unroll 1
-  for (int it = 0; it < 3; it++) {
+  for (int it = 0; it < (ONE_FACE ? 1 : 3); it++) {
     if (R.separated || R.exact) break;
     int axis = 0; float bl = 3.0e38f;
     if (!(done & 1u)) { axis = 0; bl = lb0; }
@@ -1707,9 +1778,10 @@ DEV void hull_patch(const DevModel* m, const GeomW& G1, const GeomW& G2, const C
 // narrow_pair_cached: the caches H1 / H2 are ready (k_narrow stages them in LDS), rb1 / rb2 = the geoms' bounding radii
 // FACES_ONLY (k_narrow's row pass, policy G16: four pairs per wavefront, one per DPP row): the plane and flat-face closed forms only; returns
 // false when the pair needs the iterative query (MPR / EPA), which the caller then runs with the whole wavefront.  Otherwise returns true.
-template <class Cache, class GP = G64, bool FACES_ONLY = false>
+template <class Cache, class GP = G64, bool FACES_ONLY = false, bool ONE_FACE = false>
 DEV bool narrow_pair_cached(const DevModel* m, const GeomW& G1, const GeomW& G2, float rb1, float rb2, const Cache& H1, const Cache& H2, PairContacts& out,
                             unsigned int* prof = nullptr) {
+  static_assert(!ONE_FACE || FACES_ONLY, "the one-face scan has no iterative query behind it");
 #ifdef SO101_DEBUG_CLOCKS
   unsigned long long qp_ = SO101_CLOCK();
 #endif
@@ -1731,8 +1803,8 @@ DEV bool narrow_pair_cached(const DevModel* m, const GeomW& G1, const GeomW& G2,
   for (int k = 0; k < 3; k++) { best.f[k] = 0.f; best.c[k] = 0.f; best.u[k] = 0.f; best.v[k] = 0.f; }
 #pragma unroll
   for (int k = 0; k < NCPP; k++) { best.P.p[k][0] = 0.f; best.P.p[k][1] = 0.f; best.P.p[k][2] = 0.f; }
-  scan_faces<Cache, GP>(m, G1, G2, H2, 0, best, prof);
-  if (!best.separated && !best.exact) scan_faces<Cache, GP>(m, G2, G1, H1, 1, best, prof);
+  scan_faces<Cache, GP, ONE_FACE>(m, G1, G2, H2, 0, best, prof);
+  if constexpr (!ONE_FACE) { if (!best.separated && !best.exact) scan_faces<Cache, GP>(m, G2, G1, H1, 1, best, prof); }
   QPROF(2)
   if (best.separated) return true;
   float depth = 0.f, nrm[3] = {0.f, 0.f, 0.f}, pos[3] = {0.f, 0.f, 0.f};

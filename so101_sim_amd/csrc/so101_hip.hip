@@ -306,6 +306,53 @@ int build_model(so101_sim* s, const BlobView& b) {
         }
     }
   }
+  // support-vertex lists (so101_model.hpp DevModel::hl_entry): per hull and cube-map cell the vertices that can win a support query there
+  std::vector<float> hle; std::vector<unsigned int> hlo((size_t)ngeom * (HL_CELLS + 1), 0u);
+  const bool hl_off_env = getenv("SO101_NO_HL") != nullptr;          // (tests and kernel experiments: every query scans the whole hull, as until round 6)
+  for (int g = 0; g < ngeom; g++) {
+    unsigned int* off = &hlo[(size_t)g * (HL_CELLS + 1)];
+    if (gtype[g] != G_MESH || hl_off_env) { for (int c = 0; c <= HL_CELLS; c++) off[c] = (unsigned int)(hle.size() / 4); continue; }
+    const int n = gvn[g]; const float* V = &mv[3 * (size_t)gva[g]];
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int k = 0; k < n; k++) for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], (double)V[3 * k + a]); hi[a] = std::max(hi[a], (double)V[3 * k + a]); }
+    const double diam = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+    std::vector<double> S((size_t)(HL_GRID + 1) * (HL_GRID + 1) * n);          // scores of every vertex at the grid points of one face
+    std::vector<double> cn((size_t)(HL_GRID + 1) * (HL_GRID + 1));
+    for (int face = 0; face < 6; face++) {
+      int ax = face / 2; double sg = (face & 1) ? -1.0 : 1.0;
+      for (int iu = 0; iu <= HL_GRID; iu++)
+        for (int iv = 0; iv <= HL_GRID; iv++) {
+          double c[3]; c[ax] = sg; c[(ax + 1) % 3] = -1.0 + 2.0 * iu / HL_GRID; c[(ax + 2) % 3] = -1.0 + 2.0 * iv / HL_GRID;
+          size_t pt = (size_t)iu * (HL_GRID + 1) + iv;
+          cn[pt] = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+          double* sp = &S[pt * n];
+          for (int k = 0; k < n; k++) sp[k] = V[3 * k] * c[0] + V[3 * k + 1] * c[1] + V[3 * k + 2] * c[2];
+        }
+      for (int iu = 0; iu < HL_GRID; iu++)
+        for (int iv = 0; iv < HL_GRID; iv++) {
+          const size_t pts[4] = {(size_t)iu * (HL_GRID + 1) + iv, (size_t)(iu + 1) * (HL_GRID + 1) + iv, (size_t)iu * (HL_GRID + 1) + iv + 1, (size_t)(iu + 1) * (HL_GRID + 1) + iv + 1};
+          int win[4]; double eps[4];
+          for (int q = 0; q < 4; q++) {
+            const double* sp = &S[pts[q] * n]; int w = 0;
+            for (int k = 1; k < n; k++) if (sp[k] > sp[w]) w = k;
+            win[q] = w; eps[q] = 4e-3 * diam * cn[pts[q]] + 1e-6;
+          }
+          off[(face * HL_GRID + iu) * HL_GRID + iv] = (unsigned int)(hle.size() / 4);
+          for (int k = 0; k < n; k++) {
+            bool keep = true;
+            for (int w = 0; w < 4 && keep; w++) {            // beaten by corner winner w at ALL four corners by more than the widening: out
+              bool some = false;
+              for (int q = 0; q < 4; q++) some = some || S[pts[q] * n + k] >= S[pts[q] * n + win[w]] - eps[q];
+              keep = some;
+            }
+            if (keep) { hle.push_back(V[3 * k]); hle.push_back(V[3 * k + 1]); hle.push_back(V[3 * k + 2]); float fi; unsigned int ui = (unsigned int)k; memcpy(&fi, &ui, 4); hle.push_back(fi); }
+          }
+        }
+    }
+    off[HL_CELLS] = (unsigned int)(hle.size() / 4);
+  }
+  M.hl_entry = nullptr; M.hl_off = nullptr;
+  if (!hl_off_env && !(upload(s, hle, &M.hl_entry) && upload(s, hlo, &M.hl_off))) return SO101_ERR_HIP;
   const bool sbt_off = getenv("SO101_NO_SBT") != nullptr;          // (tests and kernel experiments, read at every so101_create: the oriented-box filter alone, as until round 5)
   M.hull_sbt = nullptr;
   bool ok = (sbt_off || upload(s, sbt, &M.hull_sbt)) &&
@@ -654,7 +701,10 @@ static int enqueue_pipelined(so101_sim* s, hipStream_t st, const so101::StepIO& 
     static const int chunk_env_l = getenv("SO101_NARROW_CHUNK_LIGHT") ? atoi(getenv("SO101_NARROW_CHUNK_LIGHT")) : 0;
     // measured at 4096 envs (heavy / light pairs per fetch -> env-steps/s): 3/3 707 k, 1/3 684 k, 2/3 712 k, 2/4 720 k, 1/4 692 k, 2/2 679 k
     // (a handful of envs: one pair per fetch - 16 wavefronts share an env's dozen pairs, and the step is a chain of dependent launches)
-    int ch = chunk_env >= 1 && chunk_env <= NARROW_CHUNK ? chunk_env : (n <= 16 ? 1 : (n <= 8192 ? 2 : NARROW_CHUNK));
+    // (round 6, with the support-bound tables and the fast path for flat faces the light pairs no longer hide a second heavy pair behind the first:
+    //  heavy pairs one per fetch and 1.25 wavefronts per env 763 -> 781 k env-steps/s at 4096 envs, 439 -> 461 k at 2048, each alone +1 %; at 8192
+    //  envs 893 -> 880 k, so two per fetch and 1.5 wavefronts per env stay there)
+    int ch = chunk_env >= 1 && chunk_env <= NARROW_CHUNK ? chunk_env : (n <= 4096 ? 1 : (n <= 8192 ? 2 : NARROW_CHUNK));
     // (round 5, work items + LDS hull pool of 1024 slots: light pairs per fetch 4 / 3 / 2 / 1 -> 718 / 736 / 740 / 604 k env-steps/s at 4096 envs - four
     //  light pairs with a 512-slot hull among them overflow the pool and stage late -; 32 768 envs, row-pass instance: 4 -> 1078 k, 2 -> 938 k)
     int cl = chunk_env_l >= 1 && chunk_env_l <= NARROW_CHUNK ? chunk_env_l : (n <= 16 ? 1 : (n <= 8192 ? 2 : NARROW_CHUNK));
@@ -669,7 +719,7 @@ static int enqueue_pipelined(so101_sim* s, hipStream_t st, const so101::StepIO& 
     // most what fills 256 CUs - a smaller narrowphase grid leaves slots to the other chains' solve kernels
     // (round 4, with the heavy-first work list: 1.5 waves per env 725 k, 2 per env 718 k, 2.5 per env 697 k env-steps/s at 4096 envs)
     static const int nw_env = getenv("SO101_NARROW_WAVES_Q") ? atoi(getenv("SO101_NARROW_WAVES_Q")) : 0;      // (kernel experiments: quarter waves per env)
-    const int nw_quarters = nw_env > 0 ? nw_env : (n <= 8192 ? 6 : 8);
+    const int nw_quarters = nw_env > 0 ? nw_env : (n <= 4096 ? 5 : (n <= 8192 ? 6 : 8));
     int nw = (int)((long long)ng * nw_quarters / 4);
     // (a handful of envs - the reference's own N = 1: a step is a chain of dependent single-env launches, so the pairs of an env are spread
     //  over 16 wavefronts instead of queued on one or two)

@@ -70,11 +70,21 @@ struct DevModel {
   // d / |d|_inf, times |d|_inf, is an UPPER bound of h(d) - a few per cent of the hull's size above it, against the tens of per cent of an
   // oriented box around a curved shell piece.  Built at so101_create from the blob's vertices (so101_hip.hip); used by obb_filter.
   const float* hull_sbt;
+  // support-vertex lists of the mesh geoms (round 6; NULL: none).  The cube-map of directions is cut into 6 x HL_GRID x HL_GRID cells; hl_off[g * (HL_CELLS
+  // + 1) + c] .. [.. + c + 1] is the range of cell c's entries in hl_entry, four floats each: x, y, z of a vertex (the floats of vx / vy / vz) and its
+  // index within the hull (bits).  A cell's list holds, in increasing index order, every vertex that can be the support point for SOME direction of the
+  // cell widened by 4e-3 rad: a vertex v is left out only when one of the four vertices that win at the cell's corners beats it at all four corners by
+  // more than the widening - then it loses everywhere in between by linearity (so101_hip.hip).  Median 10-17 of a hull's 200-1080 vertices.
+  const float* hl_entry;
+  const unsigned int* hl_off;
 };
 #ifndef SBT_GRID
 #define SBT_GRID 5
 #endif
 #define SBT_DIM (6 * SBT_GRID * SBT_GRID)
+#define HL_GRID 8
+#define HL_CELLS (6 * HL_GRID * HL_GRID)
+#define HL_MAX 128               // a list longer than two vertices per lane is not used (the query scans the whole hull as before)
 
 // Per-env launch parameters that are not part of the model.
 struct StepParams {

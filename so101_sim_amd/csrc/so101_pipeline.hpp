@@ -74,9 +74,8 @@ DEV bool heavy_pair(const DevModel* m, int g1, int g2) {
   return t1 != G_PLANE && t1 != G_BOX && t2 != G_PLANE && t2 != G_BOX;
 }
 // one geom of an item (one lane): world-frame GeomW by load_geom_at() with per-lane loads (policy G16: plain loads, no uniformity claims)
-DEV void item_put_geom(const DevModel* m, const EnvLDS& L, int g, unsigned int* it) {
+DEV void item_put_geom(const DevModel* m, const EnvLDS& L, int g, unsigned int* it, GeomW& G) {
   int d = m->geom_dyn[g];
-  GeomW G;
   load_geom_at<G16>(m, g, L.xpos[d < 0 ? 0 : d], L.xmat[d < 0 ? 0 : d], G);
   it[ITEM_G_TYPE] = (unsigned int)G.type; it[ITEM_G_VADR] = (unsigned int)G.vadr; it[ITEM_G_VNUM] = (unsigned int)G.vnum;
 #pragma unroll
@@ -120,8 +119,20 @@ DEV void publish_candidates(const DevModel* m, const EnvLDS& L, const PipeBuffer
       unsigned int pos = heavy ? (unsigned int)(hb + hseen + wave_prefix(mh)) : W.conres_cap - 1u - (unsigned int)(lb + lseen + wave_prefix(ml));
       unsigned int it[ITEM_WORDS];
       it[0] = (unsigned int)(base + k); it[1] = w;
-      item_put_geom(m, L, g1, it + ITEM_GEOM0); item_put_geom(m, L, g2, it + ITEM_GEOM1);
+      GeomW G1, G2;
+      item_put_geom(m, L, g1, it + ITEM_GEOM0, G1); item_put_geom(m, L, g2, it + ITEM_GEOM1, G2);
+      // round 6: a flat face against a hull - the cell of the hull's support-vertex lists that the query's first support direction falls into, so
+      // that k_narrow can fetch those few vertices right behind the item instead of staging the whole hull (so101_device.hpp HullSub); word 46 = first
+      // entry, word 47 = entries (1 .. HL_MAX) | cell << 8, or 0: none
       it[46] = 0u; it[47] = 0u;
+      if (m->hl_off) {
+        int cell = light_first_cell(G1, G2);
+        if (cell >= 0) {
+          const unsigned int* o = m->hl_off + (size_t)g2 * (HL_CELLS + 1) + cell;
+          unsigned int a = o[0], cnt = o[1] - a;
+          if (cnt >= 1u && cnt <= (unsigned int)HL_MAX) { it[46] = a; it[47] = cnt | ((unsigned int)cell << 8); }
+        }
+      }
       uint4* dst = (uint4*)(W.items + (size_t)pos * ITEM_WORDS);
 #pragma unroll
       for (int q = 0; q < ITEM_WORDS / 4; q++) dst[q] = make_uint4(it[4 * q], it[4 * q + 1], it[4 * q + 2], it[4 * q + 3]);

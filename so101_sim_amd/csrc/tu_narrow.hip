@@ -99,6 +99,7 @@ __global__ void __launch_bounds__(64, NarrowCfg<ROWS>::waves) k_narrow(const Dev
           int o = h ? ITEM_GEOM1 : ITEM_GEOM0;
           int vadr = item_i(it[j], o + ITEM_G_VADR), vnum = item_i(it[j], o + ITEM_G_VNUM);
           int n = hull_lds_slots(item_i(it[j], o + ITEM_G_TYPE), vnum);
+          if (!ROWS && item_i(it[j], 47) != 0) n = 0;          // (a fast item: its hull is only staged if the fast path hands the pair back, below)
           if (n && used + n <= HULL_POOL) {
             off[2 * j + h] = used;
             for (int k = 0; k < n; k += 256) {
@@ -189,6 +190,41 @@ __global__ void __launch_bounds__(64, NarrowCfg<ROWS>::waves) k_narrow(const Dev
       unsigned int rec = (unsigned int)item_i(word, 0), w = (unsigned int)item_i(word, 1);
       GeomW G1, G2; float rb1, rb2;
       item_geom(word, ITEM_GEOM0, G1, rb1); item_geom(word, ITEM_GEOM1, G2, rb2);
+      // ---- fast path (round 6): a plane / box face against a hull whose work item names a cell of the hull's support-vertex lists.  Those entries
+      // (two per lane at most) ARE the hull for the query's first support direction and its patch samples: one coalesced load instead of staging
+      // 256-512 vertices in LDS, one or two vertices per lane instead of four to sixteen in every scan.  Same arithmetic on the same floats, the same
+      // winners: the record is the one the full query writes (the fused step scans the whole hull and the identity tests compare the two).  A pair
+      // the first face does not settle goes through the full query below.
+      if constexpr (!ROWS) {
+        unsigned int fw = (unsigned int)item_i(word, 47);
+        if (fw != 0u && ldc(&m->hl_entry) != nullptr && light_first_cell(G1, G2) == (int)(fw >> 8)) {
+          const int fcnt = (int)(fw & 255u);
+          const float* E = ldc(&m->hl_entry) + 4 * (size_t)(unsigned int)item_i(word, 46);
+          HullSub S1, S2;
+#pragma unroll
+          for (int q = 0; q < 2; q++) {
+            int k = lane + WAVE * q;
+            bool in = k < fcnt;
+            float4 ev; ev.x = 0.f; ev.y = 0.f; ev.z = 0.f; ev.w = 0.f;
+            if (in) ev = *(const float4*)(E + 4 * (size_t)k);
+            S2.x[q] = ev.x; S2.y[q] = ev.y; S2.z[q] = ev.z; S2.i[q] = in ? __float_as_int(ev.w) : 0x7fffffff;
+            S1.x[q] = 0.f; S1.y[q] = 0.f; S1.z[q] = 0.f; S1.i[q] = 0x7fffffff;
+          }
+          PairContacts fpc;
+          if (narrow_pair_cached<HullSub, G64, true, true>(m, G1, G2, rb1, rb2, S1, S2, fpc)) {
+            if (lane == 0) {
+              float* r = W.conres + (size_t)rec * CONRES_DIM;
+              r[0] = (float)__popc(fpc.valid); r[1] = fpc.nrm[0]; r[2] = fpc.nrm[1]; r[3] = fpc.nrm[2];
+              int o = 4;
+#pragma unroll
+              for (int q = 0; q < NCPP; q++)
+                if ((fpc.valid >> q) & 1u) { r[o] = fpc.dist[q]; r[o + 1] = fpc.pos[q][0]; r[o + 2] = fpc.pos[q][1]; r[o + 3] = fpc.pos[q][2]; o += 4; }
+              if (SO101_CLOCKS_ON) W.ticks[w] = ((unsigned int)(SO101_CLOCK() - t0) & 0x0fffffffu) | ((unsigned int)__popc(fpc.valid) << 28);
+            }
+            continue;
+          }
+        }
+      }
       HullLDS H1{pool, 0}, H2{pool, 0};
       int n1 = hull_lds_slots(G1.type, G1.vnum), n2 = hull_lds_slots(G2.type, G2.vnum);
       if (o1 >= 0) { H1.p = pool + 3 * o1; H1.n = n1; }
