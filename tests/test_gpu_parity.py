@@ -127,11 +127,13 @@ def test_probe_outlier_states_of_round_6(make_sim, blobs, golden):
     pc.check_probe_outliers(make_sim, blobs, golden)
 
 
-def test_support_bound_tables_change_no_contact(blobs):
-    """Round 6: the broadphase drops a candidate pair when a hull's support-bound table (DevModel::hull_sbt) proves a separating plane beyond the
-    oriented boxes' fifteen axes.  A dropped pair would have ended in "no intersection", so nothing downstream may change: two handles, one
-    created with SO101_NO_SBT=1 (no tables), the same seed and random actions across a time limit - states and task outputs bit for bit,
-    fewer candidates with the tables."""
+@pytest.mark.parametrize("switch", ["SO101_NO_SBT", "SO101_NO_HL"])
+def test_support_tables_change_no_contact(blobs, switch):
+    """Round 6.  SO101_NO_SBT: the broadphase drops a candidate pair when a hull's support-bound table (DevModel::hull_sbt) proves a separating
+    plane beyond the oriented boxes' fifteen axes - a dropped pair would have ended in "no intersection".  SO101_NO_HL: k_narrow serves a flat
+    face against a hull from the few vertices that can win in the cube-map cell of the face normal (DevModel::hl_entry) instead of the whole
+    hull - the same support points.  Neither may change anything downstream: two handles, one created with the switch set (no tables), the same
+    seed and random actions across a time limit - states and task outputs bit for bit (and fewer candidates with the support-bound tables)."""
     import os
     n, steps = 512, 30
     rng = np.random.RandomState(4)
@@ -141,11 +143,11 @@ def test_support_bound_tables_change_no_contact(blobs):
     traces, cands = [], []
     for off in (False, True):
         if off:
-            os.environ["SO101_NO_SBT"] = "1"
+            os.environ[switch] = "1"
         try:
             sim = ArraySim(blobs["f32"], n, backend="gpu", seed=3, last_step=12, settle_max_substeps=200)
         finally:
-            os.environ.pop("SO101_NO_SBT", None)
+            os.environ.pop(switch, None)
         sim.reset()
         tr, nc = [], 0.0
         for t in range(steps):
@@ -156,7 +158,7 @@ def test_support_bound_tables_change_no_contact(blobs):
     for t, (a, b) in enumerate(zip(*traces)):
         assert np.all(np.isfinite(a))
         np.testing.assert_array_equal(a, b, err_msg=f"step {t}")
-    assert cands[0] < 0.95 * cands[1], cands
+    assert cands[0] < 0.95 * cands[1] if switch == "SO101_NO_SBT" else cands[0] == cands[1], cands
 
 
 def test_three_launch_chains_match_fused(make_sim, golden):
