@@ -33,7 +33,9 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # four launch chains need t
 
 ALGO_BYTES_PER_ENV_STEP = 620      # fused 10-substep step, fp32, per env-step
 HBM_SPEC_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-VALU_PEAK_TFLOPS = 157.3           # MI355X_MICROARCH.md: fp32 vector peak (256 CUs x 4 SIMD x 16 lanes x 2 x 2.4 GHz)
+VALU_PEAK_TFLOPS = 157.3           # MI355X_MICROARCH.md: fp32 vector peak (256 CUs x 4 SIMDs x 32 lanes x 2 flop x 2.4 GHz)
+VALU_SUSTAINED_TINST = 0.81        # T wave64 VALU instructions/s the device sustains on plain v_fma_f32 with >= 2 wavefronts per SIMD, measured
+                                   # (scripts/microbench/valu_issue.hip, profiles/r06_valu_issue.txt: 103 TFLOP/s; the clock sags to 1.5-2.0 GHz under that load)
 DEFAULT_ENVS = {"handover": 4096, "pickplace": 16384, "mixed": 32768}
 
 
@@ -594,6 +596,7 @@ def main():
                              "valu_tflops_equiv": pmc.get("valu_insts_per_step", 0) * 64 * 2 / (kernel_ms * 1e-3) / 1e12,
                              "peak_tflops": VALU_PEAK_TFLOPS,
                              "frac": pmc.get("valu_insts_per_step", 0) * 64 * 2 / (kernel_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
+                             "frac_of_measured_issue_rate": pmc.get("valu_insts_per_step", 0) / (kernel_ms * 1e-3) / 1e12 / VALU_SUSTAINED_TINST,
                              "active_lane_fraction": pmc.get("active_lane_fraction"),
                              "wait_fraction": pmc.get("wait_fraction"), "source": f"profiles/pmc_{build_hash}.json"},
                          "note": "HBM fraction as the metric asks: algorithmic bytes (620 B/env-step x envs) / device time of the step's launch "
